@@ -1,0 +1,199 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by running the *reference itself* (imported
+read-only from /root/reference through oracle/ref_import.py) on seeded synthetic parameters and inputs.
+
+Run in the build container only:   python -m oracle.gen_golden
+Only OUTPUTS are stored; every input / parameter is re-drawn from numpy.random.default_rng(seed) through
+oracle.torch_oracle.{state_dict_spec, synth_state, synth_batch}, so the fixtures stay small.
+
+Fixture families
+  head_<name>.npz    reference SlotAttention (+conv1x1/PE/loss glue of SlotModel.forward) on random features
+  model_<name>.npz   reference SlotModel fwd+bwd (whole network), fp32 and an fp64 "truth" run
+  engine_mnist.npz   reference engine.train_one_epoch, 2 steps of config 1 at tiny batch: record + parameter sums
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_import as R          # noqa: E402
+from oracle import torch_oracle as O        # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# name -> (C, spc, N-side, L, loss_status, power, B, Cin)  -- the five BASELINE configs' head shapes + edge cases
+HEAD_CASES = {
+    "c1_mnist": (10, 1, 9, 1, 1, 1, 4, 512),
+    "c2_in10_pos": (10, 1, 7, 3, 1, 2, 4, 2048),
+    "c3_in10_neg": (10, 1, 7, 3, -1, 2, 4, 2048),
+    "c4_cub200": (200, 1, 7, 3, 1, 2, 3, 2048),
+    "c5_in100_spc3": (100, 3, 7, 3, 1, 2, 3, 2048),
+    "tiny_spc2": (3, 2, 3, 2, 1, 1, 2, 64),
+    "one_token": (5, 1, 1, 1, 1, 2, 2, 64),
+    "grid9_spc3": (7, 3, 9, 3, -1, 2, 2, 256),
+}
+
+# name -> (arch, C, spc, L, ls, power, B, H, in_chans, mnist)
+MODEL_CASES = {
+    "resnet18_mnist_64": ("resnet18", 10, 1, 1, 1, 1, 4, 64, 1, True),
+    "resnest26d_96": ("resnest26d", 10, 1, 3, 1, 2, 4, 96, 3, False),
+    "resnest26d_224": ("resnest26d", 10, 1, 3, 1, 2, 6, 224, 3, False),
+    "resnest50d_64_spc3": ("resnest50d", 12, 3, 3, -1, 2, 3, 64, 3, False),
+}
+LAMBDA = "1"
+
+
+def head_inputs(case, seed=100):
+    C, spc, side, L, ls, power, B, Cin = HEAD_CASES[case]
+    rng = np.random.default_rng(seed)
+    feat = np.maximum(rng.standard_normal((B, Cin, side, side)), 0.0).astype(np.float32)  # post-ReLU backbone output
+    labels = rng.integers(0, C, B).astype(np.int64)
+    spec = {k: v for k, v in O.state_dict_spec("resnet18", C, spc, L).items()
+            if not k.startswith("backbone.")}
+    spec["conv1x1.weight"] = (64, Cin, 1, 1)
+    P = O.synth_state(spec, seed + 1)
+    return torch.from_numpy(feat), torch.from_numpy(labels), P
+
+
+def run_reference_head(case, dtype):
+    """Reference SlotAttention + the glue lines of SlotModel.forward (slot_model.py:108-121), verbatim calls."""
+    C, spc, side, L, ls, power, B, Cin = HEAD_CASES[case]
+    feat, labels, P = head_inputs(case)
+    R.install_shims()
+    from sloter.utils.position_encode import build_position_encoding   # noqa: reference
+    slot = R.build_reference_slot_attention(C, spc, 64, loss_status=ls, power=power, to_k_layer=L)
+    slot.load_state_dict({k[5:]: v for k, v in P.items() if k.startswith("slot.")})
+    conv = torch.nn.Conv2d(Cin, 64, 1)
+    conv.load_state_dict({"weight": P["conv1x1.weight"], "bias": P["conv1x1.bias"]})
+    pos = build_position_encoding("sine", hidden_dim=64)
+    slot, conv = slot.to(dtype), conv.to(dtype)
+    feat = feat.to(dtype).requires_grad_(True)
+    store = []
+    with R.capture_python_sigmoid(store):
+        x = torch.relu(conv(feat))
+        pe = pos(x)
+        x_pe = x + pe
+        b, n, r, c = x.shape
+        x = x.reshape((b, n, -1)).permute((0, 2, 1))
+        x_pe = x_pe.reshape((b, n, -1)).permute((0, 2, 1))
+        logits, attn_loss = slot(x_pe, x)
+    output = torch.nn.functional.log_softmax(logits, dim=1)
+    nll = torch.nn.functional.nll_loss(output, labels)
+    loss = nll + float(LAMBDA) * attn_loss
+    loss.backward()
+    # dfeat / d_conv_w are large (B*Cin*N, d*Cin): keep a digest + a leading sub-block (channels 0..15 / 0..31)
+    res = dict(logits=logits, log_probs=output, loss=loss, nll=nll, area=attn_loss, attn=store[-1],
+               pe=pe[0], dfeat_head=feat.grad[:, :16], dfeat_digest=torch.from_numpy(grad_digest(feat.grad)),
+               d_conv_w_head=conv.weight.grad[:, :32],
+               d_conv_w_digest=torch.from_numpy(grad_digest(conv.weight.grad)), d_conv_b=conv.bias.grad)
+    for k, p in slot.named_parameters():
+        res["d_slot." + k] = p.grad if p.grad is not None else torch.zeros(0)
+    res["vis"] = torch.from_numpy(O.vis_maps(store[-1], C, spc, 0))
+    return {k: v.detach().numpy() for k, v in res.items()}
+
+
+def model_inputs(case, seed=200):
+    arch, C, spc, L, ls, power, B, H, in_chans, mnist = MODEL_CASES[case]
+    spec = O.state_dict_spec(arch, C, spc, L, in_chans=in_chans, mnist_stem=mnist)
+    P = O.synth_state(spec, seed)
+    images, labels = O.synth_batch(B, in_chans, H, C, seed + 1)
+    return spec, P, images, labels
+
+
+def grad_digest(g):
+    """A gradient tensor reduced to (sum, abs-sum, first 16 entries) -- enough to pin it, small enough to commit."""
+    f = g.detach().double().flatten()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item()], f[:16].numpy()])
+
+
+def run_reference_model(case, dtype):
+    arch, C, spc, L, ls, power, B, H, in_chans, mnist = MODEL_CASES[case]
+    spec, P, images, labels = model_inputs(case)
+    args = R.make_args(model=arch, num_classes=C, slots_per_class=spc, channel=O.ARCHS[arch]["channel"],
+                       to_k_layer=L, power=power, loss_status=ls, lambda_value=LAMBDA,
+                       dataset="MNIST" if mnist else "ImageNet")
+    m = R.build_reference_slot_model(args, feature_size=-(-H // 32))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec.keys()), "state_dict_spec order/keys differ from the reference"
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(spec[k]), (k, sd[k].shape, spec[k])
+    m.load_state_dict(P)
+    m = m.to(dtype)
+    m.train()
+    store = []
+    with R.capture_python_sigmoid(store):
+        out, losses = m(images.to(dtype), labels)
+    losses[0].backward()
+    res = dict(log_probs=out, loss=losses[0], nll=losses[1], area=losses[2], attn=store[-1])
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    res["grad_keys"] = np.array([k for k in grads if grads[k] is not None])
+    res["grad_digest"] = np.stack([grad_digest(grads[k]) for k in grads if grads[k] is not None])
+    sd2 = m.state_dict()
+    bn_keys = [k for k in sd2 if k.endswith("running_mean") or k.endswith("running_var")]
+    res["bn_digest"] = np.stack([grad_digest(sd2[k]) for k in bn_keys])
+    res["unused"] = np.array([k for k in grads if grads[k] is None])
+    out_np = {}
+    for k, v in res.items():
+        out_np[k] = v.detach().numpy() if isinstance(v, torch.Tensor) else v
+    # eval-mode forward (running statistics) on the post-step buffers
+    m.eval()
+    with torch.no_grad():
+        out_np["eval_log_probs"] = m(images.to(dtype)).numpy()
+    return out_np
+
+
+def run_reference_engine():
+    """engine.train_one_epoch + evaluate of the reference on a 2-batch synthetic loader (config 1, tiny)."""
+    R.install_shims()
+    import engine as ref_engine                             # noqa: reference
+    from tools.calculate_tool import MetricLog              # noqa: reference
+    arch, C, spc, L = "resnet18", 10, 1, 1
+    args = R.make_args(model=arch, num_classes=C, slots_per_class=spc, channel=512, to_k_layer=L, power=1,
+                       loss_status=1, lambda_value=LAMBDA, dataset="MNIST")
+    m = R.build_reference_slot_model(args, feature_size=2)
+    spec = O.state_dict_spec(arch, C, spc, L, in_chans=1, mnist_stem=True)
+    m.load_state_dict(O.synth_state(spec, 300))
+    loader = []
+    for i in range(2):
+        img, lab = O.synth_batch(4, 1, 64, C, 310 + i)
+        loader.append({"image": img.double(), "label": lab})
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    log = MetricLog()
+    ref_engine.train_one_epoch(m, loader, opt, torch.device("cpu"), log.record, 0)
+    ref_engine.evaluate(m, loader, torch.device("cpu"), log.record, 0)
+    sd = m.state_dict()
+    keys = [k for k in sd if sd[k].dtype.is_floating_point]
+    return dict(
+        record_train=np.array([log.record["train"][k][0] for k in ("loss", "acc", "log_loss", "att_loss")]),
+        record_val=np.array([log.record["val"][k][0] for k in ("loss", "acc", "log_loss", "att_loss")]),
+        param_keys=np.array(keys), param_digest=np.stack([grad_digest(sd[k]) for k in keys]))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    for case in HEAD_CASES:
+        f32 = run_reference_head(case, torch.float32)
+        f64 = run_reference_head(case, torch.float64)
+        blob = {"f32_" + k: v for k, v in f32.items()}
+        blob.update({"f64_" + k: v for k, v in f64.items() if k in ("logits", "log_probs", "loss", "nll", "area",
+                                                                     "attn")})
+        np.savez_compressed(os.path.join(OUT, f"head_{case}.npz"), **blob)
+        print("head", case, "logit fp32-vs-fp64 gap", np.abs(f32["logits"] - f64["logits"]).max())
+    for case in MODEL_CASES:
+        f32 = run_reference_model(case, torch.float32)
+        f64 = run_reference_model(case, torch.float64)
+        blob = {"f32_" + k: v for k, v in f32.items()}
+        blob.update({"f64_" + k: v for k, v in f64.items() if k in ("log_probs", "loss", "nll", "area", "attn",
+                                                                     "grad_digest", "eval_log_probs")})
+        np.savez_compressed(os.path.join(OUT, f"model_{case}.npz"), **blob)
+        print("model", case, "log_probs fp32-vs-fp64 gap", np.abs(f32["log_probs"] - f64["log_probs"]).max())
+    np.savez_compressed(os.path.join(OUT, "engine_mnist.npz"), **run_reference_engine())
+    print("done ->", OUT)
+
+
+if __name__ == "__main__":
+    main()
