@@ -1,0 +1,140 @@
+/* scouter_hip.h -- C ABI of libscouter_hip.so, the MI355X (gfx950 / CDNA4) implementation of SCOUTER's xSlot
+ * training hot path.
+ *
+ * The reference (wbw520/scouter) is pure Python over PyTorch; it has NO native plugin / FFI interface to copy
+ * (SURVEY.md section 8b).  Each entry point below therefore replaces a PyTorch op *call site* of the reference
+ * (cited as file:line under /root/reference) and is what a binding for that call site would bind to.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a `void* stream` (hipStream_t); no torch types;
+ *   - every function is asynchronous on `stream`, re-entrant, keeps no global mutable state, never allocates
+ *     device memory (callers pass workspaces sized by the *_workspace_bytes helpers), never throws or exits;
+ *   - return 0 on success, <0 on error (SC_ERR_* below); the message is in scouter_last_error() (thread-local);
+ *   - tensors are caller-owned, dense, 16-byte aligned fp32 unless stated;
+ *   - activations are NHWC ("[M = B*H*W][C]"), convolution weights are HWIO ([kh][kw][Cin/groups][Cout]).
+ */
+#ifndef SCOUTER_HIP_H
+#define SCOUTER_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_OK 0
+#define SC_ERR_ARG (-1)
+#define SC_ERR_LAUNCH (-2)
+#define SC_ERR_UNSUPPORTED (-3)
+#define SC_ERR_WORKSPACE (-4)
+
+int scouter_abi_version(void);
+const char* scouter_last_error(void);
+
+/* optional per-kernel-class hipEvent timing used by bench.py's roofline leg.
+ * classes: 0 conv_fwd, 1 conv_dgrad, 2 conv_wgrad, 3 xslot_fwd, 4 xslot_bwd, 5 bn, 6 other
+ * scouter_prof_collect fills out[7][4] = {launches, total ms, algorithmic flops, algorithmic bytes}. */
+void scouter_prof_enable(int on);
+int scouter_prof_collect(double* out);
+
+/* ---- convolution = nn.Conv2d call sites: timm/models/resnet.py:491-501 (stem, blocks), resnest.py:111-143,
+ * layers/split_attn.py:54-60 (grouped 3x3, fc1, fc2), sloter/slot_model.py:108 (conv1x1) and their autograd
+ * backward (engine.py:33).  fp32 implicit GEMM on v_mfma_f32_32x32x2_f32.  Per-group channels must be multiples
+ * of 32.  `bias` (per Cout), `addend` (same shape as the output) may be NULL; relu applies last. */
+int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* addend, float* y, int B,
+                           int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int relu,
+                           void* stream);
+int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
+                             int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, void* stream);
+size_t scouter_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                            int groups);
+int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
+                             int kw, int stride, int pad, int groups, void* ws, size_t ws_bytes, void* stream);
+/* stem (Cin < 32): im2col of the NCHW image into [M][Kpad] rows so the stem runs as a 1x1 conv on the same path */
+int scouter_im2col_nchw_f32(const float* x, float* col, int B, int Cin, int H, int W, int k, int stride, int pad,
+                            int Kpad, void* stream);
+int scouter_pad_rows_f32(const float* w, float* wpad, long nvalid, long ntotal, void* stream);
+
+/* ---- BatchNorm2d (+ReLU, +residual add): timm/models/resnet.py:383 (norm_layer), BasicBlock :172-199,
+ * ResNestBottleneck resnest.py:111-143.  Training mode: batch statistics (fp64 accumulation), running stats
+ * updated with `momentum` and the unbiased variance; eval mode: running stats.
+ * Saves mean/rstd and the fused scale = gamma*rstd, shift = beta - mean*scale for the backward. */
+size_t scouter_colreduce_workspace_bytes(long M, int C);
+int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                       int training, int relu, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
+                       void* ws, size_t ws_bytes, void* stream);
+/* g = dy * (ymask > 0) (ymask may be NULL); dgamma/dbeta may be NULL (frozen); gout (may be NULL) receives g. */
+int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean, const float* rstd,
+                       const float* scale, long M, int C, int training, float* dgamma, float* dbeta, float* dx,
+                       float* gout, void* ws, size_t ws_bytes, void* stream);
+/* out[c] = alpha * sum_m a[m][c] * (b ? b[m][c] : 1)  -- bias gradients, d(initial_slots) */
+int scouter_colsum_f32(const float* a, const float* b, float* out, long M, int C, float alpha, void* ws,
+                       size_t ws_bytes, void* stream);
+int scouter_relu_bwd_f32(const float* dy, const float* y, float* dx, long n, void* stream);
+int scouter_axpby_f32(const float* a, const float* b, float* y, float alpha, float beta, long n, void* stream);
+
+/* ---- pooling: MaxPool2d(3,2,1) resnet.py:412; AvgPool2d(3,s,1) resnest.py:93 (avd); AvgPool2d(2,s,ceil,
+ * count_include_pad=False) resnet.py:300 (downsample_avg) */
+int scouter_pool_out_size(int in, int k, int stride, int pad, int ceil_mode);
+int scouter_maxpool_fwd_f32(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C, int k,
+                            int stride, int pad, void* stream);
+int scouter_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, float* dx, int B, int H, int W, int C, int k,
+                            int stride, int pad, void* stream);
+int scouter_avgpool_fwd_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride, int pad,
+                            int ceil_mode, int count_include_pad, void* stream);
+int scouter_avgpool_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, int k, int stride, int pad,
+                            int ceil_mode, int count_include_pad, void* stream);
+int scouter_transpose_f32(const float* in, float* out, int batch, int rows, int cols, void* stream);
+
+/* ---- split attention glue: timm/models/layers/split_attn.py:62-80 (radix 2, cardinality 1) */
+size_t scouter_sa_workspace_bytes(int B, int HW, int C2);
+int scouter_sa_reduce_f32(const float* x, const float* dout, float* out, int B, int HW, int Cp, int mode, void* ws,
+                          size_t ws_bytes, void* stream);
+int scouter_radix_softmax_fwd_f32(const float* z, float* a, int B, int Cp, void* stream);
+int scouter_radix_softmax_bwd_f32(const float* a, const float* da, float* dz, int B, int Cp, void* stream);
+int scouter_sa_apply_fwd_f32(const float* x, const float* a, float* out, int B, int HW, int Cp, void* stream);
+int scouter_sa_apply_bwd_f32(const float* dout, const float* a, const float* dgap, float* dx, int B, int HW, int Cp,
+                             void* stream);
+
+/* ---- xSlot head: sloter/utils/position_encode.py:26-46; sloter/utils/slot_attention.py:44-96;
+ * sloter/slot_model.py:117-121; tools/calculate_tool.py:4-7 */
+int scouter_posenc_sine_f32(float* pe /* [h*w][d] token-major */, int h, int w, int d, void* stream);
+/* X: [B][N][d] tokens after conv1x1+ReLU; PE: [N][d]; tok_w / tok_b: HOST arrays of L device pointers, one
+ * [d][d] (out,in) weight / [d] bias per to_k Linear; slots0: [S][d];
+ * GRU weights in nn.GRU layout (gate order r,z,n).  Outputs: logits [B][S/spc], attn [B][S][N] (last iteration),
+ * area_part [B] (per-image sum of attn).  Saved for backward: Ksave [B][N][d], Hsave [L][B][N][d] (the INPUT of
+ * every to_k layer: Hsave[0] = X+PE), states [T-1][B][S][d] (slots entering iterations 2..T). */
+int scouter_xslot_fwd_f32(const float* X, const float* PE, const float* const* tok_w, const float* const* tok_b,
+                          const float* slots0,
+                          const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int B, int N,
+                          int d, int S, int spc, int T, int L, float loss_status, float* logits, float* attn,
+                          float* area_part, float* Ksave, float* Hsave, float* states, void* stream);
+size_t scouter_xslot_bwd_workspace_bytes(int B, int N, int d, int S, int T);
+/* dlogits: [B][S/spc]; g_area_sum: device scalar dL/d(sum attn_T).  Outputs: dX [B][N][d]; dgi, dgh
+ * [T-1][B][S][3d] and Usave [T-1][B][S][d] (operands of the GRU weight-gradient GEMMs); ds0 [B][S][d];
+ * dZ [L][B][N][d] (pre-activation gradients of the to_k layers). */
+int scouter_xslot_bwd_f32(const float* X, const float* PE, const float* const* tok_w, const float* slots0,
+                          const float* w_ih,
+                          const float* w_hh, const float* b_ih, const float* b_hh, const float* Ksave,
+                          const float* Hsave, const float* states, const float* dlogits, const float* g_area_sum,
+                          int B, int N, int d, int S, int spc, int T, int L, float loss_status, float* dX, float* dgi,
+                          float* dgh, float* Usave, float* ds0, float* dZ, void* ws, size_t ws_bytes, void* stream);
+/* stats[0..4] = loss, nll, area**power, top-1 accuracy, area.  labels: int64 (may be NULL -> log_softmax only). */
+int scouter_slot_loss_fwd_f32(const float* logits, const long* labels, const float* area_part, int n_area_part, int B,
+                              int C, double area_count, float lambda, float power, float* logp, float* stats,
+                              void* stream);
+int scouter_slot_loss_bwd_f32(const float* logp, const long* labels, const float* stats, const float* g_loss,
+                              const float* g_nll, const float* g_term, const float* g_logp, int B, int C,
+                              double area_count, float lambda, float power, float* dlogits, float* g_area_sum,
+                              void* stream);
+
+/* ---- optimizer: torch.optim.AdamW defaults (train.py:146).  chunk table = array of {float* param; long offset
+ * into the flat grad/moment arenas; int n; int pad} built by the host (scouter_adamw_chunk_bytes() each). */
+int scouter_adamw_chunk_bytes(void);
+int scouter_adamw_step_f32(const void* chunk_table, int nchunks, const float* grads, float* exp_avg,
+                           float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay,
+                           int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

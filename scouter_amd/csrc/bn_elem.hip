@@ -1,0 +1,485 @@
+// Train-mode BatchNorm (+ReLU, +residual) forward/backward, column sums, pooling, layout transposes.
+// NHWC activations viewed as [M = B*H*W][C]; every kernel is HBM-bound: float4 accesses, lanes along C
+// (coalesced), batch statistics accumulated in fp64 (E[x^2]-E[x]^2 is then safe), deterministic two-level
+// reductions (per-block partials -> finalize) instead of atomics.
+// Replaces nn.BatchNorm2d / ReLU / MaxPool2d / AvgPool2d of the reference backbone (timm/models/resnet.py:383,
+// 404-412, 292-306; resnest.py:93,128-129) and their autograd backward.
+#include "common.h"
+
+#define MAXB 1024   // max partial blocks of a column reduction
+
+struct ColGeom { long M; int C; int tpr; int rpb; int cslab; };
+
+__host__ __device__ static inline ColGeom col_geom(long M, int C) {
+    ColGeom g;
+    g.M = M; g.C = C;
+    // channels handled by one blockIdx.y: the whole row when its float4 count divides 256, else 1024-wide slabs
+    g.cslab = (C / 4 <= 256 && 256 % (C / 4) == 0) ? C : 1024;
+    g.tpr = g.cslab / 4;                   // threads per row (one float4 each)
+    g.rpb = 256 / g.tpr;                   // rows per block pass
+    return g;
+}
+
+static int col_blocks(long M, const ColGeom& g) {
+    long nb = (M + (long)g.rpb * 8 - 1) / ((long)g.rpb * 8);   // >= 8 row passes per block
+    if (nb > MAXB) nb = MAXB;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+// Per-block partial column sums of up to two quantities produced by `F(row, col4) -> (float4 u, float4 v)`.
+// partial layout: [block][C][2] doubles.
+template <int MODE>   // 0: (x, x*x)   1: (g, g*xhat) with g = dy*(mask>0)   2: (x, 0)   3: (a*b, 0)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                             const float* __restrict__ p2,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, double* __restrict__ part,
+                                                             ColGeom g) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x;
+    const int cq = tid % g.tpr, rl = tid / g.tpr;
+    const int c = blockIdx.y * g.cslab + cq * 4;
+    double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+    if (rl < g.rpb && c < g.C) {
+        f32x4 mu = {0, 0, 0, 0}, rs = {1, 1, 1, 1};
+        if (MODE == 1) { mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
+        for (long r = (long)blockIdx.x * g.rpb + rl; r < g.M; r += (long)gridDim.x * g.rpb) {
+            const long off = r * g.C + c;
+            f32x4 a = *(const f32x4*)(p0 + off);
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s[k] += a[k]; t[k] += (double)a[k] * a[k]; }
+            } else if (MODE == 1) {
+                if (p1) {
+                    f32x4 y = *(const f32x4*)(p1 + off);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[k] = y[k] > 0.f ? a[k] : 0.f;
+                }
+                f32x4 x = *(const f32x4*)(p2 + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s[k] += a[k]; t[k] += (double)a[k] * ((x[k] - mu[k]) * rs[k]); }
+            } else if (MODE == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += a[k];
+            } else {
+                f32x4 b = *(const f32x4*)(p1 + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += (double)a[k] * b[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = s[k]; red[tid * 8 + 4 + k] = t[k]; }
+    __syncthreads();
+    if (rl == 0 && c < g.C) {
+        for (int j = 1; j < g.rpb; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += red[(j * g.tpr + cq) * 8 + k]; t[k] += red[(j * g.tpr + cq) * 8 + 4 + k]; }
+        double* o = part + ((long)blockIdx.x * g.C + c) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k * 2] = s[k]; o[k * 2 + 1] = t[k]; }
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                         float eps, int training, float* __restrict__ mean_o,
+                                         float* __restrict__ rstd_o, float* __restrict__ scale_o,
+                                         float* __restrict__ shift_o) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        double s = 0, t = 0;
+        for (int b = 0; b < nb; ++b) { s += part[((long)b * C + c) * 2]; t += part[((long)b * C + c) * 2 + 1]; }
+        mean = s / (double)M;
+        var = t / (double)M - mean * mean;
+        if (var < 0) var = 0;
+        if (rmean) {
+            const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+        }
+    } else { mean = rmean[c]; var = rvar[c]; }
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = (gamma ? gamma[c] : 1.f) * rstd;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    scale_o[c] = sc;
+    shift_o[c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
+}
+
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ res, float* __restrict__ y,
+                                                              long n4, int C, int relu) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        f32x4 v = *(const f32x4*)(x + i * 4);
+        const f32x4 a = *(const f32x4*)(scale + c), b = *(const f32x4*)(shift + c);
+        v = v * a + b;
+        if (res) v += *(const f32x4*)(res + i * 4);
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        *(f32x4*)(y + i * 4) = v;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, long M, int C, int training,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ c1,
+                                       float* __restrict__ c2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, t = 0;
+    for (int b = 0; b < nb; ++b) { s += part[((long)b * C + c) * 2]; t += part[((long)b * C + c) * 2 + 1]; }
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)t;
+    c1[c] = training ? (float)(s / (double)M) : 0.f;
+    c2[c] = training ? (float)(t / (double)M) : 0.f;
+}
+
+// dx = gamma*rstd * (g - c1 - xhat*c2),  g = dy * (ymask > 0);  optionally also writes g (the residual-branch grad)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                           const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ scale, const float* __restrict__ c1,
+                                                           const float* __restrict__ c2, float* __restrict__ dx,
+                                                           float* __restrict__ gout, long n4, int C) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        f32x4 g = *(const f32x4*)(dy + i * 4);
+        if (ymask) {
+            const f32x4 y = *(const f32x4*)(ymask + i * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
+        }
+        const f32x4 xv = *(const f32x4*)(x + i * 4);
+        const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), sc = *(const f32x4*)(scale + c);
+        const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c);
+        const f32x4 xh = (xv - mu) * rs;
+        *(f32x4*)(dx + i * 4) = sc * (g - k1 - xh * k2);
+        if (gout) *(f32x4*)(gout + i * 4) = g;
+    }
+}
+
+__global__ void colsum_finalize_kernel(const double* __restrict__ part, int nb, int C, float* __restrict__ out,
+                                       float alpha) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int b = 0; b < nb; ++b) s += part[((long)b * C + c) * 2];
+    out[c] = (float)(s * alpha);
+}
+
+// g = dy * (y > 0)   (ReLU backward where no BN follows, e.g. the head's conv1x1+ReLU)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ dx, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 g = *(const f32x4*)(dy + i * 4);
+        const f32x4 v = *(const f32x4*)(y + i * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = v[k] > 0.f ? g[k] : 0.f;
+        *(f32x4*)(dx + i * 4) = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    float* __restrict__ y, float alpha, float beta, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = *(const f32x4*)(a + i * 4) * alpha;
+        if (b) v += *(const f32x4*)(b + i * 4) * beta;
+        *(f32x4*)(y + i * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pooling (NHWC)
+// ---------------------------------------------------------------------------------------------------------------
+struct PoolGeom { int B, H, W, C, Ho, Wo, k, stride, pad, count_pad; };
+
+// max pool: first maximum in (ky,kx) scan order wins (PyTorch CPU semantics); argmax tap stored as uint8
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          unsigned char* __restrict__ arg, PoolGeom g) {
+    const int c4n = g.C / 4;
+    const long n = (long)g.B * g.Ho * g.Wo * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long p = i / c4n;
+        const int ox = (int)(p % g.Wo); p /= g.Wo;
+        const int oy = (int)(p % g.Ho);
+        const int b = (int)(p / g.Ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        for (int ky = 0; ky < g.k; ++ky) {
+            const int iy = oy * g.stride - g.pad + ky;
+            if (iy < 0 || iy >= g.H) continue;
+            for (int kx = 0; kx < g.k; ++kx) {
+                const int ix = ox * g.stride - g.pad + kx;
+                if (ix < 0 || ix >= g.W) continue;
+                const f32x4 v = *(const f32x4*)(x + (((long)b * g.H + iy) * g.W + ix) * g.C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = ky * g.k + kx; }
+            }
+        }
+        const long o = (((long)b * g.Ho + oy) * g.Wo + ox) * g.C + c;
+        *(f32x4*)(y + o) = best;
+        if (arg) *(uchar4*)(arg + o) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                          const unsigned char* __restrict__ arg,
+                                                          float* __restrict__ dx, PoolGeom g) {
+    const int c4n = g.C / 4;
+    const long n = (long)g.B * g.H * g.W * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long p = i / c4n;
+        const int ix = (int)(p % g.W); p /= g.W;
+        const int iy = (int)(p % g.H);
+        const int b = (int)(p / g.H);
+        f32x4 acc = {0, 0, 0, 0};
+        for (int ky = 0; ky < g.k; ++ky) {
+            const int ty = iy + g.pad - ky;
+            if (ty < 0 || ty % g.stride) continue;
+            const int oy = ty / g.stride;
+            if (oy >= g.Ho) continue;
+            for (int kx = 0; kx < g.k; ++kx) {
+                const int tx = ix + g.pad - kx;
+                if (tx < 0 || tx % g.stride) continue;
+                const int ox = tx / g.stride;
+                if (ox >= g.Wo) continue;
+                const long o = (((long)b * g.Ho + oy) * g.Wo + ox) * g.C + c;
+                const uchar4 a = *(const uchar4*)(arg + o);
+                const f32x4 d = *(const f32x4*)(dy + o);
+                const int tap = ky * g.k + kx;
+                if (a.x == tap) acc[0] += d[0];
+                if (a.y == tap) acc[1] += d[1];
+                if (a.z == tap) acc[2] += d[2];
+                if (a.w == tap) acc[3] += d[3];
+            }
+        }
+        *(f32x4*)(dx + i * 4) = acc;
+    }
+}
+
+__device__ __forceinline__ float avg_div(const PoolGeom& g, int oy, int ox) {
+    // PyTorch avg_pool2d divisor: count_include_pad -> window clipped to the padded extent; else to the input
+    int y0 = oy * g.stride - g.pad, x0 = ox * g.stride - g.pad;
+    int y1 = min(y0 + g.k, g.H + g.pad), x1 = min(x0 + g.k, g.W + g.pad);
+    if (g.count_pad) return (float)((y1 - y0) * (x1 - x0));
+    y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, g.H); x1 = min(x1, g.W);
+    return (float)((y1 - y0) * (x1 - x0));
+}
+
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          PoolGeom g) {
+    const int c4n = g.C / 4;
+    const long n = (long)g.B * g.Ho * g.Wo * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long p = i / c4n;
+        const int ox = (int)(p % g.Wo); p /= g.Wo;
+        const int oy = (int)(p % g.Ho);
+        const int b = (int)(p / g.Ho);
+        f32x4 acc = {0, 0, 0, 0};
+        for (int ky = 0; ky < g.k; ++ky) {
+            const int iy = oy * g.stride - g.pad + ky;
+            if (iy < 0 || iy >= g.H) continue;
+            for (int kx = 0; kx < g.k; ++kx) {
+                const int ix = ox * g.stride - g.pad + kx;
+                if (ix < 0 || ix >= g.W) continue;
+                acc += *(const f32x4*)(x + (((long)b * g.H + iy) * g.W + ix) * g.C + c);
+            }
+        }
+        *(f32x4*)(y + i * 4) = acc / avg_div(g, oy, ox);
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                          PoolGeom g) {
+    const int c4n = g.C / 4;
+    const long n = (long)g.B * g.H * g.W * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long p = i / c4n;
+        const int ix = (int)(p % g.W); p /= g.W;
+        const int iy = (int)(p % g.H);
+        const int b = (int)(p / g.H);
+        f32x4 acc = {0, 0, 0, 0};
+        for (int ky = 0; ky < g.k; ++ky) {
+            const int ty = iy + g.pad - ky;
+            if (ty < 0 || ty % g.stride) continue;
+            const int oy = ty / g.stride;
+            if (oy >= g.Ho) continue;
+            for (int kx = 0; kx < g.k; ++kx) {
+                const int tx = ix + g.pad - kx;
+                if (tx < 0 || tx % g.stride) continue;
+                const int ox = tx / g.stride;
+                if (ox >= g.Wo) continue;
+                acc += *(const f32x4*)(dy + (((long)b * g.Ho + oy) * g.Wo + ox) * g.C + c) / avg_div(g, oy, ox);
+            }
+        }
+        *(f32x4*)(dx + i * 4) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout: NCHW <-> NHWC (32x32 LDS tile transpose of the [C][HW] plane of every image)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float t[32][33];
+    const long boff = (long)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) t[j][threadIdx.x] = in[boff + (long)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) out[boff + (long)c * rows + r] = t[threadIdx.x][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------------------------------------------
+static inline int ew_blocks(long n) { long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+
+extern "C" size_t scouter_colreduce_workspace_bytes(long M, int C) { (void)M; return (size_t)MAXB * C * 2 * sizeof(double); }
+
+#define COL_CHECKS(name)                                                                             \
+    SC_REQUIRE(M > 0 && C > 0 && C % 4 == 0, name ": bad shape M=%ld C=%d (C must be a multiple of 4)", M, C); \
+    ColGeom g = col_geom(M, C);                                                                      \
+    SC_REQUIRE(g.cslab % 4 == 0 && 256 % g.tpr == 0, name ": unsupported channel count %d", C);      \
+    const int nb = col_blocks(M, g);                                                                 \
+    if (!ws || ws_bytes < (size_t)nb * C * 2 * sizeof(double)) {                                     \
+        sc_set_error(name ": workspace too small");                                                  \
+        return SC_ERR_WORKSPACE;                                                                     \
+    }                                                                                                \
+    dim3 pgrid(nb, (C + g.cslab - 1) / g.cslab);
+
+extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum,
+                                  float eps, int training, int relu, float* mean_out, float* rstd_out,
+                                  float* scale_out, float* shift_out, void* ws, size_t ws_bytes, void* stream) {
+    SC_REQUIRE(x && y && mean_out && rstd_out && scale_out && shift_out, "bn_fwd: null pointer");
+    SC_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
+    COL_CHECKS("bn_fwd")
+    hipStream_t st = (hipStream_t)stream;
+    ScProfScope prof(SC_PROF_BN, st, 0, 12.0 * M * C);
+    if (training)
+        hipLaunchKernelGGL(colsum_partial_kernel<0>, pgrid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
+                           (double*)ws, g);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(sc_cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+                       gamma, beta, running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out,
+                       shift_out);
+    const long n4 = M * C / 4;
+    hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, scale_out, shift_out,
+                       residual, y, n4, C, relu);
+    return sc_check_launch("bn_fwd");
+}
+
+extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean,
+                                  const float* rstd, const float* scale, long M, int C, int training, float* dgamma,
+                                  float* dbeta, float* dx, float* gout, void* ws, size_t ws_bytes, void* stream) {
+    SC_REQUIRE(dy && x && mean && rstd && scale && dx, "bn_bwd: null pointer");
+    COL_CHECKS("bn_bwd")
+    const size_t coef_off = (size_t)nb * C * 2 * sizeof(double);
+    if (ws_bytes < coef_off + 2 * (size_t)C * sizeof(float)) {
+        sc_set_error("bn_bwd: workspace too small");
+        return SC_ERR_WORKSPACE;
+    }
+    float* c1 = (float*)((char*)ws + coef_off);
+    float* c2 = c1 + C;
+    hipStream_t st = (hipStream_t)stream;
+    ScProfScope prof(SC_PROF_BN, st, 0, 28.0 * M * C);
+    hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, (double*)ws, g);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+                       training, dgamma, dbeta, c1, c2);
+    const long n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale, c1,
+                       c2, dx, gout, n4, C);
+    return sc_check_launch("bn_bwd");
+}
+
+// out[c] = alpha * sum_m a[m][c] (* b[m][c] when b != NULL)
+extern "C" int scouter_colsum_f32(const float* a, const float* b, float* out, long M, int C, float alpha, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    SC_REQUIRE(a && out, "colsum: null pointer");
+    COL_CHECKS("colsum")
+    hipStream_t st = (hipStream_t)stream;
+    if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, pgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, (double*)ws, g);
+    else hipLaunchKernelGGL(colsum_partial_kernel<2>, pgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sc_cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, nb, C, out, alpha);
+    return sc_check_launch("colsum");
+}
+
+extern "C" int scouter_relu_bwd_f32(const float* dy, const float* y, float* dx, long n, void* stream) {
+    SC_REQUIRE(dy && y && dx && n % 4 == 0, "relu_bwd: null pointer or n %% 4 != 0");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n / 4);
+    return sc_check_launch("relu_bwd");
+}
+
+extern "C" int scouter_axpby_f32(const float* a, const float* b, float* y, float alpha, float beta, long n,
+                                 void* stream) {
+    SC_REQUIRE(a && y && n % 4 == 0, "axpby: null pointer or n %% 4 != 0");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, y, alpha, beta, n / 4);
+    return sc_check_launch("axpby");
+}
+
+static int pool_out(int in, int k, int s, int p, int ceil_mode) {
+    int o = ceil_mode ? (in + 2 * p - k + s - 1) / s + 1 : (in + 2 * p - k) / s + 1;
+    if (ceil_mode && (o - 1) * s >= in + p) --o;   // last window must start inside the input or left padding
+    return o;
+}
+extern "C" int scouter_pool_out_size(int in, int k, int stride, int pad, int ceil_mode) {
+    return pool_out(in, k, stride, pad, ceil_mode);
+}
+
+#define POOL_SETUP(name)                                                                                       \
+    SC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && k <= 15 && stride > 0, name ": bad shape"); \
+    PoolGeom g{B, H, W, C, pool_out(H, k, stride, pad, ceil_mode), pool_out(W, k, stride, pad, ceil_mode), k, stride, \
+               pad, count_include_pad};                                                                        \
+    hipStream_t st = (hipStream_t)stream;
+
+extern "C" int scouter_maxpool_fwd_f32(const float* x, float* y, unsigned char* argmax, int B, int H, int W, int C,
+                                       int k, int stride, int pad, void* stream) {
+    const int ceil_mode = 0, count_include_pad = 0;
+    POOL_SETUP("maxpool_fwd")
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 4)), dim3(256), 0, st, x, y, argmax, g);
+    return sc_check_launch("maxpool_fwd");
+}
+extern "C" int scouter_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, float* dx, int B, int H, int W,
+                                       int C, int k, int stride, int pad, void* stream) {
+    const int ceil_mode = 0, count_include_pad = 0;
+    POOL_SETUP("maxpool_bwd")
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)B * H * W * C / 4)), dim3(256), 0, st, dy, argmax, dx, g);
+    return sc_check_launch("maxpool_bwd");
+}
+extern "C" int scouter_avgpool_fwd_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride, int pad,
+                                       int ceil_mode, int count_include_pad, void* stream) {
+    POOL_SETUP("avgpool_fwd")
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 4)), dim3(256), 0, st, x, y, g);
+    return sc_check_launch("avgpool_fwd");
+}
+extern "C" int scouter_avgpool_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, int k, int stride,
+                                       int pad, int ceil_mode, int count_include_pad, void* stream) {
+    POOL_SETUP("avgpool_bwd")
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks((long)B * H * W * C / 4)), dim3(256), 0, st, dy, dx, g);
+    return sc_check_launch("avgpool_bwd");
+}
+
+// in: [batch][rows][cols] -> out: [batch][cols][rows]   (NCHW->NHWC: rows=C, cols=H*W;  NHWC->NCHW: rows=H*W, cols=C)
+extern "C" int scouter_transpose_f32(const float* in, float* out, int batch, int rows, int cols, void* stream) {
+    SC_REQUIRE(in && out && batch > 0 && rows > 0 && cols > 0, "transpose: bad arguments");
+    dim3 grid(sc_cdiv(cols, 32), sc_cdiv(rows, 32), batch);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, in, out, rows, cols);
+    return sc_check_launch("transpose");
+}

@@ -1,0 +1,72 @@
+// Shared device/host helpers for the scouter_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define SC_OK 0
+#define SC_ERR_ARG (-1)
+#define SC_ERR_LAUNCH (-2)
+#define SC_ERR_UNSUPPORTED (-3)
+#define SC_ERR_WORKSPACE (-4)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// thread-local error text: the ABI never throws and never exits (include/scouter_hip.h)
+void sc_set_error(const char* fmt, ...);
+int sc_check_launch(const char* what);
+
+#define SC_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            sc_set_error(__VA_ARGS__);        \
+            return SC_ERR_ARG;                \
+        }                                     \
+    } while (0)
+
+#define SC_UNSUPPORTED(cond, ...)             \
+    do {                                      \
+        if (!(cond)) {                        \
+            sc_set_error(__VA_ARGS__);        \
+            return SC_ERR_UNSUPPORTED;        \
+        }                                     \
+    } while (0)
+
+// ---- optional per-kernel-class timing (bench.py's roofline leg): hipEvents recorded on the launch stream
+enum ScProfClass { SC_PROF_CONV_FWD = 0, SC_PROF_CONV_DGRAD = 1, SC_PROF_CONV_WGRAD = 2, SC_PROF_XSLOT_FWD = 3,
+                   SC_PROF_XSLOT_BWD = 4, SC_PROF_BN = 5, SC_PROF_OTHER = 6, SC_PROF_NCLASS = 7 };
+struct ScProfScope {
+    int cls;
+    hipStream_t stream;
+    int slot;
+    ScProfScope(int cls, hipStream_t stream, double flops, double bytes);
+    ~ScProfScope();
+};
+
+static inline int sc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    // v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// bijective XCD-aware remap of a linear workgroup id (8 XCDs; consecutive logical ids share an XCD's L2)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

@@ -1,0 +1,359 @@
+// Split-attention glue (ResNeSt), stem im2col, sine positional encoding, loss head, fused AdamW, metrics.
+// Reference call sites: timm/models/layers/split_attn.py:62-80 (radix sum, GAP, RadixSoftmax, weighted sum);
+// sloter/utils/position_encode.py:26-46; sloter/slot_model.py:117-121 (log_softmax, NLL, lambda*area);
+// train.py:146 (AdamW); tools/calculate_tool.py:4-7 (top-1).
+#include "common.h"
+
+static inline int ew_blocks(long n) { long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// split attention
+// ---------------------------------------------------------------------------------------------------------------
+// Per-image column sums over the HW rows of x[b] ([HW][C2], C2 = radix*C'), optionally of x*w (w: [HW][C'] broadcast
+// over the radix halves).  partial: [B][nsplit][C2] doubles.
+template <bool WITH_W>
+__global__ __launch_bounds__(256) void sa_colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                double* __restrict__ part, int HW, int C2, int Cp,
+                                                                int tpr, int rpb, int rows_per_split) {
+    __shared__ double red[256 * 4];
+    const int tid = threadIdx.x, cq = tid % tpr, rl = tid / tpr, b = blockIdx.y, sp = blockIdx.x;
+    const int c = cq * 4;
+    const int r0 = sp * rows_per_split, r1 = min(HW, r0 + rows_per_split);
+    double s[4] = {0, 0, 0, 0};
+    const float* xb = x + (long)b * HW * C2;
+    const float* wb = WITH_W ? w + (long)b * HW * Cp : nullptr;
+    for (int r = r0 + rl; r < r1; r += rpb) {
+        f32x4 v = *(const f32x4*)(xb + (long)r * C2 + c);
+        if (WITH_W) v *= *(const f32x4*)(wb + (long)r * Cp + (c % Cp));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[tid * 4 + k] = s[k];
+    __syncthreads();
+    if (rl == 0) {
+        for (int j = 1; j < rpb; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += red[(j * tpr + cq) * 4 + k];
+        double* o = part + ((long)b * gridDim.x + sp) * C2 + c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = s[k];
+    }
+}
+
+// gap[b][c] = alpha * sum_splits (part[b][s][c] + part[b][s][Cp+c])     (fold_radix = 1)
+// out[b][c2] = alpha * sum_splits part[b][s][c2]                          (fold_radix = 0)
+__global__ void sa_colsum_finalize_kernel(const double* __restrict__ part, float* __restrict__ out, int B, int nsplit,
+                                          int C2, int Cp, int fold_radix, float alpha) {
+    const int Co = fold_radix ? Cp : C2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * Co) return;
+    const int b = (int)(i / Co), c = (int)(i % Co);
+    double s = 0;
+    for (int k = 0; k < nsplit; ++k) {
+        const double* p = part + ((long)b * nsplit + k) * C2;
+        s += p[c];
+        if (fold_radix) for (int r = 1; r * Cp < C2; ++r) s += p[r * Cp + c];
+    }
+    out[i] = (float)(s * alpha);
+}
+
+// radix-2 softmax over (z[b][c], z[b][Cp+c])  (RadixSoftmax with cardinality 1, split_attn.py:20-28)
+__global__ void radix_softmax_fwd_kernel(const float* __restrict__ z, float* __restrict__ a, int B, int Cp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * Cp) return;
+    const int b = (int)(i / Cp), c = (int)(i % Cp);
+    const float z0 = z[(long)b * 2 * Cp + c], z1 = z[(long)b * 2 * Cp + Cp + c];
+    const float m = fmaxf(z0, z1), e0 = expf(z0 - m), e1 = expf(z1 - m), inv = 1.f / (e0 + e1);
+    a[(long)b * 2 * Cp + c] = e0 * inv;
+    a[(long)b * 2 * Cp + Cp + c] = e1 * inv;
+}
+__global__ void radix_softmax_bwd_kernel(const float* __restrict__ a, const float* __restrict__ da,
+                                         float* __restrict__ dz, int B, int Cp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * Cp) return;
+    const int b = (int)(i / Cp), c = (int)(i % Cp);
+    const long i0 = (long)b * 2 * Cp + c, i1 = i0 + Cp;
+    const float dot = a[i0] * da[i0] + a[i1] * da[i1];
+    dz[i0] = a[i0] * (da[i0] - dot);
+    dz[i1] = a[i1] * (da[i1] - dot);
+}
+
+// out[b,hw,c] = x[b,hw,c]*a[b,c] + x[b,hw,Cp+c]*a[b,Cp+c]
+__global__ __launch_bounds__(256) void sa_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                           float* __restrict__ out, long n4, int HW, int Cp) {
+    const int c4n = Cp / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long row = i / c4n;                 // b*HW + hw
+        const int b = (int)(row / HW);
+        const f32x4 x0 = *(const f32x4*)(x + row * 2 * Cp + c), x1 = *(const f32x4*)(x + row * 2 * Cp + Cp + c);
+        const f32x4 a0 = *(const f32x4*)(a + (long)b * 2 * Cp + c), a1 = *(const f32x4*)(a + (long)b * 2 * Cp + Cp + c);
+        *(f32x4*)(out + i * 4) = x0 * a0 + x1 * a1;
+    }
+}
+// dx[b,hw,r*Cp+c] = dout[b,hw,c]*a[b,r*Cp+c] + dgap[b,c]*inv_hw
+__global__ __launch_bounds__(256) void sa_apply_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                                           const float* __restrict__ dgap, float* __restrict__ dx,
+                                                           long n4, int HW, int Cp, float inv_hw) {
+    const int c4n = Cp / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long row = i / c4n;
+        const int b = (int)(row / HW);
+        const f32x4 d = *(const f32x4*)(dout + i * 4);
+        const f32x4 gp = *(const f32x4*)(dgap + (long)b * Cp + c) * inv_hw;
+        const f32x4 a0 = *(const f32x4*)(a + (long)b * 2 * Cp + c), a1 = *(const f32x4*)(a + (long)b * 2 * Cp + Cp + c);
+        *(f32x4*)(dx + row * 2 * Cp + c) = d * a0 + gp;
+        *(f32x4*)(dx + row * 2 * Cp + Cp + c) = d * a1 + gp;
+    }
+}
+
+static int sa_plan(int HW, int C2, int* tpr, int* rpb, int* nsplit, int* rps) {
+    if (C2 % 4 || C2 > 1024 || 256 % (C2 / 4)) return -1;
+    *tpr = C2 / 4;
+    *rpb = 256 / *tpr;
+    int ns = HW / (*rpb * 8);
+    if (ns < 1) ns = 1;
+    if (ns > 32) ns = 32;
+    *nsplit = ns;
+    *rps = (HW + ns - 1) / ns;
+    return 0;
+}
+extern "C" size_t scouter_sa_workspace_bytes(int B, int HW, int C2) { (void)HW; return (size_t)B * 32 * C2 * sizeof(double); }
+
+// mode 0: gap[b][c]  = mean_hw (x[.,c] + x[.,Cp+c])          (out: [B][Cp])
+// mode 1: da[b][c2]  = sum_hw dout[b,hw,c2 % Cp] * x[b,hw,c2] (out: [B][2Cp])
+extern "C" int scouter_sa_reduce_f32(const float* x, const float* dout, float* out, int B, int HW, int Cp, int mode,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    const int C2 = 2 * Cp;
+    int tpr, rpb, ns, rps;
+    SC_REQUIRE(x && out && B > 0 && HW > 0, "sa_reduce: bad arguments");
+    SC_UNSUPPORTED(sa_plan(HW, C2, &tpr, &rpb, &ns, &rps) == 0, "sa_reduce: unsupported channel count %d", C2);
+    if (!ws || ws_bytes < (size_t)B * ns * C2 * sizeof(double)) { sc_set_error("sa_reduce: workspace too small"); return SC_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(ns, B);
+    if (mode == 0) {
+        hipLaunchKernelGGL(sa_colsum_partial_kernel<false>, grid, dim3(256), 0, st, x, nullptr, (double*)ws, HW, C2, Cp, tpr, rpb, rps);
+        hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * Cp, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 1, 1.f / HW);
+    } else {
+        SC_REQUIRE(dout, "sa_reduce: dout missing");
+        hipLaunchKernelGGL(sa_colsum_partial_kernel<true>, grid, dim3(256), 0, st, x, dout, (double*)ws, HW, C2, Cp, tpr, rpb, rps);
+        hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * C2, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 0, 1.f);
+    }
+    return sc_check_launch("sa_reduce");
+}
+extern "C" int scouter_radix_softmax_fwd_f32(const float* z, float* a, int B, int Cp, void* stream) {
+    hipLaunchKernelGGL(radix_softmax_fwd_kernel, dim3(sc_cdiv((long)B * Cp, 256)), dim3(256), 0, (hipStream_t)stream, z, a, B, Cp);
+    return sc_check_launch("radix_softmax_fwd");
+}
+extern "C" int scouter_radix_softmax_bwd_f32(const float* a, const float* da, float* dz, int B, int Cp, void* stream) {
+    hipLaunchKernelGGL(radix_softmax_bwd_kernel, dim3(sc_cdiv((long)B * Cp, 256)), dim3(256), 0, (hipStream_t)stream, a, da, dz, B, Cp);
+    return sc_check_launch("radix_softmax_bwd");
+}
+extern "C" int scouter_sa_apply_fwd_f32(const float* x, const float* a, float* out, int B, int HW, int Cp, void* stream) {
+    SC_REQUIRE(Cp % 4 == 0, "sa_apply: Cp %% 4 != 0");
+    const long n4 = (long)B * HW * Cp / 4;
+    hipLaunchKernelGGL(sa_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, a, out, n4, HW, Cp);
+    return sc_check_launch("sa_apply_fwd");
+}
+extern "C" int scouter_sa_apply_bwd_f32(const float* dout, const float* a, const float* dgap, float* dx, int B, int HW,
+                                        int Cp, void* stream) {
+    SC_REQUIRE(Cp % 4 == 0, "sa_apply_bwd: Cp %% 4 != 0");
+    const long n4 = (long)B * HW * Cp / 4;
+    hipLaunchKernelGGL(sa_apply_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, dout, a, dgap, dx, n4, HW, Cp, 1.f / HW);
+    return sc_check_launch("sa_apply_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stem: im2col of the NCHW input image into [M = B*Ho*Wo][Kpad] rows, k = (ky*kw + kx)*Cin + ci, zero padded, so
+// the small-Cin stem convolution and its weight gradient run on the generic MFMA GEMM path as a 1x1 conv.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, float* __restrict__ col, int B,
+                                                          int Cin, int H, int W, int Ho, int Wo, int k, int stride,
+                                                          int pad, int Kpad) {
+    const long n = (long)B * Ho * Wo * Kpad;
+    const int K = k * k * Cin;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % Kpad);
+        long p = i / Kpad;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float v = 0.f;
+        if (kk < K) {
+            const int ci = kk % Cin, tap = kk / Cin, ky = tap / k, kx = tap % k;
+            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long)b * Cin + ci) * H + iy) * W + ix];
+        }
+        col[i] = v;
+    }
+}
+// wpad[Kpad][Cout] = {w[K][Cout]; 0}
+__global__ void pad_rows_kernel(const float* __restrict__ w, float* __restrict__ wpad, long nvalid, long ntotal) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ntotal) wpad[i] = i < nvalid ? w[i] : 0.f;
+}
+extern "C" int scouter_im2col_nchw_f32(const float* x, float* col, int B, int Cin, int H, int W, int k, int stride,
+                                       int pad, int Kpad, void* stream) {
+    SC_REQUIRE(x && col && Kpad >= k * k * Cin && Kpad % 32 == 0, "im2col: bad arguments");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const long n = (long)B * Ho * Wo * Kpad;
+    hipLaunchKernelGGL(im2col_nchw_kernel, dim3(ew_blocks(n) * 2), dim3(256), 0, (hipStream_t)stream, x, col, B, Cin, H, W, Ho, Wo, k, stride, pad, Kpad);
+    return sc_check_launch("im2col");
+}
+extern "C" int scouter_pad_rows_f32(const float* w, float* wpad, long nvalid, long ntotal, void* stream) {
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(sc_cdiv(ntotal, 256)), dim3(256), 0, (hipStream_t)stream, w, wpad, nvalid, ntotal);
+    return sc_check_launch("pad_rows");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sine positional encoding, token-major table pe[n = y*w + x][d]   (position_encode.py:26-46, fp32 like the reference)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void posenc_sine_kernel(float* __restrict__ pe, int h, int w, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h * w * d) return;
+    const int c = i % d, n = i / d, y = n / w, x = n % w, npf = d / 2;
+    const float eps = 1e-6f, scale = 6.283185307179586f;
+    const bool from_y = c < npf;
+    const int k = from_y ? c : c - npf;
+    const float embed = from_y ? (float)(y + 1) / ((float)h + eps) * scale : (float)(x + 1) / ((float)w + eps) * scale;
+    const float dim_t = powf(10000.f, (float)(2 * (k / 2)) / (float)npf);
+    const float v = embed / dim_t;
+    pe[i] = (k & 1) ? cosf(v) : sinf(v);
+}
+extern "C" int scouter_posenc_sine_f32(float* pe, int h, int w, int d, void* stream) {
+    SC_REQUIRE(pe && h > 0 && w > 0 && d > 0 && d % 2 == 0, "posenc_sine: bad arguments");
+    hipLaunchKernelGGL(posenc_sine_kernel, dim3(sc_cdiv((long)h * w * d, 256)), dim3(256), 0, (hipStream_t)stream, pe, h, w, d);
+    return sc_check_launch("posenc_sine");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// loss head: log_softmax + NLL(mean) + lambda * area**power, top-1 count; and its backward.
+//   stats[0]=loss  [1]=nll  [2]=area**power  [3]=#correct/B  [4]=area (mean of A_T)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slot_loss_fwd_kernel(const float* __restrict__ logits,
+                                                            const long* __restrict__ labels,
+                                                            const float* __restrict__ area_part, int n_part,
+                                                            int B, int C, double area_count, float lambda,
+                                                            float power,
+                                                            float* __restrict__ logp, float* __restrict__ stats) {
+    __shared__ float red[2][256];
+    float nll = 0.f, corr = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* row = logits + (long)b * C;
+        float m = -INFINITY;
+        int am = 0;
+        for (int c = 0; c < C; ++c) if (row[c] > m) { m = row[c]; am = c; }
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(row[c] - m);
+        const float lse = m + logf(s);
+        for (int c = 0; c < C; ++c) logp[(long)b * C + c] = row[c] - lse;
+        if (labels) {
+            const int y = (int)labels[b];
+            nll -= row[y] - lse;
+            corr += (am == y) ? 1.f : 0.f;
+        }
+    }
+    red[0][threadIdx.x] = nll; red[1][threadIdx.x] = corr;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && stats) {
+        double asum = 0.0;                      // per-image partial sums added in a fixed order
+        for (int k = 0; k < n_part; ++k) asum += area_part[k];
+        const float area = area_part ? (float)(asum / area_count) : 0.f;
+        const float term = area_part ? powf(area, power) : 0.f;
+        const float n = labels ? red[0][0] / B : 0.f;
+        stats[0] = n + lambda * term;
+        stats[1] = n;
+        stats[2] = term;
+        stats[3] = labels ? red[1][0] / B : 0.f;
+        stats[4] = area;
+    }
+}
+// upstream grads (device scalars, NULL = 0): g_loss, g_nll, g_term ; g_logp [B][C] or NULL
+//   dlogits = dlogp - softmax * rowsum(dlogp),  dlogp = g_logp - (g_loss+g_nll)/B * onehot(y)
+//   g_area_sum = (lambda*g_loss + g_term) * power * area**(power-1) / area_count
+__global__ __launch_bounds__(256) void slot_loss_bwd_kernel(const float* __restrict__ logp,
+                                                            const long* __restrict__ labels,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ g_loss,
+                                                            const float* __restrict__ g_nll,
+                                                            const float* __restrict__ g_term,
+                                                            const float* __restrict__ g_logp, int B, int C,
+                                                            double area_count, float lambda, float power,
+                                                            float* __restrict__ dlogits, float* __restrict__ g_area_sum) {
+    const float gl = g_loss ? g_loss[0] : 0.f, gn = g_nll ? g_nll[0] : 0.f, gt = g_term ? g_term[0] : 0.f;
+    const float wn = labels ? (gl + gn) / B : 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float rs = 0.f;
+        const int y = labels ? (int)labels[b] : -1;
+        for (int c = 0; c < C; ++c) {
+            float d = g_logp ? g_logp[(long)b * C + c] : 0.f;
+            if (c == y) d -= wn;
+            rs += d;
+        }
+        for (int c = 0; c < C; ++c) {
+            float d = g_logp ? g_logp[(long)b * C + c] : 0.f;
+            if (c == y) d -= wn;
+            dlogits[(long)b * C + c] = d - expf(logp[(long)b * C + c]) * rs;
+        }
+    }
+    if (threadIdx.x == 0 && g_area_sum) {
+        const float area = stats[4];
+        const float dterm = lambda * gl + gt;
+        const float dpow = power == 1.f ? 1.f : power * powf(area, power - 1.f);
+        g_area_sum[0] = (float)((double)(dterm * dpow) / area_count);
+    }
+}
+extern "C" int scouter_slot_loss_fwd_f32(const float* logits, const long* labels, const float* area_part,
+                                         int n_area_part, int B, int C, double area_count, float lambda, float power,
+                                         float* logp, float* stats, void* stream) {
+    SC_REQUIRE(logits && logp && B > 0 && C > 0, "slot_loss_fwd: bad arguments");
+    hipLaunchKernelGGL(slot_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, area_part, n_area_part, B, C, area_count, lambda, power, logp, stats);
+    return sc_check_launch("slot_loss_fwd");
+}
+extern "C" int scouter_slot_loss_bwd_f32(const float* logp, const long* labels, const float* stats, const float* g_loss,
+                                         const float* g_nll, const float* g_term, const float* g_logp, int B, int C,
+                                         double area_count, float lambda, float power, float* dlogits,
+                                         float* g_area_sum, void* stream) {
+    SC_REQUIRE(logp && dlogits && B > 0 && C > 0, "slot_loss_bwd: bad arguments");
+    hipLaunchKernelGGL(slot_loss_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, labels, stats, g_loss, g_nll, g_term, g_logp, B, C, area_count, lambda, power, dlogits, g_area_sum);
+    return sc_check_launch("slot_loss_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused multi-tensor AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias-corrected moments)
+// chunk table entry i: param pointer, offset of the chunk inside the flat grad / moment arenas, length
+// ---------------------------------------------------------------------------------------------------------------
+struct AdamChunk { float* p; long off; int n; int pad; };
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ chunks, const float* __restrict__ grads,
+                                                    float* __restrict__ m, float* __restrict__ v, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float rsqrt_bc2) {
+    const AdamChunk ch = chunks[blockIdx.x];
+    const float step = lr / bc1;
+    for (int i = threadIdx.x; i < ch.n; i += 256) {
+        const float g = grads[ch.off + i];
+        float p = ch.p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[ch.off + i] + (1.f - b1) * g;
+        const float vi = b2 * v[ch.off + i] + (1.f - b2) * g * g;
+        m[ch.off + i] = mi;
+        v[ch.off + i] = vi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        ch.p[i] = p - step * (mi / denom);
+    }
+}
+extern "C" int scouter_adamw_step_f32(const void* chunk_table, int nchunks, const float* grads, float* exp_avg,
+                                      float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                      float weight_decay, int step, void* stream) {
+    SC_REQUIRE(chunk_table && grads && exp_avg && exp_avg_sq && nchunks > 0 && step > 0, "adamw_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunk_table,
+                       grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                       (float)(1.0 / sqrt(bc2)));
+    return sc_check_launch("adamw_step");
+}
+extern "C" int scouter_adamw_chunk_bytes(void) { return (int)sizeof(AdamChunk); }

@@ -1,0 +1,405 @@
+// Fused xSlot backward (hand-derived; the maths is oracle/xslot_manual.py, checked against autograd).
+// One workgroup (4 waves, one per SIMD -> 512 registers per lane) per image.  For t = T-1 .. 0 the iteration's
+// forward is recomputed from the saved slot state s_t, then in the slot-per-lane register layout:
+//   GRU backward (t < T-1)      -> dgi, dgh (stored: operands of the weight-gradient GEMMs), dU, dh_prev
+//   dA = dU X^T / d (+ area)    -> G = dA * A(1-A),  g_i = sum_j G_ij D_ij,  c0 = sum_i g_i / r_i      [barrier]
+//   dD = G tau/r_i - g_i tau/r_i^2 + c0  ->  ds_t = d^-1/2 dD K + dh_prev
+// The two contractions over the SLOT index (dK += dD^T s_t, dX += A^T dU / d) cannot be done with slots on the
+// lanes; A_t, dD_t, dU_t go to an L2-resident scratch and a final phase contracts them tile by tile, then runs the
+// to_k MLP backward.  Weight gradients of the GRU / to_k layers are plain GEMMs over all (image, slot) rows and
+// are left to the generic wgrad kernel (deterministic split-K) by the host.
+#include "xslot_common.h"
+
+struct XsBwdArgs {
+    const float* X; const float* PE; const float* tok_w[8]; const float* slots0;
+    const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;
+    const float* Ksave; const float* Hsave; const float* states; const float* dlogits; const float* g_area_sum;
+    float* dX; float* dgi; float* dgh; float* Usave; float* ds0; float* dZ; float* ws;
+    int B, N, S, C, spc, T, L;
+    float loss_status;
+};
+
+template <int NT>
+__device__ __forceinline__ void xs_store_tile(float* base, int ld, const f32x16 (&m)[NT], int l31, int hh) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = m[t][4 * q + e];
+            *(f32x4*)(base + (long)l31 * ld + 32 * t + 8 * q + 4 * hh) = v;
+        }
+}
+template <int NT>
+__device__ __forceinline__ void xs_load_tile(const float* base, int ld, f32x16 (&m)[NT], int l31, int hh, bool ok) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *(const f32x4*)(base + (long)l31 * ld + 32 * t + 8 * q + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[t][4 * q + e] = v[e];
+        }
+}
+// acc += sum_{r<16} Mt[row_base + kidx(0,r,hh)][col0 + l31] * b[r]     (one 32-deep k-tile, rows of Mt = k)
+__device__ __forceinline__ void xs_mm_tr_tile(const float* __restrict__ Mt, int row_base, int col0, const f32x16& b,
+                                              f32x16& acc, int l31, int hh) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = mfma32(Mt[(row_base + xs_kidx(0, r, hh)) * XS_LD + col0 + l31], b[r], acc);
+    XS_REGION_END();
+}
+
+template <int NJT>
+__global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
+    constexpr int NP = 32 * NJT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Xs = lds;
+    float* Ks = Xs + NP * XS_LD;
+    float* Wih = Ks + NP * XS_LD;
+    float* Whh = Wih + 192 * XS_LD;
+    float* bias = Whh + 192 * XS_LD;        // br | bz | b_in | b_hn
+    float* red = bias + 256;                // tau_part[16] | c0_part[16]
+    float* r_s = red + 32;                  // [512] r_i
+    float* g_s = r_s + 512;                 // [512] g_i
+    // final-phase buffers alias the GRU weights
+    float* dZa = Wih;                       // [NP][68]
+    float* dZb = dZa + NP * XS_LD;          // [NP][68]
+    float* dXs = dZb + NP * XS_LD;          // [NP][68]
+    float* Wt = dXs + NP * XS_LD;           // [64][68]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x, N = a.N, S = a.S, T = a.T;
+    const int ntiles = (S + 31) >> 5, Sp = ntiles * 32, TPW = (ntiles + 3) >> 2;
+    const float scale = 0.125f, inv_d = 1.f / XS_D;
+    // scratch of this image: dsn [Sp][64] | per t: A [Sp][NP], dD [Sp][NP], dU [Sp][64]
+    const long per_img = (long)Sp * (64 + (long)T * (2 * NP + 64));
+    float* dsn = a.ws + (long)b * per_img;
+    auto As_t = [&](int t) { return dsn + (long)Sp * 64 + (long)t * Sp * (2 * NP + 64); };
+    auto dDs_t = [&](int t) { return As_t(t) + (long)Sp * NP; };
+    auto dUs_t = [&](int t) { return dDs_t(t) + (long)Sp * NP; };
+
+    // ---- stage X, K, GRU weights
+    for (int c = tid; c < NP * 16; c += 256) {
+        const int r = c >> 4, q = c & 15;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f}, k = x;
+        if (r < N) {
+            x = *(const f32x4*)(a.X + ((long)b * N + r) * XS_D + q * 4);
+            k = *(const f32x4*)(a.Ksave + ((long)b * N + r) * XS_D + q * 4);
+        }
+        *(f32x4*)(Xs + r * XS_LD + q * 4) = x;
+        *(f32x4*)(Ks + r * XS_LD + q * 4) = k;
+    }
+    xs_load_mat(Wih, a.w_ih, 192, tid, 256);
+    xs_load_mat(Whh, a.w_hh, 192, tid, 256);
+    {
+        const int g = tid & 63, k = tid >> 6;
+        bias[tid] = k == 0 ? a.b_ih[g] + a.b_hh[g] : k == 1 ? a.b_ih[64 + g] + a.b_hh[64 + g]
+                  : k == 2 ? a.b_ih[128 + g] : a.b_hh[128 + g];
+    }
+    const float g_area = a.g_area_sum ? a.g_area_sum[0] : 0.f;
+    __syncthreads();
+
+    for (int it = T - 1; it >= 0; --it) {
+        const bool last = it == T - 1;
+        const float* sbase = it == 0 ? a.slots0 : a.states + ((long)(it - 1) * a.B + b) * S * XS_D;
+        // ================= phase A: r_i, tau
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int ti = wave + 4 * tt;
+            if (ti >= ntiles) continue;
+            const int i = ti * 32 + l31;
+            f32x16 h[2], D[NJT];
+            xs_load_tile<2>(sbase + (long)ti * 32 * XS_D, XS_D, h, l31, hh, i < S);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                xs_zero(D[jt]);
+                xs_mm_kc(Ks, 32 * jt, h, D[jt], l31, hh);
+                D[jt] *= scale;
+            }
+            const float r = xs_rowsum<NJT>(D);
+            if (hh == 0) r_s[i] = r;
+            const float tr = xs_tilesum(r);
+            if (lane == 0) red[ti] = tr;
+        }
+        __syncthreads();
+        float tau = 0.f;
+        for (int k = 0; k < ntiles; ++k) tau += red[k];
+        // ================= phase B1
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int ti = wave + 4 * tt;
+            if (ti >= ntiles) continue;
+            const int i = ti * 32 + l31;
+            const bool iok = i < S;
+            f32x16 h[2], U[2], dU[2], dhp[2];
+            xs_load_tile<2>(sbase + (long)ti * 32 * XS_D, XS_D, h, l31, hh, iok);
+            const float r = r_s[i];
+            {   // D, A = sigmoid(D / r * tau); both are parked in the scratch while the GRU section runs
+                f32x16 D[NJT], A[NJT];
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    xs_zero(D[jt]);
+                    xs_mm_kc(Ks, 32 * jt, h, D[jt], l31, hh);
+                    D[jt] *= scale;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float v = xs_sigmoid(D[jt][e] / r * tau);
+                        A[jt][e] = (iok && xs_kidx(jt, e, hh) < N) ? v : 0.f;
+                    }
+                }
+                xs_store_tile<NJT>(As_t(it) + (long)ti * 32 * NP, NP, A, l31, hh);
+                xs_store_tile<NJT>(dDs_t(it) + (long)ti * 32 * NP, NP, D, l31, hh);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    xs_zero(U[ct]);
+                    xs_mm_tr<NJT>(Xs, 32 * ct, A, U[ct], l31, hh);
+                    U[ct] *= inv_d;
+                    xs_zero(dhp[ct]);
+                }
+            }
+            if (last) {
+                const float du = iok ? a.loss_status * a.dlogits[(long)b * a.C + i / a.spc] : 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dU[ct][e] = du;
+            } else {
+                f32x16 dsx[2];
+                xs_load_tile<2>(dsn + (long)ti * 32 * 64, 64, dsx, l31, hh, true);
+                xs_zero(dU[0]); xs_zero(dU[1]);
+                const long row = ((long)it * a.B + b) * S + i;
+                if (iok) xs_store_tile<2>(a.Usave + (row - l31) * XS_D, XS_D, U, l31, hh);   // row-l31 = tile row 0
+#pragma unroll
+                for (int gt = 0; gt < 2; ++gt) {
+                    f32x16 ar, az, ain, ahn;
+                    xs_zero(ar); xs_zero(az); xs_zero(ain); xs_zero(ahn);
+                    xs_mm_kc(Wih, 32 * gt, U, ar, l31, hh);
+                    xs_mm_kc(Whh, 32 * gt, h, ar, l31, hh);
+                    xs_mm_kc(Wih, 64 + 32 * gt, U, az, l31, hh);
+                    xs_mm_kc(Whh, 64 + 32 * gt, h, az, l31, hh);
+                    xs_mm_kc(Wih, 128 + 32 * gt, U, ain, l31, hh);
+                    xs_mm_kc(Whh, 128 + 32 * gt, h, ahn, l31, hh);
+                    // gate values -> their pre-activation gradients, in place
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int g = xs_kidx(gt, e, hh);
+                        const float rg = xs_sigmoid(ar[e] + bias[g]);
+                        const float zg = xs_sigmoid(az[e] + bias[64 + g]);
+                        const float hnb = ahn[e] + bias[192 + g];
+                        const float ng = tanhf(ain[e] + bias[128 + g] + rg * hnb);
+                        const float ds = dsx[gt][e];
+                        const float da_n = ds * (1.f - zg) * (1.f - ng * ng);
+                        const float da_z = ds * (h[gt][e] - ng) * zg * (1.f - zg);
+                        const float da_r = da_n * hnb * rg * (1.f - rg);
+                        dhp[gt][e] += ds * zg;
+                        ar[e] = da_r; az[e] = da_z; ain[e] = da_n; ahn[e] = da_n * rg;
+                    }
+                    if (iok) {
+                        float* gi = a.dgi + row * 192 + 32 * gt + 4 * hh;
+                        float* gh = a.dgh + row * 192 + 32 * gt + 4 * hh;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v0, v1, v2, v3;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v0[e] = ar[4 * q + e]; v1[e] = az[4 * q + e]; v2[e] = ain[4 * q + e]; v3[e] = ahn[4 * q + e]; }
+                            *(f32x4*)(gi + 8 * q) = v0; *(f32x4*)(gi + 64 + 8 * q) = v1; *(f32x4*)(gi + 128 + 8 * q) = v2;
+                            *(f32x4*)(gh + 8 * q) = v0; *(f32x4*)(gh + 64 + 8 * q) = v1; *(f32x4*)(gh + 128 + 8 * q) = v3;
+                        }
+                    }
+                    // dU^T += W_ih^T dgi^T ; dh_prev^T += W_hh^T dgh^T   (k = the 32 hidden units of this g-tile)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        xs_mm_tr_tile(Wih, 32 * gt, 32 * ct, ar, dU[ct], l31, hh);
+                        xs_mm_tr_tile(Wih, 64 + 32 * gt, 32 * ct, az, dU[ct], l31, hh);
+                        xs_mm_tr_tile(Wih, 128 + 32 * gt, 32 * ct, ain, dU[ct], l31, hh);
+                        xs_mm_tr_tile(Whh, 32 * gt, 32 * ct, ar, dhp[ct], l31, hh);
+                        xs_mm_tr_tile(Whh, 64 + 32 * gt, 32 * ct, az, dhp[ct], l31, hh);
+                        xs_mm_tr_tile(Whh, 128 + 32 * gt, 32 * ct, ahn, dhp[ct], l31, hh);
+                    }
+                }
+            }
+            if (!iok) {   // padded slots carry nothing
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) { xs_zero(dU[ct]); xs_zero(dhp[ct]); }
+            }
+            xs_store_tile<2>(dsn + (long)ti * 32 * 64, 64, dhp, l31, hh);         // stash dh_prev (same lanes re-read it)
+            xs_store_tile<2>(dUs_t(it) + (long)ti * 32 * 64, 64, dU, l31, hh);
+            // dA^T = X dU^T / d (+ area term), G = dA * A (1 - A), g_i = sum_j G_ij D_ij
+            float gsum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                f32x16 dA, Aj[1], Dj[1];
+                xs_load_tile<1>(As_t(it) + (long)ti * 32 * NP + 32 * jt, NP, Aj, l31, hh, true);
+                xs_load_tile<1>(dDs_t(it) + (long)ti * 32 * NP + 32 * jt, NP, Dj, l31, hh, true);
+                xs_zero(dA);
+                xs_mm_kc(Xs, 32 * jt, dU, dA, l31, hh);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float av = Aj[0][e];
+                    float v = dA[e] * inv_d + (last ? g_area : 0.f);
+                    v = (iok && xs_kidx(jt, e, hh) < N) ? v * av * (1.f - av) : 0.f;
+                    gsum += v * Dj[0][e];
+                    Aj[0][e] = v;                                   // G
+                }
+                xs_store_tile<1>(dDs_t(it) + (long)ti * 32 * NP + 32 * jt, NP, Aj, l31, hh);   // stash G over D
+            }
+            gsum += __shfl_xor(gsum, 32, 64);
+            if (hh == 0) g_s[i] = gsum;
+            const float tc = xs_tilesum(iok ? gsum / r : 0.f);
+            if (lane == 0) red[16 + ti] = tc;
+        }
+        __syncthreads();
+        float c0 = 0.f;
+        for (int k = 0; k < ntiles; ++k) c0 += red[16 + k];
+        // ================= phase B2: dD, ds_t
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int ti = wave + 4 * tt;
+            if (ti >= ntiles) continue;
+            const int i = ti * 32 + l31;
+            const bool iok = i < S;
+            f32x16 G[NJT], ds[2], dhp[2];
+            xs_load_tile<NJT>(dDs_t(it) + (long)ti * 32 * NP, NP, G, l31, hh, true);
+            xs_load_tile<2>(dsn + (long)ti * 32 * 64, 64, dhp, l31, hh, true);
+            const float r = r_s[i], gi = g_s[i];
+            const float k1 = tau / r, k2 = gi * tau / (r * r);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    G[jt][e] = (iok && xs_kidx(jt, e, hh) < N) ? G[jt][e] * k1 - k2 + c0 : 0.f;
+            xs_store_tile<NJT>(dDs_t(it) + (long)ti * 32 * NP, NP, G, l31, hh);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                xs_zero(ds[ct]);
+                xs_mm_tr<NJT>(Ks, 32 * ct, G, ds[ct], l31, hh);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ds[ct][e] = iok ? ds[ct][e] * scale + dhp[ct][e] : 0.f;
+            }
+            if (it > 0) xs_store_tile<2>(dsn + (long)ti * 32 * 64, 64, ds, l31, hh);
+            else if (iok) xs_store_tile<2>(a.ds0 + ((long)b * S + ti * 32) * XS_D, XS_D, ds, l31, hh);
+        }
+        __syncthreads();
+    }
+
+    // ================= final phase: contractions over the slot index
+    //   dK[j][c]  = d^-1/2 sum_t sum_i dD_t[i][j] s_t[i][c]      dXa[j][c] = 1/d sum_t sum_i A_t[i][j] dU_t[i][c]
+    __threadfence_block();
+    __syncthreads();
+    for (int job = wave; job < NJT * 4; job += 4) {
+        const int prod = job & 1, ct = (job >> 1) & 1, jt = job >> 2;
+        f32x16 acc;
+        xs_zero(acc);
+        for (int t = 0; t < T; ++t) {
+            const float* P = (prod == 0 ? dDs_t(t) : As_t(t)) + 32 * jt + l31;          // [i][NP]
+            const float* Q;
+            int ldq;
+            if (prod == 1) { Q = dUs_t(t); ldq = 64; }
+            else { Q = t == 0 ? a.slots0 : a.states + ((long)(t - 1) * a.B + b) * S * XS_D; ldq = XS_D; }
+            Q += 32 * ct + l31;
+            for (int i0 = 0; i0 < Sp; i0 += 16) {
+                float pv[8], qv[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int i = i0 + 2 * s + hh;
+                    pv[s] = P[(long)i * NP];
+                    qv[s] = (prod == 1 || i < S) ? Q[(long)i * ldq] : 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = mfma32(pv[s], qv[s], acc);
+            }
+        }
+        float* dst = prod == 0 ? dZa : dXs;
+        const float sc = prod == 0 ? scale : inv_d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[(32 * jt + mfma32_row(e, lane)) * XS_LD + 32 * ct + l31] = acc[e] * sc;
+    }
+    // ================= to_k MLP backward: dZ_{L-1} = dK ; dH_{l-1} = dZ_l W_l ; dZ_{l-1} = dH_{l-1} * (H_{l-1} > 0)
+    float* dZin = dZa;
+    float* dZout = dZb;
+    for (int l = a.L - 1; l >= 0; --l) {
+        __syncthreads();
+        xs_load_mat(Wt, a.tok_w[l], XS_D, tid, 256);
+        for (int c = tid; c < N * 16; c += 256) {           // dZ_l -> global (operand of the to_k weight-gradient GEMM)
+            const int r = c >> 4, q = c & 15;
+            *(f32x4*)(a.dZ + (((long)l * a.B + b) * N + r) * XS_D + q * 4) = *(const f32x4*)(dZin + r * XS_LD + q * 4);
+        }
+        __syncthreads();
+        for (int tile = wave; tile < NJT * 2; tile += 4) {
+            const int jt = tile >> 1, ct = tile & 1;
+            f32x16 acc;
+            xs_zero(acc);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 av = *(const f32x4*)(dZin + (32 * jt + l31) * XS_LD + 32 * t + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc = mfma32(av[e], Wt[(32 * t + 8 * q + 4 * hh + e) * XS_LD + 32 * ct + l31], acc);
+                }
+            const int c = 32 * ct + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = 32 * jt + mfma32_row(e, lane);
+                float v = acc[e];
+                if (l > 0) {
+                    const float hv = j < N ? a.Hsave[(((long)l * a.B + b) * N + j) * XS_D + c] : 0.f;   // H_l = input of layer l
+                    dZout[j * XS_LD + c] = hv > 0.f ? v : 0.f;
+                } else if (j < N) {
+                    a.dX[((long)b * N + j) * XS_D + c] = v + dXs[j * XS_LD + c];
+                }
+            }
+        }
+        float* tmp = dZin; dZin = dZout; dZout = tmp;
+    }
+}
+
+static size_t xs_bwd_lds_bytes(int NJT) { return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 32 + 1024) * sizeof(float); }
+
+extern "C" size_t scouter_xslot_bwd_workspace_bytes(int B, int N, int d, int S, int T) {
+    (void)d;
+    const long Sp = (S + 31) / 32 * 32, NP = (N + 31) / 32 * 32;
+    return (size_t)B * Sp * (64 + (long)T * (2 * NP + 64)) * sizeof(float);
+}
+
+extern "C" int scouter_xslot_bwd_f32(const float* X, const float* PE, const float* const* tok_w, const float* slots0,
+                                     const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                     const float* Ksave, const float* Hsave, const float* states,
+                                     const float* dlogits, const float* g_area_sum, int B, int N, int d, int S,
+                                     int spc, int T, int L, float loss_status, float* dX, float* dgi, float* dgh,
+                                     float* Usave, float* ds0, float* dZ, void* ws, size_t ws_bytes, void* stream) {
+    SC_REQUIRE(X && tok_w && slots0 && w_ih && w_hh && b_ih && b_hh && Ksave && dlogits && dX && ds0 && dZ && ws,
+               "xslot_bwd: null pointer");
+    SC_REQUIRE((T <= 1) || (states && dgi && dgh && Usave), "xslot_bwd: missing GRU buffers");
+    SC_REQUIRE(Hsave, "xslot_bwd: missing to_k activations");
+    SC_REQUIRE(B > 0 && N > 0 && S > 0 && spc > 0 && S % spc == 0 && T >= 1 && L >= 1, "xslot_bwd: bad dims");
+    SC_UNSUPPORTED(d == XS_D && N <= XS_MAX_N && S <= 512 && T <= 8, "xslot_bwd: unsupported dims d=%d N=%d S=%d T=%d",
+                   d, N, S, T);
+    if (ws_bytes < scouter_xslot_bwd_workspace_bytes(B, N, d, S, T)) {
+        sc_set_error("xslot_bwd: workspace too small");
+        return SC_ERR_WORKSPACE;
+    }
+    SC_UNSUPPORTED(L <= 8, "xslot_bwd: at most 8 to_k layers (got %d)", L);
+    XsBwdArgs a{X, PE, {}, slots0, w_ih, w_hh, b_ih, b_hh, Ksave, Hsave, states, dlogits, g_area_sum,
+                dX, dgi, dgh, Usave, ds0, dZ, (float*)ws, B, N, S, S / spc, spc, T, L, loss_status};
+    for (int l = 0; l < L; ++l) {
+        SC_REQUIRE(tok_w[l], "xslot_bwd: null to_k layer %d", l);
+        a.tok_w[l] = tok_w[l];
+    }
+    const int NJT = (N + 31) / 32;
+    const size_t lds = xs_bwd_lds_bytes(NJT);
+    hipStream_t st = (hipStream_t)stream;
+    const double flops = 2.0 * (double)B * (2.0 * L * N * d * d + (double)T * 4.0 * S * N * d + (T - 1) * 12.0 * S * d * d);
+    ScProfScope prof(SC_PROF_XSLOT_BWD, st, flops, 4.0 * B * (3.0 * N * d + (double)S * d));
+#define XSB_LAUNCH(NJT_)                                                                                   \
+    do {                                                                                                   \
+        auto kern = xslot_bwd_kernel<NJT_>;                                                                \
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, a);                                          \
+    } while (0)
+    if (NJT == 1) XSB_LAUNCH(1);
+    else if (NJT == 2) XSB_LAUNCH(2);
+    else XSB_LAUNCH(3);
+#undef XSB_LAUNCH
+    return sc_check_launch("xslot_bwd");
+}

@@ -1,0 +1,81 @@
+// Shared pieces of the fused xSlot kernels (forward: xslot_fwd.hip, backward: xslot_bwd.hip).
+//
+// Register choreography ("slot-per-lane"): every per-slot matrix M[i][k] (slots s, updates U, gate
+// pre-activations, D^T columns ...) of a 32-slot tile is held TRANSPOSED in MFMA accumulator layout:
+//     lane (i = lane&31, hh = lane>>5), register r of k-tile t   <->   M[i][ kidx(t, r, hh) ]
+//     kidx(t, r, hh) = 32 t + 8 (r>>2) + 4 hh + (r&3)
+// which is exactly what v_mfma_f32_32x32x2_f32 produces for  Out^T[k][i] = sum_c W[k][c] * In^T[c][i]
+// (rows = k, cols = lane&31 = i).  Such a register set can be fed straight back as the B operand
+// (B[k = hh][n = i]) of the next MFMA, one register per k-step, so
+//     D^T = K s^T  ->  A = sigmoid(...)  ->  U^T = X^T A^T  ->  gates^T = W U^T + W h^T  ->  s'^T
+// never leaves the register file.  The A operands come from LDS: either a row-major matrix whose rows are
+// the OUTPUT index (k contiguous: four k-steps per ds_read_b128, "mm_kc") or one whose rows are the
+// CONTRACTION index (ds_read_b32, lanes along the output index, "mm_tr").
+#pragma once
+#include "common.h"
+
+#define XS_D 64          // hidden_dim (train.py:53); the kernels are specialised for d = 64
+#define XS_LD 68         // LDS row stride (floats): 16B-aligned rows, conflict-free ds_read_b128 over 16 rows
+#define XS_MAX_N 96      // tokens per image: N <= 96 (7x7 and the reference's 9x9 grid); NJT = ceil(N/32) token tiles
+
+// Ends a scheduling region: without it the compiler hoists the LDS operand loads of many MFMA blocks ahead
+// (everything is unrolled) and runs out of the 512-entry register file.
+#define XS_REGION_END() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ int xs_kidx(int t, int r, int hh) { return 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3); }
+
+// acc[rows row0..row0+31][i] += sum_{k<64} M[row0 + l31][k] * B^T[k][i] ; M row-major in LDS (k contiguous)
+__device__ __forceinline__ void xs_mm_kc(const float* __restrict__ M, int row0, const f32x16 (&b)[2], f32x16& acc,
+                                         int l31, int hh) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *(const f32x4*)(M + (row0 + l31) * XS_LD + 32 * t + 8 * q + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], b[t][4 * q + e], acc);
+        }
+    XS_REGION_END();
+}
+// acc[cols col0..col0+31][i] += sum_{k<64} Mt[k][col0 + l31] * B^T[k][i] ; Mt row-major in LDS with rows = k
+template <int NT>
+__device__ __forceinline__ void xs_mm_tr(const float* __restrict__ Mt, int col0, const f32x16 (&b)[NT], f32x16& acc,
+                                         int l31, int hh) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc = mfma32(Mt[xs_kidx(t, r, hh) * XS_LD + col0 + l31], b[t][r], acc);
+    XS_REGION_END();
+}
+
+__device__ __forceinline__ void xs_zero(f32x16& v) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.f;
+}
+__device__ __forceinline__ float xs_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// in-lane sum of an NT-tile register set + the partner half-wave: sum over all 32*NT k of M[i][k]
+template <int NT>
+__device__ __forceinline__ float xs_rowsum(const f32x16 (&m)[NT]) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += m[t][r];
+    return s + __shfl_xor(s, 32, 64);
+}
+// sum over the 32 slots of a tile (lanes 0..31; both half-waves hold the same per-slot value)
+__device__ __forceinline__ float xs_tilesum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// cooperative copy of a [rows][64] row-major global matrix into LDS [rows][XS_LD]
+__device__ __forceinline__ void xs_load_mat(float* __restrict__ dst, const float* __restrict__ src, int rows,
+                                            int tid, int nthreads) {
+    for (int c = tid; c < rows * 16; c += nthreads) {
+        const int r = c >> 4, q = c & 15;
+        *(f32x4*)(dst + r * XS_LD + q * 4) = *(const f32x4*)(src + r * XS_D + q * 4);
+    }
+}

@@ -1,0 +1,383 @@
+"""Tensor-level wrappers over the C ABI (include/scouter_hip.h): shape checks, output allocation, raw pointers and
+the current HIP stream.  PyTorch provides device memory and streams only -- every arithmetic op below runs in a
+hand-written HIP kernel of libscouter_hip.so, and there is no CPU / ATen fallback (CPU tensors raise).
+
+Layouts: activations NHWC (torch tensors of shape [B, H, W, C], contiguous); convolution weights are
+nn.Parameters of LOGICAL shape (Cout, Cin/g, kh, kw) whose PHYSICAL storage is HWIO ([kh][kw][Cin/g][Cout])."""
+import torch
+
+from . import _native
+
+F32 = torch.float32
+_ws = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=F32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError("scouter_amd: %s is on %s -- the xSlot path runs on a HIP device only (no CPU fallback)"
+                           % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("scouter_amd: %s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("scouter_amd: %s must be contiguous" % name)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def workspace(nbytes, device):
+    """Per-device scratch (grown on demand).  All kernels run on the current stream, so sharing it is safe."""
+    key = (device.type, device.index)
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = w
+    return w
+
+
+def hwio(weight):
+    """Physical HWIO view [kh, kw, Cin/g, Cout] of a logical-OIHW conv weight; relayouts (once) if needed."""
+    v = weight.permute(2, 3, 1, 0)
+    if not v.is_contiguous():
+        with torch.no_grad():
+            weight.data = weight.data.permute(2, 3, 1, 0).contiguous().permute(3, 2, 0, 1)
+        v = weight.permute(2, 3, 1, 0)
+    return v
+
+
+def oihw_view(flat, cout, cin_g, kh, kw):
+    """Logical (Cout, Cin/g, kh, kw) view over a flat HWIO buffer."""
+    return flat.view(kh, kw, cin_g, cout).permute(3, 2, 0, 1)
+
+
+def conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------------------------
+def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, relu=False):
+    _chk(x, "x"); _chk(w_hwio, "weight"); _chk(bias, "bias"); _chk(addend, "addend")
+    B, H, W, Cin = x.shape
+    kh, kw, cg, Cout = w_hwio.shape
+    assert cg * groups == Cin, (x.shape, w_hwio.shape, groups)
+    y = torch.empty((B, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout), dtype=F32, device=x.device)
+    L = _native.lib()
+    _native.check(L.scouter_conv2d_fwd_f32(_p(x), _p(w_hwio), _p(bias), _p(addend), _p(y), B, H, W, Cin, Cout, kh, kw,
+                                           stride, pad, groups, int(relu), _stream()), "conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1):
+    _chk(dy, "dy"); _chk(w_hwio, "weight"); _chk(addend, "addend")
+    B, H, W, Cin = x_shape
+    kh, kw, cg, Cout = w_hwio.shape
+    dx = torch.empty(x_shape, dtype=F32, device=dy.device)
+    L = _native.lib()
+    _native.check(L.scouter_conv2d_dgrad_f32(_p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride,
+                                             pad, groups, _stream()), "conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1):
+    """Writes dW (HWIO, contiguous, e.g. a slice of the flat gradient arena)."""
+    _chk(x, "x"); _chk(dy, "dy"); _chk(dw_hwio, "dw")
+    B, H, W, Cin = x.shape
+    kh, kw, cg, Cout = dw_hwio.shape
+    L = _native.lib()
+    need = L.scouter_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, groups)
+    ws = workspace(need, x.device)
+    _native.check(L.scouter_conv2d_wgrad_f32(_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, stride, pad,
+                                             groups, _p(ws), ws.numel(), _stream()), "conv2d_wgrad")
+    return dw_hwio
+
+
+def matmul_tn(a, b, out):
+    """out[Ka][Kb] = a^T b for row-major a [M][Ka], b [M][Kb] (Ka, Kb multiples of 32): the weight-gradient GEMM of
+    a Linear layer, run as a 1x1-conv wgrad (deterministic split over M)."""
+    M, Ka = a.shape
+    Kb = b.shape[1]
+    return conv2d_wgrad(a.view(1, 1, M, Ka), b.view(1, 1, M, Kb), out.view(1, 1, Ka, Kb))
+
+
+def im2col_nchw(x, k, stride, pad, kpad):
+    _chk(x, "image")
+    B, Cin, H, W = x.shape
+    Ho, Wo = conv_out(H, k, stride, pad), conv_out(W, k, stride, pad)
+    col = torch.empty((B, Ho, Wo, kpad), dtype=F32, device=x.device)
+    _native.check(_native.lib().scouter_im2col_nchw_f32(_p(x), _p(col), B, Cin, H, W, k, stride, pad, kpad, _stream()),
+                  "im2col")
+    return col
+
+
+def pad_rows(w_flat, nvalid, ntotal):
+    out = torch.empty(ntotal, dtype=F32, device=w_flat.device)
+    _native.check(_native.lib().scouter_pad_rows_f32(_p(w_flat), _p(out), nvalid, ntotal, _stream()), "pad_rows")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# batch norm / elementwise
+# ---------------------------------------------------------------------------------------------------------------
+def _col_ws(M, C, device):
+    L = _native.lib()
+    return workspace(L.scouter_colreduce_workspace_bytes(M, C) + 8 * C + 64, device)
+
+
+def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=None, momentum=0.1, eps=1e-5):
+    """x: [..., C] NHWC.  Returns (y, saved) with saved = (mean, rstd, scale, shift) packed as one [4, C] tensor."""
+    _chk(x, "x"); _chk(residual, "residual")
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = torch.empty_like(x)
+    saved = torch.empty((4, C), dtype=F32, device=x.device)
+    ws = _col_ws(M, C, x.device)
+    _native.check(_native.lib().scouter_bn_fwd_f32(
+        _p(x), _p(y), _p(residual), M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
+        int(training), int(relu), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]), _p(ws), ws.numel(),
+        _stream()), "bn_fwd")
+    return y, saved
+
+
+def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=False):
+    _chk(dy, "dy"); _chk(ymask, "ymask"); _chk(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    gout = torch.empty_like(x) if want_gout else None
+    ws = _col_ws(M, C, x.device)
+    _native.check(_native.lib().scouter_bn_bwd_f32(
+        _p(dy), _p(ymask), _p(x), _p(saved[0]), _p(saved[1]), _p(saved[2]), M, C, int(training), _p(dgamma), _p(dbeta),
+        _p(dx), _p(gout), _p(ws), ws.numel(), _stream()), "bn_bwd")
+    return dx, gout
+
+
+def colsum(a, out, b=None, alpha=1.0):
+    C = a.shape[-1]
+    M = a.numel() // C
+    ws = _col_ws(M, C, a.device)
+    _native.check(_native.lib().scouter_colsum_f32(_p(a), _p(b), _p(out), M, C, alpha, _p(ws), ws.numel(), _stream()),
+                  "colsum")
+    return out
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty_like(dy)
+    _native.check(_native.lib().scouter_relu_bwd_f32(_p(dy), _p(y), _p(dx), dy.numel(), _stream()), "relu_bwd")
+    return dx
+
+
+def axpby(a, b=None, alpha=1.0, beta=1.0, out=None):
+    out = torch.empty_like(a) if out is None else out
+    _native.check(_native.lib().scouter_axpby_f32(_p(a), _p(b), _p(out), alpha, beta, a.numel(), _stream()), "axpby")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pooling / layout
+# ---------------------------------------------------------------------------------------------------------------
+def pool_out(n, k, s, p, ceil_mode=False):
+    return _native.lib().scouter_pool_out_size(n, k, s, p, int(ceil_mode))
+
+
+def maxpool_fwd(x, k=3, stride=2, pad=1, want_argmax=True):
+    _chk(x, "x")
+    B, H, W, C = x.shape
+    y = torch.empty((B, pool_out(H, k, stride, pad), pool_out(W, k, stride, pad), C), dtype=F32, device=x.device)
+    arg = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if want_argmax else None
+    _native.check(_native.lib().scouter_maxpool_fwd_f32(_p(x), _p(y), _p(arg), B, H, W, C, k, stride, pad, _stream()),
+                  "maxpool_fwd")
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, x_shape, k=3, stride=2, pad=1):
+    B, H, W, C = x_shape
+    dx = torch.empty(x_shape, dtype=F32, device=dy.device)
+    _native.check(_native.lib().scouter_maxpool_bwd_f32(_p(dy), _p(arg), _p(dx), B, H, W, C, k, stride, pad, _stream()),
+                  "maxpool_bwd")
+    return dx
+
+
+def avgpool_fwd(x, k, stride, pad, ceil_mode, count_include_pad):
+    _chk(x, "x")
+    B, H, W, C = x.shape
+    y = torch.empty((B, pool_out(H, k, stride, pad, ceil_mode), pool_out(W, k, stride, pad, ceil_mode), C), dtype=F32,
+                    device=x.device)
+    _native.check(_native.lib().scouter_avgpool_fwd_f32(_p(x), _p(y), B, H, W, C, k, stride, pad, int(ceil_mode),
+                                                        int(count_include_pad), _stream()), "avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, x_shape, k, stride, pad, ceil_mode, count_include_pad):
+    B, H, W, C = x_shape
+    dx = torch.empty(x_shape, dtype=F32, device=dy.device)
+    _native.check(_native.lib().scouter_avgpool_bwd_f32(_p(dy), _p(dx), B, H, W, C, k, stride, pad, int(ceil_mode),
+                                                        int(count_include_pad), _stream()), "avgpool_bwd")
+    return dx
+
+
+def nchw_to_nhwc(x):
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, C), dtype=F32, device=x.device)
+    _native.check(_native.lib().scouter_transpose_f32(_p(x), _p(out), B, C, H * W, _stream()), "transpose")
+    return out
+
+
+def nhwc_to_nchw(x):
+    _chk(x, "x")
+    B, H, W, C = x.shape
+    out = torch.empty((B, C, H, W), dtype=F32, device=x.device)
+    _native.check(_native.lib().scouter_transpose_f32(_p(x), _p(out), B, H * W, C, _stream()), "transpose")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# split attention glue
+# ---------------------------------------------------------------------------------------------------------------
+def _sa_ws(B, HW, C2, device):
+    return workspace(_native.lib().scouter_sa_workspace_bytes(B, HW, C2), device)
+
+
+def sa_gap(x):
+    """x: [B, H, W, 2C'] -> gap [B, C'] = mean_hw(x[..., :C'] + x[..., C':])"""
+    B, H, W, C2 = x.shape
+    out = torch.empty((B, C2 // 2), dtype=F32, device=x.device)
+    ws = _sa_ws(B, H * W, C2, x.device)
+    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), None, _p(out), B, H * W, C2 // 2, 0, _p(ws), ws.numel(),
+                                                      _stream()), "sa_gap")
+    return out
+
+
+def sa_dattn(x, dout):
+    """da[b, r*C'+c] = sum_hw dout[b,hw,c] * x[b,hw,r*C'+c]"""
+    B, H, W, C2 = x.shape
+    out = torch.empty((B, C2), dtype=F32, device=x.device)
+    ws = _sa_ws(B, H * W, C2, x.device)
+    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), _p(dout), _p(out), B, H * W, C2 // 2, 1, _p(ws), ws.numel(),
+                                                      _stream()), "sa_dattn")
+    return out
+
+
+def radix_softmax_fwd(z):
+    a = torch.empty_like(z)
+    _native.check(_native.lib().scouter_radix_softmax_fwd_f32(_p(z), _p(a), z.shape[0], z.shape[1] // 2, _stream()),
+                  "radix_softmax_fwd")
+    return a
+
+
+def radix_softmax_bwd(a, da):
+    dz = torch.empty_like(a)
+    _native.check(_native.lib().scouter_radix_softmax_bwd_f32(_p(a), _p(da), _p(dz), a.shape[0], a.shape[1] // 2,
+                                                              _stream()), "radix_softmax_bwd")
+    return dz
+
+
+def sa_apply_fwd(x, a):
+    B, H, W, C2 = x.shape
+    out = torch.empty((B, H, W, C2 // 2), dtype=F32, device=x.device)
+    _native.check(_native.lib().scouter_sa_apply_fwd_f32(_p(x), _p(a), _p(out), B, H * W, C2 // 2, _stream()),
+                  "sa_apply_fwd")
+    return out
+
+
+def sa_apply_bwd(dout, a, dgap):
+    B, H, W, Cp = dout.shape
+    dx = torch.empty((B, H, W, 2 * Cp), dtype=F32, device=dout.device)
+    _native.check(_native.lib().scouter_sa_apply_bwd_f32(_p(dout), _p(a), _p(dgap), _p(dx), B, H * W, Cp, _stream()),
+                  "sa_apply_bwd")
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# xSlot head
+# ---------------------------------------------------------------------------------------------------------------
+_pe_cache = {}
+
+
+def posenc_sine(h, w, d, device):
+    """Token-major sine positional encoding [h*w, d] (constant per grid; cached per device)."""
+    key = (h, w, d, device.type, device.index)
+    pe = _pe_cache.get(key)
+    if pe is None:
+        pe = torch.empty((h * w, d), dtype=F32, device=device)
+        _native.check(_native.lib().scouter_posenc_sine_f32(_p(pe), h, w, d, _stream()), "posenc_sine")
+        _pe_cache[key] = pe
+    return pe
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def xslot_fwd(X, PE, tok_w, tok_b, slots0, w_ih, w_hh, b_ih, b_hh, spc, T, loss_status):
+    """tok_w / tok_b: lists of the L to_k Linear weights [d,d] (out,in) / biases [d]."""
+    for n, t in (("X", X), ("PE", PE), ("slots0", slots0), ("w_ih", w_ih), ("w_hh", w_hh), ("b_ih", b_ih),
+                 ("b_hh", b_hh)) + tuple(("to_k", t) for t in list(tok_w) + list(tok_b)):
+        _chk(t, n)
+    B, N, d = X.shape
+    S, L = slots0.shape[0], len(tok_w)
+    dev = X.device
+    out = dict(
+        logits=torch.empty((B, S // spc), dtype=F32, device=dev), attn=torch.empty((B, S, N), dtype=F32, device=dev),
+        area_part=torch.empty((B,), dtype=F32, device=dev), K=torch.empty((B, N, d), dtype=F32, device=dev),
+        H=torch.empty((L, B, N, d), dtype=F32, device=dev),
+        states=torch.empty((max(T - 1, 1), B, S, d), dtype=F32, device=dev))
+    _native.check(_native.lib().scouter_xslot_fwd_f32(
+        _p(X), _p(PE), _ptr_array(tok_w), _ptr_array(tok_b), _p(slots0), _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), B, N, d,
+        S, spc, T, L,
+        float(loss_status), _p(out["logits"]), _p(out["attn"]), _p(out["area_part"]), _p(out["K"]), _p(out["H"]),
+        _p(out["states"]), _stream()), "xslot_fwd")
+    return out
+
+
+def xslot_bwd(X, PE, tok_w, slots0, w_ih, w_hh, b_ih, b_hh, saved, dlogits, g_area_sum, spc, T, loss_status):
+    B, N, d = X.shape
+    S, L = slots0.shape[0], len(tok_w)
+    dev = X.device
+    Lb = _native.lib()
+    ws = workspace(Lb.scouter_xslot_bwd_workspace_bytes(B, N, d, S, T), dev)
+    nt = max(T - 1, 1)
+    out = dict(dX=torch.empty((B, N, d), dtype=F32, device=dev),
+               dgi=torch.empty((nt, B, S, 3 * d), dtype=F32, device=dev),
+               dgh=torch.empty((nt, B, S, 3 * d), dtype=F32, device=dev),
+               U=torch.empty((nt, B, S, d), dtype=F32, device=dev),
+               ds0=torch.empty((B, S, d), dtype=F32, device=dev), dZ=torch.empty((L, B, N, d), dtype=F32, device=dev))
+    _native.check(Lb.scouter_xslot_bwd_f32(
+        _p(X), _p(PE), _ptr_array(tok_w), _p(slots0), _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), _p(saved["K"]),
+        _p(saved["H"]),
+        _p(saved["states"]), _p(dlogits), _p(g_area_sum), B, N, d, S, spc, T, L, float(loss_status), _p(out["dX"]),
+        _p(out["dgi"]), _p(out["dgh"]), _p(out["U"]), _p(out["ds0"]), _p(out["dZ"]), _p(ws), ws.numel(), _stream()),
+        "xslot_bwd")
+    return out
+
+
+def slot_loss_fwd(logits, labels, area_part, area_count, lam, power):
+    """Returns (log_probs [B,C], stats [5] = loss, nll, area**power, top-1, area)."""
+    B, C = logits.shape
+    logp = torch.empty_like(logits)
+    stats = torch.zeros(8, dtype=F32, device=logits.device)
+    _chk(labels, "labels", torch.int64)
+    _native.check(_native.lib().scouter_slot_loss_fwd_f32(
+        _p(logits), _p(labels), _p(area_part), 0 if area_part is None else area_part.numel(), B, C, float(area_count),
+        float(lam), float(power), _p(logp), _p(stats), _stream()), "slot_loss_fwd")
+    return logp, stats
+
+
+def slot_loss_bwd(logp, labels, stats, g_loss, g_nll, g_term, g_logp, area_count, lam, power):
+    B, C = logp.shape
+    dlogits = torch.empty_like(logp)
+    g_area = torch.empty(1, dtype=F32, device=logp.device)
+    _native.check(_native.lib().scouter_slot_loss_bwd_f32(
+        _p(logp), _p(labels), _p(stats), _p(g_loss), _p(g_nll), _p(g_term), _p(g_logp), B, C, float(area_count),
+        float(lam), float(power), _p(dlogits), _p(g_area), _stream()), "slot_loss_bwd")
+    return dlogits, g_area

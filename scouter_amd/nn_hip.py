@@ -1,0 +1,176 @@
+"""Layer primitives with EXPLICIT forward / backward over NHWC device tensors (the host side of the HIP path).
+
+The reference leaves sequencing of the backward pass to torch.autograd over ~1400 tiny ATen kernels
+(SURVEY.md section 2.2).  Here every layer has `fwd(x, save, ...) -> (y, ctx)` and `bwd(dy, ctx, ...) -> dx`
+that launch the hand-written kernels directly; parameter gradients are written straight into one flat fp32
+arena (GradArena) whose slices are exposed as `param.grad`, so the data-parallel all-reduce and the fused AdamW
+see a single contiguous buffer.  Modules keep the reference's parameter / buffer names so state_dicts are
+interchangeable; conv weights have the reference's logical (Cout, Cin/g, kh, kw) shape
+over an HWIO physical layout."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+
+class Act(nn.Module):
+    """Placeholder for the reference's ReLU modules (keeps nn.Sequential indices, e.g. backbone.conv1.{0,1,3,4,6})."""
+
+    def forward(self, x):   # pragma: no cover - activation is fused into the neighbouring kernel
+        raise RuntimeError("activation is fused; call the parent module")
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d(bias optional) -> scouter_conv2d_{fwd,dgrad,wgrad}_f32.  Per-group channels must be multiples of 32."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, groups=1, bias=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.groups = stride, padding, groups
+        k = kernel_size
+        w = torch.empty(k, k, in_channels // groups, out_channels)
+        self.weight = nn.Parameter(w.permute(3, 2, 0, 1))          # logical OIHW, physical HWIO
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self._dw = self._db = None                                  # arena slices, set by GradArena
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # timm resnet.py:447-448
+        if bias:
+            bound = 1.0 / math.sqrt(in_channels // groups * k * k)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def fwd(self, x, save, relu=False, addend=None):
+        y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu)
+        return y, (x if save else None)
+
+    def bwd(self, dy, ctx, need_dx=True, addend=None):
+        x = ctx
+        if self._dw is not None:
+            K.conv2d_wgrad(x, dy, self._dw, self.stride, self.padding, self.groups)
+        if self._db is not None:
+            K.colsum(dy, self._db)
+        if not need_dx:
+            return None
+        return K.conv2d_dgrad(dy, K.hwio(self.weight), tuple(x.shape), addend, self.stride, self.padding, self.groups)
+
+
+class StemConv2d(Conv2d):
+    """First convolution of the network (Cin = 1 or 3, NCHW image in): im2col into [M][Kpad] rows (zero padded to a
+    multiple of 32) + the generic MFMA GEMM, for the forward and the weight gradient.  No input gradient."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding):
+        nn.Module.__init__(self)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.groups = stride, padding, 1
+        k = kernel_size
+        self.kdim = k * k * in_channels
+        self.kpad = (self.kdim + 31) // 32 * 32
+        self.weight = nn.Parameter(torch.empty(k, k, in_channels, out_channels).permute(3, 2, 0, 1))
+        self.bias = None
+        self._dw = self._db = None
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+
+    def fwd(self, x_nchw, save, relu=False, addend=None):
+        col = K.im2col_nchw(x_nchw, self.kernel_size, self.stride, self.padding, self.kpad)
+        wflat = K.hwio(self.weight).reshape(-1)
+        wpad = K.pad_rows(wflat, wflat.numel(), self.kpad * self.out_channels).view(1, 1, self.kpad, self.out_channels)
+        y = K.conv2d_fwd(col, wpad, None, addend, 1, 0, 1, relu)
+        return y, (col if save else None)
+
+    def bwd(self, dy, ctx, need_dx=False, addend=None):
+        if need_dx:
+            raise NotImplementedError("gradient w.r.t. the input image is not part of the training hot path")
+        if self._dw is not None:
+            dwpad = torch.empty((1, 1, self.kpad, self.out_channels), dtype=torch.float32, device=dy.device)
+            K.conv2d_wgrad(ctx, dy, dwpad)
+            n = self.kdim * self.out_channels
+            K.axpby(dwpad.view(-1)[:n], None, 1.0, 0.0, out=self._dw.reshape(-1))
+        return None
+
+
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d (eps 1e-5, momentum 0.1) with ReLU / residual-add fused into the apply pass."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._dg = self._db = None
+
+    def fwd(self, x, save, relu=False, residual=None, tracked=None):
+        y, saved = K.bn_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
+                            residual, self.momentum, self.eps)
+        if self.training and tracked is not None:
+            tracked.append(self.num_batches_tracked)
+        return y, ((x, y if relu else None, saved, self.training) if save else None)
+
+    def bwd(self, dy, ctx, want_gout=False):
+        x, ymask, saved, training = ctx
+        return K.bn_bwd(dy, ymask, x, saved, training, self._dg, self._db, want_gout)
+
+
+class GradArena:
+    """One flat fp32 buffer holding the gradient of every trainable parameter, in named_parameters() order.
+    `param.grad` are views into it (conv weights with the parameter's own HWIO strides).  Parameters that never
+    receive a gradient on this path (slot.to_q.*, reference slot_attention.py:52-53) are excluded, like the
+    `find_unused_parameters=True` of the reference's DDP wrap (train.py:140)."""
+
+    def __init__(self, model, exclude=("to_q",)):
+        self.entries = []       # (name, param, offset, numel)
+        off = 0
+        for name, p in model.named_parameters():
+            if not p.requires_grad or any(e in name for e in exclude):
+                continue
+            self.entries.append((name, p, off, p.numel()))
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off
+        dev = self.entries[0][1].device if self.entries else torch.device("cpu")
+        self.flat = torch.zeros(max(off, 4), dtype=torch.float32, device=dev)
+        self.views = {}
+        for name, p, o, n in self.entries:
+            seg = self.flat[o:o + n]
+            if p.dim() == 4:
+                co, cg, kh, kw = p.shape
+                self.views[name] = seg.view(kh, kw, cg, co).permute(3, 2, 0, 1)
+            elif p.dim() == 2 and getattr(p, "_hip_transposed", False):
+                self.views[name] = seg.view(p.shape[1], p.shape[0]).t()
+            else:
+                self.views[name] = seg.view(p.shape)
+        self._bind(model)
+
+    def _bind(self, model):
+        mods = dict(model.named_modules())
+        for name, p, o, n in self.entries:
+            mod_name, _, leaf = name.rpartition(".")
+            m = mods[mod_name]
+            seg = self.flat[o:o + n]
+            if isinstance(m, Conv2d):
+                if leaf == "weight":
+                    co, cg, kh, kw = p.shape
+                    m._dw = seg.view(kh, kw, cg, co)
+                else:
+                    m._db = seg
+            elif isinstance(m, BatchNorm2d):
+                if leaf == "weight":
+                    m._dg = seg
+                else:
+                    m._db = seg
+            else:
+                hook = getattr(m, "_bind_grad", None)
+                if hook is None:
+                    raise RuntimeError("no gradient binding for parameter %s" % name)
+                hook(leaf, seg)
+
+    def attach(self):
+        """Expose the arena slices as param.grad (PyTorch semantics: .grad holds the gradient of the last backward)."""
+        for name, p, o, n in self.entries:
+            p.grad = self.views[name]
+
+    def matches(self, model):
+        cur = [(n, p) for n, p in model.named_parameters() if p.requires_grad and "to_q" not in n]
+        return len(cur) == len(self.entries) and all(a[1] is b[1] and b[1].device == self.flat.device
+                                                     for a, b in zip(cur, self.entries))

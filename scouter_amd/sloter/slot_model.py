@@ -1,0 +1,174 @@
+"""SlotModel on the MI355X HIP path -- mirrors sloter/slot_model.py:10-127 of the reference (same constructor
+`args`, attributes, state_dict keys and return structure: `log_probs` or `[log_probs, [loss, nll, area_loss]]`).
+
+The whole step (backbone -> conv1x1+ReLU -> sine PE -> fused xSlot -> log_softmax/NLL + lambda*area) is ONE autograd
+node: the forward launches the HIP kernels layer by layer and records what each layer's hand-written backward
+needs; `loss.backward()` then runs those backward kernels in reverse and writes every parameter gradient into a
+flat arena (`param.grad` are views of it).  There is no ATen arithmetic on the path and no CPU fallback."""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from ..nn_hip import Conv2d, GradArena
+from ..timm.models import create_model
+from .utils.position_encode import build_position_encoding
+from .utils.slot_attention import SlotAttention
+
+
+class Identical(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def load_backbone(args):
+    """reference slot_model.py:18-52 (resnet-family branch; the other timm families are out of scope)."""
+    in_chans = 1 if args.dataset == "MNIST" else 3
+    bone = create_model(args.model, pretrained=False, num_classes=args.num_classes, in_chans=in_chans)
+    if getattr(args, "pre_trained", False):
+        print("note: pretrained ImageNet weights cannot be downloaded here; load them with load_state_dict")
+    if args.dataset == "MNIST":
+        from ..nn_hip import StemConv2d
+        bone.conv1 = StemConv2d(1, 64, 3, 2, 1)                 # slot_model.py:23-24
+    if args.use_slot:
+        if getattr(args, "use_pre", False):
+            checkpoint = torch.load(f"saved_model/{args.dataset}_no_slot_checkpoint.pth", map_location="cpu")
+            new_state_dict = OrderedDict((k[9:], v) for k, v in checkpoint["model"].items())   # strip `backbone.`
+            bone.load_state_dict(new_state_dict)
+            print("load pre dataset parameter over")
+        if not getattr(args, "grad", False):
+            if "res" not in args.model:
+                raise RuntimeError("only the resnet / resnest backbones are built")
+            bone.global_pool = Identical()
+            bone.fc = Identical()
+    return bone
+
+
+class _FusedStep(torch.autograd.Function):
+    """The single autograd node of the model.  `anchor` is a dummy leaf that ties the outputs into the graph;
+    parameter gradients are delivered through the flat arena (param.grad views), not through autograd edges."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, x, target):
+        ctx.set_materialize_grads(False)
+        logp, stats, state = model._forward_impl(x, target, save=True)
+        ctx.model, ctx.state = model, state
+        return logp, stats[0], stats[1], stats[2]
+
+    @staticmethod
+    def backward(ctx, g_logp, g_loss, g_nll, g_term):
+        ctx.model._backward_impl(ctx.state, g_logp, g_loss, g_nll, g_term)
+        ctx.state = None
+        return None, None, None, None
+
+
+class SlotModel(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.use_slot = args.use_slot
+        self.backbone = load_backbone(args)
+        if not self.use_slot:
+            raise NotImplementedError("use_slot=False (the FC baseline, slot_model.py:75-77) is not part of the "
+                                      "xSlot hot path yet (SURVEY.md section 8f item 3)")
+        self.feature_size = 9            # kept for attribute compatibility; the grid is derived from the features
+        self.channel = args.channel
+        self.slots_per_class = args.slots_per_class
+        self.conv1x1 = Conv2d(self.channel, args.hidden_dim, 1, 1, 0, bias=True)
+        if args.pre_trained:
+            self.dfs_freeze(self.backbone, args.freeze_layers)
+        self.slot = SlotAttention(args.num_classes, self.slots_per_class, args.hidden_dim, vis=args.vis,
+                                  vis_id=args.vis_id, loss_status=args.loss_status, power=args.power,
+                                  to_k_layer=args.to_k_layer)
+        self.position_emb = build_position_encoding("sine", hidden_dim=args.hidden_dim)
+        self.lambda_value = float(args.lambda_value)
+        self._arena = None
+        self._anchor = None
+        self._post_backward_hooks = []       # called with the GradArena after every backward (data-parallel reduce)
+        self.last_stats = None               # device tensor [loss, nll, area**power, top1, area] of the last forward
+
+    def dfs_freeze(self, model, freeze_layer_num):
+        """reference slot_model.py:79-94"""
+        if freeze_layer_num == 0:
+            return
+        unfreeze_layers = ["layer4", "layer3", "layer2", "layer1"][:4 - freeze_layer_num]
+        for name, child in model.named_children():
+            if any(u in name for u in unfreeze_layers):
+                continue
+            for param in child.parameters():
+                param.requires_grad = False
+            self.dfs_freeze(child, freeze_layer_num)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def grad_arena(self):
+        if self._arena is None or not self._arena.matches(self):
+            self._arena = GradArena(self)
+        return self._arena
+
+    def _head_forward(self, feat, target, save):
+        """feat: NHWC backbone features [B, h, w, channel] -> (log_probs, stats, head state)."""
+        if feat.shape[-1] != self.channel:
+            raise RuntimeError("backbone produced %d channels, args.channel is %d" % (feat.shape[-1], self.channel))
+        xmap, cctx = self.conv1x1.fwd(feat, save, relu=True)                  # slot_model.py:108-109
+        B, h, w, d = xmap.shape
+        PE = self.position_emb.table(h, w, feat.device)                       # slot_model.py:110-111
+        so = self.slot.fwd(xmap.view(B, h * w, d), PE)                        # slot_model.py:116
+        S, N = self.slot.num_slots, h * w
+        if target is not None and target.dtype != torch.int64:
+            target = target.long()
+        logp, stats = K.slot_loss_fwd(so["logits"], target, so["area_part"], B * S * N, self.lambda_value,
+                                      self.slot.power)                        # slot_model.py:117-121
+        self.last_stats = stats
+        if self.slot.vis:
+            self.slot.save_vis()
+        return logp, stats, ((cctx, xmap, PE, so, logp, stats, target) if save else None)
+
+    def _head_backward(self, hstate, g_logp, g_loss, g_nll, g_term, need_dfeat=True):
+        cctx, xmap, PE, so, logp, stats, target = hstate
+        B, h, w, d = xmap.shape
+        S, N = self.slot.num_slots, h * w
+        f32 = lambda g: None if g is None else g.float().contiguous()
+        dlogits, g_area = K.slot_loss_bwd(logp, target, stats, f32(g_loss), f32(g_nll), f32(g_term), f32(g_logp),
+                                          B * S * N, self.lambda_value, self.slot.power)
+        dX = self.slot.bwd(xmap.view(B, N, d), PE, so, dlogits, g_area)
+        dxr = K.relu_bwd(dX.view(B, h, w, d), xmap)
+        return self.conv1x1.bwd(dxr, cctx, need_dx=need_dfeat)
+
+    def _forward_impl(self, x, target, save):
+        if not x.is_cuda:
+            raise RuntimeError("scouter_amd.SlotModel runs on a HIP device (got a %s tensor); there is no CPU fallback "
+                               "-- the CPU restatement lives in oracle/ and is test infrastructure only" % x.device)
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        tracked = []
+        feat, bctx = self.backbone.features_fwd(x, save, tracked)             # NHWC [B, h, w, channel]
+        logp, stats, hstate = self._head_forward(feat, target, save)
+        if tracked:
+            torch._foreach_add_(tracked, 1)                                   # BatchNorm num_batches_tracked
+        return logp, stats, ((bctx, hstate) if save else None)
+
+    def _backward_impl(self, state, g_logp, g_loss, g_nll, g_term):
+        bctx, hstate = state
+        arena = self.grad_arena()
+        need = self.backbone._first_trainable_stage() < 5
+        dfeat = self._head_backward(hstate, g_logp, g_loss, g_nll, g_term, need_dfeat=need)
+        if need:
+            self.backbone.features_bwd(dfeat, bctx)
+        arena.attach()
+        for hook in self._post_backward_hooks:
+            hook(arena)
+
+    def forward(self, x, target=None):
+        train_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if train_graph:
+            if self._anchor is None or self._anchor.device != x.device:
+                self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            self.grad_arena()
+            output, loss, nll, attn_loss = _FusedStep.apply(self._anchor, self, x, target)
+        else:
+            output, stats, _ = self._forward_impl(x, target, save=False)
+            loss, nll, attn_loss = stats[0], stats[1], stats[2]
+        if target is not None:
+            return [output, [loss, nll, attn_loss]]
+        return output

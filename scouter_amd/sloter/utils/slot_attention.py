@@ -1,0 +1,162 @@
+"""xSlot attention module on the fused HIP kernels -- mirrors sloter/utils/slot_attention.py:9-96 of the reference
+(same constructor, parameter names and return values).  As in the reference: `to_q` exists but is unused
+(:52-53), there is no softmax (:55-57), `eps` is unused, logits come from the last iteration's updates (:96)."""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from ... import kernels as K
+
+
+class _LinearParams(nn.Module):
+    """Parameter holder with nn.Linear's names / init (the arithmetic runs inside the fused kernels)."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        bound = 1.0 / math.sqrt(dim_in)
+        self.weight = nn.Parameter(torch.empty(dim_out, dim_in).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(dim_out).uniform_(-bound, bound))
+        self._g = {}
+
+    def _bind_grad(self, leaf, seg):
+        self._g[leaf] = seg.view(self.weight.shape) if leaf == "weight" else seg
+
+
+class _GRUParams(nn.Module):
+    """Parameter holder with nn.GRU(d, d)'s names / init (gate order r, z, n)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        bound = 1.0 / math.sqrt(dim)
+        self.weight_ih_l0 = nn.Parameter(torch.empty(3 * dim, dim).uniform_(-bound, bound))
+        self.weight_hh_l0 = nn.Parameter(torch.empty(3 * dim, dim).uniform_(-bound, bound))
+        self.bias_ih_l0 = nn.Parameter(torch.empty(3 * dim).uniform_(-bound, bound))
+        self.bias_hh_l0 = nn.Parameter(torch.empty(3 * dim).uniform_(-bound, bound))
+        self._g = {}
+
+    def _bind_grad(self, leaf, seg):
+        self._g[leaf] = seg.view(getattr(self, leaf).shape)
+
+    def flatten_parameters(self):
+        pass
+
+
+class _ReLUMarker(nn.Module):
+    pass
+
+
+class SlotAttention(nn.Module):
+    def __init__(self, num_classes, slots_per_class, dim, iters=3, eps=1e-8, vis=False, vis_id=0, loss_status=1,
+                 power=1, to_k_layer=1):
+        super().__init__()
+        self.num_classes = num_classes
+        self.slots_per_class = slots_per_class
+        self.num_slots = num_classes * slots_per_class
+        self.iters = iters
+        self.eps = eps
+        self.scale = dim ** -0.5
+        self.loss_status = loss_status
+        mu = torch.randn(1, 1, dim).expand(1, self.num_slots, -1)
+        sigma = torch.randn(1, 1, dim).abs().expand(1, self.num_slots, -1)   # torch>=2 rejects a signed std (:25)
+        self.initial_slots = nn.Parameter(torch.normal(mu, sigma))
+        self.to_q = nn.Sequential(_LinearParams(dim, dim))
+        mods = [_LinearParams(dim, dim)]
+        for _ in range(1, to_k_layer):
+            mods += [_ReLUMarker(), _LinearParams(dim, dim)]
+        self.to_k = nn.Sequential(*mods)
+        self.gru = _GRUParams(dim)
+        self.vis = vis
+        self.vis_id = vis_id
+        self.power = power
+        self.dim = dim
+        self._g = {}
+        self.last_attn = None        # [B, S, N] fp32 attention of the last iteration (the "attention map" artifact)
+
+    def _bind_grad(self, leaf, seg):
+        self._g[leaf] = seg.view(self.initial_slots.shape)
+
+    def _to_k_layers(self):
+        return [m for m in self.to_k if isinstance(m, _LinearParams)]
+
+    # ---- explicit forward / backward used by SlotModel's fused autograd node
+    def fwd(self, X, PE):
+        """X: [B, N, d] tokens (post conv1x1+ReLU), PE: [N, d].  Returns the kernel outputs dict (logits, attn,
+        area_part + the tensors saved for the backward)."""
+        lay = self._to_k_layers()
+        g = self.gru
+        out = K.xslot_fwd(X, PE, [m.weight for m in lay], [m.bias for m in lay], self.initial_slots[0],
+                          g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, self.slots_per_class,
+                          self.iters, self.loss_status)
+        self.last_attn = out["attn"]
+        return out
+
+    def bwd(self, X, PE, saved, dlogits, g_area_sum):
+        """Returns dX [B, N, d]; writes the gradients of initial_slots / to_k / gru into the bound arena slices."""
+        lay = self._to_k_layers()
+        g = self.gru
+        T, B, S, d = self.iters, X.shape[0], self.num_slots, self.dim
+        r = K.xslot_bwd(X, PE, [m.weight for m in lay], self.initial_slots[0], g.weight_ih_l0, g.weight_hh_l0,
+                        g.bias_ih_l0, g.bias_hh_l0, saved, dlogits, g_area_sum, self.slots_per_class, T,
+                        self.loss_status)
+        if "initial_slots" in self._g:
+            K.colsum(r["ds0"].view(B, S * d), self._g["initial_slots"].view(-1))
+        if T > 1:
+            M = (T - 1) * B * S
+            dgi, dgh, U = r["dgi"].view(M, 3 * d), r["dgh"].view(M, 3 * d), r["U"].view(M, d)
+            if "weight_ih_l0" in g._g:
+                K.matmul_tn(dgi, U, g._g["weight_ih_l0"])
+            if "weight_hh_l0" in g._g:
+                # hidden state entering GRU step t: s_0 (initial slots, same for every image) then the saved states
+                sprev = torch.empty((T - 1, B, S, d), dtype=torch.float32, device=X.device)
+                K.axpby(self.initial_slots.expand(B, S, d).contiguous(), None, 1.0, 0.0, out=sprev[0])
+                for t in range(1, T - 1):
+                    K.axpby(saved["states"][t - 1], None, 1.0, 0.0, out=sprev[t])
+                K.matmul_tn(dgh, sprev.view(M, d), g._g["weight_hh_l0"])
+            if "bias_ih_l0" in g._g:
+                K.colsum(dgi, g._g["bias_ih_l0"])
+            if "bias_hh_l0" in g._g:
+                K.colsum(dgh, g._g["bias_hh_l0"])
+        else:
+            for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+                if k in g._g:
+                    g._g[k].zero_()
+        N = X.shape[1]
+        for l, m in enumerate(lay):
+            dz, hin = r["dZ"][l].view(B * N, d), saved["H"][l].view(B * N, d)
+            if "weight" in m._g:
+                K.matmul_tn(dz, hin, m._g["weight"])
+            if "bias" in m._g:
+                K.colsum(dz, m._g["bias"])
+        return r["dX"]
+
+    def vis_maps(self, attn=None):
+        """The uint8 per-class maps of `--vis true` (slot_attention.py:68-83) for image `vis_id`."""
+        a = (self.last_attn if attn is None else attn).detach().float().cpu()
+        if self.slots_per_class > 1:
+            a = a.reshape(a.shape[0], self.num_classes, self.slots_per_class, a.shape[-1]).sum(2)
+        a = a[self.vis_id]
+        side = int(a.size(1) ** 0.5)
+        a = ((a - a.min()) / (a.max() - a.min()) * 255.).reshape(a.shape[0], side, side)
+        return a.numpy().astype(np.uint8)
+
+    def save_vis(self, folder="sloter/vis"):
+        import os
+        from PIL import Image
+        os.makedirs(folder, exist_ok=True)
+        for i, image in enumerate(self.vis_maps()):
+            Image.fromarray(image, mode="L").save(os.path.join(folder, "slot_%d.png" % i))
+
+    def forward(self, inputs, inputs_x):
+        """Reference signature (slot_attention.py:44): inputs = x + pe, inputs_x = x, both [B, N, d].
+        Inference helper (no autograd through this entry point -- training goes through SlotModel)."""
+        with torch.no_grad():
+            X = inputs_x.float().contiguous()
+            PE = (inputs.float() - X)[0].contiguous()     # the encoding is batch-invariant (slot_model.py:110-111)
+            out = self.fwd(X, PE)
+            B, S, N = out["attn"].shape
+            area = out["area_part"].sum() / (B * S * N)
+            if self.vis:
+                self.save_vis()
+            return out["logits"], torch.pow(area, self.power)

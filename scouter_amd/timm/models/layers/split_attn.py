@@ -1,0 +1,50 @@
+"""Split-attention convolution (ResNeSt), radix 2 / cardinality 1 -- HIP forward + hand-written backward.
+Mirrors timm/models/layers/split_attn.py:31-80 of the reference (module / parameter names: conv, bn0, fc1, bn1, fc2).
+Channel layout of the radix conv output: [radix 0: C' channels | radix 1: C' channels] (split_attn.py:64-66)."""
+import torch.nn as nn
+
+from ....nn_hip import Act, BatchNorm2d, Conv2d
+from .... import kernels as K
+
+
+class SplitAttnConv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, groups=1, radix=2,
+                 reduction_factor=4):
+        super().__init__()
+        if radix != 2 or groups != 1:
+            raise NotImplementedError("scouter_amd supports the radix-2 / cardinality-1 split attention of "
+                                      "resnest26d / resnest50d only")
+        self.radix = radix
+        mid_chs = out_channels * radix
+        attn_chs = max(in_channels * radix // reduction_factor, 32)
+        self.conv = Conv2d(in_channels, mid_chs, kernel_size, stride, padding, groups=groups * radix, bias=False)
+        self.bn0 = BatchNorm2d(mid_chs)
+        self.act0 = Act()
+        self.fc1 = Conv2d(out_channels, attn_chs, 1, bias=True)
+        self.bn1 = BatchNorm2d(attn_chs)
+        self.act1 = Act()
+        self.fc2 = Conv2d(attn_chs, mid_chs, 1, bias=True)
+
+    def fwd(self, x, save, tracked=None):
+        c, c_conv = self.conv.fwd(x, save)
+        h, c_bn0 = self.bn0.fwd(c, save, relu=True, tracked=tracked)           # [B,H,W,2C']
+        B = h.shape[0]
+        gap = K.sa_gap(h)                                                        # split_attn.py:63-68
+        z1, c_fc1 = self.fc1.fwd(gap.view(B, 1, 1, -1), save)
+        g1, c_bn1 = self.bn1.fwd(z1, save, relu=True, tracked=tracked)
+        z2, c_fc2 = self.fc2.fwd(g1, save)
+        a = K.radix_softmax_fwd(z2.view(B, -1))                                  # split_attn.py:20-28,75
+        out = K.sa_apply_fwd(h, a)                                               # split_attn.py:76-79
+        return out, ((c_conv, c_bn0, c_fc1, c_bn1, c_fc2, h, a) if save else None)
+
+    def bwd(self, dout, ctx):
+        c_conv, c_bn0, c_fc1, c_bn1, c_fc2, h, a = ctx
+        B = h.shape[0]
+        da = K.sa_dattn(h, dout)
+        dz2 = K.radix_softmax_bwd(a, da)
+        dg1 = self.fc2.bwd(dz2.view(B, 1, 1, -1), c_fc2, True)
+        dz1, _ = self.bn1.bwd(dg1, c_bn1)
+        dgap = self.fc1.bwd(dz1, c_fc1, True)
+        dh = K.sa_apply_bwd(dout, a, dgap.view(B, -1))
+        dc, _ = self.bn0.bwd(dh, c_bn0)
+        return self.conv.bwd(dc, c_conv, True)

@@ -1,0 +1,65 @@
+"""ResNeSt bottleneck (radix 2, cardinality 1, avd after the split-attention conv, avg-pool downsample).
+Mirrors timm/models/resnest.py:58-143 and :161-189 of the reference."""
+import torch.nn as nn
+
+from ...nn_hip import Act, BatchNorm2d, Conv2d
+from .layers.split_attn import SplitAttnConv2d
+from .resnet import AvgPool2dSpec, ResNet
+
+
+class ResNestBottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, radix=2, avd=True, avd_first=False, **_):
+        super().__init__()
+        if avd_first or not avd:
+            raise NotImplementedError("only the avd / avd_last configuration of resnest26d/50d is supported")
+        gw = planes
+        avd_stride = stride if stride > 1 else 0          # `is_first` is never set by ResNet._make_layer
+        self.conv1 = Conv2d(inplanes, gw, 1)
+        self.bn1 = BatchNorm2d(gw)
+        self.act1 = Act()
+        self.conv2 = SplitAttnConv2d(gw, gw, 3, 1, 1, radix=radix)
+        self.avd_last = AvgPool2dSpec(3, avd_stride, 1) if avd_stride > 0 else None
+        self.conv3 = Conv2d(gw, planes * 4, 1)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.act3 = Act()
+        self.downsample = downsample
+
+    def zero_init_last_bn(self):
+        nn.init.zeros_(self.bn3.weight)
+
+    def fwd(self, x, save, tracked):
+        c1, k1 = self.conv1.fwd(x, save)
+        h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked)
+        sa, ksa = self.conv2.fwd(h1, save, tracked)
+        p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
+        c3, k3 = self.conv3.fwd(p, save)
+        res, kd = (x, None) if self.downsample is None else self.downsample.fwd(x, save, tracked)
+        out, b3 = self.bn3.fwd(c3, save, relu=True, residual=res, tracked=tracked)
+        return out, ((k1, b1, ksa, tuple(sa.shape), k3, b3, kd) if save else None)
+
+    def bwd(self, dout, ctx, need_dx=True):
+        k1, b1, ksa, sa_shape, k3, b3, kd = ctx
+        dc3, dres = self.bn3.bwd(dout, b3, want_gout=True)
+        dp = self.conv3.bwd(dc3, k3, True)
+        dsa = self.avd_last.bwd(dp, sa_shape) if self.avd_last is not None else dp
+        dh1 = self.conv2.bwd(dsa, ksa)
+        dc1, _ = self.bn1.bwd(dh1, b1)
+        dxres = dres if self.downsample is None else self.downsample.bwd(dres, kd, need_dx)
+        return self.conv1.bwd(dc1, k1, need_dx, addend=dxres)
+
+
+def _resnest(layers, pretrained, num_classes, in_chans, **kwargs):
+    if pretrained:
+        raise RuntimeError("pretrained weights cannot be downloaded here; load a state_dict instead")
+    return ResNet(ResNestBottleneck, layers, num_classes=num_classes, in_chans=in_chans, stem_type="deep",
+                  stem_width=32, avg_down=True, block_args=dict(radix=2, avd=True, avd_first=False), **kwargs)
+
+
+def resnest26d(pretrained=False, num_classes=1000, in_chans=3, **kwargs):
+    return _resnest([2, 2, 2, 2], pretrained, num_classes, in_chans, **kwargs)
+
+
+def resnest50d(pretrained=False, num_classes=1000, in_chans=3, **kwargs):
+    return _resnest([3, 4, 6, 3], pretrained, num_classes, in_chans, **kwargs)

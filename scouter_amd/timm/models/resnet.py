@@ -1,0 +1,205 @@
+"""ResNet trunk + BasicBlock on the HIP layers.  Mirrors timm/models/resnet.py:134-199 (BasicBlock), :273-306
+(downsample_conv / downsample_avg), :380-509 (ResNet) of the reference for the configurations the xSlot path
+uses: stem '' (7x7, or the MNIST 3x3 1-channel stem swapped in by sloter/slot_model.py:23-24) and 'deep'
+(32-32-64), output stride 32, no drop-path / drop-block / anti-aliasing.  Activations are NHWC internally."""
+import torch
+import torch.nn as nn
+
+from ...nn_hip import Act, BatchNorm2d, Conv2d, StemConv2d
+from ... import kernels as K
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class AvgPool2dSpec(nn.Module):
+    """Holds the pooling geometry of nn.AvgPool2d (the op itself runs in scouter_avgpool_*_f32)."""
+
+    def __init__(self, kernel_size, stride, padding=0, ceil_mode=False, count_include_pad=True):
+        super().__init__()
+        self.k, self.s, self.p, self.ceil, self.cip = kernel_size, stride, padding, ceil_mode, count_include_pad
+
+    def fwd(self, x):
+        return K.avgpool_fwd(x, self.k, self.s, self.p, self.ceil, self.cip)
+
+    def bwd(self, dy, x_shape):
+        return K.avgpool_bwd(dy, x_shape, self.k, self.s, self.p, self.ceil, self.cip)
+
+
+class Downsample(nn.Sequential):
+    """downsample_conv: [conv1x1(stride), bn]   downsample_avg: [pool | Identity, conv1x1, bn]"""
+
+    def fwd(self, x, save, tracked):
+        mods = list(self)
+        pool = None
+        if len(mods) == 3:
+            pool = mods[0] if isinstance(mods[0], AvgPool2dSpec) else None
+            mods = mods[1:]
+        xin = pool.fwd(x) if pool is not None else x
+        c, c_conv = mods[0].fwd(xin, save)
+        y, c_bn = mods[1].fwd(c, save, relu=False, tracked=tracked)
+        return y, ((c_conv, c_bn, pool, tuple(x.shape)) if save else None)
+
+    def bwd(self, dy, ctx, need_dx):
+        c_conv, c_bn, pool, x_shape = ctx
+        mods = list(self)[-2:]
+        dc, _ = mods[1].bwd(dy, c_bn)
+        dx = mods[0].bwd(dc, c_conv, need_dx)
+        if dx is not None and pool is not None:
+            dx = pool.bwd(dx, x_shape)
+        return dx
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, **_):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 3, stride, 1)
+        self.bn1 = BatchNorm2d(planes)
+        self.act1 = Act()
+        self.conv2 = Conv2d(planes, planes, 3, 1, 1)
+        self.bn2 = BatchNorm2d(planes)
+        self.act2 = Act()
+        self.downsample = downsample
+
+    def zero_init_last_bn(self):
+        nn.init.zeros_(self.bn2.weight)
+
+    def fwd(self, x, save, tracked):
+        c1, k1 = self.conv1.fwd(x, save)
+        h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked)
+        c2, k2 = self.conv2.fwd(h1, save)
+        res, kd = (x, None) if self.downsample is None else self.downsample.fwd(x, save, tracked)
+        out, b2 = self.bn2.fwd(c2, save, relu=True, residual=res, tracked=tracked)
+        return out, ((k1, b1, k2, b2, kd) if save else None)
+
+    def bwd(self, dout, ctx, need_dx=True):
+        k1, b1, k2, b2, kd = ctx
+        dc2, dres = self.bn2.bwd(dout, b2, want_gout=True)
+        dh1 = self.conv2.bwd(dc2, k2, True)
+        dc1, _ = self.bn1.bwd(dh1, b1)
+        dxres = dres if self.downsample is None else self.downsample.bwd(dres, kd, need_dx)
+        return self.conv1.bwd(dc1, k1, need_dx, addend=dxres)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000, in_chans=3, stem_width=64, stem_type="", avg_down=False,
+                 zero_init_last_bn=True, block_args=None, **_):
+        super().__init__()
+        block_args = block_args or {}
+        self.num_classes = num_classes
+        deep_stem = "deep" in stem_type
+        self.inplanes = stem_width * 2 if deep_stem else 64
+        if deep_stem:
+            self.conv1 = nn.Sequential(
+                StemConv2d(in_chans, stem_width, 3, 2, 1), BatchNorm2d(stem_width), Act(),
+                Conv2d(stem_width, stem_width, 3, 1, 1), BatchNorm2d(stem_width), Act(),
+                Conv2d(stem_width, self.inplanes, 3, 1, 1))
+        else:
+            self.conv1 = StemConv2d(in_chans, self.inplanes, 7, 2, 3)
+        self.bn1 = BatchNorm2d(self.inplanes)
+        self.act1 = Act()
+        self.maxpool = Identity()      # MaxPool2d(3, 2, 1) runs in scouter_maxpool_*_f32
+        chans, strides = [64, 128, 256, 512], [1, 2, 2, 2]
+        for i in range(4):
+            setattr(self, "layer%d" % (i + 1), self._make_layer(block, chans[i], layers[i], strides[i], avg_down,
+                                                                block_args))
+        self.num_features = 512 * block.expansion
+        self.global_pool = Identity()
+        self.fc = nn.Linear(self.num_features, num_classes)
+        if zero_init_last_bn:                       # resnet.py:455-458
+            for m in self.modules():
+                if hasattr(m, "zero_init_last_bn"):
+                    m.zero_init_last_bn()
+
+    def _make_layer(self, block, planes, blocks, stride, avg_down, block_args):
+        downsample = None
+        outp = planes * block.expansion
+        if stride != 1 or self.inplanes != outp:
+            if avg_down:
+                pool = AvgPool2dSpec(2, stride, ceil_mode=True, count_include_pad=False) if stride != 1 else Identity()
+                downsample = Downsample(pool, Conv2d(self.inplanes, outp, 1), BatchNorm2d(outp))
+            else:
+                downsample = Downsample(Conv2d(self.inplanes, outp, 1, stride, 0), BatchNorm2d(outp))
+        mods = [block(self.inplanes, planes, stride, downsample, **block_args)]
+        self.inplanes = outp
+        mods += [block(self.inplanes, planes, **block_args) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    # ---- explicit forward / backward over NHWC tensors
+    def features_fwd(self, x_nchw, save, tracked=None):
+        ctx = []
+        if isinstance(self.conv1, nn.Sequential):
+            s = self.conv1
+            c, k0 = s[0].fwd(x_nchw, save)
+            h, b0 = s[1].fwd(c, save, relu=True, tracked=tracked)
+            c, k1 = s[3].fwd(h, save)
+            h, b1 = s[4].fwd(c, save, relu=True, tracked=tracked)
+            c, k2 = s[6].fwd(h, save)
+            ctx.append((k0, b0, k1, b1, k2))
+        else:
+            c, k0 = self.conv1.fwd(x_nchw, save)
+            ctx.append((k0,))
+        h, bb = self.bn1.fwd(c, save, relu=True, tracked=tracked)
+        p, arg = K.maxpool_fwd(h, 3, 2, 1, want_argmax=save)
+        ctx.append((bb, arg, tuple(h.shape)))
+        x = p
+        for li in range(1, 5):
+            for blk in getattr(self, "layer%d" % li):
+                x, c_blk = blk.fwd(x, save, tracked)
+                ctx.append(c_blk)
+        return x, (ctx if save else None)
+
+    def _first_trainable_stage(self):
+        """Index of the earliest stage (0 = stem, 1..4 = layer1..4) holding a trainable parameter; 5 if none."""
+        stages = [[self.conv1, self.bn1]] + [[getattr(self, "layer%d" % i)] for i in range(1, 5)]
+        for i, mods in enumerate(stages):
+            if any(p.requires_grad for m in mods for p in m.parameters()):
+                return i
+        return 5
+
+    def features_bwd(self, dfeat, ctx):
+        first = self._first_trainable_stage()
+        blocks = [(li, blk) for li in range(1, 5) for blk in getattr(self, "layer%d" % li)]
+        d = dfeat
+        for idx in range(len(blocks) - 1, -1, -1):
+            li, blk = blocks[idx]
+            if li < first:
+                return
+            is_first_trainable = li == first and (idx == 0 or blocks[idx - 1][0] < first)
+            d = blk.bwd(d, ctx[2 + idx], need_dx=not is_first_trainable)
+        if first > 0:
+            return
+        bb, arg, hshape = ctx[1]
+        dh = K.maxpool_bwd(d, arg, hshape, 3, 2, 1)
+        dc, _ = self.bn1.bwd(dh, bb)
+        if isinstance(self.conv1, nn.Sequential):
+            s = self.conv1
+            k0, b0, k1, b1, k2 = ctx[0]
+            dh = s[6].bwd(dc, k2, True)
+            dc, _ = s[4].bwd(dh, b1)
+            dh = s[3].bwd(dc, k1, True)
+            dc, _ = s[1].bwd(dh, b0)
+            s[0].bwd(dc, k0, False)
+        else:
+            self.conv1.bwd(dc, ctx[0][0], False)
+
+    @torch.no_grad()
+    def forward_features(self, x):
+        """NCHW in -> NCHW out (inference helper; training goes through SlotModel's fused autograd node)."""
+        feat, _ = self.features_fwd(x.float().contiguous(), False)
+        return K.nhwc_to_nchw(feat)
+
+    def forward(self, x):
+        x = self.forward_features(x)
+        x = self.global_pool(x).flatten(1)        # resnet.py:505
+        return self.fc(x)
+
+
+def resnet18(pretrained=False, num_classes=1000, in_chans=3, **kwargs):
+    if pretrained:
+        raise RuntimeError("pretrained weights cannot be downloaded here; load a state_dict instead")
+    return ResNet(BasicBlock, [2, 2, 2, 2], num_classes=num_classes, in_chans=in_chans, **kwargs)

@@ -1,0 +1,83 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/scouter_hip.h declares, the
+module surface mirrors the reference (state_dict keys / shapes, constructor args), conv weights keep the HWIO
+physical layout through load_state_dict/.to(), and CPU tensors are refused (no fallback)."""
+import argparse
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(model="resnest26d", C=10, spc=1, L=3, mnist=False, **kw):
+    d = dict(model=model, pre_trained=False, num_classes=C, dataset="MNIST" if mnist else "ImageNet", use_slot=True,
+             use_pre=False, grad=False, channel=O.ARCHS[model]["channel"], slots_per_class=spc, hidden_dim=64,
+             freeze_layers=0, vis=False, vis_id=0, loss_status=1, power=2, to_k_layer=L, lambda_value="1")
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as G
+    G.build()
+    from scouter_amd import _native
+    assert os.path.exists(_native.LIB_PATH)
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = [n for n, _, _ in _native.declared_symbols()]
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), n
+    assert _native.lib().scouter_abi_version() == 1
+
+
+@pytest.mark.parametrize("model,C,spc,L,mnist", [("resnet18", 10, 1, 1, True), ("resnest26d", 10, 1, 3, False),
+                                                 ("resnest50d", 100, 3, 3, False)])
+def test_state_dict_matches_reference_layout(model, C, spc, L, mnist):
+    from scouter_amd.sloter.slot_model import SlotModel
+    m = SlotModel(_args(model, C, spc, L, mnist))
+    spec = O.state_dict_spec(model, C, spc, L, in_chans=1 if mnist else 3, mnist_stem=mnist)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(spec[k]), k
+    # round trip through a reference-layout state dict keeps values and the HWIO physical layout
+    P = O.synth_state(spec, 3)
+    m.load_state_dict(P)
+    w = m.backbone.layer1[0].conv1.weight
+    assert w.permute(2, 3, 1, 0).is_contiguous()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), P[k]), k
+
+
+def test_cpu_input_is_refused_not_emulated():
+    from scouter_amd.sloter.slot_model import SlotModel
+    m = SlotModel(_args("resnet18", mnist=True, L=1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(2, 1, 64, 64), torch.tensor([0, 1]))
+
+
+def test_freeze_layers_matches_reference_rule():
+    from scouter_amd.sloter.slot_model import SlotModel
+    m = SlotModel(_args("resnest26d", pre_trained=True, freeze_layers=2))
+    frozen = {n.split(".")[1] for n, p in m.named_parameters() if not p.requires_grad}
+    assert frozen == {"conv1", "bn1", "layer1", "layer2"}
+
+
+def test_grad_arena_views_alias_flat_buffer():
+    from scouter_amd.nn_hip import GradArena
+    from scouter_amd.sloter.slot_model import SlotModel
+    m = SlotModel(_args("resnet18", mnist=True, L=1))
+    a = GradArena(m)
+    assert "slot.to_q.0.weight" not in a.views
+    total = sum((p.numel() + 3) // 4 * 4 for n, p in m.named_parameters() if "to_q" not in n)
+    assert a.numel == total
+    a.flat.copy_(torch.arange(a.flat.numel(), dtype=torch.float32))
+    name, p, off, n = a.entries[0]
+    assert a.views[name].shape == p.shape and a.views[name].stride() == p.stride()
+    hw = a.views[name].permute(2, 3, 1, 0).reshape(-1)
+    assert torch.equal(hw, a.flat[off:off + n])

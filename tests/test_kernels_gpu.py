@@ -1,0 +1,254 @@
+"""Kernel-level parity (-m gpu): every HIP op called through the C ABI vs torch-CPU maths (fp64 where cheap).
+fp32 tolerances are stated per test; they follow fp32 accumulation over the contraction length."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def K():
+    from scouter_amd import kernels
+    return kernels
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().float().cuda()
+
+
+def from_nhwc(t):
+    return t.cpu().permute(0, 3, 1, 2).double()
+
+
+def to_hwio(w):
+    return w.permute(2, 3, 1, 0).contiguous().float().cuda()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s, p, g
+    (2, 14, 14, 64, 128, 3, 1, 1, 1),
+    (2, 14, 14, 64, 128, 3, 1, 1, 2),      # ResNeSt radix conv (groups = 2)
+    (3, 7, 7, 256, 64, 1, 1, 0, 1),        # ragged M (147 rows)
+    (2, 16, 16, 64, 64, 3, 2, 1, 1),       # resnet18 strided 3x3
+    (2, 16, 16, 64, 128, 1, 2, 0, 1),      # resnet18 downsample_conv
+    (2, 20, 20, 32, 32, 3, 1, 1, 1),       # stem 32->32 (N = 32 tile)
+    (4, 28, 28, 128, 512, 1, 1, 0, 1),     # wide N, several M tiles
+    (1, 9, 9, 2048, 64, 1, 1, 0, 1),       # head conv1x1 (K = 2048)
+    (2, 12, 12, 512, 1024, 3, 1, 1, 2),    # layer4 radix conv
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    B, H, W, Cin, Cout, k, s, p, g = case
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.standard_normal((B, Cin, H, W)))
+    w = torch.from_numpy(rng.standard_normal((Cout, Cin // g, k, k)) / np.sqrt(Cin // g * k * k))
+    bias = torch.from_numpy(rng.standard_normal(Cout))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, bias, s, p, 1, g)
+    add = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
+    dy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
+    y_ref.backward(dy)
+    kk = K()
+    y = kk.conv2d_fwd(nhwc(x), to_hwio(w), bias.float().cuda(), None, s, p, g, False)
+    tol = 2e-5 * np.sqrt(Cin // g * k * k)
+    np.testing.assert_allclose(from_nhwc(y).numpy(), y_ref.detach().numpy(), atol=tol, rtol=1e-5)
+    y2 = kk.conv2d_fwd(nhwc(x), to_hwio(w), None, nhwc(add), s, p, g, True)
+    np.testing.assert_allclose(from_nhwc(y2).numpy(), torch.relu(F.conv2d(x, w, None, s, p, 1, g) + add).numpy(),
+                               atol=tol, rtol=1e-5)
+    dx = kk.conv2d_dgrad(nhwc(dy), to_hwio(w), (B, H, W, Cin), None, s, p, g)
+    np.testing.assert_allclose(from_nhwc(dx).numpy(), xr.grad.numpy(), atol=2e-5 * np.sqrt(Cout // g * k * k), rtol=1e-5)
+    dw = torch.empty((k, k, Cin // g, Cout), dtype=torch.float32, device="cuda")
+    kk.conv2d_wgrad(nhwc(x), nhwc(dy), dw, s, p, g)
+    dw_ref = wr.grad.permute(2, 3, 1, 0).numpy()
+    np.testing.assert_allclose(dw.cpu().double().numpy(), dw_ref, atol=3e-5 * np.sqrt(B * y_ref.shape[2] * y_ref.shape[3]),
+                               rtol=1e-5)
+
+
+def test_wgrad_split_reduction_large_m():
+    """Many pixels -> several split-K slabs + the deterministic slab reduction."""
+    B, H, W, Cin, Cout = 8, 56, 56, 32, 64
+    rng = np.random.default_rng(2)
+    x = torch.from_numpy(rng.standard_normal((B, Cin, H, W)).astype(np.float32))
+    dy = torch.from_numpy(rng.standard_normal((B, Cout, H, W)).astype(np.float32))
+    kk = K()
+    dw = torch.empty((3, 3, Cin, Cout), dtype=torch.float32, device="cuda")
+    kk.conv2d_wgrad(nhwc(x), nhwc(dy), dw, 1, 1, 1)
+    dw2 = torch.empty_like(dw)
+    kk.conv2d_wgrad(nhwc(x), nhwc(dy), dw2, 1, 1, 1)
+    assert torch.equal(dw, dw2), "wgrad must be deterministic"
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), 1, 1).permute(2, 3, 1, 0)
+    np.testing.assert_allclose(dw.cpu().double().numpy(), ref.numpy(), atol=5e-3, rtol=1e-4)
+
+
+def test_stem_im2col_path():
+    """3-channel 3x3/2 stem as im2col (K 27 -> 32) + 1x1 conv; also its weight gradient."""
+    rng = np.random.default_rng(3)
+    B, Cin, H, Cout, k, s, p = 3, 3, 34, 32, 3, 2, 1
+    x = torch.from_numpy(rng.standard_normal((B, Cin, H, H)))
+    w = torch.from_numpy(rng.standard_normal((Cout, Cin, k, k)) * 0.2)
+    kk = K()
+    col = kk.im2col_nchw(x.float().cuda(), k, s, p, 32)
+    wflat = to_hwio(w).reshape(-1)
+    wpad = kk.pad_rows(wflat, k * k * Cin * Cout, 32 * Cout).view(1, 1, 32, Cout)
+    y = kk.conv2d_fwd(col, wpad)
+    ref = F.conv2d(x, w, None, s, p)
+    np.testing.assert_allclose(from_nhwc(y).numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+    dy = torch.from_numpy(rng.standard_normal(tuple(ref.shape)))
+    dw = torch.empty((1, 1, 32, Cout), dtype=torch.float32, device="cuda")
+    kk.conv2d_wgrad(col, nhwc(dy), dw)
+    dref = torch.nn.grad.conv2d_weight(x, tuple(w.shape), dy, s, p).permute(2, 3, 1, 0).reshape(27, Cout)
+    np.testing.assert_allclose(dw.view(32, Cout)[:27].cpu().double().numpy(), dref.numpy(), atol=5e-4, rtol=1e-5)
+    assert float(dw.view(32, Cout)[27:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,relu,res", [((4, 14, 14, 64), True, False), ((3, 7, 7, 2048), False, True),
+                                            ((6, 1, 1, 32), True, False), ((2, 28, 28, 32), True, True)])
+def test_bn_fwd_bwd(shape, relu, res):
+    rng = np.random.default_rng(4)
+    B, H, W, C = shape
+    x = torch.from_numpy(rng.standard_normal((B, C, H, W)) * 2 + 0.5)
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, C))
+    beta = torch.from_numpy(rng.standard_normal(C) * 0.1)
+    rm = torch.from_numpy(rng.standard_normal(C) * 0.1)
+    rv = torch.from_numpy(rng.uniform(0.5, 1.5, C))
+    r = torch.from_numpy(rng.standard_normal((B, C, H, W))) if res else None
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    if res:
+        y_ref = y_ref + r
+    if relu:
+        y_ref = torch.relu(y_ref)
+    dy = torch.from_numpy(rng.standard_normal((B, C, H, W)))
+    y_ref.backward(dy)
+    kk = K()
+    rm_d, rv_d = rm.float().cuda(), rv.float().cuda()
+    xd = nhwc(x)
+    y, saved = kk.bn_fwd(xd, gamma.float().cuda(), beta.float().cuda(), rm_d, rv_d, True, relu, nhwc(r) if res else None)
+    np.testing.assert_allclose(from_nhwc(y).numpy(), y_ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rm_ref.numpy(), atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rv_ref.numpy(), atol=1e-6, rtol=1e-5)
+    dg = torch.empty(C, dtype=torch.float32, device="cuda")
+    db = torch.empty(C, dtype=torch.float32, device="cuda")
+    dx, gout = kk.bn_bwd(nhwc(dy), y if relu else None, xd, saved, True, dg, db, want_gout=True)
+    sc = float(xr.grad.abs().max())
+    np.testing.assert_allclose(from_nhwc(dx).numpy(), xr.grad.numpy(), atol=3e-5 * max(sc, 1), rtol=1e-4)
+    np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.numpy(), atol=1e-4 * max(float(gr.grad.abs().max()), 1), rtol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.numpy(), atol=1e-4 * max(float(br.grad.abs().max()), 1), rtol=1e-4)
+    mask = (y_ref.detach() > 0).double() if relu else 1.0
+    np.testing.assert_allclose(from_nhwc(gout).numpy(), (dy * mask).numpy(), atol=1e-6)
+    # eval mode uses the running statistics
+    y_e, _ = kk.bn_fwd(xd, gamma.float().cuda(), beta.float().cuda(), rm_d, rv_d, False, False)
+    ref_e = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, False, 0.1, 1e-5)
+    np.testing.assert_allclose(from_nhwc(y_e).numpy(), ref_e.numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_pools():
+    rng = np.random.default_rng(5)
+    kk = K()
+    x = torch.from_numpy(rng.standard_normal((2, 32, 17, 17)))
+    dy_of = lambda y: torch.from_numpy(rng.standard_normal(tuple(y.shape)))
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    dy = dy_of(y_ref)
+    y_ref.backward(dy)
+    y, arg = kk.maxpool_fwd(nhwc(x))
+    np.testing.assert_array_equal(from_nhwc(y).numpy(), y_ref.detach().float().double().numpy())
+    dx = kk.maxpool_bwd(nhwc(dy), arg, (2, 17, 17, 32))
+    np.testing.assert_allclose(from_nhwc(dx).numpy(), xr.grad.numpy(), atol=1e-6)
+    for (k, s, p, ceil, cip) in [(3, 2, 1, False, True), (2, 2, 0, True, False), (3, 1, 1, False, True)]:
+        xr = x.clone().requires_grad_(True)
+        y_ref = F.avg_pool2d(xr, k, s, p, ceil_mode=ceil, count_include_pad=cip)
+        dy = dy_of(y_ref)
+        y_ref.backward(dy)
+        y = kk.avgpool_fwd(nhwc(x), k, s, p, ceil, cip)
+        assert tuple(y.shape[1:3]) == tuple(y_ref.shape[2:])
+        np.testing.assert_allclose(from_nhwc(y).numpy(), y_ref.detach().numpy(), atol=1e-6)
+        dx = kk.avgpool_bwd(nhwc(dy), (2, 17, 17, 32), k, s, p, ceil, cip)
+        np.testing.assert_allclose(from_nhwc(dx).numpy(), xr.grad.numpy(), atol=1e-6)
+    t = kk.nhwc_to_nchw(nhwc(x))
+    np.testing.assert_array_equal(t.cpu().numpy(), x.float().numpy())
+    np.testing.assert_array_equal(kk.nchw_to_nhwc(x.float().cuda()).cpu().numpy(), nhwc(x).cpu().numpy())
+
+
+def test_split_attention_glue():
+    rng = np.random.default_rng(6)
+    kk = K()
+    B, H, W, Cp = 3, 10, 10, 64
+    x = torch.from_numpy(rng.standard_normal((B, H, W, 2 * Cp)))
+    z = torch.from_numpy(rng.standard_normal((B, 2 * Cp)))
+    dout = torch.from_numpy(rng.standard_normal((B, H, W, Cp)))
+    xd = x.float().cuda()
+    gap = kk.sa_gap(xd)
+    np.testing.assert_allclose(gap.cpu().numpy(), (x[..., :Cp] + x[..., Cp:]).mean((1, 2)).numpy(), atol=1e-6)
+    a = kk.radix_softmax_fwd(z.float().cuda())
+    a_ref = torch.softmax(z.view(B, 2, Cp), 1).view(B, 2 * Cp)
+    np.testing.assert_allclose(a.cpu().numpy(), a_ref.numpy(), atol=1e-6)
+    out = kk.sa_apply_fwd(xd, a)
+    out_ref = x[..., :Cp] * a_ref[:, None, None, :Cp] + x[..., Cp:] * a_ref[:, None, None, Cp:]
+    np.testing.assert_allclose(out.cpu().numpy(), out_ref.numpy(), atol=1e-5)
+    da = kk.sa_dattn(xd, dout.float().cuda())
+    da_ref = torch.cat([(dout * x[..., :Cp]).sum((1, 2)), (dout * x[..., Cp:]).sum((1, 2))], 1)
+    np.testing.assert_allclose(da.cpu().numpy(), da_ref.numpy(), atol=1e-4, rtol=1e-5)
+    dz = kk.radix_softmax_bwd(a, da)
+    zr = z.clone().requires_grad_(True)
+    torch.softmax(zr.view(B, 2, Cp), 1).view(B, 2 * Cp).backward(da_ref)
+    np.testing.assert_allclose(dz.cpu().numpy(), zr.grad.numpy(), atol=1e-4, rtol=1e-4)
+    dgap = torch.from_numpy(rng.standard_normal((B, Cp)))
+    dx = kk.sa_apply_bwd(dout.float().cuda(), a, dgap.float().cuda())
+    dx_ref = torch.cat([dout * a_ref[:, None, None, :Cp], dout * a_ref[:, None, None, Cp:]], -1) + \
+        torch.cat([dgap, dgap], 1)[:, None, None, :] / (H * W)
+    np.testing.assert_allclose(dx.cpu().numpy(), dx_ref.numpy(), atol=1e-5)
+
+
+def test_colsum_relu_axpby_matmul_tn():
+    rng = np.random.default_rng(7)
+    kk = K()
+    a = torch.from_numpy(rng.standard_normal((37, 640)).astype(np.float32))
+    out = torch.empty(640, dtype=torch.float32, device="cuda")
+    kk.colsum(a.cuda(), out)
+    np.testing.assert_allclose(out.cpu().numpy(), a.double().sum(0).numpy(), atol=1e-5)
+    y = torch.from_numpy(rng.standard_normal((37, 640)).astype(np.float32))
+    np.testing.assert_array_equal(kk.relu_bwd(a.cuda(), y.cuda()).cpu().numpy(), (a * (y > 0)).numpy())
+    np.testing.assert_allclose(kk.axpby(a.cuda(), y.cuda(), 2.0, -0.5).cpu().numpy(), (2 * a - 0.5 * y).numpy(), atol=1e-6)
+    p = torch.from_numpy(rng.standard_normal((700, 192)).astype(np.float32))
+    q = torch.from_numpy(rng.standard_normal((700, 64)).astype(np.float32))
+    o = torch.empty((192, 64), dtype=torch.float32, device="cuda")
+    kk.matmul_tn(p.cuda(), q.cuda(), o)
+    np.testing.assert_allclose(o.cpu().numpy(), (p.double().t() @ q.double()).numpy(), atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("h,w", [(7, 7), (9, 9), (1, 1), (3, 5)])
+def test_posenc(h, w):
+    from oracle import torch_oracle as O
+    pe = K().posenc_sine(h, w, 64, torch.device("cuda"))
+    ref = O.posenc_sine(h, w, 64).reshape(64, h * w).t()
+    np.testing.assert_allclose(pe.cpu().numpy(), ref.numpy(), atol=2e-6)
+
+
+def test_loss_fwd_bwd():
+    rng = np.random.default_rng(8)
+    kk = K()
+    B, C, S, N, lam, power = 9, 10, 10, 49, 0.7, 2
+    logits = torch.from_numpy(rng.standard_normal((B, C)) * 3)
+    y = torch.from_numpy(rng.integers(0, C, B))
+    area_part = torch.from_numpy(rng.uniform(100, 200, B))
+    lr = logits.clone().requires_grad_(True)
+    ar = area_part.clone().requires_grad_(True)
+    logp = F.log_softmax(lr, 1)
+    nll = F.nll_loss(logp, y)
+    term = (ar.sum() / (B * S * N)) ** power
+    loss = nll + lam * term
+    loss.backward()
+    lp, stats = kk.slot_loss_fwd(logits.float().cuda(), y.cuda(), area_part.float().cuda(), B * S * N, lam, power)
+    np.testing.assert_allclose(lp.cpu().numpy(), logp.detach().numpy(), atol=2e-6)
+    acc = float((logits.argmax(1) == y).double().mean())
+    np.testing.assert_allclose(stats[:4].cpu().numpy(), [float(loss), float(nll), float(term), acc], rtol=2e-6, atol=1e-6)
+    one = torch.ones(1, dtype=torch.float32, device="cuda")
+    dl, ga = kk.slot_loss_bwd(lp, y.cuda(), stats, one, None, None, None, B * S * N, lam, power)
+    np.testing.assert_allclose(dl.cpu().numpy(), lr.grad.numpy(), atol=1e-6)
+    np.testing.assert_allclose(float(ga), float(ar.grad[0]), rtol=1e-5)

@@ -1,0 +1,138 @@
+"""Whole-network parity (-m gpu): SlotModel on the HIP path vs the golden vectors generated from the reference
+(tests/golden/model_*.npz) and vs the CPU oracle on the same seeded parameters / inputs -- forward, every parameter
+gradient, BatchNorm running statistics, eval-mode forward."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_oracle as O                                        # noqa: E402
+from oracle.gen_golden import MODEL_CASES, LAMBDA, model_inputs, grad_digest   # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def build(case):
+    from scouter_amd.sloter.slot_model import SlotModel
+    arch, C, spc, L, ls, power, B, H, in_chans, mnist = MODEL_CASES[case]
+    args = argparse.Namespace(model=arch, pre_trained=False, num_classes=C, dataset="MNIST" if mnist else "ImageNet",
+                              use_slot=True, use_pre=False, grad=False, channel=O.ARCHS[arch]["channel"],
+                              slots_per_class=spc, hidden_dim=64, freeze_layers=0, vis=False, vis_id=0,
+                              loss_status=ls, power=power, to_k_layer=L, lambda_value=LAMBDA)
+    spec, P, images, labels = model_inputs(case)
+    m = SlotModel(args)
+    assert list(m.state_dict().keys()) == list(spec.keys())
+    m.load_state_dict(P)
+    return m.cuda(), P, images, labels
+
+
+def oracle_run(case, dtype):
+    arch, C, spc, L, ls, power, B, H, in_chans, mnist = MODEL_CASES[case]
+    spec, P, images, labels = model_inputs(case)
+    P = {k: (v.to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in P.items()}
+    keys = O.trainable_keys(P)
+    leaves = {k: P[k].clone().requires_grad_(True) for k in keys}
+    Q = dict(P)
+    Q.update(leaves)
+    cfg = dict(model=arch, num_classes=C, slots_per_class=spc, loss_status=ls, power=power, lambda_value=float(LAMBDA))
+    aux = {}
+    out, losses = O.slot_model_forward(Q, images.to(dtype), labels, cfg, training=True, aux=aux)
+    losses[0].backward()
+    return out, losses, aux, leaves, Q
+
+
+@pytest.mark.parametrize("case", ["resnet18_mnist_64", "resnest26d_96", "resnest50d_64_spc3"])
+def test_model_fwd_bwd_parity(case):
+    g = np.load(os.path.join(GOLD, "model_%s.npz" % case))
+    m, P, images, labels = build(case)
+    m.train()
+    out, (loss, nll, area) = m(images.cuda(), labels.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    floor = float(np.abs(g["f32_log_probs"] - g["f64_log_probs"]).max())
+    tol = max(1e-4, 3 * floor)
+    err = np.abs(out.detach().cpu().numpy() - g["f64_log_probs"]).max()
+    assert err <= tol, (err, tol, floor)
+    np.testing.assert_allclose(m.slot.last_attn.cpu().numpy(), g["f64_attn"], atol=max(1e-4, tol), rtol=0)
+    np.testing.assert_allclose([float(loss), float(nll), float(area)],
+                               [float(g["f64_loss"]), float(g["f64_nll"]), float(g["f64_area"])], atol=tol, rtol=1e-4)
+    # gradients vs the oracle's fp64 autograd (full tensors)
+    _, _, _, leaves, Q = oracle_run(case, torch.float64)
+    named = dict(m.named_parameters())
+    assert named["slot.to_q.0.weight"].grad is None and named["slot.to_q.0.bias"].grad is None
+    worst = 0.0
+    for k, ref in leaves.items():
+        mine = named[k].grad.detach().cpu().double()
+        r = ref.grad
+        scale = float(r.abs().max())
+        if k.endswith("conv2.fc1.bias"):                     # bias in front of a train-mode BN: exact gradient 0
+            assert float(mine.abs().max()) < 1e-3
+            continue
+        e = float((mine - r).abs().max())
+        worst = max(worst, e / max(scale, 1e-6))
+        assert e <= 2e-2 * scale + 50 * floor + 2e-5, (k, e, scale)
+    # BN running statistics after one training forward
+    sd = m.state_dict()
+    for k in Q:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(sd[k].cpu().numpy(), Q[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == 1
+    # eval-mode forward on the updated buffers
+    m.eval()
+    with torch.no_grad():
+        ev = m(images.cuda())
+    np.testing.assert_allclose(ev.cpu().numpy(), g["f64_eval_log_probs"], atol=max(tol, 2e-4), rtol=1e-3)
+    print(case, "max |log_probs - fp64 ref| = %.3g (ref fp32 noise %.3g), worst rel grad err %.3g" % (err, floor, worst))
+
+
+def test_full_size_resnest26d_224_against_reference_fp64_digests():
+    """BASELINE input size (224x224), batch 6: log_probs / attention vs the reference's fp64 run, every gradient vs
+    the reference's fp64 gradient digest (sum, abs-sum, first 16 entries)."""
+    case = "resnest26d_224"
+    g = np.load(os.path.join(GOLD, "model_%s.npz" % case))
+    m, P, images, labels = build(case)
+    m.train()
+    out, (loss, nll, area) = m(images.cuda(), labels.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    floor = float(np.abs(g["f32_log_probs"] - g["f64_log_probs"]).max())
+    tol = max(1e-4, 3 * floor)
+    assert np.abs(out.detach().cpu().numpy() - g["f64_log_probs"]).max() <= tol
+    np.testing.assert_allclose(m.slot.last_attn.cpu().numpy(), g["f64_attn"], atol=tol, rtol=0)
+    named = dict(m.named_parameters())
+    for k, d in zip(g["f32_grad_keys"], g["f64_grad_digest"]):
+        k = str(k)
+        if k.endswith("conv2.fc1.bias"):
+            continue
+        mine = grad_digest(named[k].grad.detach().cpu())
+        assert abs(mine[0] - d[0]) <= 2e-2 * d[1] + 2e-4, k
+        assert abs(mine[1] - d[1]) <= 2e-2 * d[1] + 2e-4, k
+        scale = max(d[1] / max(named[k].numel(), 1), 1e-8)
+        np.testing.assert_allclose(mine[2:], d[2:], atol=50 * scale * 2e-2 + 2e-5, rtol=5e-2, err_msg=k)
+
+
+def test_frozen_backbone_and_no_cpu_fallback():
+    from scouter_amd.sloter.slot_model import SlotModel
+    args = argparse.Namespace(model="resnet18", pre_trained=True, num_classes=10, dataset="MNIST", use_slot=True,
+                              use_pre=False, grad=False, channel=512, slots_per_class=1, hidden_dim=64,
+                              freeze_layers=2, vis=False, vis_id=0, loss_status=1, power=1, to_k_layer=1,
+                              lambda_value="1")
+    m = SlotModel(args)
+    frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
+    assert any(n.startswith("backbone.layer2") for n in frozen) and not any("layer3" in n for n in frozen)
+    x = torch.randn(2, 1, 64, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, torch.tensor([1, 2]))
+    m = m.cuda()
+    out, losses = m(x.cuda(), torch.tensor([1, 2]).cuda())
+    losses[0].backward()
+    for n, p in m.named_parameters():
+        if not p.requires_grad or "to_q" in n:
+            assert p.grad is None
+        else:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
