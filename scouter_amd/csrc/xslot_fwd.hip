@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
                         const float rg = xs_sigmoid(ar[r] + bias[g]);
                         const float zg = xs_sigmoid(az[r] + bias[64 + g]);
                         const float ng = tanhf(ain[r] + bias[128 + g] + rg * (ahn[r] + bias[192 + g]));
-                        hn[gt][r] = (1.f - zg) * ng + zg * h[tt][gt][r];
+                        hn[gt][r] = i < S ? (1.f - zg) * ng + zg * h[tt][gt][r] : 0.f;   // padded slots stay 0 (tau!)
                     }
                 }
                 h[tt][0] = hn[0];

@@ -1,0 +1,102 @@
+"""Fused multi-tensor AdamW on the HIP path (one kernel launch per step) with torch.optim.AdamW's interface and
+numerics (reference train.py:146: `torch.optim.AdamW(params, lr=args.lr)` -- betas (0.9, 0.999), eps 1e-8,
+weight_decay 1e-2; `args.weight_decay` is ignored by the reference and therefore here too).
+
+Gradients are read from the model's flat GradArena (param.grad are views of it); exp_avg / exp_avg_sq live in two
+flat arenas with the same offsets, so `step()` is a single launch over a chunk table."""
+import ctypes
+import struct
+
+import torch
+
+from . import _native
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    CHUNK = 65536
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._plan = None
+
+    # ---- plan: one chunk table per param group over a private flat layout (offsets 16B-aligned)
+    def _build_plan(self):
+        plans = []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                plans.append(None)
+                continue
+            dev = ps[0].device
+            if dev.type != "cuda":
+                raise RuntimeError("FusedAdamW runs on a HIP device only (no CPU fallback)")
+            base = min(p.grad.data_ptr() for p in ps)
+            end = max(p.grad.data_ptr() + p.grad.numel() * 4 for p in ps)
+            span = (end - base) // 4
+            rows = []
+            for p in ps:
+                g = p.grad
+                if g.dtype != torch.float32 or p.dtype != torch.float32:
+                    raise RuntimeError("FusedAdamW: fp32 parameters / gradients only")
+                # parameter and gradient must share the same dense physical layout (true for the arena views)
+                if g.stride() != p.stride():
+                    raise RuntimeError("FusedAdamW: gradient layout differs from the parameter's")
+                off = (g.data_ptr() - base) // 4
+                n = p.numel()
+                for c0 in range(0, n, self.CHUNK):
+                    rows.append((p.data_ptr() + 4 * c0, off + c0, min(self.CHUNK, n - c0)))
+            blob = b"".join(struct.pack("<QqiI", a, o, n, 0) for a, o, n in rows)
+            assert len(blob) == len(rows) * _native.lib().scouter_adamw_chunk_bytes()
+            table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            state = self.state.setdefault("_flat_%d" % len(plans), {})
+            if "exp_avg" not in state or state["exp_avg"].numel() != span or state["exp_avg"].device != dev:
+                state["exp_avg"] = torch.zeros(span, dtype=torch.float32, device=dev)
+                state["exp_avg_sq"] = torch.zeros(span, dtype=torch.float32, device=dev)
+                state.setdefault("step", 0)
+            plans.append(dict(table=table, n=len(rows), base=base, span=span, ids=[id(p) for p in ps],
+                              gptrs=[p.grad.data_ptr() for p in ps], pptrs=[p.data_ptr() for p in ps], state=state))
+        self._plan = plans
+
+    def _plan_valid(self):
+        if self._plan is None:
+            return False
+        for group, plan in zip(self.param_groups, self._plan):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if plan is None:
+                if ps:
+                    return False
+                continue
+            if [id(p) for p in ps] != plan["ids"] or [p.grad.data_ptr() for p in ps] != plan["gptrs"] \
+                    or [p.data_ptr() for p in ps] != plan["pptrs"]:
+                return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self._plan_valid():
+            self._build_plan()
+        L = _native.lib()
+        for group, plan in zip(self.param_groups, self._plan):
+            if plan is None:
+                continue
+            st = plan["state"]
+            st["step"] += 1
+            b1, b2 = group["betas"]
+            grads = ctypes.c_void_p(plan["base"])
+            _native.check(L.scouter_adamw_step_f32(plan["table"].data_ptr(), plan["n"], grads,
+                                                   st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                   float(group["weight_decay"]), int(st["step"]),
+                                                   torch.cuda.current_stream().cuda_stream), "adamw_step")
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients live in the model's flat arena and are overwritten by every backward; keeping the views in
+        place (set_to_none=False by default here) avoids re-planning each step."""
+        if set_to_none:
+            super().zero_grad(set_to_none=True)
