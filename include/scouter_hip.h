@@ -56,7 +56,7 @@ int scouter_pad_rows_f32(const float* w, float* wpad, long nvalid, long ntotal, 
 /* ---- BatchNorm2d (+ReLU, +residual add): timm/models/resnet.py:383 (norm_layer), BasicBlock :172-199,
  * ResNestBottleneck resnest.py:111-143.  Training mode: batch statistics (fp64 accumulation), running stats
  * updated with `momentum` and the unbiased variance; eval mode: running stats.
- * Saves mean/rstd and the fused scale = gamma*rstd, shift = beta - mean*scale for the backward. */
+ * y = (x - mean) * scale + shift with scale = gamma*rstd, shift = beta; mean/rstd/scale are saved for the backward. */
 size_t scouter_colreduce_workspace_bytes(long M, int C);
 int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum, float eps,

@@ -107,10 +107,11 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int nb
     mean_o[c] = (float)mean;
     rstd_o[c] = rstd;
     scale_o[c] = sc;
-    shift_o[c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
+    shift_o[c] = beta ? beta[c] : 0.f;        // applied as (x - mean) * scale + beta: no cancellation when |mean| >> std
 }
 
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ mean,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ res, float* __restrict__ y,
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         f32x4 v = *(const f32x4*)(x + i * 4);
-        const f32x4 a = *(const f32x4*)(scale + c), b = *(const f32x4*)(shift + c);
-        v = v * a + b;
+        const f32x4 a = *(const f32x4*)(scale + c), b = *(const f32x4*)(shift + c), mu = *(const f32x4*)(mean + c);
+        v = (v - mu) * a + b;
         if (res) v += *(const f32x4*)(res + i * 4);
         if (relu) {
 #pragma unroll
@@ -381,8 +382,8 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
                        gamma, beta, running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out,
                        shift_out);
     const long n4 = M * C / 4;
-    hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, scale_out, shift_out,
-                       residual, y, n4, C, relu);
+    hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, scale_out,
+                       shift_out, residual, y, n4, C, relu);
     return sc_check_launch("bn_fwd");
 }
 

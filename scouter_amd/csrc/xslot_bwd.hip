@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     float* Wih = Ks + NP * XS_LD;
     float* Whh = Wih + 192 * XS_LD;
     float* bias = Whh + 192 * XS_LD;        // br | bz | b_in | b_hn
-    float* red = bias + 256;                // tau_part[16] | c0_part[16]
+    double* ksum = (double*)(bias + 256);   // [64] column sums of K (fp64)
+    double* red64 = ksum + 64;              // tau_part[16]
+    float* red = (float*)(red64 + 16);      // (unused)[16] | c0_part[16]
     float* r_s = red + 32;                  // [512] r_i
     float* g_s = r_s + 512;                 // [512] g_i
     // final-phase buffers alias the GRU weights
@@ -100,6 +102,8 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     }
     const float g_area = a.g_area_sum ? a.g_area_sum[0] : 0.f;
     __syncthreads();
+    xs_colsum_f64(Ks, NP, ksum, tid);
+    __syncthreads();
 
     for (int it = T - 1; it >= 0; --it) {
         const bool last = it == T - 1;
@@ -109,22 +113,17 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             const int ti = wave + 4 * tt;
             if (ti >= ntiles) continue;
             const int i = ti * 32 + l31;
-            f32x16 h[2], D[NJT];
+            f32x16 h[2];
             xs_load_tile<2>(sbase + (long)ti * 32 * XS_D, XS_D, h, l31, hh, i < S);
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                xs_zero(D[jt]);
-                xs_mm_kc(Ks, 32 * jt, h, D[jt], l31, hh);
-                D[jt] *= scale;
-            }
-            const float r = xs_rowsum<NJT>(D);
-            if (hh == 0) r_s[i] = r;
-            const float tr = xs_tilesum(r);
-            if (lane == 0) red[ti] = tr;
+            const double r64 = xs_rowdot_f64(h, ksum, hh) * (double)scale;       // same fp64 normaliser as the forward
+            if (hh == 0) r_s[i] = (float)r64;
+            const double tr = xs_tilesum_f64(r64);
+            if (lane == 0) red64[ti] = tr;
         }
         __syncthreads();
-        float tau = 0.f;
-        for (int k = 0; k < ntiles; ++k) tau += red[k];
+        double tau64 = 0.0;
+        for (int k = 0; k < ntiles; ++k) tau64 += red64[k];
+        const float tau = (float)tau64;
         // ================= phase B1
         for (int tt = 0; tt < TPW; ++tt) {
             const int ti = wave + 4 * tt;
@@ -354,7 +353,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     }
 }
 
-static size_t xs_bwd_lds_bytes(int NJT) { return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 32 + 1024) * sizeof(float); }
+static size_t xs_bwd_lds_bytes(int NJT) { return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 16) + 32 + 1024) * sizeof(float); }
 
 extern "C" size_t scouter_xslot_bwd_workspace_bytes(int B, int N, int d, int S, int T) {
     (void)d;

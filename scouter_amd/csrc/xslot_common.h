@@ -64,6 +64,31 @@ __device__ __forceinline__ float xs_rowsum(const f32x16 (&m)[NT]) {
         for (int r = 0; r < 16; ++r) s += m[t][r];
     return s + __shfl_xor(s, 32, 64);
 }
+// r_i = sum_j D_ij = d^-1/2 * s_i . (sum_j K_j): the normaliser the reference divides by (slot_attention.py:56) is
+// ill-conditioned (mixed-sign terms cancel), so it is evaluated in fp64 from the fp32 operands -- by linearity this
+// is the same quantity as the row sum of D, without the fp32 cancellation noise.  ksum: [64] doubles in LDS.
+__device__ __forceinline__ double xs_rowdot_f64(const f32x16 (&s)[2], const double* __restrict__ ksum, int hh) {
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += (double)s[t][r] * ksum[xs_kidx(t, r, hh)];
+    return acc + __shfl_xor(acc, 32, 64);
+}
+__device__ __forceinline__ double xs_tilesum_f64(double v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// column sums of K (rows < NP of an [NP][XS_LD] LDS matrix; rows >= N are zero) in fp64, by threads 0..63
+__device__ __forceinline__ void xs_colsum_f64(const float* __restrict__ Ks, int NP, double* __restrict__ ksum, int tid) {
+    if (tid < XS_D) {
+        double a = 0.0;
+        for (int j = 0; j < NP; ++j) a += (double)Ks[j * XS_LD + tid];
+        ksum[tid] = a;
+    }
+}
+
 // sum over the 32 slots of a tile (lanes 0..31; both half-waves hold the same per-slot value)
 __device__ __forceinline__ float xs_tilesum(float v) {
 #pragma unroll

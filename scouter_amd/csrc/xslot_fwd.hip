@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
     float* Wih = Ks + NP * XS_LD;           // [192][68]
     float* Whh = Wih + 192 * XS_LD;         // [192][68]
     float* bias = Whh + 192 * XS_LD;        // br | bz | b_in | b_hn  (4 x 64)
-    float* tau_part = bias + 256;           // [T<=8][16]
-    float* area_s = tau_part + 128;         // [16]
+    double* ksum = (double*)(bias + 256);   // [64]  column sums of K (fp64)
+    double* tau_part = ksum + 64;           // [T<=8][16]
+    float* area_s = (float*)(tau_part + 128);   // [16]
     float* usum = area_s + 16;              // [<=512] per-slot sum_k U_T[i][k]
     // MLP scratch aliases the (not yet loaded) GRU weight region
     float* H0 = Wih;                        // [NP][68]
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
         float* tmp = Hin; Hin = Hout; Hout = tmp;
     }
     __syncthreads();
+    xs_colsum_f64(Ks, NP, ksum, tid);
     // ---- phase 2: GRU weights + combined biases
     xs_load_mat(Wih, a.w_ih, 192, tid, nthr);
     xs_load_mat(Whh, a.w_hh, 192, tid, nthr);
@@ -121,32 +123,22 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
     }
     for (int it = 0; it < a.T; ++it) {
         const bool last = it == a.T - 1;
-        f32x16 Dk[NJT];                          // kept across the barrier only when TPW == 1
         float rr[TPW];
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
             const int ti = wave + NW * tt;
             rr[tt] = 0.f;
             if (ti < ntiles) {
-                f32x16 D[NJT];
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) {
-                    xs_zero(D[jt]);
-                    xs_mm_kc(Ks, 32 * jt, h[tt], D[jt], l31, hh);
-                    D[jt] *= scale;
-                }
-                rr[tt] = xs_rowsum<NJT>(D);
-                const float tr = xs_tilesum(rr[tt]);
+                const double r64 = xs_rowdot_f64(h[tt], ksum, hh) * (double)scale;    // r_i (padded slots: exactly 0)
+                rr[tt] = (float)r64;
+                const double tr = xs_tilesum_f64(r64);
                 if (lane == 0) tau_part[it * 16 + ti] = tr;
-                if (TPW == 1) {
-#pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) Dk[jt] = D[jt];
-                }
             }
         }
         __syncthreads();
-        float tau = 0.f;
-        for (int k = 0; k < ntiles; ++k) tau += tau_part[it * 16 + k];
+        double tau64 = 0.0;
+        for (int k = 0; k < ntiles; ++k) tau64 += tau_part[it * 16 + k];
+        const float tau = (float)tau64;
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
             const int ti = wave + NW * tt;
@@ -155,12 +147,9 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
             f32x16 A[NJT];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) {
-                if (TPW == 1) A[jt] = Dk[jt];
-                else {
-                    xs_zero(A[jt]);
-                    xs_mm_kc(Ks, 32 * jt, h[tt], A[jt], l31, hh);
-                    A[jt] *= scale;
-                }
+                xs_zero(A[jt]);
+                xs_mm_kc(Ks, 32 * jt, h[tt], A[jt], l31, hh);
+                A[jt] *= scale;
             }
             float asum = 0.f;
 #pragma unroll
@@ -239,7 +228,7 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
     }
 }
 
-static size_t xs_fwd_lds_bytes(int NJT) { return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 128 + 16 + 512) * sizeof(float); }
+static size_t xs_fwd_lds_bytes(int NJT) { return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 128) + 16 + 512) * sizeof(float); }
 
 extern "C" int scouter_xslot_fwd_f32(const float* X, const float* PE, const float* const* tok_w,
                                      const float* const* tok_b, const float* slots0, const float* w_ih, const float* w_hh, const float* b_ih,
