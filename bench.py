@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the full xSlot training step (BASELINE.json configs[1]: resnest26d + positive
+xSlot, 10 classes, channel 2048, to_k_layer 3, power 2, T=3, 224x224, per-GPU batch 70, fp32) on N MI355X.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W            (one rank per GPU, gradients all-reduced over RCCL/xGMI)
+
+A step = zero_grad -> forward -> loss -> backward (+ gradient all-reduce) -> AdamW, on a synthetic batch already
+resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline      the dominant kernel class (fp32-MFMA implicit-GEMM convolution): algorithmic FLOPs / hipEvent time
+                measured over the timed region on the launch stream, vs the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline  the CPU oracle (oracle/torch_oracle.py, a port of the reference's PyTorch path) timed on this box's
+                host cores on a bounded sample of the same workload (rank 0, N=1 only)."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(model="resnest26d", num_classes=10, slots_per_class=1, channel=2048, to_k_layer=3, power=2, loss_status=1,
+           lambda_value="1", hidden_dim=64, img_size=224, batch=70)
+FWD_GFLOP_PER_IMG = 7.243 + 0.0159          # backbone conv + head, SURVEY.md section 8d / Appendix B
+PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md chip table
+PROF_CLASSES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "xslot_fwd", "xslot_bwd", "bn", "other"]
+
+
+def make_args(cfg):
+    return argparse.Namespace(model=cfg["model"], pre_trained=False, num_classes=cfg["num_classes"], dataset="ImageNet",
+                              use_slot=True, use_pre=False, grad=False, channel=cfg["channel"],
+                              slots_per_class=cfg["slots_per_class"], hidden_dim=cfg["hidden_dim"], freeze_layers=0,
+                              vis=False, vis_id=0, loss_status=cfg["loss_status"], power=cfg["power"],
+                              to_k_layer=cfg["to_k_layer"], lambda_value=cfg["lambda_value"])
+
+
+def synth_batch(B, size, C, rank, device):
+    rng = np.random.default_rng(1234 + rank)
+    x = torch.from_numpy(rng.standard_normal((B, 3, size, size), dtype=np.float32)).to(device)
+    y = torch.from_numpy(rng.integers(0, C, B).astype(np.int64)).to(device)
+    return x, y
+
+
+def cpu_baseline(cfg, sample_b=16, steps=1):
+    """The CPU oracle's train step (the port of the reference's PyTorch-CPU path) on a bounded sample."""
+    from oracle import torch_oracle as O
+    cores = min(os.cpu_count() or 1, 32)           # beyond ~32 threads torch-CPU convolution on a small batch slows down
+    torch.set_num_threads(cores)
+    spec = O.state_dict_spec(cfg["model"], cfg["num_classes"], cfg["slots_per_class"], cfg["to_k_layer"])
+    P = O.synth_state(spec, 0)
+    ocfg = dict(model=cfg["model"], num_classes=cfg["num_classes"], slots_per_class=cfg["slots_per_class"],
+                loss_status=cfg["loss_status"], power=cfg["power"], lambda_value=float(cfg["lambda_value"]))
+    tr = O.OracleTrainer(P, ocfg, lr=1e-4)
+    img, lab = O.synth_batch(sample_b, 3, cfg["img_size"], cfg["num_classes"], 1234)
+    tr.step(img, lab)                                   # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        tr.step(img, lab)
+    dt = (time.time() - t0) / steps
+    return {"value": round(sample_b / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d timed train steps (+1 warm-up) of the torch-CPU oracle, batch %d of the same %s %dx%d "
+                      "workload, torch.set_num_threads(%d)" % (steps, sample_b, cfg["model"], cfg["img_size"],
+                                                               cfg["img_size"], cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=CFG["batch"], help="per-GPU batch (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with hipEvents in the timed region")
+    a = ap.parse_args()
+
+    import __graft_entry__ as G
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        G.build()
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+        dist.barrier()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    from scouter_amd import _native
+    from scouter_amd.optim import FusedAdamW
+    from scouter_amd.parallel import DistributedDataParallel
+    from scouter_amd.sloter.slot_model import SlotModel
+
+    cfg = dict(CFG, batch=a.batch)
+    torch.manual_seed(0)
+    model = SlotModel(make_args(cfg))
+    for m in model.modules():                          # exercise every layer: last-BN gamma = 1
+        if hasattr(m, "zero_init_last_bn"):
+            torch.nn.init.ones_((m.bn3 if hasattr(m, "bn3") else m.bn2).weight)
+    model = model.to(device).train()
+    net = DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    x, y = synth_batch(cfg["batch"], cfg["img_size"], cfg["num_classes"], rank, device)
+
+    def step():
+        opt.zero_grad()
+        out, losses = net(x, y)
+        losses[0].backward()
+        opt.step()
+        return losses
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    L = _native.lib()
+    fence()
+    if not a.no_prof:
+        L.scouter_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    fence()
+    dt = time.perf_counter() - t0
+    L.scouter_prof_enable(0)
+    prof = (ctypes.c_double * (len(PROF_CLASSES) * 4))()
+    L.scouter_prof_collect(prof)
+    loss_val = float(losses[0])
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+
+    if rank == 0:
+        imgs = world * cfg["batch"] * a.steps
+        value = imgs / dt
+        kern = {}
+        for i, name in enumerate(PROF_CLASSES):
+            n, ms, fl, by = prof[4 * i:4 * i + 4]
+            if n > 0:
+                kern[name] = {"launches_per_step": n / a.steps, "ms_per_step": ms / a.steps,
+                              "avg_us": 1e3 * ms / n, "tflops": (fl / (ms * 1e-3)) / 1e12 if fl else None,
+                              "gbps_algorithmic": (by / (ms * 1e-3)) / 1e9 if by else None}
+        conv = [k for k in ("conv_fwd", "conv_dgrad", "conv_wgrad") if k in kern]
+        roofline = None
+        if conv:
+            dom = max(conv, key=lambda k: kern[k]["ms_per_step"])
+            ach = kern[dom]["tflops"]
+            roofline = {"bound": "mfma", "kernel": dom + " (fp32 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(kern[dom]["avg_us"], 2),
+                        "whole_step_frac": round(value * 3 * FWD_GFLOP_PER_IMG * 1e9 / world
+                                                 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
+        line = {"metric": "images/sec training step (resnest26d+xSlot, 224^2, bs70)", "value": round(value, 2),
+                "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BASELINE configs[1]: ImageNet-10 resnest26d + positive xSlot, channel 2048, "
+                                       "T=3, to_k_layer 3, power 2, 224x224, per-GPU batch %d, random init, AdamW "
+                                       "lr 1e-4" % cfg["batch"],
+                           "global_batch": world * cfg["batch"], "parallelism": "dp%d" % world,
+                           "step": "zero_grad+fwd+loss+bwd(+allreduce)+adamw", "final_loss": round(loss_val, 5)},
+                "roofline": roofline, "kernels": kern}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,7 @@
 // 404-412, 292-306; resnest.py:93,128-129) and their autograd backward.
 #include "common.h"
 
-#define MAXB 1024   // max partial blocks of a column reduction
+#define MAXB 2048   // max partial blocks of a column reduction
 
 struct ColGeom { long M; int C; int tpr; int rpb; int cslab; };
 
@@ -43,7 +43,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (rl < g.rpb && c < g.C) {
         f32x4 mu = {0, 0, 0, 0}, rs = {1, 1, 1, 1};
         if (MODE == 1) { mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
-        for (long r = (long)blockIdx.x * g.rpb + rl; r < g.M; r += (long)gridDim.x * g.rpb) {
+        const long rstep = (long)gridDim.x * g.rpb;
+        long r = (long)blockIdx.x * g.rpb + rl;
+        if (MODE == 0 || MODE == 2) {          // single-operand passes: 4 independent rows in flight per thread
+            for (; r + 3 * rstep < g.M; r += 4 * rstep) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(p0 + (r + u * rstep) * g.C + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        s[k] += v[u][k];
+                        if (MODE == 0) t[k] += (double)v[u][k] * v[u][k];
+                    }
+            }
+        }
+        for (; r < g.M; r += rstep) {
             const long off = r * g.C + c;
             f32x4 a = *(const f32x4*)(p0 + off);
             if (MODE == 0) {
@@ -81,18 +97,32 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
+// Sums the per-block partials of 32 channels per workgroup: 8 lanes split the nb partials, fixed-order combine.
+__device__ __forceinline__ void partial_reduce(const double* __restrict__ part, int nb, int C, int c, int bl,
+                                               double& s, double& t, double (*red)[32][2]) {
+    s = 0; t = 0;
+    if (c < C)
+        for (int b = bl; b < nb; b += 8) { s += part[((long)b * C + c) * 2]; t += part[((long)b * C + c) * 2 + 1]; }
+    red[bl][threadIdx.x & 31][0] = s;
+    red[bl][threadIdx.x & 31][1] = t;
+    __syncthreads();
+    if (bl == 0) {
+        for (int k = 1; k < 8; ++k) { s += red[k][threadIdx.x & 31][0]; t += red[k][threadIdx.x & 31][1]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                          float eps, int training, float* __restrict__ mean_o,
                                          float* __restrict__ rstd_o, float* __restrict__ scale_o,
                                          float* __restrict__ shift_o) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double mean, var;
+    __shared__ double red[8][32][2];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), bl = threadIdx.x >> 5;
+    double mean, var, s = 0, t = 0;
+    if (training) partial_reduce(part, nb, C, c, bl, s, t, red);
+    if (bl != 0 || c >= C) return;
     if (training) {
-        double s = 0, t = 0;
-        for (int b = 0; b < nb; ++b) { s += part[((long)b * C + c) * 2]; t += part[((long)b * C + c) * 2 + 1]; }
         mean = s / (double)M;
         var = t / (double)M - mean * mean;
         if (var < 0) var = 0;
@@ -130,13 +160,15 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, long M, int C, int training,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ c1,
-                                       float* __restrict__ c2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, t = 0;
-    for (int b = 0; b < nb; ++b) { s += part[((long)b * C + c) * 2]; t += part[((long)b * C + c) * 2 + 1]; }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
+                                                              int training, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ c1,
+                                                              float* __restrict__ c2) {
+    __shared__ double red[8][32][2];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), bl = threadIdx.x >> 5;
+    double s, t;
+    partial_reduce(part, nb, C, c, bl, s, t, red);
+    if (bl != 0 || c >= C) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)t;
     c1[c] = training ? (float)(s / (double)M) : 0.f;
@@ -167,12 +199,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
-__global__ void colsum_finalize_kernel(const double* __restrict__ part, int nb, int C, float* __restrict__ out,
-                                       float alpha) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0;
-    for (int b = 0; b < nb; ++b) s += part[((long)b * C + c) * 2];
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int nb, int C,
+                                                              float* __restrict__ out, float alpha) {
+    __shared__ double red[8][32][2];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), bl = threadIdx.x >> 5;
+    double s, t;
+    partial_reduce(part, nb, C, c, bl, s, t, red);
+    if (bl != 0 || c >= C) return;
     out[c] = (float)(s * alpha);
 }
 
@@ -378,7 +411,7 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
     if (training)
         hipLaunchKernelGGL(colsum_partial_kernel<0>, pgrid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                            (double*)ws, g);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(sc_cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(sc_cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, nb, M, C,
                        gamma, beta, running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out,
                        shift_out);
     const long n4 = M * C / 4;
@@ -402,7 +435,7 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
     hipStream_t st = (hipStream_t)stream;
     ScProfScope prof(SC_PROF_BN, st, 0, 28.0 * M * C);
     hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, (double*)ws, g);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, nb, M, C,
                        training, dgamma, dbeta, c1, c2);
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale, c1,
@@ -418,7 +451,7 @@ extern "C" int scouter_colsum_f32(const float* a, const float* b, float* out, lo
     hipStream_t st = (hipStream_t)stream;
     if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, pgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, (double*)ws, g);
     else hipLaunchKernelGGL(colsum_partial_kernel<2>, pgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sc_cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, nb, C, out, alpha);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sc_cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, nb, C, out, alpha);
     return sc_check_launch("colsum");
 }
 
