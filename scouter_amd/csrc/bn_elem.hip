@@ -6,7 +6,7 @@
 // 404-412, 292-306; resnest.py:93,128-129) and their autograd backward.
 #include "common.h"
 
-#define MAXB 2048   // max partial blocks of a column reduction
+#define MAXB 1024   // max partial blocks of a column reduction
 
 struct ColGeom { long M; int C; int tpr; int rpb; int cslab; };
 
@@ -97,17 +97,34 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
-// Sums the per-block partials of 32 channels per workgroup: 8 lanes split the nb partials, fixed-order combine.
+// Sums the per-block partials of FIN_CH channels per workgroup: 32 lanes split the nb partials (4 loads in flight
+// each), fixed-order combine through LDS.
+#define FIN_CH 8
+#define FIN_LANES 32
 __device__ __forceinline__ void partial_reduce(const double* __restrict__ part, int nb, int C, int c, int bl,
-                                               double& s, double& t, double (*red)[32][2]) {
-    s = 0; t = 0;
-    if (c < C)
-        for (int b = bl; b < nb; b += 8) { s += part[((long)b * C + c) * 2]; t += part[((long)b * C + c) * 2 + 1]; }
-    red[bl][threadIdx.x & 31][0] = s;
-    red[bl][threadIdx.x & 31][1] = t;
+                                               double& s, double& t, double (*red)[FIN_CH][2]) {
+    double s4[4] = {0, 0, 0, 0}, t4[4] = {0, 0, 0, 0};
+    if (c < C) {
+        int b = bl;
+        for (; b + 3 * FIN_LANES < nb; b += 4 * FIN_LANES) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double2 v = *(const double2*)(part + ((long)(b + u * FIN_LANES) * C + c) * 2);
+                s4[u] += v.x; t4[u] += v.y;
+            }
+        }
+        for (; b < nb; b += FIN_LANES) {
+            const double2 v = *(const double2*)(part + ((long)b * C + c) * 2);
+            s4[0] += v.x; t4[0] += v.y;
+        }
+    }
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    t = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    red[bl][threadIdx.x % FIN_CH][0] = s;
+    red[bl][threadIdx.x % FIN_CH][1] = t;
     __syncthreads();
     if (bl == 0) {
-        for (int k = 1; k < 8; ++k) { s += red[k][threadIdx.x & 31][0]; t += red[k][threadIdx.x & 31][1]; }
+        for (int k = 1; k < FIN_LANES; ++k) { s += red[k][threadIdx.x % FIN_CH][0]; t += red[k][threadIdx.x % FIN_CH][1]; }
     }
 }
 
@@ -117,8 +134,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
                                          float eps, int training, float* __restrict__ mean_o,
                                          float* __restrict__ rstd_o, float* __restrict__ scale_o,
                                          float* __restrict__ shift_o) {
-    __shared__ double red[8][32][2];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), bl = threadIdx.x >> 5;
+    __shared__ double red[FIN_LANES][FIN_CH][2];
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), bl = threadIdx.x / FIN_CH;
     double mean, var, s = 0, t = 0;
     if (training) partial_reduce(part, nb, C, c, bl, s, t, red);
     if (bl != 0 || c >= C) return;
@@ -164,8 +181,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                               int training, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ c1,
                                                               float* __restrict__ c2) {
-    __shared__ double red[8][32][2];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), bl = threadIdx.x >> 5;
+    __shared__ double red[FIN_LANES][FIN_CH][2];
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), bl = threadIdx.x / FIN_CH;
     double s, t;
     partial_reduce(part, nb, C, c, bl, s, t, red);
     if (bl != 0 || c >= C) return;
@@ -201,8 +218,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int nb, int C,
                                                               float* __restrict__ out, float alpha) {
-    __shared__ double red[8][32][2];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), bl = threadIdx.x >> 5;
+    __shared__ double red[FIN_LANES][FIN_CH][2];
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), bl = threadIdx.x / FIN_CH;
     double s, t;
     partial_reduce(part, nb, C, c, bl, s, t, red);
     if (bl != 0 || c >= C) return;
@@ -411,7 +428,7 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
     if (training)
         hipLaunchKernelGGL(colsum_partial_kernel<0>, pgrid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                            (double*)ws, g);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(sc_cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
                        gamma, beta, running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out,
                        shift_out);
     const long n4 = M * C / 4;
@@ -435,7 +452,7 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
     hipStream_t st = (hipStream_t)stream;
     ScProfScope prof(SC_PROF_BN, st, 0, 28.0 * M * C);
     hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, (double*)ws, g);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
                        training, dgamma, dbeta, c1, c2);
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale, c1,
@@ -451,7 +468,7 @@ extern "C" int scouter_colsum_f32(const float* a, const float* b, float* out, lo
     hipStream_t st = (hipStream_t)stream;
     if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, pgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, (double*)ws, g);
     else hipLaunchKernelGGL(colsum_partial_kernel<2>, pgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sc_cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, nb, C, out, alpha);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, C, out, alpha);
     return sc_check_launch("colsum");
 }
 

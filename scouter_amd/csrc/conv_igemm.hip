@@ -402,7 +402,9 @@ static WgradPlan wgrad_plan(const ConvGeom& g) {
     p.ci_tiles = g.Cg / p.bm;
     p.co_tiles = g.Ng / p.bn;
     p.tiles = (long)p.ci_tiles * p.co_tiles * g.groups * g.R * g.S;
-    long want = 2048 / p.tiles;                          // ~4 blocks per CU-slot in flight
+    // enough blocks to fill 256 CUs x 2 blocks twice over, but few splits for big weight tensors: every split costs a
+    // full-size slab write + read in the reduction kernel
+    long want = 1024 / p.tiles;
     if (want < 1) want = 1;
     long chunks = (g.M + BK - 1) / BK;
     long cps = (chunks + want - 1) / want;               // K-chunks (of 32 pixels) per split
