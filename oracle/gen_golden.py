@@ -8,7 +8,8 @@ oracle.torch_oracle.{state_dict_spec, synth_state, synth_batch}, so the fixtures
 Fixture families
   head_<name>.npz    reference SlotAttention (+conv1x1/PE/loss glue of SlotModel.forward) on random features
   model_<name>.npz   reference SlotModel fwd+bwd (whole network), fp32 and an fp64 "truth" run
-  engine_mnist.npz   reference engine.train_one_epoch, 2 steps of config 1 at tiny batch: record + parameter sums
+  engine_mnist.npz   reference engine.train_one_epoch + evaluate, 2 steps of config 1 (batch 16, 128x128): record +
+                     parameter digests
 """
 import os
 import sys
@@ -42,6 +43,7 @@ MODEL_CASES = {
     "resnest50d_64_spc3": ("resnest50d", 12, 3, 3, -1, 2, 3, 64, 3, False),
 }
 LAMBDA = "1"
+ENGINE_BATCH, ENGINE_SIZE = 16, 128      # engine fixture: 2 AdamW steps of config 1 at reduced batch / resolution
 
 
 def head_inputs(case, seed=100):
@@ -151,12 +153,12 @@ def run_reference_engine():
     arch, C, spc, L = "resnet18", 10, 1, 1
     args = R.make_args(model=arch, num_classes=C, slots_per_class=spc, channel=512, to_k_layer=L, power=1,
                        loss_status=1, lambda_value=LAMBDA, dataset="MNIST")
-    m = R.build_reference_slot_model(args, feature_size=2)
+    m = R.build_reference_slot_model(args, feature_size=ENGINE_SIZE // 32)
     spec = O.state_dict_spec(arch, C, spc, L, in_chans=1, mnist_stem=True)
     m.load_state_dict(O.synth_state(spec, 300))
     loader = []
     for i in range(2):
-        img, lab = O.synth_batch(4, 1, 64, C, 310 + i)
+        img, lab = O.synth_batch(ENGINE_BATCH, 1, ENGINE_SIZE, C, 310 + i)
         loader.append({"image": img.double(), "label": lab})
     params = [p for p in m.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4)

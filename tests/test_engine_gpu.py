@@ -1,0 +1,110 @@
+"""Engine / optimizer parity on the GPU: FusedAdamW vs the torch.optim.AdamW maths restated in the oracle; the
+engine loop (train_one_epoch + evaluate, 2 steps of config 1 at tiny batch) vs the record and post-step parameters
+the REFERENCE's own engine.py produced (tests/golden/engine_mnist.npz); data-parallel equivalence of the head."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_oracle as O                           # noqa: E402
+from oracle.gen_golden import grad_digest, ENGINE_BATCH, ENGINE_SIZE   # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_fused_adamw_matches_adamw_maths():
+    from scouter_amd.optim import FusedAdamW
+    rng = np.random.default_rng(0)
+    shapes = [(64, 32, 3, 3), (70000,), (3, 5), (1, 10, 64)]
+    ps = [torch.nn.Parameter(torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()) for s in shapes]
+    flat = torch.zeros(sum((p.numel() + 3) // 4 * 4 for p in ps), device="cuda")
+    off = 0
+    for p in ps:                       # gradients as views of one flat buffer (what GradArena provides)
+        p.grad = flat[off:off + p.numel()].view(p.shape)
+        off += (p.numel() + 3) // 4 * 4
+    ref_p = [p.detach().cpu().double().clone() for p in ps]
+    ref_m = [torch.zeros_like(r) for r in ref_p]
+    ref_v = [torch.zeros_like(r) for r in ref_p]
+    opt = FusedAdamW(ps, lr=1e-2)
+    for step in range(1, 4):
+        g = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in shapes]
+        for p, gi in zip(ps, g):
+            p.grad.copy_(gi.cuda())
+        opt.step()
+        for r, gi, m, v in zip(ref_p, g, ref_m, ref_v):
+            O.adamw_step(r, gi.double(), m, v, step, lr=1e-2)
+    for p, r in zip(ps, ref_p):
+        np.testing.assert_allclose(p.detach().cpu().double().numpy(), r.numpy(), rtol=2e-6, atol=2e-7)
+
+
+def _mnist_args():
+    return argparse.Namespace(model="resnet18", pre_trained=False, num_classes=10, dataset="MNIST", use_slot=True,
+                              use_pre=False, grad=False, channel=512, slots_per_class=1, hidden_dim=64,
+                              freeze_layers=0, vis=False, vis_id=0, loss_status=1, power=1, to_k_layer=1,
+                              lambda_value="1")
+
+
+def test_engine_two_steps_match_reference_engine_fixture():
+    from scouter_amd import engine
+    from scouter_amd.optim import FusedAdamW
+    from scouter_amd.sloter.slot_model import SlotModel
+    from scouter_amd.tools.calculate_tool import MetricLog
+    g = np.load(os.path.join(GOLD, "engine_mnist.npz"))
+    spec = O.state_dict_spec("resnet18", 10, 1, 1, in_chans=1, mnist_stem=True)
+    m = SlotModel(_mnist_args())
+    m.load_state_dict(O.synth_state(spec, 300))
+    m = m.cuda()
+    loader = []
+    for i in range(2):
+        img, lab = O.synth_batch(ENGINE_BATCH, 1, ENGINE_SIZE, 10, 310 + i)
+        loader.append({"image": img.double(), "label": lab})
+    opt = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    log = MetricLog()
+    dev = torch.device("cuda")
+    engine.train_one_epoch(m, loader, opt, dev, log.record, 0)
+    engine.evaluate(m, loader, dev, log.record, 0)
+    rec_t = np.array([log.record["train"][k][0] for k in ("loss", "acc", "log_loss", "att_loss")])
+    rec_v = np.array([log.record["val"][k][0] for k in ("loss", "acc", "log_loss", "att_loss")])
+    # record entries are rounded to 3 dp by the engine (engine.py:45-48); train-mode entries must agree to that
+    # rounding; the eval-mode loss (running statistics after only two momentum-0.1 updates, |loss| ~ 10, no batch
+    # normalisation to absorb the +-lr Adam sign noise described below) to 5e-3 relative, accuracy exactly.
+    np.testing.assert_allclose(rec_t, g["record_train"], atol=1.01e-3)
+    np.testing.assert_allclose(rec_v, g["record_val"], atol=2.01e-3, rtol=5e-3)
+    assert rec_v[1] == g["record_val"][1]
+    # Post-step parameters.  Adam's first steps move EVERY entry by ~lr*sign(g): an entry whose gradient is within fp32
+    # noise of zero can legitimately step the other way, so per entry the bound is 2 steps x 2 lr = 4e-4 (+ rounding),
+    # while the tensor-level sums must agree much more tightly.
+    sd = m.state_dict()
+    for k, d in zip(g["param_keys"], g["param_digest"]):
+        mine = grad_digest(sd[str(k)].cpu())
+        n = sd[str(k)].numel()
+        assert abs(mine[1] - d[1]) <= 1e-3 * d[1] + 1e-6, str(k)
+        assert abs(mine[0] - d[0]) <= 4e-4 * 0.05 * n + 1e-4 * d[1] + 1e-6, str(k)
+        np.testing.assert_allclose(mine[2:], d[2:], atol=4.1e-4, rtol=1e-3, err_msg=str(k))
+
+
+def test_head_data_parallel_equivalence():
+    """mean-of-shard gradients == full-batch gradients for the head (power 1 so that the area term is linear in the
+    batch): what the flat all-reduce of scouter_amd.parallel computes across ranks."""
+    from scouter_amd.sloter.slot_model import SlotModel
+    rng = np.random.default_rng(3)
+    B, Cin, side = 8, 512, 7
+    feat = torch.from_numpy(np.maximum(rng.standard_normal((B, side, side, Cin)), 0).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.integers(0, 10, B)).cuda()
+    m = SlotModel(_mnist_args()).cuda()
+    one = torch.ones((), device="cuda")
+
+    m.grad_arena()                      # bind the gradient arena before the first backward (SlotModel.forward does)
+
+    def grads(f, t):
+        _, _, hs = m._head_forward(f.contiguous(), t, True)
+        m._head_backward(hs, None, one, None, None, True)
+        return m.grad_arena().flat.clone()
+    full = grads(feat, y)
+    shard = 0.5 * (grads(feat[:4], y[:4]) + grads(feat[4:], y[4:]))
+    scale = float(full.abs().max())
+    assert float((full - shard).abs().max()) <= 2e-5 * max(scale, 1.0)

@@ -7,7 +7,8 @@ import pytest
 import torch
 
 from oracle import torch_oracle as O
-from oracle.gen_golden import HEAD_CASES, MODEL_CASES, LAMBDA, head_inputs, model_inputs, grad_digest
+from oracle.gen_golden import (HEAD_CASES, MODEL_CASES, LAMBDA, ENGINE_BATCH, ENGINE_SIZE, head_inputs, model_inputs,
+                               grad_digest)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -141,13 +142,13 @@ def test_model_oracle_fp64_matches_reference_fp64_full_size():
 
 
 def test_engine_oracle_matches_reference_fixture():
-    """2 training steps + eval of config 1 at tiny batch: MetricLog record entries and post-step parameters."""
+    """2 training steps + eval of config 1 (batch 16, 128x128): MetricLog record entries and post-step parameters."""
     g = load("engine_mnist")
     spec = O.state_dict_spec("resnet18", 10, 1, 1, in_chans=1, mnist_stem=True)
     P = O.synth_state(spec, 300)
     cfg = dict(model="resnet18", num_classes=10, slots_per_class=1, loss_status=1, power=1, lambda_value=1.0)
     tr = O.OracleTrainer(P, cfg, lr=1e-4)
-    batches = [O.synth_batch(4, 1, 64, 10, 310 + i) for i in range(2)]
+    batches = [O.synth_batch(ENGINE_BATCH, 1, ENGINE_SIZE, 10, 310 + i) for i in range(2)]
     run = np.zeros(4)
     for img, lab in batches:
         out, losses, acc, _ = tr.step(img, lab)
