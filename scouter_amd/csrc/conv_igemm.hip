@@ -12,6 +12,8 @@
 // reads and the global prefetch of the next K-tile hide under it -- no reshaping tricks, exact fp32 (fmaf chain).
 #include "common.h"
 
+#include <type_traits>
+
 struct ConvGeom {
     int B, H, W, C;   // tensor feeding the A operand, NHWC, C = all channels
     int Ho, Wo;       // pixel grid of the GEMM rows
@@ -35,7 +37,7 @@ struct TileCfg {
 // ----------------------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ----------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool DGRAD>
+template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ addend, float* __restrict__ dst,
@@ -59,63 +61,89 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     const int cpt = g.Cg / BK;                 // K chunks per filter tap
     const int KT = g.R * g.S * cpt;
 
-    // ---- per-thread A rows (fixed for the whole K loop)
+    // ---- per-thread A rows (fixed for the whole K loop): pointer of filter tap (0,0) + a validity bit per tap, so
+    // the in-loop address work is one 64-bit add of a wave-uniform tap offset and a bit test (the general
+    // bounds/stride arithmetic per load cost ~25 VALU issues each and measurably starved the MFMA issue)
+    const float* a_ptr[AI];
+    unsigned a_mask[AI];
     int a_y[AI], a_x[AI];
     long a_base[AI];
-    bool a_ok[AI];
     const int a_col = (tid & 7) * 4;
+    constexpr bool lin = !(DGRAD && STRIDED);          // source pixel is linear in the tap index
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const long m = m0 + (tid >> 3) + 32 * i;
-        a_ok[i] = m < g.M;
-        const long mm = a_ok[i] ? m : 0;
+        const bool okm = m < g.M;
+        const long mm = okm ? m : 0;
         const int hw = g.Ho * g.Wo;
         const int b = (int)(mm / hw), rem = (int)(mm % hw);
         const int y = rem / g.Wo, x = rem % g.Wo;
         a_base[i] = (long)b * g.H * g.W;
         if (DGRAD) { a_y[i] = y + g.pad; a_x[i] = x + g.pad; }
         else       { a_y[i] = y * g.stride - g.pad; a_x[i] = x * g.stride - g.pad; }
+        unsigned mask = 0;
+        for (int r = 0; r < g.R; ++r)
+            for (int q = 0; q < g.S; ++q) {
+                int iy, ix;
+                bool ok = okm;
+                if (DGRAD) {
+                    const int ty = a_y[i] - r, tx = a_x[i] - q;
+                    ok = ok && ty >= 0 && tx >= 0;
+                    iy = ty / g.stride; ix = tx / g.stride;
+                    ok = ok && (iy * g.stride == ty) && (ix * g.stride == tx);
+                } else { iy = a_y[i] + r; ix = a_x[i] + q; ok = ok && iy >= 0 && ix >= 0; }
+                ok = ok && iy < g.H && ix < g.W;
+                mask |= (ok ? 1u : 0u) << (r * g.S + q);
+            }
+        a_mask[i] = mask;
+        a_ptr[i] = src + (a_base[i] + (long)a_y[i] * g.W + a_x[i]) * g.C + grp * g.Cg + a_col;
     }
     const float* wbase = wgt + (long)grp * (DGRAD ? g.Cg : g.Ng);   // group offset along the contiguous Cout axis
 
+    // ---- software pipeline (per wave; the MFMA stream never waits for memory inside a K-tile):
+    //   global -> registers G   two tiles ahead        (issued in the shadow of tile k's MFMAs, phase 1)
+    //   G -> LDS[(k+1)&1]        one tile ahead         (phase 1)                       -> barrier
+    //   LDS -> fragment registers, per HALF K-tile (16 of the 32 k's): F1(k) during phase 1, F0(k+1) during phase 2
+    // Counters on the first version (fragments fetched at the top of every tile) showed the matrix pipe 64 % busy:
+    // the two co-resident blocks convoy and sit in their LDS round trips together.
     f32x4 ra[AI], rb[BI];
-    auto load_tile = [&](int kt) {
+    auto load_a = [&](int kt) {
         const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
         const int r = tap / g.S, q = tap - r * g.S;
+        // wave-uniform element offset of this (tap, channel chunk) relative to tap (0,0)
+        const long toff = (DGRAD ? -((long)r * g.W + q) : ((long)r * g.W + q)) * g.C + c0;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            int iy, ix;
-            bool ok = a_ok[i];
-            if (DGRAD) {
-                const int ty = a_y[i] - r, tx = a_x[i] - q;
-                ok = ok && ty >= 0 && tx >= 0;
-                if (g.stride == 1) { iy = ty; ix = tx; }
-                else {
-                    iy = ty / g.stride; ix = tx / g.stride;
-                    ok = ok && (iy * g.stride == ty) && (ix * g.stride == tx);
-                }
-            } else { iy = a_y[i] + r; ix = a_x[i] + q; ok = ok && iy >= 0 && ix >= 0; }
-            ok = ok && iy < g.H && ix < g.W;
+            const bool ok = (a_mask[i] >> tap) & 1u;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *(const f32x4*)(src + (a_base[i] + (long)iy * g.W + ix) * g.C + grp * g.Cg + c0 + a_col);
+            if (lin) {
+                if (ok) v = *(const f32x4*)(a_ptr[i] + toff);
+            } else if (ok) {                            // strided dgrad (resnet18 only): general addressing
+                const int iy = (a_y[i] - r) / g.stride, ix = (a_x[i] - q) / g.stride;
+                v = *(const f32x4*)(src + (a_base[i] + (long)iy * g.W + ix) * g.C + grp * g.Cg + c0 + a_col);
+            }
             ra[i] = v;
         }
-#pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            if (B_KC) {   // rows = n (ci), contiguous k (co)
-                const int n = n0 + (tid >> 3) + 32 * i;
-                rb[i] = *(const f32x4*)(wbase + (long)tap * g.wtap + (long)n * g.wrow + c0 + a_col);
-            } else {      // rows = k (ci), contiguous n (co)
-                const int c = tid + 256 * i, krow = c / (BN / 4), col4 = c % (BN / 4);
-                rb[i] = *(const f32x4*)(wbase + (long)tap * g.wtap + (long)(c0 + krow) * g.wrow + n0 + col4 * 4);
-            }
-        }
     };
-    auto store_tile = [&](int buf) {
+    const float* b_ptr[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        if (B_KC) b_ptr[i] = wbase + (long)(n0 + (tid >> 3) + 32 * i) * g.wrow + a_col;
+        else { const int c = tid + 256 * i, krow = c / (BN / 4), col4 = c % (BN / 4); b_ptr[i] = wbase + (long)krow * g.wrow + n0 + col4 * 4; }
+    }
+    auto load_b = [&](int kt) {
+        const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+        const long woff = (long)tap * g.wtap + (B_KC ? (long)c0 : (long)c0 * g.wrow);     // wave-uniform
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[i] = *(const f32x4*)(b_ptr[i] + woff);
+    };
+    auto store_a = [&](int buf) {
         float* As = lds + buf * T::STAGE;
-        float* Bs = As + T::A_ELEMS;
 #pragma unroll
         for (int i = 0; i < AI; ++i) *(f32x4*)(As + ((tid >> 3) + 32 * i) * LDK + a_col) = ra[i];
+    };
+    auto store_b = [&](int buf) {
+        float* Bs = lds + buf * T::STAGE + T::A_ELEMS;
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             if (B_KC) *(f32x4*)(Bs + ((tid >> 3) + 32 * i) * LDK + a_col) = rb[i];
@@ -131,45 +159,82 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto compute = [&](int buf) {
+    // half-tile fragments: p = 0 -> k-steps 0..7, p = 1 -> k-steps 8..15 (lane half h covers k = 16 h + step)
+    f32x4 fa[2][MT][2];
+    f32x4 fbk[2][NT][2];
+    float fbv[2][8][NT];
+    auto frag_a = [&](int buf, auto P) {
+        constexpr int pp = decltype(P)::value;
         const float* As = lds + buf * T::STAGE;
-        const float* Bs = As + T::A_ELEMS;
-        f32x4 a[MT][4];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[i][q] = *(const f32x4*)(As + (wm * WM + i * 32 + l31) * LDK + h * 16 + q * 4);
-        f32x4 bk[NT][4];
+            for (int q = 0; q < 2; ++q)
+                fa[pp][i][q] = *(const f32x4*)(As + (wm * WM + i * 32 + l31) * LDK + h * 16 + (2 * pp + q) * 4);
+    };
+    auto frag_b = [&](int buf, auto P) {
+        constexpr int pp = decltype(P)::value;
+        const float* Bs = lds + buf * T::STAGE + T::A_ELEMS;
         if (B_KC) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    bk[j][q] = *(const f32x4*)(Bs + (wn * WN + j * 32 + l31) * LDK + h * 16 + q * 4);
+                for (int q = 0; q < 2; ++q)
+                    fbk[pp][j][q] = *(const f32x4*)(Bs + (wn * WN + j * 32 + l31) * LDK + h * 16 + (2 * pp + q) * 4);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fbv[pp][s][j] = Bs[(h * 16 + 8 * pp + s) * BN + wn * WN + j * 32 + l31];
         }
+    };
+    auto mma = [&](auto P, int s0, int s1) {          // k-steps [s0, s1) of half pp
+        constexpr int pp = decltype(P)::value;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            float bv[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                bv[j] = B_KC ? bk[j][s >> 2][s & 3] : Bs[(h * 16 + s) * BN + wn * WN + j * 32 + l31];
+        for (int s = s0; s < s1; ++s)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(a[i][s >> 2][s & 3], bv[j], acc[i][j]);
-        }
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = mfma32(fa[pp][i][s >> 2][s & 3], B_KC ? fbk[pp][j][s >> 2][s & 3] : fbv[pp][s][j],
+                                       acc[i][j]);
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+#define SB() __builtin_amdgcn_sched_barrier(0)
 
-    load_tile(0);
-    store_tile(0);
+    // prologue: tile 0 -> LDS[0], tile 1 -> registers, F0(0) -> fragment registers
+    load_a(0); load_b(0);
+    store_a(0); store_b(0);
+    if (KT > 1) { load_a(1); load_b(1); }
     __syncthreads();
+    frag_a(0, P0{}); frag_b(0, P0{});
     for (int kt = 0; kt < KT; ++kt) {
-        const bool more = kt + 1 < KT;
-        if (more) load_tile(kt + 1);
-        compute(kt & 1);
-        if (more) store_tile((kt + 1) & 1);
+        const int cur = kt & 1, nxt = cur ^ 1;
+        const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
+        // ---- phase 1: MFMAs of F0(kt); in their shadow: F1(kt) <- LDS[cur], G(kt+1) -> LDS[nxt], G(kt+2) <- global
+        SB();
+        frag_a(cur, P1{});
+        mma(P0{}, 0, 1); SB();
+        frag_b(cur, P1{});
+        mma(P0{}, 1, 2); SB();
+        if (has1) store_a(nxt);
+        mma(P0{}, 2, 4); SB();
+        if (has1) store_b(nxt);
+        mma(P0{}, 4, 5); SB();
+        if (has2) load_a(kt + 2);
+        mma(P0{}, 5, 7); SB();
+        if (has2) load_b(kt + 2);
+        mma(P0{}, 7, 8); SB();
         __syncthreads();
+        // ---- phase 2: MFMAs of F1(kt); in their shadow: F0(kt+1) <- LDS[nxt]
+        SB();
+        if (has1) frag_a(nxt, P0{});
+        mma(P1{}, 0, 1); SB();
+        if (has1) frag_b(nxt, P0{});
+        mma(P1{}, 1, 8); SB();
     }
+#undef SB
 
     // ---- epilogue: one 128-B row segment per (register, half-wave)
 #pragma unroll
@@ -220,37 +285,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     const int KT = (int)((mend - mbeg + BK - 1) / BK);
     const int hw = g.Ho * g.Wo;
 
+    // per-thread pixel state of its A rows, advanced by BK pixels per chunk without divisions
+    int pb[AI], py[AI], px[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int c = tid + 256 * i, prow = c / (BM / 4);
+        const long m = mbeg + prow;
+        pb[i] = (int)(m / hw);
+        const int rem = (int)(m % hw);
+        py[i] = rem / g.Wo;
+        px[i] = rem - py[i] * g.Wo;
+    }
+    const int a_c4 = ((tid % (BM / 4)) * 4), b_c4 = ((tid % (BN / 4)) * 4);
+    const float* actg = act + grp * g.Cg + ci0 + a_c4;
+    const float* dyg = dy + grp * g.Ng + co0 + b_c4;
     f32x4 ra[AI], rb[BI];
-    auto load_tile = [&](int kt) {
-        const long mb = mbeg + (long)kt * BK;
+    long a_m = mbeg;                    // first pixel of the chunk the next load_a fetches
+    auto load_a = [&]() {
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int c = tid + 256 * i, prow = c / (BM / 4), col4 = c % (BM / 4);
-            const long m = mb + prow;
+            const int c = tid + 256 * i, prow = c / (BM / 4);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < mend) {
-                const int b = (int)(m / hw), rem = (int)(m % hw);
-                const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-                const int iy = oy * g.stride - g.pad + r, ix = ox * g.stride - g.pad + q;
-                if (iy >= 0 && ix >= 0 && iy < g.H && ix < g.W)
-                    v = *(const f32x4*)(act + (((long)b * g.H + iy) * g.W + ix) * g.C + grp * g.Cg + ci0 + col4 * 4);
-            }
+            const int iy = py[i] * g.stride - g.pad + r, ix = px[i] * g.stride - g.pad + q;
+            if (a_m + prow < mend && iy >= 0 && ix >= 0 && iy < g.H && ix < g.W)
+                v = *(const f32x4*)(actg + (((long)pb[i] * g.H + iy) * g.W + ix) * g.C);
             ra[i] = v;
+            px[i] += BK;                                 // advance this row by one chunk
+            while (px[i] >= g.Wo) { px[i] -= g.Wo; ++py[i]; }
+            while (py[i] >= g.Ho) { py[i] -= g.Ho; ++pb[i]; }
         }
+        a_m += BK;
+    };
+    long b_m = mbeg;
+    auto load_b = [&]() {
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            const int c = tid + 256 * i, prow = c / (BN / 4), col4 = c % (BN / 4);
-            const long m = mb + prow;
+            const int c = tid + 256 * i, prow = c / (BN / 4);
+            const long m = b_m + prow;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < mend) v = *(const f32x4*)(dy + m * g.N + grp * g.Ng + co0 + col4 * 4);
+            if (m < mend) v = *(const f32x4*)(dyg + m * g.N);
             rb[i] = v;
         }
+        b_m += BK;
     };
-    auto store_tile = [&](int buf) {
+    auto store_a = [&](int buf) {
         float* As = lds + buf * STAGE;
-        float* Bs = As + BK * BM;
 #pragma unroll
         for (int i = 0; i < AI; ++i) *(f32x4*)(As + (tid + 256 * i) * 4) = ra[i];
+    };
+    auto store_b = [&](int buf) {
+        float* Bs = lds + buf * STAGE + BK * BM;
 #pragma unroll
         for (int i = 0; i < BI; ++i) *(f32x4*)(Bs + (tid + 256 * i) * 4) = rb[i];
     };
@@ -261,35 +345,57 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    auto compute = [&](int buf) {
+    // half-chunk fragments (same software pipeline as igemm_kernel): this wave's SPW k-steps split in two halves
+    constexpr int HS = SPW / 2;
+    float fa[2][HS][MT], fb[2][HS][NT];
+    auto frag = [&](int buf, auto P) {
+        constexpr int pp = decltype(P)::value;
         const float* As = lds + buf * STAGE;
         const float* Bs = As + BK * BM;
 #pragma unroll
-        for (int ss = 0; ss < SPW; ++ss) {
-            const int s = wk * SPW + ss;
-            float av[MT], bv[NT];
+        for (int ss = 0; ss < HS; ++ss) {
+            const int s = wk * SPW + pp * HS + ss;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = As[(h * 16 + s) * BM + wm * WM + i * 32 + l31];
+            for (int i = 0; i < MT; ++i) fa[pp][ss][i] = As[(h * 16 + s) * BM + wm * WM + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = Bs[(h * 16 + s) * BN + wn * WN + j * 32 + l31];
+            for (int j = 0; j < NT; ++j) fb[pp][ss][j] = Bs[(h * 16 + s) * BN + wn * WN + j * 32 + l31];
+        }
+    };
+    auto mma = [&](auto P, int s0, int s1) {
+        constexpr int pp = decltype(P)::value;
+#pragma unroll
+        for (int ss = s0; ss < s1; ++ss)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
-        }
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fa[pp][ss][i], fb[pp][ss][j], acc[i][j]);
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+#define SB() __builtin_amdgcn_sched_barrier(0)
     if (KT > 0) {
-        load_tile(0);
-        store_tile(0);
+        load_a(); load_b();
+        store_a(0); store_b(0);
+        if (KT > 1) { load_a(); load_b(); }
     }
     __syncthreads();
+    if (KT > 0) frag(0, P0{});
     for (int kt = 0; kt < KT; ++kt) {
-        const bool more = kt + 1 < KT;
-        if (more) load_tile(kt + 1);
-        compute(kt & 1);
-        if (more) store_tile((kt + 1) & 1);
+        const int cur = kt & 1, nxt = cur ^ 1;
+        const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
+        SB();
+        frag(cur, P1{});
+        mma(P0{}, 0, HS / 2); SB();
+        if (has1) { store_a(nxt); store_b(nxt); }
+        if (has2) load_a();
+        mma(P0{}, HS / 2, HS); SB();
+        if (has2) load_b();
         __syncthreads();
+        SB();
+        if (has1) frag(nxt, P0{});
+        mma(P1{}, 0, HS); SB();
     }
+#undef SB
     float* o = out + (long)blockIdx.y * slab + (long)tap * g.Cg * g.N;
     if (WK == 1) {
 #pragma unroll
@@ -322,26 +428,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     }
 }
 
-// sums the split slabs in a fixed order (deterministic); optional accumulate into dst
-__global__ void slab_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst, long n, int splits,
-                                   long slab) {
-    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    f32x4 s = *(const f32x4*)(part + i);
-    for (int k = 1; k < splits; ++k) s += *(const f32x4*)(part + (long)k * slab + i);
-    *(f32x4*)(dst + i) = s;
+// Sums the split slabs in a fixed order (deterministic).  Block = 8 float4 columns x 32 split-lanes: each lane adds
+// every 32nd slab with 4 loads in flight, then a fixed-order LDS combine -- a thread per element looping over
+// hundreds of splits would serialise that many dependent HBM/L2 round trips.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                                          long n, int splits, long slab) {
+    __shared__ f32x4 red[32][8];
+    const int q = threadIdx.x & 7, lane = threadIdx.x >> 3;
+    const long i = ((long)blockIdx.x * 8 + q) * 4;
+    f32x4 s4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        int k = lane;
+        for (; k + 96 < splits; k += 128) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += *(const f32x4*)(part + (long)(k + 32 * u) * slab + i);
+        }
+        for (; k < splits; k += 32) s4[0] += *(const f32x4*)(part + (long)k * slab + i);
+    }
+    red[lane][q] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    __syncthreads();
+    if (lane == 0 && i < n) {
+        f32x4 s = red[0][q];
+        for (int k = 1; k < 32; ++k) s += red[k][q];
+        *(f32x4*)(dst + i) = s;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
 // host dispatch
 // ----------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool DGRAD>
-static void launch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
+template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED>
+static void launch_igemm_s(const float* src, const float* w, const float* bias, const float* addend, float* dst,
                          const ConvGeom& g, int relu, hipStream_t st) {
     const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
     dim3 grid(mtiles * ntiles * g.groups);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD>), grid, dim3(256), 0, st, src, w, bias, addend, dst, g,
-                       relu, mtiles, ntiles);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED>), grid, dim3(256), 0, st, src, w, bias, addend,
+                       dst, g, relu, mtiles, ntiles);
+}
+template <int BM, int BN, int WM, int WN, bool DGRAD>
+static void launch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
+                         const ConvGeom& g, int relu, hipStream_t st) {
+    if (DGRAD && g.stride != 1) launch_igemm_s<BM, BN, WM, WN, DGRAD, true>(src, w, bias, addend, dst, g, relu, st);
+    else launch_igemm_s<BM, BN, WM, WN, DGRAD, false>(src, w, bias, addend, dst, g, relu, st);
 }
 
 template <bool DGRAD>
@@ -467,7 +597,7 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
     if (rc) return rc;
     if (p.splits > 1) {
         const long n = slab;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(n / 4, 256)), dim3(256), 0, st, (const float*)ws, dw, n,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(n / 4, 8)), dim3(256), 0, st, (const float*)ws, dw, n,
                            p.splits, slab);
         rc = sc_check_launch("conv2d_wgrad_reduce");
     }
