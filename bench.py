@@ -86,7 +86,8 @@ def main():
     if rank == 0:
         G.build()
     import torch.distributed as dist
-    if world > 1:
+    force_dp = bool(os.environ.get("SCOUTER_FORCE_DP"))      # dev: exercise the RCCL path with a 1-rank group
+    if world > 1 or (force_dp and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
@@ -107,7 +108,7 @@ def main():
         if hasattr(m, "zero_init_last_bn"):
             torch.nn.init.ones_((m.bn3 if hasattr(m, "bn3") else m.bn2).weight)
     model = model.to(device).train()
-    net = DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
+    net = DistributedDataParallel(model, device_ids=[local_rank]) if (world > 1 or dist.is_initialized()) else model
     opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
     x, y = synth_batch(cfg["batch"], cfg["img_size"], cfg["num_classes"], rank, device)
 
@@ -120,7 +121,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -140,7 +141,7 @@ def main():
     L.scouter_prof_collect(prof)
     loss_val = float(losses[0])
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
@@ -178,7 +179,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -165,6 +165,13 @@ class GradArena:
                     raise RuntimeError("no gradient binding for parameter %s" % name)
                 hook(leaf, seg)
 
+    def first_offset(self, prefix):
+        """Arena offset of the first parameter whose name starts with `prefix` (None if there is none)."""
+        for name, p, o, n in self.entries:
+            if name.startswith(prefix):
+                return o
+        return None
+
     def attach(self):
         """Expose the arena slices as param.grad (PyTorch semantics: .grad holds the gradient of the last backward)."""
         for name, p, o, n in self.entries:

@@ -21,41 +21,88 @@ class DistributedDataParallel(nn.Module):
         self.process_group = process_group
         self.broadcast_buffers = broadcast_buffers
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        if self.world_size > 1:
+        self._active = dist.is_initialized()          # a 1-rank group still runs the collectives (used by tests)
+        if self._active:
             self._sync_module_states()
-        module._post_backward_hooks.append(self._reduce_gradients)
+        self._pending = []
+        self._buf_flat = None
+        if self._active and broadcast_buffers:
+            self._flatten_float_buffers()
+        module._grad_ready_hooks.append(self._launch_bucket)
+        module._post_backward_hooks.append(self._finish_gradients)
 
     def _float_buffers(self):
         return [b for b in self.module.buffers() if b.dtype.is_floating_point]
 
-    def _sync_module_states(self):
-        with torch.no_grad():
-            for t in list(self.module.parameters()) + list(self.module.buffers()):
-                dist.broadcast(t.data, src=0, group=self.process_group)
+    @staticmethod
+    def _dense(t):
+        """A contiguous tensor sharing t's storage (conv weights are logical-OIHW views over an HWIO buffer)."""
+        if t.is_contiguous():
+            return t
+        if t.dim() == 4 and t.permute(2, 3, 1, 0).is_contiguous():
+            return t.permute(2, 3, 1, 0)
+        raise RuntimeError("parameter with an unexpected memory layout: %s / %s" % (tuple(t.shape), t.stride()))
 
-    def _broadcast_buffers(self):
-        bufs = self._float_buffers()
-        if not bufs:
+    def _coalesced_broadcast(self, tensors):
+        """One broadcast from rank 0 for a list of same-dtype tensors (memory movement only)."""
+        if not tensors:
             return
-        flat = torch.cat([b.reshape(-1) for b in bufs])      # memory movement only (coalesced broadcast)
+        dense = [self._dense(t.data) for t in tensors]
+        flat = torch.cat([d.reshape(-1) for d in dense])
         dist.broadcast(flat, src=0, group=self.process_group)
         off = 0
         with torch.no_grad():
-            for b in bufs:
-                n = b.numel()
-                b.copy_(flat[off:off + n].view_as(b))
+            for d in dense:
+                n = d.numel()
+                d.copy_(flat[off:off + n].view_as(d))
                 off += n
 
-    def _reduce_gradients(self, arena):
-        if self.world_size <= 1:
+    def _sync_module_states(self):
+        ts = list(self.module.parameters()) + list(self.module.buffers())
+        for dtype in sorted({t.dtype for t in ts}, key=str):
+            self._coalesced_broadcast([t for t in ts if t.dtype == dtype])
+
+    def _flatten_float_buffers(self):
+        """Re-point every floating-point buffer (BatchNorm running statistics) at a slice of ONE flat tensor so the
+        per-step DDP-style buffer broadcast is a single collective without gather/scatter copies."""
+        named = [(m, n, b) for m in self.module.modules() for n, b in m._buffers.items()
+                 if b is not None and b.dtype == torch.float32]
+        if not named:
             return
-        dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM, group=self.process_group)
+        flat = torch.cat([b.detach().reshape(-1) for _, _, b in named])
+        off = 0
+        for m, n, b in named:
+            k = b.numel()
+            m._buffers[n] = flat[off:off + k].view(b.shape)
+            off += k
+        self._buf_flat, self._buf_first = flat, named[0][0]._buffers[named[0][1]]
+
+    def _broadcast_buffers(self):
+        if self._buf_flat is not None and self._buf_first.data_ptr() == self._buf_flat.data_ptr():
+            dist.broadcast(self._buf_flat, src=0, group=self.process_group)
+        else:                                   # buffers were re-allocated (e.g. module.to(...)): gather / scatter
+            self._coalesced_broadcast(self._float_buffers())
+
+    def _launch_bucket(self, arena, lo, hi):
+        """arena.flat[lo:hi] is final: start its sum-all-reduce now (asynchronously on RCCL's stream, ordered after
+        the kernels already queued on the compute stream) so that it overlaps the rest of the backward pass."""
+        if not self._active or hi <= lo:
+            return
+        self._pending.append(dist.all_reduce(arena.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.process_group,
+                                             async_op=True))
+
+    def _finish_gradients(self, arena):
+        if not self._active:
+            return
+        for work in self._pending:
+            work.wait()                  # makes the compute stream wait for the collective (no host sync on NCCL)
+        self._pending = []
         if arena.flat.is_cuda:
             K.axpby(arena.flat, None, 1.0 / self.world_size, 0.0, out=arena.flat)
         else:                                                 # gloo/CPU plumbing tests only
             arena.flat.mul_(1.0 / self.world_size)
 
     def forward(self, *args, **kwargs):
-        if self.world_size > 1 and self.broadcast_buffers and self.module.training and torch.is_grad_enabled():
+        if self._active and self.broadcast_buffers and self.module.training and torch.is_grad_enabled():
             self._broadcast_buffers()
         return self.module(*args, **kwargs)

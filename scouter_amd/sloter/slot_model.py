@@ -85,6 +85,7 @@ class SlotModel(nn.Module):
         self._arena = None
         self._anchor = None
         self._post_backward_hooks = []       # called with the GradArena after every backward (data-parallel reduce)
+        self._grad_ready_hooks = []          # called (arena, lo, hi) as soon as arena.flat[lo:hi] is final
         self.last_stats = None               # device tensor [loss, nll, area**power, top1, area] of the last forward
 
     def dfs_freeze(self, model, freeze_layer_num):
@@ -153,8 +154,20 @@ class SlotModel(nn.Module):
         arena = self.grad_arena()
         need = self.backbone._first_trainable_stage() < 5
         dfeat = self._head_backward(hstate, g_logp, g_loss, g_nll, g_term, need_dfeat=need)
+        # gradient ranges become final from the END of the arena (head, layer4) towards its start (stem)
+        done_hi = [arena.numel]
+
+        def stage_done(name):
+            lo = arena.first_offset("backbone." + name + ".")
+            if lo is not None and lo < done_hi[0]:
+                for hook in self._grad_ready_hooks:
+                    hook(arena, lo, done_hi[0])
+                done_hi[0] = lo
         if need:
-            self.backbone.features_bwd(dfeat, bctx)
+            self.backbone.features_bwd(dfeat, bctx, stage_done if self._grad_ready_hooks else None)
+        if self._grad_ready_hooks and done_hi[0] > 0:
+            for hook in self._grad_ready_hooks:
+                hook(arena, 0, done_hi[0])
         arena.attach()
         for hook in self._post_backward_hooks:
             hook(arena)

@@ -161,7 +161,9 @@ class ResNet(nn.Module):
                 return i
         return 5
 
-    def features_bwd(self, dfeat, ctx):
+    def features_bwd(self, dfeat, ctx, on_stage_done=None):
+        """`on_stage_done(name)` is called when every gradient of layer4 / layer3 / layer2 / layer1 has been
+        written (used to launch that stage's gradient all-reduce while earlier layers are still in backward)."""
         first = self._first_trainable_stage()
         blocks = [(li, blk) for li in range(1, 5) for blk in getattr(self, "layer%d" % li)]
         d = dfeat
@@ -171,6 +173,8 @@ class ResNet(nn.Module):
                 return
             is_first_trainable = li == first and (idx == 0 or blocks[idx - 1][0] < first)
             d = blk.bwd(d, ctx[2 + idx], need_dx=not is_first_trainable)
+            if on_stage_done is not None and (idx == 0 or blocks[idx - 1][0] != li):
+                on_stage_done("layer%d" % li)
         if first > 0:
             return
         bb, arg, hshape = ctx[1]

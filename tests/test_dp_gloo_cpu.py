@@ -28,6 +28,7 @@ class Stub(nn.Module):
         self.conv = Conv2d(32, 64, 3, 1, 1)
         self.bn = BatchNorm2d(64)
         self._post_backward_hooks = []
+        self._grad_ready_hooks = []
         self.arena = None
 
     def forward(self, fill):
@@ -35,6 +36,11 @@ class Stub(nn.Module):
         if self.arena is None:
             self.arena = GradArena(self)
         self.arena.flat.fill_(fill)            # "backward": every gradient element = fill
+        half = self.arena.numel // 2 // 4 * 4
+        for h in self._grad_ready_hooks:            # two buckets, tail first (like the real backward)
+            h(self.arena, half, self.arena.numel)
+        for h in self._grad_ready_hooks:
+            h(self.arena, 0, half)
         self.arena.attach()
         for h in self._post_backward_hooks:
             h(self.arena)

@@ -108,3 +108,34 @@ def test_head_data_parallel_equivalence():
     shard = 0.5 * (grads(feat[:4], y[:4]) + grads(feat[4:], y[4:]))
     scale = float(full.abs().max())
     assert float((full - shard).abs().max()) <= 2e-5 * max(scale, 1.0)
+
+
+def test_data_parallel_wrapper_on_rccl_single_rank_group():
+    """The RCCL path on device tensors (1-rank 'nccl' group): construction broadcast of the permuted-layout conv
+    weights, per-step buffer broadcast, bucketed async gradient all-reduce + 1/world scale.  Gradients must equal
+    the un-wrapped model's bit for bit (sum over one rank, scale by 1)."""
+    import socket
+    import torch.distributed as dist
+    from scouter_amd.parallel import DistributedDataParallel
+    from scouter_amd.sloter.slot_model import SlotModel
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        spec = O.state_dict_spec("resnet18", 10, 1, 1, in_chans=1, mnist_stem=True)
+        P = O.synth_state(spec, 300)
+        img, lab = O.synth_batch(4, 1, 64, 10, 310)
+        grads = []
+        for wrap in (False, True):
+            m = SlotModel(_mnist_args())
+            m.load_state_dict(P)
+            m = m.cuda().train()
+            net = DistributedDataParallel(m, device_ids=[0]) if wrap else m
+            out, losses = net(img.cuda(), lab.cuda())
+            losses[0].backward()
+            torch.cuda.synchronize()
+            grads.append(m.grad_arena().flat.clone())
+            if wrap:
+                assert len(m._grad_ready_hooks) == 1 and net._pending == []
+        assert torch.equal(grads[0], grads[1])
+    finally:
+        dist.destroy_process_group()
