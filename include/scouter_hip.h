@@ -127,6 +127,13 @@ int scouter_slot_loss_bwd_f32(const float* logp, const long* labels, const float
                               double area_count, float lambda, float power, float* dlogits, float* g_area_sum,
                               void* stream);
 
+/* ---- FC baseline head (`use_slot=False`): global average pool = scouter_avgpool_*_f32 with k = H, then
+ * nn.Linear (weight [C][K], sloter/slot_model.py:116-125, timm/models/resnet.py:503-509).  dx / dw / db may be NULL. */
+int scouter_linear_small_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int K, int C,
+                                 void* stream);
+int scouter_linear_small_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                                 int B, int K, int C, void* stream);
+
 /* ---- optimizer: torch.optim.AdamW defaults (train.py:146).  chunk table = array of {float* param; long offset
  * into the flat grad/moment arenas; int n; int pad} built by the host (scouter_adamw_chunk_bytes() each). */
 int scouter_adamw_chunk_bytes(void);

@@ -106,7 +106,9 @@ def model_inputs(case, seed=200):
 def grad_digest(g):
     """A gradient tensor reduced to (sum, abs-sum, first 16 entries) -- enough to pin it, small enough to commit."""
     f = g.detach().double().flatten()
-    return np.concatenate([[f.sum().item(), f.abs().sum().item()], f[:16].numpy()])
+    head = np.zeros(16)
+    head[:min(16, f.numel())] = f[:16].numpy()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item()], head])
 
 
 def run_reference_model(case, dtype):
@@ -143,6 +145,24 @@ def run_reference_model(case, dtype):
     with torch.no_grad():
         out_np["eval_log_probs"] = m(images.to(dtype)).numpy()
     return out_np
+
+
+def run_reference_fc(dtype):
+    """FC baseline (use_slot=False, slot_model.py:75-77,123-125): resnet18 MNIST stem, batch 4, 64x64."""
+    arch, C, B, H = "resnet18", 10, 4, 64
+    args = R.make_args(model=arch, num_classes=C, channel=512, dataset="MNIST", use_slot=False)
+    m = R.build_reference_slot_model(args)
+    spec = O.state_dict_spec(arch, C, 1, 1, in_chans=1, mnist_stem=True, use_slot=False)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    m.load_state_dict(O.synth_state(spec, 400))
+    m = m.to(dtype).train()
+    images, labels = O.synth_batch(B, 1, H, C, 401)
+    out, losses = m(images.to(dtype), labels)
+    losses[0].backward()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    return dict(log_probs=out.detach().numpy(), loss=losses[0].detach().numpy(),
+                grad_keys=np.array(list(grads)), grad_digest=np.stack([grad_digest(g) for g in grads.values()]))
 
 
 def run_reference_engine():
@@ -193,6 +213,10 @@ def main():
                                                                      "grad_digest", "eval_log_probs")})
         np.savez_compressed(os.path.join(OUT, f"model_{case}.npz"), **blob)
         print("model", case, "log_probs fp32-vs-fp64 gap", np.abs(f32["log_probs"] - f64["log_probs"]).max())
+    fc32, fc64 = run_reference_fc(torch.float32), run_reference_fc(torch.float64)
+    blob = {"f32_" + k: v for k, v in fc32.items()}
+    blob.update({"f64_" + k: v for k, v in fc64.items()})
+    np.savez_compressed(os.path.join(OUT, "model_fc_resnet18_mnist_64.npz"), **blob)
     np.savez_compressed(os.path.join(OUT, "engine_mnist.npz"), **run_reference_engine())
     print("done ->", OUT)
 

@@ -357,3 +357,60 @@ extern "C" int scouter_adamw_step_f32(const void* chunk_table, int nchunks, cons
     return sc_check_launch("adamw_step");
 }
 extern "C" int scouter_adamw_chunk_bytes(void) { return (int)sizeof(AdamChunk); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// small dense classifier (nn.Linear with few outputs: the FC baseline `use_slot=False`, slot_model.py:116-125 /
+// timm resnet.py:503-509).  B x K x C is tiny (70 x 2048 x 10): one wave per output element, wave-shuffle reduce.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int B, int K, int C) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= B * C) return;
+    const int b = o / C, c = o % C;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += x[(long)b * K + k] * w[(long)c * K + k];
+    s = wave_sum(s);
+    if (lane == 0) y[o] = s + (bias ? bias[c] : 0.f);
+}
+// dx[b][k] = sum_c dy[b][c] w[c][k]
+__global__ __launch_bounds__(256) void linear_small_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int B, int K, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * K) return;
+    const int b = (int)(i / K), k = (int)(i % K);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += dy[(long)b * C + c] * w[(long)c * K + k];
+    dx[i] = s;
+}
+// dw[c][k] = sum_b dy[b][c] x[b][k] ; db[c] = sum_b dy[b][c]   (fixed summation order -> deterministic)
+__global__ __launch_bounds__(256) void linear_small_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int B,
+                                                                 int K, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)C * K) {
+        const int c = (int)(i / K), k = (int)(i % K);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dy[(long)b * C + c] * x[(long)b * K + k];
+        dw[i] = s;
+    }
+    if (db && i < C) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dy[(long)b * C + i];
+        db[i] = s;
+    }
+}
+extern "C" int scouter_linear_small_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int K,
+                                            int C, void* stream) {
+    SC_REQUIRE(x && w && y && B > 0 && K > 0 && C > 0, "linear_small_fwd: bad arguments");
+    hipLaunchKernelGGL(linear_small_fwd_kernel, dim3(sc_cdiv((long)B * C, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, K, C);
+    return sc_check_launch("linear_small_fwd");
+}
+extern "C" int scouter_linear_small_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw,
+                                            float* db, int B, int K, int C, void* stream) {
+    SC_REQUIRE(dy && x && w && B > 0 && K > 0 && C > 0, "linear_small_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) hipLaunchKernelGGL(linear_small_dgrad_kernel, dim3(sc_cdiv((long)B * K, 256)), dim3(256), 0, st, dy, w, dx, B, K, C);
+    if (dw) hipLaunchKernelGGL(linear_small_wgrad_kernel, dim3(sc_cdiv((long)C * K, 256)), dim3(256), 0, st, dy, x, dw, db, B, K, C);
+    return sc_check_launch("linear_small_bwd");
+}

@@ -381,3 +381,25 @@ def slot_loss_bwd(logp, labels, stats, g_loss, g_nll, g_term, g_logp, area_count
         _p(logp), _p(labels), _p(stats), _p(g_loss), _p(g_nll), _p(g_term), _p(g_logp), B, C, float(area_count),
         float(lam), float(power), _p(dlogits), _p(g_area), _stream()), "slot_loss_bwd")
     return dlogits, g_area
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# FC baseline head
+# ---------------------------------------------------------------------------------------------------------------
+def linear_small_fwd(x, w, bias):
+    _chk(x, "x"); _chk(w, "weight"); _chk(bias, "bias")
+    B, Kd = x.shape
+    C = w.shape[0]
+    y = torch.empty((B, C), dtype=F32, device=x.device)
+    _native.check(_native.lib().scouter_linear_small_fwd_f32(_p(x), _p(w), _p(bias), _p(y), B, Kd, C, _stream()),
+                  "linear_small_fwd")
+    return y
+
+
+def linear_small_bwd(dy, x, w, dw=None, db=None, need_dx=True):
+    B, Kd = x.shape
+    C = w.shape[0]
+    dx = torch.empty_like(x) if need_dx else None
+    _native.check(_native.lib().scouter_linear_small_bwd_f32(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, Kd, C,
+                                                             _stream()), "linear_small_bwd")
+    return dx

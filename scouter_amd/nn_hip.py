@@ -113,6 +113,21 @@ class BatchNorm2d(nn.Module):
         return K.bn_bwd(dy, ymask, x, saved, training, self._dg, self._db, want_gout)
 
 
+class LinearParams(nn.Module):
+    """Parameter holder with nn.Linear's names / init; the arithmetic runs in the HIP kernels of the owner."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        bound = 1.0 / math.sqrt(in_features)
+        self.weight = nn.Parameter(torch.empty(out_features, in_features).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
+        self._g = {}
+
+    def _bind_grad(self, leaf, seg):
+        self._g[leaf] = seg.view(self.weight.shape) if leaf == "weight" else seg
+
+
 class GradArena:
     """One flat fp32 buffer holding the gradient of every trainable parameter, in named_parameters() order.
     `param.grad` are views into it (conv weights with the parameter's own HWIO strides).  Parameters that never

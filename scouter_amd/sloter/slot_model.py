@@ -68,9 +68,15 @@ class SlotModel(nn.Module):
         super().__init__()
         self.use_slot = args.use_slot
         self.backbone = load_backbone(args)
-        if not self.use_slot:
-            raise NotImplementedError("use_slot=False (the FC baseline, slot_model.py:75-77) is not part of the "
-                                      "xSlot hot path yet (SURVEY.md section 8f item 3)")
+        self._arena = None
+        self._anchor = None
+        self._post_backward_hooks = []       # called with the GradArena after every backward (data-parallel reduce)
+        self._grad_ready_hooks = []          # called (arena, lo, hi) as soon as arena.flat[lo:hi] is final
+        self.last_stats = None               # device tensor [loss, nll, area**power, top1, area] of the last forward
+        if not self.use_slot:                # FC baseline (slot_model.py:75-77): backbone + global pool + fc
+            if args.pre_trained:
+                self.dfs_freeze(self.backbone, args.freeze_layers)
+            return
         self.feature_size = 9            # kept for attribute compatibility; the grid is derived from the features
         self.channel = args.channel
         self.slots_per_class = args.slots_per_class
@@ -82,11 +88,6 @@ class SlotModel(nn.Module):
                                   to_k_layer=args.to_k_layer)
         self.position_emb = build_position_encoding("sine", hidden_dim=args.hidden_dim)
         self.lambda_value = float(args.lambda_value)
-        self._arena = None
-        self._anchor = None
-        self._post_backward_hooks = []       # called with the GradArena after every backward (data-parallel reduce)
-        self._grad_ready_hooks = []          # called (arena, lo, hi) as soon as arena.flat[lo:hi] is final
-        self.last_stats = None               # device tensor [loss, nll, area**power, top1, area] of the last forward
 
     def dfs_freeze(self, model, freeze_layer_num):
         """reference slot_model.py:79-94"""
@@ -106,8 +107,24 @@ class SlotModel(nn.Module):
             self._arena = GradArena(self)
         return self._arena
 
+    def _fc_forward(self, feat, target, save):
+        logits, cctx = self.backbone.classifier_fwd(feat, save)
+        if target is not None and target.dtype != torch.int64:
+            target = target.long()
+        logp, stats = K.slot_loss_fwd(logits, target, None, 1.0, 0.0, 1.0)      # slot_model.py:117,124
+        self.last_stats = stats
+        return logp, stats, ((cctx, logp, stats, target) if save else None)
+
+    def _fc_backward(self, hstate, g_logp, g_loss, g_nll, g_term, need_dfeat=True):
+        cctx, logp, stats, target = hstate
+        f32 = lambda g: None if g is None else g.float().contiguous()
+        dlogits, _ = K.slot_loss_bwd(logp, target, stats, f32(g_loss), f32(g_nll), None, f32(g_logp), 1.0, 0.0, 1.0)
+        return self.backbone.classifier_bwd(dlogits, cctx, need_dfeat)
+
     def _head_forward(self, feat, target, save):
         """feat: NHWC backbone features [B, h, w, channel] -> (log_probs, stats, head state)."""
+        if not self.use_slot:
+            return self._fc_forward(feat, target, save)
         if feat.shape[-1] != self.channel:
             raise RuntimeError("backbone produced %d channels, args.channel is %d" % (feat.shape[-1], self.channel))
         xmap, cctx = self.conv1x1.fwd(feat, save, relu=True)                  # slot_model.py:108-109
@@ -125,6 +142,8 @@ class SlotModel(nn.Module):
         return logp, stats, ((cctx, xmap, PE, so, logp, stats, target) if save else None)
 
     def _head_backward(self, hstate, g_logp, g_loss, g_nll, g_term, need_dfeat=True):
+        if not self.use_slot:
+            return self._fc_backward(hstate, g_logp, g_loss, g_nll, g_term, need_dfeat)
         cctx, xmap, PE, so, logp, stats, target = hstate
         B, h, w, d = xmap.shape
         S, N = self.slot.num_slots, h * w
@@ -183,5 +202,5 @@ class SlotModel(nn.Module):
             output, stats, _ = self._forward_impl(x, target, save=False)
             loss, nll, attn_loss = stats[0], stats[1], stats[2]
         if target is not None:
-            return [output, [loss, nll, attn_loss]]
+            return [output, [loss, nll, attn_loss]] if self.use_slot else [output, [loss]]
         return output

@@ -8,20 +8,7 @@ import torch
 from torch import nn
 
 from ... import kernels as K
-
-
-class _LinearParams(nn.Module):
-    """Parameter holder with nn.Linear's names / init (the arithmetic runs inside the fused kernels)."""
-
-    def __init__(self, dim_in, dim_out):
-        super().__init__()
-        bound = 1.0 / math.sqrt(dim_in)
-        self.weight = nn.Parameter(torch.empty(dim_out, dim_in).uniform_(-bound, bound))
-        self.bias = nn.Parameter(torch.empty(dim_out).uniform_(-bound, bound))
-        self._g = {}
-
-    def _bind_grad(self, leaf, seg):
-        self._g[leaf] = seg.view(self.weight.shape) if leaf == "weight" else seg
+from ...nn_hip import LinearParams as _LinearParams
 
 
 class _GRUParams(nn.Module):

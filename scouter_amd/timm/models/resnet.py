@@ -5,7 +5,7 @@ uses: stem '' (7x7, or the MNIST 3x3 1-channel stem swapped in by sloter/slot_mo
 import torch
 import torch.nn as nn
 
-from ...nn_hip import Act, BatchNorm2d, Conv2d, StemConv2d
+from ...nn_hip import Act, BatchNorm2d, Conv2d, LinearParams, StemConv2d
 from ... import kernels as K
 
 
@@ -109,7 +109,7 @@ class ResNet(nn.Module):
                                                                 block_args))
         self.num_features = 512 * block.expansion
         self.global_pool = Identity()
-        self.fc = nn.Linear(self.num_features, num_classes)
+        self.fc = LinearParams(self.num_features, num_classes)
         if zero_init_last_bn:                       # resnet.py:455-458
             for m in self.modules():
                 if hasattr(m, "zero_init_last_bn"):
@@ -197,10 +197,27 @@ class ResNet(nn.Module):
         feat, _ = self.features_fwd(x.float().contiguous(), False)
         return K.nhwc_to_nchw(feat)
 
+    # ---- classifier head of the FC baseline: global average pool + Linear (resnet.py:503-509)
+    def classifier_fwd(self, feat, save):
+        B, H, W, C = feat.shape
+        pooled = K.avgpool_fwd(feat, H, H, 0, False, True).view(B, C)
+        logits = K.linear_small_fwd(pooled, self.fc.weight, self.fc.bias)
+        return logits, ((pooled, (B, H, W, C)) if save else None)
+
+    def classifier_bwd(self, dlogits, ctx, need_dfeat):
+        pooled, (B, H, W, C) = ctx
+        dpooled = K.linear_small_bwd(dlogits, pooled, self.fc.weight, self.fc._g.get("weight"), self.fc._g.get("bias"),
+                                     need_dx=need_dfeat)
+        if not need_dfeat:
+            return None
+        return K.avgpool_bwd(dpooled.view(B, 1, 1, C), (B, H, W, C), H, H, 0, False, True)
+
+    @torch.no_grad()
     def forward(self, x):
-        x = self.forward_features(x)
-        x = self.global_pool(x).flatten(1)        # resnet.py:505
-        return self.fc(x)
+        feat, _ = self.features_fwd(x.float().contiguous(), False)
+        if isinstance(self.fc, LinearParams):
+            return self.classifier_fwd(feat, False)[0]
+        return K.nhwc_to_nchw(feat).flatten(1)    # global_pool / fc replaced by Identical (slot_model.py:38-40)
 
 
 def resnet18(pretrained=False, num_classes=1000, in_chans=3, **kwargs):

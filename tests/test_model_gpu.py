@@ -147,3 +147,31 @@ def test_frozen_backbone_and_no_cpu_fallback():
             assert p.grad is None
         else:
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_fc_baseline_mode_parity():
+    """use_slot=False: backbone -> global average pool -> fc -> log_softmax/NLL, forward and every gradient, vs the
+    reference fixture (fp64 run) and the state_dict layout incl. backbone.fc.*"""
+    from scouter_amd.sloter.slot_model import SlotModel
+    g = np.load(os.path.join(GOLD, "model_fc_resnet18_mnist_64.npz"))
+    args = argparse.Namespace(model="resnet18", pre_trained=False, num_classes=10, dataset="MNIST", use_slot=False,
+                              use_pre=False, grad=False, channel=512, slots_per_class=1, hidden_dim=64,
+                              freeze_layers=0, vis=False, vis_id=0, loss_status=1, power=1, to_k_layer=1,
+                              lambda_value="1")
+    spec = O.state_dict_spec("resnet18", 10, 1, 1, in_chans=1, mnist_stem=True, use_slot=False)
+    m = SlotModel(args)
+    assert list(m.state_dict().keys()) == list(spec.keys())
+    m.load_state_dict(O.synth_state(spec, 400))
+    m = m.cuda().train()
+    images, labels = O.synth_batch(4, 1, 64, 10, 401)
+    out, losses = m(images.cuda(), labels.cuda())
+    assert len(losses) == 1
+    losses[0].backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["f64_log_probs"], atol=1e-4)
+    np.testing.assert_allclose(float(losses[0]), float(g["f64_loss"]), atol=1e-4)
+    named = dict(m.named_parameters())
+    for k, d in zip(g["f64_grad_keys"], g["f64_grad_digest"]):
+        mine = grad_digest(named[str(k)].grad.detach().cpu())
+        assert abs(mine[1] - d[1]) <= 2e-3 * d[1] + 1e-5, str(k)
+        np.testing.assert_allclose(mine[2:], d[2:], atol=2e-3 * max(abs(d[2:]).max(), 1e-4) + 1e-6, rtol=5e-3, err_msg=str(k))

@@ -164,3 +164,19 @@ def test_engine_oracle_matches_reference_fixture():
     np.testing.assert_allclose(np.round(run / 2, 3), g["record_val"], atol=1.01e-3)
     for k, d in zip(g["param_keys"], g["param_digest"]):
         np.testing.assert_allclose(grad_digest(tr.P[str(k)]), d, rtol=2e-4, atol=2e-5, err_msg=str(k))
+
+
+def test_fc_baseline_oracle_matches_reference_fixture():
+    """use_slot=False (slot_model.py:75-77,123-125): backbone + global average pool + fc."""
+    g = load("model_fc_resnet18_mnist_64")
+    spec = O.state_dict_spec("resnet18", 10, 1, 1, in_chans=1, mnist_stem=True, use_slot=False)
+    P = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in O.synth_state(spec, 400).items()}
+    keys = [k for k in O.trainable_keys(P)]
+    leaves = {k: P[k].clone().requires_grad_(True) for k in keys}
+    Q = dict(P); Q.update(leaves)
+    images, labels = O.synth_batch(4, 1, 64, 10, 401)
+    out, losses = O.fc_model_forward(Q, images.double(), labels, "resnet18", training=True)
+    losses[0].backward()
+    np.testing.assert_allclose(out.detach().numpy(), g["f64_log_probs"], atol=1e-9)
+    for k, d in zip(g["f64_grad_keys"], g["f64_grad_digest"]):
+        np.testing.assert_allclose(grad_digest(leaves[str(k)].grad), d, rtol=1e-6, atol=1e-10, err_msg=str(k))
