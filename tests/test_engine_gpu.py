@@ -139,3 +139,29 @@ def test_data_parallel_wrapper_on_rccl_single_rank_group():
         assert torch.equal(grads[0], grads[1])
     finally:
         dist.destroy_process_group()
+
+
+def test_vis_inference_path_writes_reference_style_maps(tmp_path):
+    """scouter_amd.test.run: eval forward of one image, per-class uint8 maps == the oracle's vis_maps (<= 1 level)."""
+    from scouter_amd import test as vis_cli
+    from scouter_amd.sloter.slot_model import SlotModel
+    a = _mnist_args()
+    a.device, a.loss_status = "cuda", 1
+    spec = O.state_dict_spec("resnet18", 10, 1, 1, in_chans=1, mnist_stem=True)
+    P = O.synth_state(spec, 300)
+    m = SlotModel(a)
+    m.load_state_dict(P)
+    m = m.cuda()
+    img, lab = O.synth_batch(1, 1, 96, 10, 77)
+    out, pred, maps, ratio = vis_cli.run(a, m, img[0], str(tmp_path), label=int(lab[0]))
+    cfg = dict(model="resnet18", num_classes=10, slots_per_class=1, loss_status=1, power=1, lambda_value=1.0)
+    aux = {}
+    with torch.no_grad():
+        ref = O.slot_model_forward({k: (v.double() if v.dtype.is_floating_point else v) for k, v in P.items()},
+                                   img.double(), None, cfg, training=False, aux=aux)
+    np.testing.assert_allclose(out.numpy(), ref[0].numpy(), atol=1e-4)
+    ref_maps = O.vis_maps(aux["attn"], 10, 1, 0)
+    assert maps.shape == ref_maps.shape == (10, 3, 3)
+    assert np.abs(maps.astype(int) - ref_maps.astype(int)).max() <= 1
+    assert sorted(os.listdir(tmp_path)) == ["slot_%d.png" % c for c in range(10)]
+    assert 0.0 <= ratio <= 1.0
