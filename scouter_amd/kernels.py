@@ -4,6 +4,8 @@ hand-written HIP kernel of libscouter_hip.so, and there is no CPU / ATen fallbac
 
 Layouts: activations NHWC (torch tensors of shape [B, H, W, C], contiguous); convolution weights are
 nn.Parameters of LOGICAL shape (Cout, Cin/g, kh, kw) whose PHYSICAL storage is HWIO ([kh][kw][Cin/g][Cout])."""
+import os
+
 import torch
 
 from . import _native
@@ -33,8 +35,9 @@ def _p(t):
 
 
 def workspace(nbytes, device):
-    """Per-device scratch (grown on demand).  All kernels run on the current stream, so sharing it is safe."""
-    key = (device.type, device.index)
+    """Per-(device, stream) scratch, grown on demand.  Kernels on one stream are ordered, so they can share it; the
+    weight-gradient side stream gets its own."""
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -85,6 +88,45 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1):
     _native.check(L.scouter_conv2d_dgrad_f32(_p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride,
                                              pad, groups, _stream()), "conv2d_dgrad")
     return dx
+
+
+_side = {}
+SIDE_STREAM_ENABLED = os.environ.get("SCOUTER_SIDE_STREAM", "1") != "0"
+
+
+class side_stream:
+    """Context manager: run the enclosed launches on the per-device WEIGHT-GRADIENT side stream, ordered after
+    everything queued so far on the current stream.  In the backward pass only dgrad feeds the next layer; wgrad
+    (MFMA-bound) is off the critical path and overlaps the HBM-bound BatchNorm-backward passes of earlier layers.
+    `join_side_stream()` makes the current stream wait for it again."""
+
+    def __init__(self, device, *tensors):
+        self.device, self.tensors = device, tensors
+
+    def __enter__(self):
+        self.ctx = None
+        if not SIDE_STREAM_ENABLED:
+            return None
+        key = (self.device.type, self.device.index)
+        st = _side.get(key)
+        if st is None:
+            st = _side[key] = torch.cuda.Stream(device=self.device)
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        for t in self.tensors:                 # the caching allocator must not recycle them while the side stream runs
+            if t is not None:
+                t.record_stream(st)
+        self.ctx = torch.cuda.stream(st)
+        self.ctx.__enter__()
+        return st
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc) if self.ctx is not None else False
+
+
+def join_side_stream(device):
+    st = _side.get((device.type, device.index))
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
 
 
 def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1):

@@ -45,10 +45,12 @@ class Conv2d(nn.Module):
 
     def bwd(self, dy, ctx, need_dx=True, addend=None):
         x = ctx
-        if self._dw is not None:
-            K.conv2d_wgrad(x, dy, self._dw, self.stride, self.padding, self.groups)
-        if self._db is not None:
-            K.colsum(dy, self._db)
+        if self._dw is not None or self._db is not None:
+            with K.side_stream(dy.device, x, dy):           # weight / bias gradients: off the critical path
+                if self._dw is not None:
+                    K.conv2d_wgrad(x, dy, self._dw, self.stride, self.padding, self.groups)
+                if self._db is not None:
+                    K.colsum(dy, self._db)
         if not need_dx:
             return None
         return K.conv2d_dgrad(dy, K.hwio(self.weight), tuple(x.shape), addend, self.stride, self.padding, self.groups)
@@ -81,10 +83,11 @@ class StemConv2d(Conv2d):
         if need_dx:
             raise NotImplementedError("gradient w.r.t. the input image is not part of the training hot path")
         if self._dw is not None:
-            dwpad = torch.empty((1, 1, self.kpad, self.out_channels), dtype=torch.float32, device=dy.device)
-            K.conv2d_wgrad(ctx, dy, dwpad)
-            n = self.kdim * self.out_channels
-            K.axpby(dwpad.view(-1)[:n], None, 1.0, 0.0, out=self._dw.reshape(-1))
+            with K.side_stream(dy.device, ctx, dy):
+                dwpad = torch.empty((1, 1, self.kpad, self.out_channels), dtype=torch.float32, device=dy.device)
+                K.conv2d_wgrad(ctx, dy, dwpad)
+                n = self.kdim * self.out_channels
+                K.axpby(dwpad.view(-1)[:n], None, 1.0, 0.0, out=self._dw.reshape(-1))
         return None
 
 

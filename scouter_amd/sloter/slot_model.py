@@ -179,11 +179,13 @@ class SlotModel(nn.Module):
         def stage_done(name):
             lo = arena.first_offset("backbone." + name + ".")
             if lo is not None and lo < done_hi[0]:
+                K.join_side_stream(arena.flat.device)       # this stage's weight gradients ran on the side stream
                 for hook in self._grad_ready_hooks:
                     hook(arena, lo, done_hi[0])
                 done_hi[0] = lo
         if need:
             self.backbone.features_bwd(dfeat, bctx, stage_done if self._grad_ready_hooks else None)
+        K.join_side_stream(arena.flat.device)               # all weight gradients are in the arena from here on
         if self._grad_ready_hooks and done_hi[0] > 0:
             for hook in self._grad_ready_hooks:
                 hook(arena, 0, done_hi[0])

@@ -103,6 +103,8 @@ def test_head_data_parallel_equivalence():
     def grads(f, t):
         _, _, hs = m._head_forward(f.contiguous(), t, True)
         m._head_backward(hs, None, one, None, None, True)
+        from scouter_amd import kernels as Kk
+        Kk.join_side_stream(f.device)          # weight gradients run on the side stream (SlotModel._backward_impl joins)
         return m.grad_arena().flat.clone()
     full = grads(feat, y)
     shard = 0.5 * (grads(feat[:4], y[:4]) + grads(feat[4:], y[4:]))
