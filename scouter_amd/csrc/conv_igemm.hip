@@ -236,23 +236,40 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     }
 #undef SB
 
-    // ---- epilogue: one 128-B row segment per (register, half-wave)
+    // ---- epilogue: stage each wave's WMxWN accumulator tile through LDS (the K-loop buffers are free now) and write
+    // whole 16-byte row segments: 16 dwordx4 stores (+16 vector addend loads) per lane instead of 64 scalar ones --
+    // for the short-K 1x1 layers the scalar epilogue was a quarter of the block's lifetime.
+    __syncthreads();
+    constexpr int LDE = WN + 4;                               // padded row (16B aligned, breaks the 32-bank stride)
+    static_assert(4 * WM * LDE <= 2 * T::STAGE, "epilogue staging fits in the K-loop LDS");
+    float* Es = lds + wave * (WM * LDE);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const long m = m0 + wm * WM + i * 32 + mfma32_row(e, lane);
-            if (m >= g.M) continue;
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = grp * g.Ng + n0 + wn * WN + j * 32 + l31;
-                float v = acc[i][j][e];
-                if (bias) v += bias[n];
-                if (addend) v += addend[m * g.N + n];
-                if (relu) v = fmaxf(v, 0.f);
-                dst[m * g.N + n] = v;
-            }
+            for (int e = 0; e < 16; ++e) Es[(i * 32 + mfma32_row(e, lane)) * LDE + j * 32 + l31] = acc[i][j][e];
+    // each wave reads back its own tile only: no block barrier needed, just this wave's LDS writes
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
+    constexpr int QPR = WN / 4;                               // float4 per tile row
+    constexpr int RPP = 64 / QPR;                             // rows covered per pass by the 64 lanes
+    const int qcol = (lane % QPR) * 4, qrow = lane / QPR;
+    const int ncol = grp * g.Ng + n0 + wn * WN + qcol;
+    f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv4 = *(const f32x4*)(bias + ncol);
+#pragma unroll
+    for (int rr = 0; rr < WM / RPP; ++rr) {
+        const int row = rr * RPP + qrow;
+        const long m = m0 + wm * WM + row;
+        if (m >= g.M) continue;
+        f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
+        if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        *(f32x4*)(dst + m * g.N + ncol) = v;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
