@@ -38,10 +38,14 @@ int scouter_prof_collect(double* out);
 /* ---- convolution = nn.Conv2d call sites: timm/models/resnet.py:491-501 (stem, blocks), resnest.py:111-143,
  * layers/split_attn.py:54-60 (grouped 3x3, fc1, fc2), sloter/slot_model.py:108 (conv1x1) and their autograd
  * backward (engine.py:33).  fp32 implicit GEMM on v_mfma_f32_32x32x2_f32.  Per-group channels must be multiples
- * of 32.  `bias` (per Cout), `addend` (same shape as the output) may be NULL; relu applies last. */
-int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* addend, float* y, int B,
-                           int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int relu,
-                           void* stream);
+ * of 32.  `bias` (per Cout), `addend` (same shape as the output) may be NULL; relu applies last.
+ * bn_partial (may be NULL): the epilogue also writes per-M-tile fp64 (sum, sum of squares) of every output channel,
+ * [scouter_conv2d_fwd_bn_partial_rows(...)][Cout][2], which scouter_bn_fwd_f32 accepts instead of re-reading y. */
+int scouter_conv2d_fwd_bn_partial_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                       int groups);
+int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* addend, float* y,
+                           double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                           int pad, int groups, int relu, void* stream);
 int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
                              int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, void* stream);
 size_t scouter_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
@@ -61,7 +65,7 @@ size_t scouter_colreduce_workspace_bytes(long M, int C);
 int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                        int training, int relu, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
-                       void* ws, size_t ws_bytes, void* stream);
+                       const double* ext_partial, int ext_rows, void* ws, size_t ws_bytes, void* stream);
 /* g = dy * (ymask > 0) (ymask may be NULL); dgamma/dbeta may be NULL (frozen); gout (may be NULL) receives g. */
 int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean, const float* rstd,
                        const float* scale, long M, int C, int training, float* dgamma, float* dbeta, float* dx,

@@ -419,16 +419,20 @@ extern "C" size_t scouter_colreduce_workspace_bytes(long M, int C) { (void)M; re
 extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var, float momentum,
                                   float eps, int training, int relu, float* mean_out, float* rstd_out,
-                                  float* scale_out, float* shift_out, void* ws, size_t ws_bytes, void* stream) {
+                                  float* scale_out, float* shift_out, const double* ext_partial, int ext_rows,
+                                  void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(x && y && mean_out && rstd_out && scale_out && shift_out, "bn_fwd: null pointer");
     SC_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
     COL_CHECKS("bn_fwd")
     hipStream_t st = (hipStream_t)stream;
-    ScProfScope prof(SC_PROF_BN, st, 0, 12.0 * M * C);
-    if (training)
+    ScProfScope prof(SC_PROF_BN, st, 0, (ext_partial ? 8.0 : 12.0) * M * C);
+    const double* part = (const double*)ws;
+    int nparts = nb;
+    if (training && ext_partial) { part = ext_partial; nparts = ext_rows; }     // statistics came from the conv epilogue
+    else if (training)
         hipLaunchKernelGGL(colsum_partial_kernel<0>, pgrid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                            (double*)ws, g);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, part, nparts, M, C,
                        gamma, beta, running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out,
                        shift_out);
     const long n4 = M * C / 4;

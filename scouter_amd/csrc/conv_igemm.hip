@@ -41,7 +41,8 @@ template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ addend, float* __restrict__ dst,
-                                                       ConvGeom g, int relu, int mtiles, int ntiles) {
+                                                       double* __restrict__ bn_part, ConvGeom g, int relu, int mtiles,
+                                                       int ntiles) {
     constexpr bool B_KC = DGRAD;
     using T = TileCfg<BM, BN, B_KC>;
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     const int ncol = grp * g.Ng + n0 + wn * WN + qcol;
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv4 = *(const f32x4*)(bias + ncol);
+    double cs[4] = {0, 0, 0, 0}, cq[4] = {0, 0, 0, 0};        // per-column sum / sum of squares (BatchNorm statistics)
 #pragma unroll
     for (int rr = 0; rr < WM / RPP; ++rr) {
         const int row = rr * RPP + qrow;
@@ -264,11 +266,44 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
         if (m >= g.M) continue;
         f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
         if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
+        if (bn_part) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * v[e]; }
+        }
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         *(f32x4*)(dst + m * g.N + ncol) = v;
+    }
+    if (bn_part) {
+        // Fused batch statistics of the tile just written: lanes sharing a column quad (stride QPR) are combined by
+        // shuffles, the BM/WM waves sharing a column range through LDS; one fp64 (sum, sumsq) pair per column and
+        // M-tile goes to bn_part[mtile][channel][2] -- scouter_bn_fwd_f32 then skips its own read of the tensor.
+#pragma unroll
+        for (int o = QPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], o, 64); cq[e] += __shfl_xor(cq[e], o, 64); }
+        __syncthreads();                                      // every wave is done reading its staged tile
+        double* Ps = (double*)lds;                            // [4 waves][WN][2], re-uses the staging area
+        if (qrow == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { Ps[(wave * WN + qcol + e) * 2] = cs[e]; Ps[(wave * WN + qcol + e) * 2 + 1] = cq[e]; }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int wnn = tid / WN, c = tid % WN;
+            double a0 = 0, a1 = 0;
+#pragma unroll
+            for (int w = 0; w < BM / WM; ++w) {
+                const int wv = w * WAVES_N + wnn;
+                a0 += Ps[(wv * WN + c) * 2];
+                a1 += Ps[(wv * WN + c) * 2 + 1];
+            }
+            double* o = bn_part + ((long)mt_id * g.N + grp * g.Ng + n0 + tid) * 2;
+            o[0] = a0;
+            o[1] = a1;
+        }
     }
 }
 
@@ -478,49 +513,77 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // ----------------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED>
 static void launch_igemm_s(const float* src, const float* w, const float* bias, const float* addend, float* dst,
-                         const ConvGeom& g, int relu, hipStream_t st) {
+                           double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
     const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
     dim3 grid(mtiles * ntiles * g.groups);
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED>), grid, dim3(256), 0, st, src, w, bias, addend,
-                       dst, g, relu, mtiles, ntiles);
+                       dst, bn_part, g, relu, mtiles, ntiles);
 }
 template <int BM, int BN, int WM, int WN, bool DGRAD>
 static void launch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
-                         const ConvGeom& g, int relu, hipStream_t st) {
-    if (DGRAD && g.stride != 1) launch_igemm_s<BM, BN, WM, WN, DGRAD, true>(src, w, bias, addend, dst, g, relu, st);
-    else launch_igemm_s<BM, BN, WM, WN, DGRAD, false>(src, w, bias, addend, dst, g, relu, st);
+                         double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
+    if (DGRAD && g.stride != 1) launch_igemm_s<BM, BN, WM, WN, DGRAD, true>(src, w, bias, addend, dst, bn_part, g, relu, st);
+    else launch_igemm_s<BM, BN, WM, WN, DGRAD, false>(src, w, bias, addend, dst, bn_part, g, relu, st);
+}
+
+// tile choice: largest tile that still fills the chip (>= ~1.5 rounds of 256 CUs x 2 blocks); Ng is a multiple of 32
+static int igemm_tile(const ConvGeom& g) {     // 0: 128x128  1: 128x64  2: 64x64  3: 128x32
+    auto blocks = [&](int bm, int bn) { return (long)sc_cdiv(g.M, bm) * (g.Ng / bn) * g.groups; };
+    const long want = 768;
+    if (g.Ng % 128 == 0 && blocks(128, 128) >= want) return 0;
+    if (g.Ng % 64 == 0 && blocks(128, 64) >= want) return 1;
+    if (g.Ng % 64 == 0 && g.Ng >= 64) return 2;
+    return 3;
 }
 
 template <bool DGRAD>
 static int dispatch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
-                          const ConvGeom& g, int relu, hipStream_t st) {
-    // largest tile that still fills the chip (>= ~2 waves of 256 CUs x 2 blocks); Ng is a multiple of 32
-    auto blocks = [&](int bm, int bn) { return (long)sc_cdiv(g.M, bm) * (g.Ng / bn) * g.groups; };
-    const long want = 768;
-    if (g.Ng % 128 == 0 && blocks(128, 128) >= want) launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, g, relu, st);
-    else if (g.Ng % 64 == 0 && blocks(128, 64) >= want) launch_igemm<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, g, relu, st);
-    else if (g.Ng % 64 == 0 && g.Ng >= 64) launch_igemm<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, g, relu, st);
-    else launch_igemm<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, g, relu, st);
+                          double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
+    switch (igemm_tile(g)) {
+        case 0: launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+        case 1: launch_igemm<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+        case 2: launch_igemm<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+        default: launch_igemm<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+    }
     return sc_check_launch(DGRAD ? "conv2d_dgrad" : "conv2d_fwd");
 }
 
 static int conv_out(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
-extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* addend,
-                                      float* y, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
-                                      int pad, int groups, int relu, void* stream) {
-    SC_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0, "conv2d_fwd: null pointer or empty shape");
-    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_fwd: channels not divisible by groups");
+static int conv_fwd_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                         int groups) {
+    if (!(groups > 0 && Cin % groups == 0 && Cout % groups == 0)) return SC_ERR_ARG;
     const int Cg = Cin / groups, Ng = Cout / groups;
-    SC_UNSUPPORTED(Cg % 32 == 0 && Ng % 32 == 0,
-                   "conv2d_fwd: per-group channels must be multiples of 32 (got %d -> %d); use scouter_conv2d_stem_*",
-                   Cg, Ng);
-    ConvGeom g{B, H, W, Cin, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout, kh, kw, stride, pad,
-               groups, Cg, Ng, 0, Cout, Cg * Cout};
+    if (!(Cg % 32 == 0 && Ng % 32 == 0)) return SC_ERR_UNSUPPORTED;
+    g = ConvGeom{B, H, W, Cin, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout, kh, kw, stride, pad,
+                 groups, Cg, Ng, 0, Cout, Cg * Cout};
     g.M = (long)B * g.Ho * g.Wo;
-    ScProfScope prof(SC_PROF_CONV_FWD, (hipStream_t)stream, 2.0 * g.M * Cout * Cg * kh * kw,
+    return SC_OK;
+}
+
+// number of [Cout][2] fp64 rows the fused BatchNorm-statistics epilogue writes (= M tiles of the chosen kernel)
+extern "C" int scouter_conv2d_fwd_bn_partial_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                                                  int pad, int groups) {
+    ConvGeom g;
+    if (conv_fwd_geom(g, B, H, W, Cin, Cout, kh, kw, stride, pad, groups) != SC_OK) return 0;
+    return sc_cdiv(g.M, igemm_tile(g) == 2 ? 64 : 128);
+}
+
+extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* addend,
+                                      float* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh,
+                                      int kw, int stride, int pad, int groups, int relu, void* stream) {
+    SC_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0, "conv2d_fwd: null pointer or empty shape");
+    SC_REQUIRE(!(bn_partial && relu), "conv2d_fwd: fused BatchNorm statistics are taken before any activation");
+    ConvGeom g;
+    const int rc = conv_fwd_geom(g, B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
+    if (rc == SC_ERR_ARG) { sc_set_error("conv2d_fwd: channels not divisible by groups"); return rc; }
+    if (rc == SC_ERR_UNSUPPORTED) {
+        sc_set_error("conv2d_fwd: per-group channels must be multiples of 32 (got %d -> %d)", Cin / groups, Cout / groups);
+        return rc;
+    }
+    ScProfScope prof(SC_PROF_CONV_FWD, (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
                      4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
-    return dispatch_igemm<false>(x, w, bias, addend, y, g, relu, (hipStream_t)stream);
+    return dispatch_igemm<false>(x, w, bias, addend, y, bn_partial, g, relu, (hipStream_t)stream);
 }
 
 extern "C" int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H,
@@ -536,7 +599,7 @@ extern "C" int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const f
     g.M = (long)B * H * W;
     ScProfScope prof(SC_PROF_CONV_DGRAD, (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw / (stride * stride),
                      4.0 * ((double)B * Ho * Wo * Cout + (double)g.M * Cin));
-    return dispatch_igemm<true>(dy, w, nullptr, addend, dx, g, 0, (hipStream_t)stream);
+    return dispatch_igemm<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, (hipStream_t)stream);
 }
 
 struct WgradPlan { int bm, bn, ci_tiles, co_tiles, splits; long pix_per_split, tiles; };

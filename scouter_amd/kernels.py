@@ -67,16 +67,22 @@ def conv_out(n, k, s, p):
 # ---------------------------------------------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------------------------------------------
-def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, relu=False):
+def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, relu=False, bn_stats=False):
+    """bn_stats=True: the epilogue also produces the per-tile fp64 channel sums BatchNorm needs; returns
+    (y, (partial, rows)) and `bn_fwd(..., stats=(partial, rows))` then skips its own statistics pass."""
     _chk(x, "x"); _chk(w_hwio, "weight"); _chk(bias, "bias"); _chk(addend, "addend")
     B, H, W, Cin = x.shape
     kh, kw, cg, Cout = w_hwio.shape
     assert cg * groups == Cin, (x.shape, w_hwio.shape, groups)
     y = torch.empty((B, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout), dtype=F32, device=x.device)
     L = _native.lib()
-    _native.check(L.scouter_conv2d_fwd_f32(_p(x), _p(w_hwio), _p(bias), _p(addend), _p(y), B, H, W, Cin, Cout, kh, kw,
-                                           stride, pad, groups, int(relu), _stream()), "conv2d_fwd")
-    return y
+    part, rows = None, 0
+    if bn_stats:
+        rows = L.scouter_conv2d_fwd_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups)
+        part = torch.empty((rows, Cout, 2), dtype=torch.float64, device=x.device)
+    _native.check(L.scouter_conv2d_fwd_f32(_p(x), _p(w_hwio), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin, Cout,
+                                           kh, kw, stride, pad, groups, int(relu), _stream()), "conv2d_fwd")
+    return (y, (part, rows)) if bn_stats else y
 
 
 def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1):
@@ -174,8 +180,10 @@ def _col_ws(M, C, device):
     return workspace(L.scouter_colreduce_workspace_bytes(M, C) + 8 * C + 64, device)
 
 
-def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=None, momentum=0.1, eps=1e-5):
-    """x: [..., C] NHWC.  Returns (y, saved) with saved = (mean, rstd, scale, shift) packed as one [4, C] tensor."""
+def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=None, momentum=0.1, eps=1e-5,
+           stats=None):
+    """x: [..., C] NHWC.  Returns (y, saved) with saved = (mean, rstd, scale, shift) packed as one [4, C] tensor.
+    stats = (partial, rows) from conv2d_fwd(bn_stats=True) replaces the statistics pass over x."""
     _chk(x, "x"); _chk(residual, "residual")
     C = x.shape[-1]
     M = x.numel() // C
@@ -184,8 +192,8 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=N
     ws = _col_ws(M, C, x.device)
     _native.check(_native.lib().scouter_bn_fwd_f32(
         _p(x), _p(y), _p(residual), M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
-        int(training), int(relu), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]), _p(ws), ws.numel(),
-        _stream()), "bn_fwd")
+        int(training), int(relu), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]),
+        _p(stats[0]) if stats else None, stats[1] if stats else 0, _p(ws), ws.numel(), _stream()), "bn_fwd")
     return y, saved
 
 

@@ -39,8 +39,10 @@ class Conv2d(nn.Module):
             bound = 1.0 / math.sqrt(in_channels // groups * k * k)
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def fwd(self, x, save, relu=False, addend=None):
-        y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu)
+    def fwd(self, x, save, relu=False, addend=None, bn_stats=False):
+        """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd."""
+        y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
+                         bn_stats)
         return y, (x if save else None)
 
     def bwd(self, dy, ctx, need_dx=True, addend=None):
@@ -72,11 +74,11 @@ class StemConv2d(Conv2d):
         self._dw = self._db = None
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
-    def fwd(self, x_nchw, save, relu=False, addend=None):
+    def fwd(self, x_nchw, save, relu=False, addend=None, bn_stats=False):
         col = K.im2col_nchw(x_nchw, self.kernel_size, self.stride, self.padding, self.kpad)
         wflat = K.hwio(self.weight).reshape(-1)
         wpad = K.pad_rows(wflat, wflat.numel(), self.kpad * self.out_channels).view(1, 1, self.kpad, self.out_channels)
-        y = K.conv2d_fwd(col, wpad, None, addend, 1, 0, 1, relu)
+        y = K.conv2d_fwd(col, wpad, None, addend, 1, 0, 1, relu, bn_stats)
         return y, (col if save else None)
 
     def bwd(self, dy, ctx, need_dx=False, addend=None):
@@ -105,8 +107,12 @@ class BatchNorm2d(nn.Module):
         self._dg = self._db = None
 
     def fwd(self, x, save, relu=False, residual=None, tracked=None):
+        """x may be the (tensor, stats) pair a conv produced with bn_stats=True."""
+        stats = None
+        if isinstance(x, tuple):
+            x, stats = x
         y, saved = K.bn_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
-                            residual, self.momentum, self.eps)
+                            residual, self.momentum, self.eps, stats if self.training else None)
         if self.training and tracked is not None:
             tracked.append(self.num_batches_tracked)
         return y, ((x, y if relu else None, saved, self.training) if save else None)

@@ -26,11 +26,11 @@ class SplitAttnConv2d(nn.Module):
         self.fc2 = Conv2d(attn_chs, mid_chs, 1, bias=True)
 
     def fwd(self, x, save, tracked=None):
-        c, c_conv = self.conv.fwd(x, save)
+        c, c_conv = self.conv.fwd(x, save, bn_stats=self.bn0.training)
         h, c_bn0 = self.bn0.fwd(c, save, relu=True, tracked=tracked)           # [B,H,W,2C']
         B = h.shape[0]
         gap = K.sa_gap(h)                                                        # split_attn.py:63-68
-        z1, c_fc1 = self.fc1.fwd(gap.view(B, 1, 1, -1), save)
+        z1, c_fc1 = self.fc1.fwd(gap.view(B, 1, 1, -1), save, bn_stats=self.bn1.training)
         g1, c_bn1 = self.bn1.fwd(z1, save, relu=True, tracked=tracked)
         z2, c_fc2 = self.fc2.fwd(g1, save)
         a = K.radix_softmax_fwd(z2.view(B, -1))                                  # split_attn.py:20-28,75

@@ -30,11 +30,11 @@ class ResNestBottleneck(nn.Module):
         nn.init.zeros_(self.bn3.weight)
 
     def fwd(self, x, save, tracked):
-        c1, k1 = self.conv1.fwd(x, save)
+        c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
         h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked)
         sa, ksa = self.conv2.fwd(h1, save, tracked)
         p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
-        c3, k3 = self.conv3.fwd(p, save)
+        c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training)
         res, kd = (x, None) if self.downsample is None else self.downsample.fwd(x, save, tracked)
         out, b3 = self.bn3.fwd(c3, save, relu=True, residual=res, tracked=tracked)
         return out, ((k1, b1, ksa, tuple(sa.shape), k3, b3, kd) if save else None)

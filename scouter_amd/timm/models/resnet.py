@@ -38,7 +38,7 @@ class Downsample(nn.Sequential):
             pool = mods[0] if isinstance(mods[0], AvgPool2dSpec) else None
             mods = mods[1:]
         xin = pool.fwd(x) if pool is not None else x
-        c, c_conv = mods[0].fwd(xin, save)
+        c, c_conv = mods[0].fwd(xin, save, bn_stats=mods[1].training)
         y, c_bn = mods[1].fwd(c, save, relu=False, tracked=tracked)
         return y, ((c_conv, c_bn, pool, tuple(x.shape)) if save else None)
 
@@ -69,9 +69,9 @@ class BasicBlock(nn.Module):
         nn.init.zeros_(self.bn2.weight)
 
     def fwd(self, x, save, tracked):
-        c1, k1 = self.conv1.fwd(x, save)
+        c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
         h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked)
-        c2, k2 = self.conv2.fwd(h1, save)
+        c2, k2 = self.conv2.fwd(h1, save, bn_stats=self.bn2.training)
         res, kd = (x, None) if self.downsample is None else self.downsample.fwd(x, save, tracked)
         out, b2 = self.bn2.fwd(c2, save, relu=True, residual=res, tracked=tracked)
         return out, ((k1, b1, k2, b2, kd) if save else None)
@@ -134,14 +134,14 @@ class ResNet(nn.Module):
         ctx = []
         if isinstance(self.conv1, nn.Sequential):
             s = self.conv1
-            c, k0 = s[0].fwd(x_nchw, save)
+            c, k0 = s[0].fwd(x_nchw, save, bn_stats=s[1].training)
             h, b0 = s[1].fwd(c, save, relu=True, tracked=tracked)
-            c, k1 = s[3].fwd(h, save)
+            c, k1 = s[3].fwd(h, save, bn_stats=s[4].training)
             h, b1 = s[4].fwd(c, save, relu=True, tracked=tracked)
-            c, k2 = s[6].fwd(h, save)
+            c, k2 = s[6].fwd(h, save, bn_stats=self.bn1.training)
             ctx.append((k0, b0, k1, b1, k2))
         else:
-            c, k0 = self.conv1.fwd(x_nchw, save)
+            c, k0 = self.conv1.fwd(x_nchw, save, bn_stats=self.bn1.training)
             ctx.append((k0,))
         h, bb = self.bn1.fwd(c, save, relu=True, tracked=tracked)
         p, arg = K.maxpool_fwd(h, 3, 2, 1, want_argmax=save)

@@ -252,3 +252,32 @@ def test_loss_fwd_bwd():
     dl, ga = kk.slot_loss_bwd(lp, y.cuda(), stats, one, None, None, None, B * S * N, lam, power)
     np.testing.assert_allclose(dl.cpu().numpy(), lr.grad.numpy(), atol=1e-6)
     np.testing.assert_allclose(float(ga), float(ar.grad[0]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(3, 14, 14, 64, 128, 3, 1, 1, 2), (2, 9, 9, 256, 64, 1, 1, 0, 1), (5, 1, 1, 64, 32, 1, 1, 0, 1),
+                                  (2, 30, 30, 32, 32, 3, 1, 1, 1)])
+def test_conv_fused_bn_statistics(case):
+    """conv epilogue -> per-tile fp64 channel sums -> bn_fwd(stats=...) == bn_fwd computing its own statistics."""
+    B, H, W, Cin, Cout, k, s, p, g = case
+    rng = np.random.default_rng(11)
+    x = nhwc(torch.from_numpy(rng.standard_normal((B, Cin, H, W)) + 0.3))
+    w = to_hwio(torch.from_numpy(rng.standard_normal((Cout, Cin // g, k, k)) / np.sqrt(Cin // g * k * k)))
+    bias = torch.from_numpy(rng.standard_normal(Cout)).float().cuda()
+    kk = K()
+    y_plain = kk.conv2d_fwd(x, w, bias, None, s, p, g)
+    y, (part, rows) = kk.conv2d_fwd(x, w, bias, None, s, p, g, False, bn_stats=True)
+    assert torch.equal(y, y_plain)
+    M = y.numel() // Cout
+    sums = part.sum(0).cpu().numpy()
+    yd = y.double().view(M, Cout).cpu().numpy()
+    np.testing.assert_allclose(sums[:, 0], yd.sum(0), rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(sums[:, 1], (yd * yd).sum(0), rtol=1e-10, atol=1e-8)
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cout)).float().cuda()
+    beta = torch.from_numpy(rng.standard_normal(Cout)).float().cuda()
+    outs = []
+    for st in (None, (part, rows)):
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        o, saved = kk.bn_fwd(y, gamma, beta, rm, rv, True, True, stats=st)
+        outs.append((o, saved, rm, rv))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-6)
