@@ -29,7 +29,6 @@ CFG = dict(model="resnest26d", num_classes=10, slots_per_class=1, channel=2048, 
            lambda_value="1", hidden_dim=64, img_size=224, batch=70)
 FWD_GFLOP_PER_IMG = 7.243 + 0.0159          # backbone conv + head, SURVEY.md section 8d / Appendix B
 PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md chip table
-PROF_CLASSES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "xslot_fwd", "xslot_bwd", "bn", "other"]
 
 
 def make_args(cfg):
@@ -138,7 +137,7 @@ def main():
     # Per-kernel timing pass (same process, model, batch): hipEvents around every launch, on its stream.  It runs with
     # the weight-gradient side stream DISABLED: in the timed region above wgrad kernels overlap BatchNorm-backward /
     # dgrad kernels on purpose, which inflates each kernel's elapsed time and would misstate the kernels' own quality.
-    prof = (ctypes.c_double * (len(PROF_CLASSES) * 4))()
+    prof_buf = ctypes.create_string_buffer(1 << 16)
     prof_steps = 0 if a.no_prof else max(1, a.prof_steps)
     if prof_steps:
         from scouter_amd import kernels as Kmod
@@ -150,7 +149,7 @@ def main():
             step()
         fence()
         L.scouter_prof_enable(0)
-        L.scouter_prof_collect(prof)
+        L.scouter_prof_collect(prof_buf, len(prof_buf))
         Kmod.SIDE_STREAM_ENABLED = True
     loss_val = float(losses[0])
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -162,23 +161,28 @@ def main():
         imgs = world * cfg["batch"] * a.steps
         value = imgs / dt
         kern = {}
-        for i, name in enumerate(PROF_CLASSES):
-            n, ms, fl, by = prof[4 * i:4 * i + 4]
-            if n > 0:
-                kern[name] = {"launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps,
-                              "avg_us": 1e3 * ms / n, "tflops": (fl / (ms * 1e-3)) / 1e12 if fl else None,
-                              "gbps_algorithmic": (by / (ms * 1e-3)) / 1e9 if by else None}
-        conv = [k for k in ("conv_fwd", "conv_dgrad", "conv_wgrad") if k in kern]
+        for row in prof_buf.value.decode().splitlines():
+            name, n, ms, fl, by = row.split("\t")
+            n, ms, fl, by = float(n), float(ms), float(fl), float(by)
+            kern[name] = {"launches_per_step": n / prof_steps, "ms_per_step": round(ms / prof_steps, 4),
+                          "avg_us": round(1e3 * ms / n, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None,
+                          "gbps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1) if by else None}
+        conv = [k for k in kern if k.startswith(("igemm_", "wgrad<"))]
         roofline = None
         if conv:
+            # the dominant kernel INSTANCE (most time per step); its rocprofv3 row is igemm_kernel<BM,BN,..> / wgrad_kernel<..>
             dom = max(conv, key=lambda k: kern[k]["ms_per_step"])
             ach = kern[dom]["tflops"]
-            roofline = {"bound": "mfma", "kernel": dom + " (fp32 implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            tot_ms = sum(kern[k]["ms_per_step"] for k in conv)
+            tot_fl = sum(kern[k]["tflops"] * kern[k]["ms_per_step"] for k in conv)
+            roofline = {"bound": "mfma", "kernel": dom + " (fp32 implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)",
+                        "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                        "avg_launch_us": round(kern[dom]["avg_us"], 2),
-                        "measured": "hipEvents on the launch stream over %d serial steps (side stream off) right after "
-                                    "the timed region" % prof_steps,
+                        "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches_per_step"],
+                        "measured": "hipEvents on the launch stream over %d serial steps (weight-gradient side stream "
+                                    "off) right after the timed region" % prof_steps,
+                        "all_conv_kernels_tflops": round(tot_fl / tot_ms, 2),
+                        "all_conv_kernels_frac": round(tot_fl / tot_ms / PEAK_FP32_MFMA_TFLOPS, 4),
                         "whole_step_frac": round(value * 3 * FWD_GFLOP_PER_IMG * 1e9 / world
                                                  / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
         line = {"metric": "images/sec training step (resnest26d+xSlot, 224^2, bs70)", "value": round(value, 2),

@@ -29,11 +29,12 @@ extern "C" {
 int scouter_abi_version(void);
 const char* scouter_last_error(void);
 
-/* optional per-kernel-class hipEvent timing used by bench.py's roofline leg.
- * classes: 0 conv_fwd, 1 conv_dgrad, 2 conv_wgrad, 3 xslot_fwd, 4 xslot_bwd, 5 bn, 6 other
- * scouter_prof_collect fills out[7][4] = {launches, total ms, algorithmic flops, algorithmic bytes}. */
+/* optional per-kernel hipEvent timing used by bench.py's roofline leg: when enabled, every launch of the conv / BN /
+ * xSlot kernels is bracketed by two hipEvents on ITS stream and aggregated by kernel-instance name.
+ * scouter_prof_collect writes "name\tlaunches\ttotal_ms\talgorithmic_flops\talgorithmic_bytes\n" lines into buf
+ * (returns the byte count) and clears the log. */
 void scouter_prof_enable(int on);
-int scouter_prof_collect(double* out);
+int scouter_prof_collect(char* buf, int cap);
 
 /* ---- convolution = nn.Conv2d call sites: timm/models/resnet.py:491-501 (stem, blocks), resnest.py:111-143,
  * layers/split_attn.py:54-60 (grouped 3x3, fc1, fc2), sloter/slot_model.py:108 (conv1x1) and their autograd

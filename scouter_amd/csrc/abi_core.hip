@@ -31,16 +31,16 @@ extern "C" const char* scouter_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------------------------
 // profiling: when enabled every launch of a kernel class is bracketed by two hipEvents on ITS stream
 // ---------------------------------------------------------------------------------------------------------------
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; const char* name; double flops, bytes; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
-ScProfScope::ScProfScope(int cls_, hipStream_t st, double flops, double bytes) : cls(cls_), stream(st), slot(-1) {
+ScProfScope::ScProfScope(const char* name, hipStream_t st, double flops, double bytes) : stream(st), slot(-1) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
-    r.cls = cls_; r.flops = flops; r.bytes = bytes;
+    r.name = name; r.flops = flops; r.bytes = bytes;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     hipEventRecord(r.a, st);
     slot = (int)g_prof.size();
@@ -57,23 +57,33 @@ extern "C" void scouter_prof_enable(int on) {
     g_prof_on = on != 0;
 }
 
-// Synchronises the recorded events, adds {launch count, total ms, algorithmic flops, algorithmic bytes} per class
-// into out[SC_PROF_NCLASS][4] and clears the log.  Returns the number of classes.
-extern "C" int scouter_prof_collect(double* out) {
+// Synchronises the recorded events and writes one line per kernel name into `buf`:
+//   name <tab> launches <tab> total_ms <tab> algorithmic_flops <tab> algorithmic_bytes \n
+// then clears the log.  Returns the number of bytes written (truncated to cap-1), or -1 on a bad buffer.
+extern "C" int scouter_prof_collect(char* buf, int cap) {
+    if (!buf || cap <= 0) return -1;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (int i = 0; i < SC_PROF_NCLASS * 4; ++i) out[i] = 0.0;
+    struct Agg { const char* name; double n, ms, fl, by; };
+    std::vector<Agg> aggs;
     for (auto& r : g_prof) {
         float ms = 0.f;
         hipEventSynchronize(r.b);
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            out[r.cls * 4 + 0] += 1.0;
-            out[r.cls * 4 + 1] += ms;
-            out[r.cls * 4 + 2] += r.flops;
-            out[r.cls * 4 + 3] += r.bytes;
+            Agg* a = nullptr;
+            for (auto& x : aggs) if (strcmp(x.name, r.name) == 0) { a = &x; break; }
+            if (!a) { aggs.push_back(Agg{r.name, 0, 0, 0, 0}); a = &aggs.back(); }
+            a->n += 1; a->ms += ms; a->fl += r.flops; a->by += r.bytes;
         }
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
     }
     g_prof.clear();
-    return SC_PROF_NCLASS;
+    int off = 0;
+    buf[0] = 0;
+    for (auto& a : aggs) {
+        int w = snprintf(buf + off, cap - off, "%s\t%.0f\t%.6f\t%.6e\t%.6e\n", a.name, a.n, a.ms, a.fl, a.by);
+        if (w < 0 || w >= cap - off) break;
+        off += w;
+    }
+    return off;
 }

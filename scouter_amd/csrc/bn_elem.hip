@@ -425,7 +425,7 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
     SC_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
     COL_CHECKS("bn_fwd")
     hipStream_t st = (hipStream_t)stream;
-    ScProfScope prof(SC_PROF_BN, st, 0, (ext_partial ? 8.0 : 12.0) * M * C);
+    ScProfScope prof("bn_fwd(stats+finalize+apply)", st, 0, (ext_partial ? 8.0 : 12.0) * M * C);
     const double* part = (const double*)ws;
     int nparts = nb;
     if (training && ext_partial) { part = ext_partial; nparts = ext_rows; }     // statistics came from the conv epilogue
@@ -454,7 +454,7 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
     float* c1 = (float*)((char*)ws + coef_off);
     float* c2 = c1 + C;
     hipStream_t st = (hipStream_t)stream;
-    ScProfScope prof(SC_PROF_BN, st, 0, 28.0 * M * C);
+    ScProfScope prof("bn_bwd(reduce+finalize+apply)", st, 0, 28.0 * M * C);
     hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, (double*)ws, g);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
                        training, dgamma, dbeta, c1, c2);

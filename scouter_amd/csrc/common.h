@@ -34,14 +34,12 @@ int sc_check_launch(const char* what);
         }                                     \
     } while (0)
 
-// ---- optional per-kernel-class timing (bench.py's roofline leg): hipEvents recorded on the launch stream
-enum ScProfClass { SC_PROF_CONV_FWD = 0, SC_PROF_CONV_DGRAD = 1, SC_PROF_CONV_WGRAD = 2, SC_PROF_XSLOT_FWD = 3,
-                   SC_PROF_XSLOT_BWD = 4, SC_PROF_BN = 5, SC_PROF_OTHER = 6, SC_PROF_NCLASS = 7 };
+// ---- optional per-kernel timing (bench.py's roofline leg): hipEvents recorded on the launch stream around ONE kernel
+// launch, aggregated by kernel-instance name (static strings, e.g. "igemm_fwd<128x128>")
 struct ScProfScope {
-    int cls;
     hipStream_t stream;
     int slot;
-    ScProfScope(int cls, hipStream_t stream, double flops, double bytes);
+    ScProfScope(const char* name, hipStream_t stream, double flops, double bytes);
     ~ScProfScope();
 };
 

@@ -581,7 +581,8 @@ extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const floa
         sc_set_error("conv2d_fwd: per-group channels must be multiples of 32 (got %d -> %d)", Cin / groups, Cout / groups);
         return rc;
     }
-    ScProfScope prof(SC_PROF_CONV_FWD, (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
+    static const char* names[4] = {"igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>"};
+    ScProfScope prof(names[igemm_tile(g)], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
                      4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
     return dispatch_igemm<false>(x, w, bias, addend, y, bn_partial, g, relu, (hipStream_t)stream);
 }
@@ -597,7 +598,9 @@ extern "C" int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const f
     // A operand = dY [B][Ho][Wo][Cout]; GEMM rows = input pixels (H x W); columns = Cin
     ConvGeom g{B, Ho, Wo, Cout, H, W, Cin, kh, kw, stride, pad, groups, Cog, Cig, 0, Cout, Cig * Cout};
     g.M = (long)B * H * W;
-    ScProfScope prof(SC_PROF_CONV_DGRAD, (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw / (stride * stride),
+    static const char* names[4] = {"igemm_dgrad<128x128>", "igemm_dgrad<128x64>", "igemm_dgrad<64x64>",
+                                   "igemm_dgrad<128x32>"};
+    ScProfScope prof(names[igemm_tile(g)], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw / (stride * stride),
                      4.0 * ((double)B * Ho * Wo * Cout + (double)g.M * Cin));
     return dispatch_igemm<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, (hipStream_t)stream);
 }
@@ -656,10 +659,17 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
         return SC_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    ScProfScope prof(SC_PROF_CONV_WGRAD, st, 2.0 * g.M * Cout * g.Cg * kh * kw,
-                     4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
     float* out = p.splits > 1 ? (float*)ws : dw;
     dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
+    static char wname[9][24];
+    static const int wb[9][2] = {{128, 128}, {128, 64}, {128, 32}, {64, 128}, {64, 64}, {64, 32}, {32, 128}, {32, 64}, {32, 32}};
+    int wi = 8;
+    for (int k = 0; k < 9; ++k) if (wb[k][0] == p.bm && wb[k][1] == p.bn) wi = k;
+    if (!wname[wi][0]) snprintf(wname[wi], sizeof(wname[wi]), "wgrad<%dx%d>", p.bm, p.bn);
+    int rc;
+    {
+    ScProfScope prof(wname[wi], st, 2.0 * g.M * Cout * g.Cg * kh * kw,
+                     4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
 #define WG(BM_, BN_, WM_, WN_)                                                                                      \
     hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_>), grid, dim3(256), 0, st, x, dy, out, g, p.ci_tiles,     \
                        p.co_tiles, p.pix_per_split, slab)
@@ -673,10 +683,12 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
     else if (p.bm == 32 && p.bn == 64) WG(32, 64, 32, 32);
     else WG(32, 32, 32, 32);
 #undef WG
-    int rc = sc_check_launch("conv2d_wgrad");
+    }
+    rc = sc_check_launch("conv2d_wgrad");
     if (rc) return rc;
     if (p.splits > 1) {
         const long n = slab;
+        ScProfScope prof2("slab_reduce", st, 0, 4.0 * (double)slab * (p.splits + 1));
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(n / 4, 8)), dim3(256), 0, st, (const float*)ws, dw, n,
                            p.splits, slab);
         rc = sc_check_launch("conv2d_wgrad_reduce");

@@ -389,7 +389,7 @@ extern "C" int scouter_xslot_bwd_f32(const float* X, const float* PE, const floa
     const size_t lds = xs_bwd_lds_bytes(NJT);
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * (double)B * (2.0 * L * N * d * d + (double)T * 4.0 * S * N * d + (T - 1) * 12.0 * S * d * d);
-    ScProfScope prof(SC_PROF_XSLOT_BWD, st, flops, 4.0 * B * (3.0 * N * d + (double)S * d));
+    ScProfScope prof("xslot_bwd", st, flops, 4.0 * B * (3.0 * N * d + (double)S * d));
 #define XSB_LAUNCH(NJT_)                                                                                   \
     do {                                                                                                   \
         auto kern = xslot_bwd_kernel<NJT_>;                                                                \

@@ -254,7 +254,7 @@ extern "C" int scouter_xslot_fwd_f32(const float* X, const float* PE, const floa
     const size_t lds = xs_fwd_lds_bytes(NJT);
     hipStream_t st = (hipStream_t)stream;
     const double flops = (double)B * (2.0 * L * N * d * d + (double)T * 4.0 * S * N * d + (T - 1) * 12.0 * S * d * d);
-    ScProfScope prof(SC_PROF_XSLOT_FWD, st, flops, 4.0 * B * (2.0 * N * d + (double)S * N));
+    ScProfScope prof("xslot_fwd", st, flops, 4.0 * B * (2.0 * N * d + (double)S * N));
 #define XS_LAUNCH(NJT_, TPW_)                                                                                       \
     do {                                                                                                            \
         auto kern = xslot_fwd_kernel<NJT_, TPW_>;                                                                   \

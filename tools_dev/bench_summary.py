@@ -7,8 +7,7 @@ for line in sys.stdin:
     print("value %.1f %s  ms/step %.3f  n_gpus %d" % (d["value"], d["unit"], d["ms_per_step"], d["n_gpus"]))
     print("roofline", d.get("roofline"))
     for k, v in d.get("kernels", {}).items():
-        print("  %-11s %6.2f ms/step  %5.1f launches  %s TF/s  %s GB/s(alg)" % (
-            k, v["ms_per_step"], v["launches_per_step"], v["tflops"] and round(v["tflops"], 1),
-            v["gbps_algorithmic"] and round(v["gbps_algorithmic"])))
+        print("  %-30s %6.2f ms/step  %5.1f launches  avg %7.1f us  %s TF/s  %s GB/s(alg)" % (
+            k, v["ms_per_step"], v["launches_per_step"], v["avg_us"], v["tflops"], v["gbps_algorithmic"]))
     if "cpu_baseline" in d:
         print("cpu_baseline", d["cpu_baseline"])
