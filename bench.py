@@ -83,14 +83,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
-        G.build()
     import torch.distributed as dist
     force_dp = bool(os.environ.get("SCOUTER_FORCE_DP"))      # dev: exercise the RCCL path with a 1-rank group
     if world > 1 or (force_dp and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+    # build (or verify) the HIP library on rank 0 only, then let the other ranks load the finished file
+    if rank == 0:
+        G.build()
+    if dist.is_initialized():
         dist.barrier()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")

@@ -611,7 +611,6 @@ static WgradPlan wgrad_plan(const ConvGeom& g) {
     WgradPlan p;
     p.bm = (g.Cg % 128 == 0) ? 128 : (g.Cg % 64 == 0 ? 64 : 32);
     p.bn = (g.Ng % 128 == 0) ? 128 : (g.Ng % 64 == 0 ? 64 : 32);
-    if (p.bm == 128 && p.bn == 128 && (long)(g.Cg / 128) * (g.Ng / 128) * g.R * g.S * g.groups < 64) p.bm = 64;
     p.ci_tiles = g.Cg / p.bm;
     p.co_tiles = g.Ng / p.bn;
     p.tiles = (long)p.ci_tiles * p.co_tiles * g.groups * g.R * g.S;
