@@ -33,7 +33,7 @@ def load_backbone(args):
         bone.conv1 = StemConv2d(1, 64, 3, 2, 1)                 # slot_model.py:23-24
     if args.use_slot:
         if getattr(args, "use_pre", False):
-            checkpoint = torch.load(f"saved_model/{args.dataset}_no_slot_checkpoint.pth", map_location="cpu")
+            checkpoint = torch.load(f"saved_model/{args.dataset}_no_slot_checkpoint.pth", map_location="cpu", weights_only=False)
             new_state_dict = OrderedDict((k[9:], v) for k, v in checkpoint["model"].items())   # strip `backbone.`
             bone.load_state_dict(new_state_dict)
             print("load pre dataset parameter over")

@@ -62,7 +62,7 @@ def main():
     model = SlotModel(args).to(args.device)
     ckpt = args.checkpoint or os.path.join(args.output_dir, checkpoint_name(args))
     if os.path.exists(ckpt):
-        model.load_state_dict(torch.load(ckpt, map_location="cpu")["model"], strict=True)
+        model.load_state_dict(torch.load(ckpt, map_location="cpu", weights_only=False)["model"], strict=True)
         print("load", ckpt)
     else:
         print("no checkpoint found (%s): random weights" % ckpt)

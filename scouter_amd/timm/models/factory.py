@@ -15,5 +15,5 @@ def create_model(model_name, pretrained=False, num_classes=1000, in_chans=3, che
     model = _MODELS[model_name](pretrained=pretrained, num_classes=num_classes, in_chans=in_chans, **kwargs)
     if checkpoint_path:
         import torch
-        model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))
+        model.load_state_dict(torch.load(checkpoint_path, map_location="cpu", weights_only=False))
     return model

@@ -117,7 +117,7 @@ def main(args):
     output_dir = Path(args.output_dir) if args.output_dir else None
 
     if args.resume:
-        checkpoint = torch.load(args.resume, map_location="cpu")
+        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
         model_without_ddp.load_state_dict(checkpoint["model"])
         if "optimizer" in checkpoint and "lr_scheduler" in checkpoint and "epoch" in checkpoint:
             try:

@@ -167,3 +167,37 @@ def test_vis_inference_path_writes_reference_style_maps(tmp_path):
     assert np.abs(maps.astype(int) - ref_maps.astype(int)).max() <= 1
     assert sorted(os.listdir(tmp_path)) == ["slot_%d.png" % c for c in range(10)]
     assert 0.0 <= ratio <= 1.0
+
+
+def test_train_main_end_to_end_with_checkpoint_resume(tmp_path, monkeypatch):
+    """scouter_amd.train.main on seeded synthetic data: 2 epochs, reference-named checkpoint written, then --resume
+    continues from epoch 2 with the optimizer state restored; the checkpoint loads into a fresh model bit-exactly."""
+    from scouter_amd import train as T
+    from scouter_amd.sloter.slot_model import SlotModel
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SLURM_PROCID"):
+        monkeypatch.delenv(k, raising=False)
+    argv = ["--model", "resnet18", "--dataset", "MNIST", "--channel", "512", "--num_classes", "10", "--slots_per_class", "1",
+            "--power", "1", "--to_k_layer", "1", "--pre_trained", "false", "--img_size", "64", "--batch_size", "8",
+            "--synthetic_len", "16", "--epochs", "2", "--num_workers", "0", "--lr_drop", "1",
+            "--output_dir", str(tmp_path) + "/"]
+    parser = argparse.ArgumentParser(parents=[T.get_args_parser()])
+    args = parser.parse_args(argv)
+    accs = T.param_translation(args)
+    assert len(accs) == 2 and all(0.0 <= a <= 1.0 for a in accs)
+    ck = tmp_path / "MNIST_use_slot_checkpoint.pth"
+    assert ck.exists()
+    blob = torch.load(ck, map_location="cpu", weights_only=False)
+    assert blob["epoch"] == 1 and set(blob) == {"model", "optimizer", "lr_scheduler", "epoch", "args"}
+    assert blob["lr_scheduler"]["last_epoch"] == 2            # StepLR stepped once per epoch over FusedAdamW
+    m = SlotModel(args)
+    m.load_state_dict(blob["model"])
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), blob["model"][k].cpu()), k
+    # resume: one more epoch starting at epoch 2
+    args2 = parser.parse_args(argv + ["--resume", str(ck), "--epochs", "3"])
+    accs2 = T.param_translation(args2)
+    assert len(accs2) == 2
+    blob2 = torch.load(ck, map_location="cpu", weights_only=False)
+    assert blob2["epoch"] == 2
+    st = [v for k, v in blob2["optimizer"]["state"].items() if isinstance(v, dict) and "step" in v]
+    assert st and st[0]["step"] == 6                             # 2 steps/epoch x 3 epochs
