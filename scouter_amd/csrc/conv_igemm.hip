@@ -12,6 +12,7 @@
 // reads and the global prefetch of the next K-tile hide under it -- no reshaping tricks, exact fp32 (fmaf chain).
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 struct ConvGeom {
@@ -528,6 +529,11 @@ static void launch_igemm(const float* src, const float* w, const float* bias, co
 
 // tile choice: largest tile that still fills the chip (>= ~1.5 rounds of 256 CUs x 2 blocks); Ng is a multiple of 32
 static int igemm_tile(const ConvGeom& g) {     // 0: 128x128  1: 128x64  2: 64x64  3: 128x32
+    static const char* force = getenv("SCOUTER_IGEMM_TILE");      // dev override
+    if (force && force[0]) {
+        const int t = atoi(force);
+        if ((t == 0 && g.Ng % 128 == 0) || ((t == 1 || t == 2) && g.Ng % 64 == 0) || t == 3) return t;
+    }
     auto blocks = [&](int bm, int bn) { return (long)sc_cdiv(g.M, bm) * (g.Ng / bn) * g.groups; };
     const long want = 768;
     if (g.Ng % 128 == 0 && blocks(128, 128) >= want) return 0;

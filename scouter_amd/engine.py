@@ -1,15 +1,72 @@
-"""Training / evaluation loops -- mirrors engine.py:6-52 of the reference (same signatures and `record` contents).
+"""Epoch loops of the xSlot training path: `train_one_epoch`, `evaluate`, `calculation` (names / arguments /
+`record` contents as in the reference's engine.py:6-52).
 
-Difference on purpose: the reference pulls four scalars to the host per step (`loss.item()` x3 + evaluateTop1,
-engine.py:37-42 = 4 device syncs).  Here the loss head kernel already produced [loss, nll, area, top-1] in one small
-device buffer (`model.last_stats`), which is read with a single D2H copy per step."""
+What is different by design: the reference reads four scalars back to the host every step (loss.item() x3 and the
+top-1 accuracy, engine.py:37-42), i.e. four device synchronisations per step.  Here the loss-head kernel already
+leaves [loss, nll, area**power, top-1] in one small device buffer (`SlotModel.last_stats`); each step adds that
+buffer into a device-side accumulator with one tiny kernel and the host reads the accumulator ONCE per epoch, so the
+host never waits for the GPU inside the loop."""
 import torch
 
+from . import kernels as K
+
 try:
-    from tqdm.auto import tqdm
-except Exception:   # pragma: no cover
-    def tqdm(x):
-        return x
+    from tqdm.auto import tqdm as _progress
+except Exception:                                     # pragma: no cover - tqdm is optional
+    def _progress(it):
+        return it
+
+
+class _DeviceMeter:
+    """Sum of the per-step stats vectors, kept on the device until `.read()`."""
+
+    def __init__(self):
+        self.total = None
+        self.host = [0.0, 0.0, 0.0, 0.0]              # fallback path for models without `last_stats`
+
+    def add_device(self, stats):
+        if self.total is None:
+            self.total = torch.zeros(8, dtype=torch.float32, device=stats.device)
+        K.axpby(self.total, stats, 1.0, 1.0, out=self.total)
+
+    def add_host(self, loss, nll, att, acc):
+        for i, v in enumerate((loss, nll, att, acc)):
+            self.host[i] += v
+
+    def read(self):
+        dev = self.total[:4].tolist() if self.total is not None else [0.0] * 4      # the only host sync of the epoch
+        return [d + h for d, h in zip(dev, self.host)]
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def calculation(model, mode, data_loader, device, record, epoch, optimizer=None):
+    training = mode == "train"
+    meter = _DeviceMeter()
+    print("start " + mode + " :" + str(epoch))
+    steps = 0
+    for batch in _progress(data_loader):
+        images = batch["image"].to(device, dtype=torch.float32)
+        labels = batch["label"].to(device, dtype=torch.int64)
+        if training:
+            optimizer.zero_grad()
+        logits, losses = model(images, labels)
+        if training:
+            losses[0].backward()
+            optimizer.step()
+        stats = getattr(_unwrap(model), "last_stats", None)
+        if stats is not None:
+            meter.add_device(stats)
+        else:                                         # generic nn.Module: fall back to per-step host reads
+            from .tools.calculate_tool import evaluateTop1
+            meter.add_host(losses[0].item(), losses[1].item() if len(losses) > 2 else 0.0,
+                           losses[2].item() if len(losses) > 2 else 0.0, evaluateTop1(logits, labels))
+        steps += 1
+    loss, nll, att, acc = (v / max(steps, 1) for v in meter.read())
+    for field, value in (("loss", loss), ("acc", acc), ("log_loss", nll), ("att_loss", att)):
+        record[mode][field].append(round(value, 3))
 
 
 def train_one_epoch(model, data_loader, optimizer, device, record, epoch):
@@ -21,42 +78,3 @@ def train_one_epoch(model, data_loader, optimizer, device, record, epoch):
 def evaluate(model, data_loader, device, record, epoch):
     model.eval()
     calculation(model, "val", data_loader, device, record, epoch)
-
-
-def _stats_of(model):
-    m = model.module if hasattr(model, "module") else model
-    return getattr(m, "last_stats", None)
-
-
-def calculation(model, mode, data_loader, device, record, epoch, optimizer=None):
-    L = len(data_loader)
-    running_loss = running_corrects = running_att_loss = running_log_loss = 0.0
-    print("start " + mode + " :" + str(epoch))
-    for i_batch, sample_batch in enumerate(tqdm(data_loader)):
-        inputs = sample_batch["image"].to(device, dtype=torch.float32)
-        labels = sample_batch["label"].to(device, dtype=torch.int64)
-        if mode == "train":
-            optimizer.zero_grad()
-        logits, loss_list = model(inputs, labels)
-        loss = loss_list[0]
-        if mode == "train":
-            loss.backward()
-            optimizer.step()
-        stats = _stats_of(model)
-        if stats is not None and len(loss_list) > 2:
-            s = stats[:4].tolist()                        # one D2H sync: loss, nll, area**power, top-1
-            running_loss += s[0]
-            running_log_loss += s[1]
-            running_att_loss += s[2]
-            running_corrects += s[3]
-        else:
-            from .tools import calculate_tool as cal
-            running_loss += loss.item()
-            if len(loss_list) > 2:
-                running_att_loss += loss_list[2].item()
-                running_log_loss += loss_list[1].item()
-            running_corrects += cal.evaluateTop1(logits, labels)
-    record[mode]["loss"].append(round(running_loss / L, 3))
-    record[mode]["acc"].append(round(running_corrects / L, 3))
-    record[mode]["log_loss"].append(round(running_log_loss / L, 3))
-    record[mode]["att_loss"].append(round(running_att_loss / L, 3))

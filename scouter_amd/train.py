@@ -1,16 +1,22 @@
-"""Training driver -- mirrors train.py:18-238 of the reference: same argparse surface (get_args_parser), same
-main(args) flow (init dist -> SlotModel -> DP wrap -> AdamW/StepLR -> loaders -> epoch loop -> checkpoints) and
-checkpoint naming.  Launch: `python -m scouter_amd.train ...` or, for N GPUs of one node,
-`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 -m scouter_amd.train ...` (one process
-per GPU, gradients all-reduced over RCCL/xGMI).  The `--thop` cost-counting branch (train.py:91-137) is out of
-scope (it profiles FLOPs on CPU with third-party packages)."""
+"""Training driver of the MI355X xSlot path.
+
+Public surface as in the reference's train.py (`get_args_parser`, `main(args) -> [train_acc, val_acc]`,
+`param_translation(args)` with the comma-list sweeps, checkpoint file names and contents), so recipes written for it
+run unchanged:
+
+    python -m scouter_amd.train --dataset ImageNet --model resnest26d --channel 2048 --num_classes 10 ...
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m scouter_amd.train ...   # 8 GPUs
+
+One process per GPU; gradients are all-reduced over RCCL/xGMI by scouter_amd.parallel; the optimizer is the fused
+AdamW kernel.  The `--thop` FLOP-counting branch of the reference (train.py:91-137) is CPU-side tooling with
+third-party packages and is refused."""
 import argparse
 import datetime
 import time
 from pathlib import Path
 
 import torch
-from torch.utils.data import DistributedSampler
+from torch.utils.data import BatchSampler, DistributedSampler, RandomSampler, SequentialSampler
 
 from .dataset.choose_dataset import select_dataset
 from .engine import evaluate, train_one_epoch
@@ -19,161 +25,167 @@ from .parallel import DistributedDataParallel
 from .sloter.slot_model import SlotModel
 from .tools import prepare_things as prt
 from .tools.calculate_tool import MetricLog
-from .tools.prepare_things import DataLoaderX
+
+
+def _flag(text):
+    value = text.lower()
+    if value in ("yes", "true", "t", "y", "1"):
+        return True
+    if value in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Unsupported value encountered.")
+
+
+# (flag, default, type, help) -- defaults and types are the reference's (train.py:28-78); four flags stay strings so
+# that a comma list sweeps them (param_translation)
+_CLI = [
+    ("model", "resnet18", str, "backbone: resnet18 | resnest26d | resnest50d"),
+    ("dataset", "MNIST", str, "MNIST selects the 1-channel 3x3 stem"),
+    ("channel", 512, int, "channels of the backbone feature map"),
+    ("lr", 1e-4, float, None), ("lr_drop", 70, int, "StepLR period (epochs)"), ("batch_size", 64, int, "per process"),
+    ("weight_decay", 1e-4, float, "accepted and ignored, like the reference (AdamW default 1e-2 is used)"),
+    ("epochs", 10, int, None), ("num_classes", "10", str, None), ("img_size", 260, None, "input resolution"),
+    ("pre_trained", True, _flag, "freeze `freeze_layers` stages (weights must be loaded from a checkpoint)"),
+    ("use_slot", True, _flag, "xSlot head (false: global-pool + fc baseline)"),
+    ("use_pre", False, _flag, "initialise the backbone from the FC-baseline checkpoint"),
+    ("aug", False, _flag, None), ("grad", False, _flag, None), ("grad_min_level", 0.0, float, None),
+    ("iterated_evaluation_num", 1, int, "repetitions per sweep value"),
+    ("cal_area_size", False, _flag, "tag checkpoints with lambda / slots_per_class"),
+    ("thop", False, _flag, "refused (CPU FLOP counting)"),
+    ("loss_status", 1, int, "+1 positive / -1 negative explanation loss"),
+    ("freeze_layers", 2, int, None), ("hidden_dim", 64, int, None), ("slots_per_class", "3", str, None),
+    ("power", "2", str, "exponent of the attention-area loss"), ("to_k_layer", 1, int, None),
+    ("lambda_value", "1.", str, "weight of the attention-area loss"),
+    ("vis", False, _flag, "write slot attention maps"), ("vis_id", 0, int, None),
+    ("dataset_dir", "../PAN/bird_200/CUB_200_2011/CUB_200_2011/", str, None),
+    ("output_dir", "saved_model/", str, "empty string: do not save"), ("pre_dir", "pre_model/", str, None),
+    ("device", "cuda", str, None), ("num_workers", 4, int, None), ("start_epoch", 0, int, None),
+    ("resume", "", str, "checkpoint path"),
+    ("world_size", 1, int, None), ("local_rank", None, int, None), ("dist_url", "env://", str, None),
+    # additions of this build
+    ("synthetic_data", True, _flag, "seeded synthetic batches (the benchmark input)"),
+    ("synthetic_len", 256, int, "images per synthetic epoch"),
+]
 
 
 def get_args_parser():
-    def str2bool(v):
-        if v.lower() in ("yes", "true", "t", "y", "1"):
-            return True
-        if v.lower() in ("no", "false", "f", "n", "0"):
-            return False
-        raise argparse.ArgumentTypeError("Unsupported value encountered.")
-
-    p = argparse.ArgumentParser("Set SCOUTER model", add_help=False)
-    p.add_argument("--model", default="resnet18", type=str)
-    p.add_argument("--dataset", default="MNIST", type=str)
-    p.add_argument("--channel", default=512, type=int)
-    # training set
-    p.add_argument("--lr", default=0.0001, type=float)
-    p.add_argument("--lr_drop", default=70, type=int)
-    p.add_argument("--batch_size", default=64, type=int)
-    p.add_argument("--weight_decay", default=0.0001, type=float)       # unused by the reference too (train.py:146)
-    p.add_argument("--epochs", default=10, type=int)
-    p.add_argument("--num_classes", default="10", type=str)
-    p.add_argument("--img_size", default=260, help="input resolution")
-    p.add_argument("--pre_trained", default=True, type=str2bool)
-    p.add_argument("--use_slot", default=True, type=str2bool)
-    p.add_argument("--use_pre", default=False, type=str2bool)
-    p.add_argument("--aug", default=False, type=str2bool)
-    p.add_argument("--grad", default=False, type=str2bool)
-    p.add_argument("--grad_min_level", default=0., type=float)
-    p.add_argument("--iterated_evaluation_num", default=1, type=int)
-    p.add_argument("--cal_area_size", default=False, type=str2bool)
-    p.add_argument("--thop", default=False, type=str2bool)
-    # slot setting
-    p.add_argument("--loss_status", default=1, type=int)
-    p.add_argument("--freeze_layers", default=2, type=int)
-    p.add_argument("--hidden_dim", default=64, type=int)
-    p.add_argument("--slots_per_class", default="3", type=str)
-    p.add_argument("--power", default="2", type=str)
-    p.add_argument("--to_k_layer", default=1, type=int)
-    p.add_argument("--lambda_value", default="1.", type=str)
-    p.add_argument("--vis", default=False, type=str2bool)
-    p.add_argument("--vis_id", default=0, type=int)
-    # data / machine set
-    p.add_argument("--dataset_dir", default="../PAN/bird_200/CUB_200_2011/CUB_200_2011/")
-    p.add_argument("--output_dir", default="saved_model/")
-    p.add_argument("--pre_dir", default="pre_model/")
-    p.add_argument("--device", default="cuda")
-    p.add_argument("--num_workers", default=4, type=int)
-    p.add_argument("--start_epoch", default=0, type=int, metavar="N")
-    p.add_argument("--resume", default="", type=str, help="checkpoint path to resume from")
-    # distributed training parameters
-    p.add_argument("--world_size", default=1, type=int)
-    p.add_argument("--local_rank", type=int)
-    p.add_argument("--dist_url", default="env://")
-    # build-side additions (not in the reference)
-    p.add_argument("--synthetic_data", default=True, type=str2bool, help="seeded synthetic batches (benchmark input)")
-    p.add_argument("--synthetic_len", default=256, type=int)
-    return p
+    parser = argparse.ArgumentParser("Set SCOUTER model", add_help=False)
+    for name, default, typ, text in _CLI:
+        kwargs = {"default": default, "help": text}
+        if typ is not None:
+            kwargs["type"] = typ
+        parser.add_argument("--" + name, **kwargs)
+    return parser
 
 
 def checkpoint_name(args, suffix="checkpoint.pth"):
-    """reference train.py:180-189"""
-    return (f"{args.dataset}_" + ("use_slot_" if args.use_slot else "no_slot_")
-            + ("negative_" if args.use_slot and args.loss_status != 1 else "")
-            + (f"for_area_size_{args.lambda_value}_{args.slots_per_class}_" if args.cal_area_size else "") + suffix)
+    """`{dataset}_{use_slot_|no_slot_}[negative_][for_area_size_{lambda}_{spc}_]{suffix}` (reference train.py:180-189)."""
+    parts = [args.dataset, "use_slot" if args.use_slot else "no_slot"]
+    if args.use_slot and args.loss_status != 1:
+        parts.append("negative")
+    if args.cal_area_size:
+        parts += ["for_area_size", str(args.lambda_value), str(args.slots_per_class)]
+    return "_".join(parts) + "_" + suffix
+
+
+def _build_loaders(args):
+    train_set, val_set = select_dataset(args)
+    if args.distributed:
+        train_sampler, val_sampler = DistributedSampler(train_set), DistributedSampler(val_set, shuffle=False)
+    else:
+        train_sampler, val_sampler = RandomSampler(train_set), SequentialSampler(val_set)
+    train_loader = prt.DataLoaderX(train_set, batch_sampler=BatchSampler(train_sampler, args.batch_size, drop_last=True),
+                                   num_workers=args.num_workers)
+    val_loader = prt.DataLoaderX(val_set, args.batch_size, sampler=val_sampler, num_workers=args.num_workers)
+    return train_loader, val_loader, train_sampler
+
+
+def _restore(args, model, optimizer, scheduler):
+    state = torch.load(args.resume, map_location="cpu", weights_only=False)
+    model.load_state_dict(state["model"])
+    if all(k in state for k in ("optimizer", "lr_scheduler", "epoch")):
+        try:
+            optimizer.load_state_dict(state["optimizer"])
+        except Exception as err:      # a per-tensor torch.optim.AdamW state (reference checkpoint) has another layout
+            print("optimizer state not restored:", err)
+        scheduler.load_state_dict(state["lr_scheduler"])
+        args.start_epoch = state["epoch"] + 1
+
+
+def _save(args, model, optimizer, scheduler, epoch):
+    out = Path(args.output_dir)
+    names = [checkpoint_name(args)]
+    if (epoch + 1) % args.lr_drop == 0 or (epoch + 1) % 10 == 0:      # numbered copy at LR drops / every 10 epochs
+        names.append(checkpoint_name(args, "checkpoint%04d.pth" % epoch))
+    payload = {"model": model.state_dict(), "optimizer": optimizer.state_dict(), "lr_scheduler": scheduler.state_dict(),
+               "epoch": epoch, "args": args}
+    for name in names:
+        prt.save_on_master(payload, out / name)
 
 
 def main(args):
     prt.init_distributed_mode(args)
-    device = torch.device(args.device)
     if args.thop:
-        raise NotImplementedError("--thop (CPU FLOP counting with thop/tensorly) is outside the xSlot hot path")
-    model = SlotModel(args)
-    print("train model: " + ("use slot " if args.use_slot else "without slot ")
-          + ("negetive loss" if args.use_slot and args.loss_status != 1 else "positive loss"))
-    model.to(device)
-    model_without_ddp = model
-    if args.distributed:
-        model = DistributedDataParallel(model, device_ids=[args.gpu], find_unused_parameters=True)
-        model_without_ddp = model.module
-    print("number of params:", sum(p.numel() for p in model.parameters() if p.requires_grad))
-    params = [p for p in model_without_ddp.parameters() if p.requires_grad]
-    optimizer = FusedAdamW(params, lr=args.lr)
-    lr_scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=args.lr_drop)
-
-    dataset_train, dataset_val = select_dataset(args)
-    if args.distributed:
-        sampler_train = DistributedSampler(dataset_train)
-        sampler_val = DistributedSampler(dataset_val, shuffle=False)
-    else:
-        sampler_train = torch.utils.data.RandomSampler(dataset_train)
-        sampler_val = torch.utils.data.SequentialSampler(dataset_val)
-    batch_sampler_train = torch.utils.data.BatchSampler(sampler_train, args.batch_size, drop_last=True)
-    data_loader_train = DataLoaderX(dataset_train, batch_sampler=batch_sampler_train, num_workers=args.num_workers)
-    data_loader_val = DataLoaderX(dataset_val, args.batch_size, sampler=sampler_val, num_workers=args.num_workers)
-    output_dir = Path(args.output_dir) if args.output_dir else None
-
+        raise NotImplementedError("--thop (CPU FLOP counting with thop / tensorly) is outside the xSlot hot path")
+    device = torch.device(args.device)
+    net = SlotModel(args).to(device)
+    kind = ("use slot " if args.use_slot else "without slot ") + \
+        ("negetive loss" if args.use_slot and args.loss_status != 1 else "positive loss")
+    print("train model: " + kind)
+    wrapped = DistributedDataParallel(net, device_ids=[args.gpu], find_unused_parameters=True) \
+        if args.distributed else net
+    trainable = [p for p in net.parameters() if p.requires_grad]
+    print("number of params:", sum(p.numel() for p in trainable))
+    optimizer = FusedAdamW(trainable, lr=args.lr)
+    scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=args.lr_drop)
+    train_loader, val_loader, train_sampler = _build_loaders(args)
     if args.resume:
-        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
-        model_without_ddp.load_state_dict(checkpoint["model"])
-        if "optimizer" in checkpoint and "lr_scheduler" in checkpoint and "epoch" in checkpoint:
-            try:
-                optimizer.load_state_dict(checkpoint["optimizer"])
-            except Exception as e:          # a reference (per-tensor AdamW) optimizer state has a different layout
-                print("optimizer state not restored:", e)
-            lr_scheduler.load_state_dict(checkpoint["lr_scheduler"])
-            args.start_epoch = checkpoint["epoch"] + 1
+        _restore(args, net, optimizer, scheduler)
 
     print("Start training")
-    start_time = time.time()
+    started = time.time()
     log = MetricLog()
-    record = log.record
     for epoch in range(args.start_epoch, args.epochs):
         if args.distributed:
-            sampler_train.set_epoch(epoch)
-        train_one_epoch(model, data_loader_train, optimizer, device, record, epoch)
-        lr_scheduler.step()
-        if output_dir is not None:
-            paths = [output_dir / checkpoint_name(args)]
-            if (epoch + 1) % args.lr_drop == 0 or (epoch + 1) % 10 == 0:
-                paths.append(output_dir / checkpoint_name(args, f"checkpoint{epoch:04}.pth"))
-            for path in paths:
-                prt.save_on_master({"model": model_without_ddp.state_dict(), "optimizer": optimizer.state_dict(),
-                                    "lr_scheduler": lr_scheduler.state_dict(), "epoch": epoch, "args": args}, path)
-        evaluate(model, data_loader_val, device, record, epoch)
+            train_sampler.set_epoch(epoch)
+        train_one_epoch(wrapped, train_loader, optimizer, device, log.record, epoch)
+        scheduler.step()
+        if args.output_dir:
+            _save(args, net, optimizer, scheduler, epoch)
+        evaluate(wrapped, val_loader, device, log.record, epoch)
         log.print_metric()
-    print("Training time {}".format(str(datetime.timedelta(seconds=int(time.time() - start_time)))))
-    return [record["train"]["acc"][-1], record["val"]["acc"][-1]]
+    print("Training time {}".format(datetime.timedelta(seconds=int(time.time() - started))))
+    return [log.record["train"]["acc"][-1], log.record["val"]["acc"][-1]]
+
+
+_SWEEPABLE = (("num_classes", int), ("lambda_value", float), ("power", int), ("slots_per_class", int))
 
 
 def param_translation(args):
-    """reference train.py:207-231: four flags are strings so that a comma list sweeps one of them."""
-    args_dict = vars(args)
-    names, types = ["num_classes", "lambda_value", "power", "slots_per_class"], [int, float, int, int]
-    target, target_type, settings = None, None, None
-    for name, typ in zip(names, types):
-        if str(args_dict[name]).find(",") > 0:
-            target, target_type, settings = name, typ, str(args_dict[name]).split(",")
+    """Casts the four string flags; a comma list in ONE of them runs main() once per value (x iterated_evaluation_num)
+    and returns {flag-value: [main() results]} (reference train.py:207-231)."""
+    sweep = None
+    for name, cast in _SWEEPABLE:
+        raw = str(getattr(args, name))
+        if "," in raw:
+            sweep = (name, cast, raw.split(","))
         else:
-            args_dict[name] = typ(args_dict[name])
-    if target is None:
+            setattr(args, name, cast(raw))
+    if sweep is None:
         return main(args)
-    record = {}
-    for s in settings:
-        record[f"{target}-" + s] = []
-        args_dict[target] = target_type(s)
+    name, cast, values = sweep
+    results = {}
+    for value in values:
+        setattr(args, name, cast(value))
+        runs = results.setdefault("%s-%s" % (name, value), [])
         for _ in range(args.iterated_evaluation_num):
-            record[f"{target}-" + s].append(main(args))
-            print(record)
-    return record
+            runs.append(main(args))
+            print(results)
+    return results
 
 
 if __name__ == "__main__":
-    parser = argparse.ArgumentParser("model training and evaluation script", parents=[get_args_parser()])
-    args = parser.parse_args()
-    if args.output_dir:
-        Path(args.output_dir).mkdir(parents=True, exist_ok=True)
-    param_translation(args)
+    cli = argparse.ArgumentParser("model training and evaluation script", parents=[get_args_parser()]).parse_args()
+    if cli.output_dir:
+        Path(cli.output_dir).mkdir(parents=True, exist_ok=True)
+    param_translation(cli)
