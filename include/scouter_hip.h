@@ -41,14 +41,17 @@ int scouter_prof_collect(char* buf, int cap);
  * backward (engine.py:33).  fp32 implicit GEMM on v_mfma_f32_32x32x2_f32.  Per-group channels must be multiples
  * of 32.  `bias` (per Cout), `addend` (same shape as the output) may be NULL; relu applies last.
  * bn_partial (may be NULL): the epilogue also writes per-M-tile fp64 (sum, sum of squares) of every output channel,
- * [scouter_conv2d_fwd_bn_partial_rows(...)][Cout][2], which scouter_bn_fwd_f32 accepts instead of re-reading y. */
+ * [scouter_conv2d_fwd_bn_partial_rows(...)][Cout][2], which scouter_bn_fwd_f32 accepts instead of re-reading y.
+ * tile_hint: -1 = built-in heuristic, 0..3 = block tile 128x128 / 128x64 / 64x64 / 128x32 (ignored if illegal for the
+ * shape).  Results are bit-identical for every tile (same K order per output element), so callers may autotune it. */
 int scouter_conv2d_fwd_bn_partial_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
-                                       int groups);
+                                       int groups, int tile_hint);
 int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* addend, float* y,
                            double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
-                           int pad, int groups, int relu, void* stream);
+                           int pad, int groups, int relu, int tile_hint, void* stream);
 int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
-                             int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, void* stream);
+                             int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
+                             void* stream);
 size_t scouter_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
                                             int groups);
 int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,

@@ -528,12 +528,12 @@ static void launch_igemm(const float* src, const float* w, const float* bias, co
 }
 
 // tile choice: largest tile that still fills the chip (>= ~1.5 rounds of 256 CUs x 2 blocks); Ng is a multiple of 32
-static int igemm_tile(const ConvGeom& g) {     // 0: 128x128  1: 128x64  2: 64x64  3: 128x32
-    static const char* force = getenv("SCOUTER_IGEMM_TILE");      // dev override
-    if (force && force[0]) {
-        const int t = atoi(force);
-        if ((t == 0 && g.Ng % 128 == 0) || ((t == 1 || t == 2) && g.Ng % 64 == 0) || t == 3) return t;
-    }
+static bool igemm_tile_ok(const ConvGeom& g, int t) {
+    return (t == 0 && g.Ng % 128 == 0) || ((t == 1 || t == 2) && g.Ng % 64 == 0) || t == 3;
+}
+// hint >= 0: the caller's (autotuned) choice if legal for this shape; otherwise the static heuristic
+static int igemm_tile(const ConvGeom& g, int hint = -1) {     // 0: 128x128  1: 128x64  2: 64x64  3: 128x32
+    if (hint >= 0 && hint <= 3 && igemm_tile_ok(g, hint)) return hint;
     auto blocks = [&](int bm, int bn) { return (long)sc_cdiv(g.M, bm) * (g.Ng / bn) * g.groups; };
     const long want = 768;
     if (g.Ng % 128 == 0 && blocks(128, 128) >= want) return 0;
@@ -544,8 +544,8 @@ static int igemm_tile(const ConvGeom& g) {     // 0: 128x128  1: 128x64  2: 64x6
 
 template <bool DGRAD>
 static int dispatch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
-                          double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
-    switch (igemm_tile(g)) {
+                          double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st) {
+    switch (tile) {
         case 0: launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
         case 1: launch_igemm<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
         case 2: launch_igemm<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
@@ -569,15 +569,15 @@ static int conv_fwd_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, in
 
 // number of [Cout][2] fp64 rows the fused BatchNorm-statistics epilogue writes (= M tiles of the chosen kernel)
 extern "C" int scouter_conv2d_fwd_bn_partial_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
-                                                  int pad, int groups) {
+                                                  int pad, int groups, int tile_hint) {
     ConvGeom g;
     if (conv_fwd_geom(g, B, H, W, Cin, Cout, kh, kw, stride, pad, groups) != SC_OK) return 0;
-    return sc_cdiv(g.M, igemm_tile(g) == 2 ? 64 : 128);
+    return sc_cdiv(g.M, igemm_tile(g, tile_hint) == 2 ? 64 : 128);
 }
 
 extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* addend,
                                       float* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh,
-                                      int kw, int stride, int pad, int groups, int relu, void* stream) {
+                                      int kw, int stride, int pad, int groups, int relu, int tile_hint, void* stream) {
     SC_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0, "conv2d_fwd: null pointer or empty shape");
     SC_REQUIRE(!(bn_partial && relu), "conv2d_fwd: fused BatchNorm statistics are taken before any activation");
     ConvGeom g;
@@ -588,14 +588,15 @@ extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const floa
         return rc;
     }
     static const char* names[4] = {"igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>"};
-    ScProfScope prof(names[igemm_tile(g)], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
+    const int tile = igemm_tile(g, tile_hint);
+    ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
                      4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
-    return dispatch_igemm<false>(x, w, bias, addend, y, bn_partial, g, relu, (hipStream_t)stream);
+    return dispatch_igemm<false>(x, w, bias, addend, y, bn_partial, g, relu, tile, (hipStream_t)stream);
 }
 
 extern "C" int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H,
                                         int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups,
-                                        void* stream) {
+                                        int tile_hint, void* stream) {
     SC_REQUIRE(dy && w && dx && B > 0, "conv2d_dgrad: null pointer or empty shape");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad: channels not divisible by groups");
     const int Cig = Cin / groups, Cog = Cout / groups;
@@ -606,9 +607,10 @@ extern "C" int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const f
     g.M = (long)B * H * W;
     static const char* names[4] = {"igemm_dgrad<128x128>", "igemm_dgrad<128x64>", "igemm_dgrad<64x64>",
                                    "igemm_dgrad<128x32>"};
-    ScProfScope prof(names[igemm_tile(g)], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw / (stride * stride),
+    const int tile = igemm_tile(g, tile_hint);
+    ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw / (stride * stride),
                      4.0 * ((double)B * Ho * Wo * Cout + (double)g.M * Cin));
-    return dispatch_igemm<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, (hipStream_t)stream);
+    return dispatch_igemm<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream);
 }
 
 struct WgradPlan { int bm, bn, ci_tiles, co_tiles, splits; long pix_per_split, tiles; };

@@ -67,6 +67,41 @@ def conv_out(n, k, s, p):
 # ---------------------------------------------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------------------------------------------
+AUTOTUNE = os.environ.get("SCOUTER_AUTOTUNE", "1") != "0"
+_tile_cache = {}
+
+
+def _pick_tile(key, launch):
+    """Block-tile choice per (mode, layer shape): time the four tile shapes once (hipEvents on the current stream, first
+    call only) and cache the winner.  Every tile gives bit-identical results, so tuning never changes numerics."""
+    t = _tile_cache.get(key)
+    if t is not None:
+        return t
+    if not AUTOTUNE:
+        _tile_cache[key] = -1
+        return -1
+    best, best_ms = -1, None
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for cand in (0, 1, 2, 3):
+        if not launch(cand, dry=True):
+            continue
+        launch(cand)
+        ev0.record()
+        for _ in range(3):
+            launch(cand)
+        ev1.record()
+        ev1.synchronize()
+        ms = ev0.elapsed_time(ev1)
+        if best_ms is None or ms < best_ms:
+            best, best_ms = cand, ms
+    _tile_cache[key] = best
+    return best
+
+
+def _tile_legal(ng, t):
+    return (t == 0 and ng % 128 == 0) or (t in (1, 2) and ng % 64 == 0) or t == 3
+
+
 def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, relu=False, bn_stats=False):
     """bn_stats=True: the epilogue also produces the per-tile fp64 channel sums BatchNorm needs; returns
     (y, (partial, rows)) and `bn_fwd(..., stats=(partial, rows))` then skips its own statistics pass."""
@@ -76,12 +111,21 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     assert cg * groups == Cin, (x.shape, w_hwio.shape, groups)
     y = torch.empty((B, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout), dtype=F32, device=x.device)
     L = _native.lib()
+    st = _stream()
+
+    def launch(tile, dry=False, part=None):
+        if dry:
+            return _tile_legal(Cout // groups, tile)
+        _native.check(L.scouter_conv2d_fwd_f32(_p(x), _p(w_hwio), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
+                                               Cout, kh, kw, stride, pad, groups, int(relu), tile, st), "conv2d_fwd")
+        return True
+
+    tile = _pick_tile(("fwd", B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch)
     part, rows = None, 0
     if bn_stats:
-        rows = L.scouter_conv2d_fwd_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups)
+        rows = L.scouter_conv2d_fwd_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
         part = torch.empty((rows, Cout, 2), dtype=torch.float64, device=x.device)
-    _native.check(L.scouter_conv2d_fwd_f32(_p(x), _p(w_hwio), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin, Cout,
-                                           kh, kw, stride, pad, groups, int(relu), _stream()), "conv2d_fwd")
+    launch(tile, part=part)
     return (y, (part, rows)) if bn_stats else y
 
 
@@ -91,8 +135,16 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1):
     kh, kw, cg, Cout = w_hwio.shape
     dx = torch.empty(x_shape, dtype=F32, device=dy.device)
     L = _native.lib()
-    _native.check(L.scouter_conv2d_dgrad_f32(_p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride,
-                                             pad, groups, _stream()), "conv2d_dgrad")
+    st = _stream()
+
+    def launch(tile, dry=False):
+        if dry:
+            return _tile_legal(Cin // groups, tile)
+        _native.check(L.scouter_conv2d_dgrad_f32(_p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw,
+                                                 stride, pad, groups, tile, st), "conv2d_dgrad")
+        return True
+
+    launch(_pick_tile(("dgrad", B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch))
     return dx
 
 
