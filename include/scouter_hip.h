@@ -64,16 +64,21 @@ int scouter_pad_rows_f32(const float* w, float* wpad, long nvalid, long ntotal, 
 /* ---- BatchNorm2d (+ReLU, +residual add): timm/models/resnet.py:383 (norm_layer), BasicBlock :172-199,
  * ResNestBottleneck resnest.py:111-143.  Training mode: batch statistics (fp64 accumulation), running stats
  * updated with `momentum` and the unbiased variance; eval mode: running stats.
- * y = (x - mean) * scale + shift with scale = gamma*rstd, shift = beta; mean/rstd/scale are saved for the backward. */
+ * y = (x - mean) * scale + shift with scale = gamma*rstd, shift = beta; mean/rstd/scale are saved for the backward.
+ * relu_mask_out (optional, needs relu): sign bitmask of y, scouter_relu_mask_words(M*C) 64-bit words (1 bit/element);
+ * handing it to scouter_bn_bwd_f32 as relu_mask replaces the 4-byte-per-element read of ymask in both backward passes. */
+size_t scouter_relu_mask_words(long n);
 size_t scouter_colreduce_workspace_bytes(long M, int C);
 int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                        int training, int relu, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
-                       const double* ext_partial, int ext_rows, void* ws, size_t ws_bytes, void* stream);
-/* g = dy * (ymask > 0) (ymask may be NULL); dgamma/dbeta may be NULL (frozen); gout (may be NULL) receives g. */
+                       const double* ext_partial, int ext_rows, unsigned long long* relu_mask_out, void* ws,
+                       size_t ws_bytes, void* stream);
+/* g = dy * (y > 0), the sign taken from relu_mask if given, else from ymask (both may be NULL: no ReLU);
+ * dgamma/dbeta may be NULL (frozen); gout (may be NULL) receives g. */
 int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean, const float* rstd,
-                       const float* scale, long M, int C, int training, float* dgamma, float* dbeta, float* dx,
-                       float* gout, void* ws, size_t ws_bytes, void* stream);
+                       const float* scale, const unsigned long long* relu_mask, long M, int C, int training,
+                       float* dgamma, float* dbeta, float* dx, float* gout, void* ws, size_t ws_bytes, void* stream);
 /* out[c] = alpha * sum_m a[m][c] * (b ? b[m][c] : 1)  -- bias gradients, d(initial_slots) */
 int scouter_colsum_f32(const float* a, const float* b, float* out, long M, int C, float alpha, void* ws,
                        size_t ws_bytes, void* stream);

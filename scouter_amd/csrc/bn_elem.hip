@@ -27,14 +27,25 @@ static int col_blocks(long M, const ColGeom& g) {
     return (int)nb;
 }
 
+// ReLU sign bitmask (1 bit per element instead of re-reading the 4-byte activation in the backward): float4 index i
+// of the flat tensor owns bit (i & 63) of the four words mask[(i >> 6) * 4 + k], k = component.  Written with one
+// wave ballot per component by the apply pass, whose waves cover 64 consecutive float4s.
+__device__ __forceinline__ void relu_mask_apply(f32x4& g, const unsigned long long* __restrict__ mbits, long i4) {
+    const unsigned long long* w = mbits + (i4 >> 6) * 4;
+    const int bit = (int)(i4 & 63);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = ((w[k] >> bit) & 1ull) ? g[k] : 0.f;
+}
+
 // Per-block partial column sums of up to two quantities produced by `F(row, col4) -> (float4 u, float4 v)`.
 // partial layout: [block][C][2] doubles.
 template <int MODE>   // 0: (x, x*x)   1: (g, g*xhat) with g = dy*(mask>0)   2: (x, 0)   3: (a*b, 0)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
                                                              const float* __restrict__ p2,
                                                              const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, double* __restrict__ part,
-                                                             ColGeom g) {
+                                                             const float* __restrict__ rstd,
+                                                             const unsigned long long* __restrict__ mbits,
+                                                             double* __restrict__ part, ColGeom g) {
     __shared__ double red[256 * 8];
     const int tid = threadIdx.x;
     const int cq = tid % g.tpr, rl = tid / g.tpr;
@@ -66,7 +77,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { s[k] += a[k]; t[k] += (double)a[k] * a[k]; }
             } else if (MODE == 1) {
-                if (p1) {
+                if (mbits) {
+                    relu_mask_apply(a, mbits, off >> 2);
+                } else if (p1) {
                     f32x4 y = *(const f32x4*)(p1 + off);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) a[k] = y[k] > 0.f ? a[k] : 0.f;
@@ -162,7 +175,8 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ res, float* __restrict__ y,
-                                                              long n4, int C, int relu) {
+                                                              unsigned long long* __restrict__ mbits, long n4, int C,
+                                                              int relu) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         f32x4 v = *(const f32x4*)(x + i * 4);
@@ -170,6 +184,13 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
         v = (v - mu) * a + b;
         if (res) v += *(const f32x4*)(res + i * 4);
         if (relu) {
+            if (mbits) {        // i - lane is a multiple of 64 (256-thread blocks, grid stride a multiple of 256)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long b = __ballot(v[k] > 0.f);
+                    if ((threadIdx.x & 63) == 0) mbits[(i >> 6) * 4 + k] = b;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         }
@@ -197,12 +218,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ scale, const float* __restrict__ c1,
-                                                           const float* __restrict__ c2, float* __restrict__ dx,
-                                                           float* __restrict__ gout, long n4, int C) {
+                                                           const float* __restrict__ c2,
+                                                           const unsigned long long* __restrict__ mbits,
+                                                           float* __restrict__ dx, float* __restrict__ gout, long n4,
+                                                           int C) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         f32x4 g = *(const f32x4*)(dy + i * 4);
-        if (ymask) {
+        if (mbits) {
+            relu_mask_apply(g, mbits, i);
+        } else if (ymask) {
             const f32x4 y = *(const f32x4*)(ymask + i * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
@@ -416,12 +441,15 @@ extern "C" size_t scouter_colreduce_workspace_bytes(long M, int C) { (void)M; re
     }                                                                                                \
     dim3 pgrid(nb, (C + g.cslab - 1) / g.cslab);
 
+extern "C" size_t scouter_relu_mask_words(long n) { return (size_t)((n / 4 + 63) / 64) * 4; }
+
 extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var, float momentum,
                                   float eps, int training, int relu, float* mean_out, float* rstd_out,
                                   float* scale_out, float* shift_out, const double* ext_partial, int ext_rows,
-                                  void* ws, size_t ws_bytes, void* stream) {
+                                  unsigned long long* relu_mask_out, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(x && y && mean_out && rstd_out && scale_out && shift_out, "bn_fwd: null pointer");
+    SC_REQUIRE(!relu_mask_out || relu, "bn_fwd: relu_mask_out without relu");
     SC_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
     COL_CHECKS("bn_fwd")
     hipStream_t st = (hipStream_t)stream;
@@ -431,19 +459,20 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
     if (training && ext_partial) { part = ext_partial; nparts = ext_rows; }     // statistics came from the conv epilogue
     else if (training)
         hipLaunchKernelGGL(colsum_partial_kernel<0>, pgrid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
-                           (double*)ws, g);
+                           nullptr, (double*)ws, g);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, part, nparts, M, C,
                        gamma, beta, running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out,
                        shift_out);
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, scale_out,
-                       shift_out, residual, y, n4, C, relu);
+                       shift_out, residual, y, relu_mask_out, n4, C, relu);
     return sc_check_launch("bn_fwd");
 }
 
 extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean,
-                                  const float* rstd, const float* scale, long M, int C, int training, float* dgamma,
-                                  float* dbeta, float* dx, float* gout, void* ws, size_t ws_bytes, void* stream) {
+                                  const float* rstd, const float* scale, const unsigned long long* relu_mask, long M,
+                                  int C, int training, float* dgamma, float* dbeta, float* dx, float* gout, void* ws,
+                                  size_t ws_bytes, void* stream) {
     SC_REQUIRE(dy && x && mean && rstd && scale && dx, "bn_bwd: null pointer");
     COL_CHECKS("bn_bwd")
     const size_t coef_off = (size_t)nb * C * 2 * sizeof(double);
@@ -454,13 +483,15 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
     float* c1 = (float*)((char*)ws + coef_off);
     float* c2 = c1 + C;
     hipStream_t st = (hipStream_t)stream;
-    ScProfScope prof("bn_bwd(reduce+finalize+apply)", st, 0, 28.0 * M * C);
-    hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, (double*)ws, g);
+    ScProfScope prof("bn_bwd(reduce+finalize+apply)", st, 0,
+                     ((ymask && !relu_mask ? 28.0 : 20.0) + (gout ? 4.0 : 0.0) + (relu_mask ? 0.25 : 0.0)) * M * C);
+    hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, relu_mask,
+                       (double*)ws, g);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
                        training, dgamma, dbeta, c1, c2);
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale, c1,
-                       c2, dx, gout, n4, C);
+                       c2, relu_mask, dx, gout, n4, C);
     return sc_check_launch("bn_bwd");
 }
 
@@ -470,8 +501,8 @@ extern "C" int scouter_colsum_f32(const float* a, const float* b, float* out, lo
     SC_REQUIRE(a && out, "colsum: null pointer");
     COL_CHECKS("colsum")
     hipStream_t st = (hipStream_t)stream;
-    if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, pgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, (double*)ws, g);
-    else hipLaunchKernelGGL(colsum_partial_kernel<2>, pgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
+    if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, pgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
+    else hipLaunchKernelGGL(colsum_partial_kernel<2>, pgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, C, out, alpha);
     return sc_check_launch("colsum");
 }

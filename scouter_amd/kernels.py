@@ -233,23 +233,29 @@ def _col_ws(M, C, device):
 
 
 def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=None, momentum=0.1, eps=1e-5,
-           stats=None):
+           stats=None, want_mask=False):
     """x: [..., C] NHWC.  Returns (y, saved) with saved = (mean, rstd, scale, shift) packed as one [4, C] tensor.
-    stats = (partial, rows) from conv2d_fwd(bn_stats=True) replaces the statistics pass over x."""
+    stats = (partial, rows) from conv2d_fwd(bn_stats=True) replaces the statistics pass over x.
+    want_mask (with relu): returns (y, saved, mask) -- the 1-bit/element sign mask bn_bwd takes instead of y."""
     _chk(x, "x"); _chk(residual, "residual")
     C = x.shape[-1]
     M = x.numel() // C
     y = torch.empty_like(x)
     saved = torch.empty((4, C), dtype=F32, device=x.device)
     ws = _col_ws(M, C, x.device)
+    mask = None
+    if want_mask:
+        assert relu
+        mask = torch.empty(_native.lib().scouter_relu_mask_words(x.numel()), dtype=torch.int64, device=x.device)
     _native.check(_native.lib().scouter_bn_fwd_f32(
         _p(x), _p(y), _p(residual), M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
         int(training), int(relu), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]),
-        _p(stats[0]) if stats else None, stats[1] if stats else 0, _p(ws), ws.numel(), _stream()), "bn_fwd")
-    return y, saved
+        _p(stats[0]) if stats else None, stats[1] if stats else 0, _p(mask), _p(ws), ws.numel(), _stream()), "bn_fwd")
+    return (y, saved, mask) if want_mask else (y, saved)
 
 
-def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=False):
+def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=False, mask=None):
+    """ReLU sign from `mask` (bits written by bn_fwd(want_mask=True)) or from the activation `ymask`; both None: no ReLU."""
     _chk(dy, "dy"); _chk(ymask, "ymask"); _chk(x, "x")
     C = x.shape[-1]
     M = x.numel() // C
@@ -257,7 +263,8 @@ def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=Fal
     gout = torch.empty_like(x) if want_gout else None
     ws = _col_ws(M, C, x.device)
     _native.check(_native.lib().scouter_bn_bwd_f32(
-        _p(dy), _p(ymask), _p(x), _p(saved[0]), _p(saved[1]), _p(saved[2]), M, C, int(training), _p(dgamma), _p(dbeta),
+        _p(dy), _p(ymask), _p(x), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(mask), M, C, int(training), _p(dgamma),
+        _p(dbeta),
         _p(dx), _p(gout), _p(ws), ws.numel(), _stream()), "bn_bwd")
     return dx, gout
 

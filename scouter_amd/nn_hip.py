@@ -111,15 +111,17 @@ class BatchNorm2d(nn.Module):
         stats = None
         if isinstance(x, tuple):
             x, stats = x
-        y, saved = K.bn_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
-                            residual, self.momentum, self.eps, stats if self.training else None)
+        out = K.bn_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
+                       residual, self.momentum, self.eps, stats if self.training else None,
+                       want_mask=bool(relu and save))
         if self.training and tracked is not None:
             tracked.append(self.num_batches_tracked)
-        return y, ((x, y if relu else None, saved, self.training) if save else None)
+        # the backward takes the ReLU sign from a 1-bit/element mask, not from the 4-byte activation
+        return out[0], ((x, out[2] if relu else None, out[1], self.training) if save else None)
 
     def bwd(self, dy, ctx, want_gout=False):
-        x, ymask, saved, training = ctx
-        return K.bn_bwd(dy, ymask, x, saved, training, self._dg, self._db, want_gout)
+        x, mask, saved, training = ctx
+        return K.bn_bwd(dy, None, x, saved, training, self._dg, self._db, want_gout, mask=mask)
 
 
 class LinearParams(nn.Module):

@@ -135,6 +135,13 @@ def test_bn_fwd_bwd(shape, relu, res):
     dg = torch.empty(C, dtype=torch.float32, device="cuda")
     db = torch.empty(C, dtype=torch.float32, device="cuda")
     dx, gout = kk.bn_bwd(nhwc(dy), y if relu else None, xd, saved, True, dg, db, want_gout=True)
+    if relu:      # the 1-bit sign mask written by the forward gives the same backward as the activation itself
+        y2, saved2, bits = kk.bn_fwd(xd, gamma.float().cuda(), beta.float().cuda(), rm.float().cuda(), rv.float().cuda(),
+                                     True, True, nhwc(r) if res else None, want_mask=True)
+        assert torch.equal(y2, y)
+        dg2, db2 = torch.empty_like(dg), torch.empty_like(db)
+        dx2, gout2 = kk.bn_bwd(nhwc(dy), None, xd, saved2, True, dg2, db2, want_gout=True, mask=bits)
+        assert torch.equal(dx2, dx) and torch.equal(gout2, gout) and torch.equal(dg2, dg) and torch.equal(db2, db)
     sc = float(xr.grad.abs().max())
     np.testing.assert_allclose(from_nhwc(dx).numpy(), xr.grad.numpy(), atol=3e-5 * max(sc, 1), rtol=1e-4)
     np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.numpy(), atol=1e-4 * max(float(gr.grad.abs().max()), 1), rtol=1e-4)
