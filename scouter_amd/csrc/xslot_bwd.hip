@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             f32x16 h[2], U[2], dU[2], dhp[2];
             xs_load_tile<2>(sbase + (long)ti * 32 * XS_D, XS_D, h, l31, hh, iok);
             const float r = r_s[i];
+            const float ir = xs_recip(r);
             {   // D, A = sigmoid(D / r * tau); both are parked in the scratch while the GRU section runs
                 f32x16 D[NJT], A[NJT];
 #pragma unroll
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
                     D[jt] *= scale;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const float v = xs_sigmoid(D[jt][e] / r * tau);
+                        const float v = xs_sigmoid(xs_div(D[jt][e], r, ir) * tau);
                         A[jt][e] = (iok && xs_kidx(jt, e, hh) < N) ? v : 0.f;
                     }
                 }
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
                         const float rg = xs_sigmoid(ar[e] + bias[g]);
                         const float zg = xs_sigmoid(az[e] + bias[64 + g]);
                         const float hnb = ahn[e] + bias[192 + g];
-                        const float ng = tanhf(ain[e] + bias[128 + g] + rg * hnb);
+                        const float ng = xs_tanh(ain[e] + bias[128 + g] + rg * hnb);
                         const float ds = dsx[gt][e];
                         const float da_n = ds * (1.f - zg) * (1.f - ng * ng);
                         const float da_z = ds * (h[gt][e] - ng) * zg * (1.f - zg);

@@ -52,7 +52,27 @@ __device__ __forceinline__ void xs_zero(f32x16& v) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = 0.f;
 }
-__device__ __forceinline__ float xs_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, 1 ulp each): 4 instructions per
+// sigmoid instead of the ~25 of libm's expf + IEEE division, absolute error <= 2.4e-7 -- fp32-rounding level, far
+// inside the 1e-4 parity bound; the backward recomputes with the same helpers, so forward and backward agree.
+__device__ __forceinline__ float xs_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+// x / r from a per-slot reciprocal refined by one Newton step: q = x*ir, q += (x - r*q)*ir.  The residual is exact
+// (FMA), so the quotient is the correctly rounded one in all but rare double-rounding cases -- in particular
+// x == r gives exactly 1, which the reference's D / r_i produces for a single-token grid (its attention maps are then
+// constant and the `--vis` normalisation 0/0; reproduced bit for bit by tests/test_xslot_gpu.py::one_token).
+__device__ __forceinline__ float xs_recip(float r) {
+    float ir = __builtin_amdgcn_rcpf(r);
+    return __builtin_fmaf(__builtin_fmaf(-r, ir, 1.f), ir, ir);
+}
+__device__ __forceinline__ float xs_div(float x, float r, float ir) {
+    const float q = x * ir;
+    return __builtin_fmaf(__builtin_fmaf(-r, q, x), ir, q);
+}
+__device__ __forceinline__ float xs_tanh(float x) {        // 1 - 2 / (1 + e^{2x}); saturates correctly at +-inf
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
+}
 
 // in-lane sum of an NT-tile register set + the partner half-wave: sum over all 32*NT k of M[i][k]
 template <int NT>

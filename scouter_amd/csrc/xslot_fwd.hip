@@ -152,12 +152,13 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
                 A[jt] *= scale;
             }
             float asum = 0.f;
+            const float ir = xs_recip(rr[tt]);           // A = sigmoid(D / r_i * tau): one reciprocal per slot
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int j = xs_kidx(jt, r, hh);
-                    float v = xs_sigmoid(A[jt][r] / rr[tt] * tau);       // slot_attention.py:56-57
+                    float v = xs_sigmoid(xs_div(A[jt][r], rr[tt], ir) * tau);   // slot_attention.py:56-57
                     v = (i < S && j < N) ? v : 0.f;
                     A[jt][r] = v;
                     asum += v;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
                         const int g = xs_kidx(gt, r, hh);
                         const float rg = xs_sigmoid(ar[r] + bias[g]);
                         const float zg = xs_sigmoid(az[r] + bias[64 + g]);
-                        const float ng = tanhf(ain[r] + bias[128 + g] + rg * (ahn[r] + bias[192 + g]));
+                        const float ng = xs_tanh(ain[r] + bias[128 + g] + rg * (ahn[r] + bias[192 + g]));
                         hn[gt][r] = i < S ? (1.f - zg) * ng + zg * h[tt][gt][r] : 0.f;   // padded slots stay 0 (tau!)
                     }
                 }

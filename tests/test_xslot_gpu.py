@@ -64,7 +64,14 @@ def test_head_matches_reference_golden_and_oracle(case):
     np.testing.assert_allclose(stats[:3].cpu().numpy(), [float(g["f64_loss"]), float(g["f64_nll"]), float(g["f64_area"])],
                                atol=tol, rtol=1e-5)
     vis = m.slot.vis_maps()
-    assert np.abs(vis.astype(int) - g["f32_vis"].astype(int)).max() <= 1
+    ref_map = g["f64_attn"][0]
+    if C * spc == ref_map.shape[0] and float(ref_map.max() - ref_map.min()) < 1e-9:
+        # single-token grid: D / r_i == 1, every slot's attention is sigmoid(tau) and the reference's min-max
+        # normalisation is 0/0 (its uint8 image is a cast of NaN); the meaningful statement is "the map is constant"
+        a0 = so["attn"][0].cpu().numpy()
+        assert float(a0.max() - a0.min()) <= 1e-6
+    else:
+        assert np.abs(vis.astype(int) - g["f32_vis"].astype(int)).max() <= 1
     # ---- gradients against the oracle's fp64 autograd on the same inputs
     feat, labels, P = head_inputs(case)
     leaves = {k: v.double().clone().requires_grad_(True) for k, v in P.items()}
