@@ -25,8 +25,10 @@
 __device__ __forceinline__ int xs_kidx(int t, int r, int hh) { return 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3); }
 
 // acc[rows row0..row0+31][i] += sum_{k<64} M[row0 + l31][k] * B^T[k][i] ; M row-major in LDS (k contiguous)
-__device__ __forceinline__ void xs_mm_kc(const float* __restrict__ M, int row0, const f32x16 (&b)[2], f32x16& acc,
-                                         int l31, int hh) {
+// `_open` variants leave the scheduling region open so that a caller can interleave independent VALU work into the
+// MFMA shadow (xslot_fwd.hip); the plain ones close it.
+__device__ __forceinline__ void xs_mm_kc_open(const float* __restrict__ M, int row0, const f32x16 (&b)[2], f32x16& acc,
+                                              int l31, int hh) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -35,17 +37,41 @@ __device__ __forceinline__ void xs_mm_kc(const float* __restrict__ M, int row0, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = mfma32(a[e], b[t][4 * q + e], acc);
         }
+}
+__device__ __forceinline__ void xs_mm_kc(const float* __restrict__ M, int row0, const f32x16 (&b)[2], f32x16& acc,
+                                         int l31, int hh) {
+    xs_mm_kc_open(M, row0, b, acc, l31, hh);
     XS_REGION_END();
 }
 // acc[cols col0..col0+31][i] += sum_{k<64} Mt[k][col0 + l31] * B^T[k][i] ; Mt row-major in LDS with rows = k
 template <int NT>
-__device__ __forceinline__ void xs_mm_tr(const float* __restrict__ Mt, int col0, const f32x16 (&b)[NT], f32x16& acc,
-                                         int l31, int hh) {
+__device__ __forceinline__ void xs_mm_tr_open(const float* __restrict__ Mt, int col0, const f32x16 (&b)[NT],
+                                              f32x16& acc, int l31, int hh) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc = mfma32(Mt[xs_kidx(t, r, hh) * XS_LD + col0 + l31], b[t][r], acc);
+}
+template <int NT>
+__device__ __forceinline__ void xs_mm_tr(const float* __restrict__ Mt, int col0, const f32x16 (&b)[NT], f32x16& acc,
+                                         int l31, int hh) {
+    xs_mm_tr_open<NT>(Mt, col0, b, acc, l31, hh);
     XS_REGION_END();
+}
+
+// Interleave recipe for one scheduling region holding an MFMA block and an independent VALU block: every MFMA is
+// followed by up to VALU_PER vector-ALU and TRANS_PER transcendental instructions (they execute in the 64-cycle
+// shadow of the MFMA), LDS operand reads are issued DS_LEAD MFMAs ahead of their use.
+template <int N_MFMA, int MFMA_PER_DS, int VALU_PER, int TRANS_PER, int DS_LEAD = 2>
+__device__ __forceinline__ void xs_interleave() {
+    __builtin_amdgcn_sched_group_barrier(0x100, DS_LEAD, 0);
+#pragma unroll
+    for (int m = 0; m < N_MFMA; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (VALU_PER > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);
+        if (TRANS_PER > 0) __builtin_amdgcn_sched_group_barrier(0x400, TRANS_PER, 0);
+        if (m % MFMA_PER_DS == MFMA_PER_DS - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
 }
 
 __device__ __forceinline__ void xs_zero(f32x16& v) {

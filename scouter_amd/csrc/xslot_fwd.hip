@@ -17,46 +17,354 @@ struct XsFwdArgs {
     float* logits; float* attn; float* area_part; float* Ksave; float* Hsave; float* states;
     int B, N, S, C, spc, T, L;
     float loss_status;
+#ifdef XS_TIMING
+    long long* stamps;      // dev build (tools_dev/xs_phase_timing.hip): [B][64] cycle stamps of wave 0
+#endif
 };
 
+#ifdef XS_TIMING
+#define XS_STAMP() do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 64 + nstamp] = __builtin_readcyclecounter(); ++nstamp; } while (0)
+#else
+#define XS_STAMP() do { } while (0)
+#endif
+
+#ifndef XS_FWD_WAVES
+#define XS_FWD_WAVES 4
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Building blocks of one (slot tile, iteration).  "S" blocks are streams of MFMAs (+ their LDS operand reads), "V"
+// blocks are VALU work cut into PIECES of <= ~12 instructions (one 64-cycle MFMA shadow each).  xs_stream() issues
+// one S block MFMA by MFMA, calls the piece functor of an INDEPENDENT V block after each MFMA and pins that order
+// with scheduling barriers, so that -- with a single wave per SIMD -- the gate / sigmoid arithmetic of one slot tile
+// executes under the matrix instructions of another instead of between them (left to itself the compiler emits the
+// VALU block as one run of ~350 instructions during which the MFMA pipe idles).
+//   S1: D^T = (K/8) s^T          V1: A = sigmoid(D / r_i * tau)     S2: U^T = (X/64)^T A^T
+//   S3(gt): gate pre-activations of hidden units 32gt..32gt+31       V2(gt): GRU gates -> new hidden units
+// K is staged pre-scaled by d^-1/2 = 1/8 and X (transposed) by 1/d = 1/64: exact power-of-two scalings, same bits.
+// ---------------------------------------------------------------------------------------------------------------
+#define XS_XT_FLOATS(NP_) ((NP_) * XS_LD > 64 * ((NP_) + 4) ? (NP_) * XS_LD : 64 * ((NP_) + 4))
+#define XS_SB() __builtin_amdgcn_sched_barrier(0)
+struct XsLds { const float* Xs; const float* Ks; const float* Wih; const float* Whh; const float* bias; };
+struct XsNoPiece { __device__ __forceinline__ void operator()(int) const {} };
+
+// NFRAG operand fragments (one ds_read_b128 = the A operands of 4 consecutive MFMAs), read two fragments ahead of use
+template <int NFRAG, typename AddrF, typename MmaF, typename PieceF>
+__device__ __forceinline__ void xs_stream(const AddrF& addr, const MmaF& mma, const PieceF& piece) {
+    f32x4 fr[3];
+    fr[0] = *(const f32x4*)addr(0);
+    if (NFRAG > 1) fr[1] = *(const f32x4*)addr(1);
+    XS_SB();
+#pragma unroll
+    for (int f = 0; f < NFRAG; ++f) {
+        if (f + 2 < NFRAG) fr[(f + 2) % 3] = *(const f32x4*)addr(f + 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mma(f, e, fr[f % 3][e]);
+            piece(4 * f + e);
+            XS_SB();
+        }
+    }
+}
+
+template <int NJT, typename PieceF>
+__device__ __forceinline__ void xs_s1(const XsLds& m, const f32x16 (&h)[2], f32x16 (&D)[NJT], int l31, int hh,
+                                      const PieceF& piece) {
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) xs_zero(D[jt]);
+    const float* base = m.Ks + l31 * XS_LD + 4 * hh;
+    xs_stream<8 * NJT>(
+        [&](int f) { return base + (32 * (f >> 3)) * XS_LD + 32 * ((f >> 2) & 1) + 8 * (f & 3); },
+        [&](int f, int e, float a) { D[f >> 3] = mfma32(a, h[(f >> 2) & 1][4 * (f & 3) + e], D[f >> 3]); }, piece);
+}
+// X is staged TRANSPOSED (Xt[c][j], row stride 32*NJT+4): the contraction index j is contiguous, one ds_read_b128
+// feeds four MFMAs like in the other blocks
+template <int NJT, typename PieceF>
+__device__ __forceinline__ void xs_s2(const XsLds& m, const f32x16 (&A)[NJT], f32x16 (&U)[2], int l31, int hh,
+                                      const PieceF& piece) {
+    constexpr int LDT = 32 * NJT + 4;
+    xs_zero(U[0]); xs_zero(U[1]);
+    const float* base = m.Xs + l31 * LDT + 4 * hh;
+    xs_stream<8 * NJT>(
+        [&](int f) { return base + (32 * (f / (4 * NJT))) * LDT + 8 * (f % (4 * NJT)); },
+        [&](int f, int e, float a) {
+            const int ct = f / (4 * NJT), g = f % (4 * NJT);
+            U[ct] = mfma32(a, A[g >> 2][4 * (g & 3) + e], U[ct]);       // slot_attention.py:59
+        }, piece);
+}
+// six 64-deep chains: (W_ir U + W_hr h), (W_iz U + W_hz h), W_in U, W_hn h; the accumulators start from the biases
+// (b_ir+b_hr | b_iz+b_hz | b_in | b_hn), so the gate block has no bias operands
+template <typename PieceF>
+__device__ __forceinline__ void xs_s3(const XsLds& m, int gt, const f32x16 (&U)[2], const f32x16 (&h)[2],
+                                      f32x16 (&G)[4], int l31, int hh, const PieceF& piece) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *(const f32x4*)(m.bias + 64 * k + 32 * gt + 8 * q + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) G[k][4 * q + e] = bv[e];
+        }
+    const float* bi = m.Wih + (32 * gt + l31) * XS_LD + 4 * hh;
+    const float* bh = m.Whh + (32 * gt + l31) * XS_LD + 4 * hh;
+    xs_stream<48>(
+        [&](int f) {
+            const int c = f >> 3, g = f & 7;
+            return ((c & 1) ? bh : bi) + (64 * (c >> 1)) * XS_LD + 32 * (g >> 2) + 8 * (g & 3);
+        },
+        [&](int f, int e, float a) {
+            const int c = f >> 3, g = f & 7, k = c < 4 ? (c >> 1) : c - 2;
+            const float bop = (c & 1) ? h[g >> 2][4 * (g & 3) + e] : U[g >> 2][4 * (g & 3) + e];
+            G[k] = mfma32(a, bop, G[k]);
+        }, piece);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define XS_LOG2E 1.4426950408889634f
+
+// ---- V1: A = sigmoid(D / r_i * tau) (slot_attention.py:56-57) as rcp(1 + exp2(D * c)), c = -log2(e) * tau / r_i
+// folded per slot; element pairs so that the multiply / add become packed-fp32 instructions.  VALU work cannot hide
+// under this wave's own MFMAs (tools_dev/mfma_shadow_bench.hip: they serialise), so it is kept minimal: padded
+// tokens need no mask (their X^T columns are zero), padded slots get c = 0 (finite garbage that is never stored).
+template <int NJT>
+__device__ __forceinline__ void xs_v1(f32x16 (&A)[NJT], float c) {
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            f32x2 x = {A[jt][e], A[jt][e + 1]};
+            x *= c;
+            f32x2 ex = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            ex += 1.f;
+            A[jt][e] = __builtin_amdgcn_rcpf(ex[0]);
+            A[jt][e + 1] = __builtin_amdgcn_rcpf(ex[1]);
+        }
+}
+// ---- V2: GRU cell, gate order r, z, n (slot_attention.py:60-66); G = biased pre-activations (r | z | i_n | h_n)
+__device__ __forceinline__ void xs_v2(const f32x16 (&G)[4], const f32x16& hold, f32x16& hnew) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        f32x2 xr = {G[0][r], G[0][r + 1]}, xz = {G[1][r], G[1][r + 1]};
+        xr *= -XS_LOG2E; xz *= -XS_LOG2E;
+        f32x2 er = {__builtin_amdgcn_exp2f(xr[0]), __builtin_amdgcn_exp2f(xr[1])};
+        f32x2 ez = {__builtin_amdgcn_exp2f(xz[0]), __builtin_amdgcn_exp2f(xz[1])};
+        er += 1.f; ez += 1.f;
+        const f32x2 rg = {__builtin_amdgcn_rcpf(er[0]), __builtin_amdgcn_rcpf(er[1])};
+        const f32x2 zg = {__builtin_amdgcn_rcpf(ez[0]), __builtin_amdgcn_rcpf(ez[1])};
+        const f32x2 gi = {G[2][r], G[2][r + 1]}, gh = {G[3][r], G[3][r + 1]}, ho = {hold[r], hold[r + 1]};
+        f32x2 t = (gi + rg * gh) * (2.f * XS_LOG2E);                     // tanh(x) = 1 - 2 / (1 + e^{2x})
+        f32x2 et = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        et += 1.f;
+        const f32x2 rc = {__builtin_amdgcn_rcpf(et[0]), __builtin_amdgcn_rcpf(et[1])};
+        const f32x2 ng = 1.f - 2.f * rc;
+        const f32x2 hn = ng + zg * (ho - ng);                            // (1 - z) n + z h
+        hnew[r] = hn[0];
+        hnew[r + 1] = hn[1];
+    }
+}
+__device__ __forceinline__ void xs_store_half(float* sp, const f32x16& h, int hh) {     // 32 of the 64 hidden units
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = h[4 * q + e];
+        *(f32x4*)(sp + 8 * q + 4 * hh) = v;
+    }
+}
+
+// per-tile view
+struct XsTile { int ti; int i; bool iok; float r; };
+struct XsOut {
+    float* states; float* attn; float* usum; float* area_s; float* stage; float* exch;
+    int S, N, lane, l31, hh, wave;
+};
+
+// One slot tile, one iteration.  MODE 0: the wave owns the tile.  MODE 1: the tile is SHARED by the wave pair
+// (2p, 2p+1) -- both run S1 / V1 / S2 redundantly (bit-identical), each computes the GRU for 32 of the 64 hidden
+// units and they swap halves through LDS: the ntiles % 4 leftover tiles cost 0.6 instead of 1.0 tile of the critical
+// wave's time.  (The caller issues the workgroup barrier between xs_tile_shared_a and _b.)
+template <int NJT, bool LAST>
+__device__ __forceinline__ void xs_tile_head(const XsLds& m, const f32x16 (&h)[2], const XsTile& t, float tau,
+                                             const XsOut& o, f32x16 (&U)[2], bool writer) {
+    f32x16 A[NJT];
+    xs_s1<NJT>(m, h, A, o.l31, o.hh, XsNoPiece{});
+    const float c = t.iok ? -XS_LOG2E * (tau * xs_recip(t.r)) : 0.f;
+    xs_v1<NJT>(A, c);
+    XS_SB();
+    xs_s2<NJT>(m, A, U, o.l31, o.hh, XsNoPiece{});
+    if (LAST && writer) {
+        // attention map rows of this tile are one contiguous [rows][N] block in global memory: stage the tile in this
+        // wave's LDS scratch (the GRU weights are dead in the last iteration) and copy it out with coalesced stores
+        float asum = 0.f;
+        float* st = o.stage;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = xs_kidx(jt, e, o.hh);
+                if (j < o.N) { st[o.l31 * o.N + j] = A[jt][e]; asum += A[jt][e]; }
+            }
+        asum = wave_sum(t.iok ? asum : 0.f);
+        const int rows = min(32, o.S - 32 * t.ti), cnt = rows * o.N;
+        float* dst = o.attn + (long)32 * t.ti * o.N;
+        for (int k = o.lane; k < cnt; k += 64) dst[k] = st[k];
+        const float us = xs_rowsum<2>(U);
+        if (o.hh == 0 && t.iok) o.usum[t.i] = us;
+        if (o.lane == 0) o.area_s[t.ti] = asum;
+    }
+}
+template <int NJT, bool LAST>
+__device__ __forceinline__ void xs_tile_own(const XsLds& m, f32x16 (&h)[2], const XsTile& t, float tau, const XsOut& o,
+                                            long it_row) {
+    f32x16 U[2];
+    xs_tile_head<NJT, LAST>(m, h, t, tau, o, U, true);
+    if (!LAST) {
+        f32x16 G[4], hn0, hn1;
+        xs_s3(m, 0, U, h, G, o.l31, o.hh, XsNoPiece{});
+        xs_v2(G, h[0], hn0); XS_SB();
+        xs_s3(m, 1, U, h, G, o.l31, o.hh, XsNoPiece{});
+        xs_v2(G, h[1], hn1); XS_SB();
+        h[0] = hn0; h[1] = hn1;
+        if (t.iok) {
+            float* sp = o.states + (it_row + t.i) * XS_D;
+            xs_store_half(sp, h[0], o.hh);
+            xs_store_half(sp + 32, h[1], o.hh);
+        }
+    }
+}
+// shared tile, part a: everything up to this wave's half of the new state, parked in the exchange buffer
+template <int NJT, bool LAST>
+__device__ __forceinline__ void xs_tile_shared_a(const XsLds& m, f32x16 (&h)[2], const XsTile& t, float tau,
+                                                 const XsOut& o, long it_row) {
+    f32x16 U[2];
+    const int gt = o.wave & 1;
+    xs_tile_head<NJT, LAST>(m, h, t, tau, o, U, gt == 0);
+    if (!LAST) {
+        f32x16 G[4], hn;
+        xs_s3(m, gt, U, h, G, o.l31, o.hh, XsNoPiece{});
+        if (gt) xs_v2(G, h[1], hn); else xs_v2(G, h[0], hn);
+        XS_SB();
+        if (gt) h[1] = hn; else h[0] = hn;
+        float* ex = o.exch + o.wave * 1024 + o.lane * 4;          // [q][lane][4]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = hn[4 * q + e];
+            *(f32x4*)(ex + q * 256) = v;
+        }
+        if (t.iok) xs_store_half(o.states + (it_row + t.i) * XS_D + 32 * gt, hn, o.hh);
+    }
+}
+// part b (after the barrier): the partner's half
+__device__ __forceinline__ void xs_tile_shared_b(f32x16 (&h)[2], const XsOut& o) {
+    const int gt = o.wave & 1;
+    const float* ex = o.exch + (o.wave ^ 1) * 1024 + o.lane * 4;
+    f32x16 hp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *(const f32x4*)(ex + q * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hp[4 * q + e] = v[e];
+    }
+    if (gt) h[0] = hp; else h[1] = hp;
+}
+
 template <int NJT, int TPW>
-__global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
+__global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs a) {
+#ifdef XS_TIMING
+    int nstamp = 0;
+#endif
+    XS_STAMP();
     constexpr int NP = 32 * NJT;
+    constexpr int NTHR = 64 * XS_FWD_WAVES, NW = XS_FWD_WAVES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Xs = lds;                        // [NP][68]  tokens X (rows >= N zero)
-    float* Ks = Xs + NP * XS_LD;            // [NP][68]  K = to_k(X + PE) (rows >= N zero)
+    float* Xs = lds;                        // [64][NP+4]  X^T / 64 (columns >= N zero)
+    float* Ks = Xs + XS_XT_FLOATS(NP);            // [NP][68]  K / 8, K = to_k(X + PE) (rows >= N zero)
     float* Wih = Ks + NP * XS_LD;           // [192][68]
     float* Whh = Wih + 192 * XS_LD;         // [192][68]
     float* bias = Whh + 192 * XS_LD;        // br | bz | b_in | b_hn  (4 x 64)
-    double* ksum = (double*)(bias + 256);   // [64]  column sums of K (fp64)
+    double* ksum = (double*)(bias + 256);   // [64]  column sums of K/8 (fp64)
     double* tau_part = ksum + 64;           // [T<=8][16]
     float* area_s = (float*)(tau_part + 128);   // [16]
     float* usum = area_s + 16;              // [<=512] per-slot sum_k U_T[i][k]
-    // MLP scratch aliases the (not yet loaded) GRU weight region
+    // MLP scratch aliases the GRU weight region; the weights wait in registers until the MLP is done
     float* H0 = Wih;                        // [NP][68]
     float* H1 = H0 + NP * XS_LD;            // [NP][68]
     float* Wt = H1 + NP * XS_LD;            // [64][68]
+    static_assert(2 * NP + 64 <= 384, "MLP scratch fits in the GRU weight region");
 
-    const int tid = threadIdx.x, nthr = blockDim.x, NW = nthr >> 6;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.x, N = a.N, S = a.S;
     const float* Xg = a.X + (long)b * N * XS_D;
+    const float scale = 0.125f, inv_d = 1.f / XS_D;      // d^-1/2 and 1/d, d = 64
 
-    // ---- phase 0: tokens -> LDS ; H0 = X + PE
-    for (int c = tid; c < NP * 16; c += nthr) {
-        const int r = c >> 4, q = c & 15;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f}, p = x;
-        if (r < N) { x = *(const f32x4*)(Xg + r * XS_D + q * 4); p = *(const f32x4*)(a.PE + r * XS_D + q * 4); }
-        *(f32x4*)(Xs + r * XS_LD + q * 4) = x;
-        *(f32x4*)(H0 + r * XS_LD + q * 4) = x + p;
-        if (r < N) *(f32x4*)(a.Hsave + ((long)b * N + r) * XS_D + q * 4) = x + p;     // Hsave[0] = input of layer 0
+    // ---- phase 0: every global operand is requested up front (one latency, not five): tokens, first to_k weight,
+    // both GRU weight matrices (W_hh parked in registers), initial slots
+    constexpr int XQ = NP * 16 / NTHR, WQ = 192 * 16 / NTHR, TQ = 64 * 16 / NTHR;
+    float bias_v = 0.f;
+    if (tid < 256) {
+        const int g = tid & 63, k = tid >> 6;
+        bias_v = k == 0 ? a.b_ih[g] + a.b_hh[g] : k == 1 ? a.b_ih[64 + g] + a.b_hh[64 + g]
+               : k == 2 ? a.b_ih[128 + g] : a.b_hh[128 + g];
     }
+    f32x4 xr[XQ], pr[XQ], wtr[TQ], wir[WQ], whr[WQ];
+#pragma unroll
+    for (int k = 0; k < XQ; ++k) {
+        const int c = tid + k * NTHR, r = c >> 4, q = c & 15;
+        xr[k] = f32x4{0.f, 0.f, 0.f, 0.f}; pr[k] = xr[k];
+        if (r < N) { xr[k] = *(const f32x4*)(Xg + r * XS_D + q * 4); pr[k] = *(const f32x4*)(a.PE + r * XS_D + q * 4); }
+    }
+#pragma unroll
+    for (int k = 0; k < TQ; ++k) wtr[k] = *(const f32x4*)(a.tok_w[0] + (tid + k * NTHR) * 4);
+#pragma unroll
+    for (int k = 0; k < WQ; ++k) wir[k] = *(const f32x4*)(a.w_ih + (tid + k * NTHR) * 4);
+#pragma unroll
+    for (int k = 0; k < WQ; ++k) whr[k] = *(const f32x4*)(a.w_hh + (tid + k * NTHR) * 4);
+    // slot tiles: wave w owns tiles w, w+4, ...; the ntiles % 4 leftover tiles go to waves 0.. as whole tiles, or --
+    // when there are one or two of them and the exchange buffer fits (NJT <= 2) -- each is SHARED by a wave pair
+    const int ntiles = (S + 31) >> 5, nfull4 = ntiles >> 2, rem = ntiles & 3;
+    const bool share = NJT <= 2 && (rem == 1 || rem == 2);
+    int tile_id[TPW];
+    f32x16 h[TPW][2];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        int ti = wave + NW * tt;
+        if (tt >= nfull4) ti = share ? ((wave >> 1) < rem ? 4 * nfull4 + (wave >> 1) : -1)
+                                     : (tt == nfull4 && wave < rem ? 4 * nfull4 + wave : -1);
+        tile_id[tt] = ti;
+        const int i = ti * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ti >= 0 && i < S) v = *(const f32x4*)(a.slots0 + i * XS_D + 32 * t + 8 * q + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[tt][t][4 * q + e] = v[e];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < XQ; ++k) {
+        const int c = tid + k * NTHR, r = c >> 4, q = c & 15;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Xs[(q * 4 + e) * (NP + 4) + r] = xr[k][e] * inv_d;      // Xt[c][j] = X[j][c] / d
+        *(f32x4*)(H0 + r * XS_LD + q * 4) = xr[k] + pr[k];
+        if (r < N) *(f32x4*)(a.Hsave + ((long)b * N + r) * XS_D + q * 4) = xr[k] + pr[k];     // input of layer 0
+    }
+#pragma unroll
+    for (int k = 0; k < TQ; ++k) { const int c = tid + k * NTHR; *(f32x4*)(Wt + (c >> 4) * XS_LD + (c & 15) * 4) = wtr[k]; }
+    if (tid < 256) bias[tid] = bias_v;
+    XS_STAMP();
     // ---- phase 1: to_k MLP (Linear, then (ReLU, Linear)*), output tiles (jt, ot) spread over the waves
     float* Hin = H0;
     float* Hout = H1;
     for (int l = 0; l < a.L; ++l) {
-        __syncthreads();
-        xs_load_mat(Wt, a.tok_w[l], XS_D, tid, nthr);
+        if (l > 0) {
+            __syncthreads();
+            xs_load_mat(Wt, a.tok_w[l], XS_D, tid, NTHR);
+        }
         __syncthreads();
         const bool last = l == a.L - 1;
         for (int tile = wave; tile < NJT * 2; tile += NW) {
@@ -82,7 +390,7 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
                 if (!last) v = fmaxf(v, 0.f);
                 if (last) {
                     v = j < N ? v : 0.f;
-                    Ks[j * XS_LD + o] = v;
+                    Ks[j * XS_LD + o] = v * scale;
                     if (j < N) a.Ksave[((long)b * N + j) * XS_D + o] = v;
                 } else {
                     Hout[j * XS_LD + o] = v;
@@ -93,131 +401,69 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
         float* tmp = Hin; Hin = Hout; Hout = tmp;
     }
     __syncthreads();
+    XS_STAMP();
+    // ---- phase 2: GRU weights out of the registers (the MLP scratch they alias is dead), column sums of K
     xs_colsum_f64(Ks, NP, ksum, tid);
-    // ---- phase 2: GRU weights + combined biases
-    xs_load_mat(Wih, a.w_ih, 192, tid, nthr);
-    xs_load_mat(Whh, a.w_hh, 192, tid, nthr);
-    for (int c = tid; c < 256; c += nthr) {
-        const int g = c & 63, k = c >> 6;
-        bias[c] = k == 0 ? a.b_ih[g] + a.b_hh[g] : k == 1 ? a.b_ih[64 + g] + a.b_hh[64 + g]
-                : k == 2 ? a.b_ih[128 + g] : a.b_hh[128 + g];
+#pragma unroll
+    for (int k = 0; k < WQ; ++k) {
+        const int c = tid + k * NTHR;
+        *(f32x4*)(Wih + (c >> 4) * XS_LD + (c & 15) * 4) = wir[k];
+        *(f32x4*)(Whh + (c >> 4) * XS_LD + (c & 15) * 4) = whr[k];
     }
     __syncthreads();
+    XS_STAMP();
 
-    // ---- phase 3: iterations, slot tiles ti = wave + NW*tt
-    const int ntiles = (S + 31) >> 5;
-    const float scale = 0.125f;                 // d^-1/2, d = 64
-    f32x16 h[TPW][2];
-#pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) {
-        const int i = (wave + NW * tt) * 32 + l31;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (i < S) v = *(const f32x4*)(a.slots0 + i * XS_D + 32 * t + 8 * q + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[tt][t][4 * q + e] = v[e];
-            }
-    }
+    // ---- phase 3: iterations
+    const XsLds m{Xs, Ks, Wih, Whh, bias};
+    float* exch = usum + 512;                                   // [4 waves][4][64][4] (only when NJT <= 2)
+    const XsOut o{a.states, a.attn + (long)b * S * N, usum, area_s, Wih + wave * (32 * XS_MAX_N), exch,
+                  S, N, lane, l31, hh, wave};
     for (int it = 0; it < a.T; ++it) {
         const bool last = it == a.T - 1;
-        float rr[TPW];
+        const long it_row = ((long)it * a.B + b) * S;
+        XsTile tl[TPW];
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
-            const int ti = wave + NW * tt;
-            rr[tt] = 0.f;
-            if (ti < ntiles) {
-                const double r64 = xs_rowdot_f64(h[tt], ksum, hh) * (double)scale;    // r_i (padded slots: exactly 0)
-                rr[tt] = (float)r64;
+            const int ti = tile_id[tt];
+            tl[tt].ti = ti;
+            tl[tt].i = ti * 32 + l31;
+            tl[tt].iok = ti >= 0 && tl[tt].i < S;
+            tl[tt].r = 0.f;
+            if (ti >= 0) {
+                double r64 = xs_rowdot_f64(h[tt], ksum, hh);                  // r_i = s_i . sum_j K_j / 8
+                if (!tl[tt].iok) r64 = 0.0;                                   // padded slots do not enter tau
+                tl[tt].r = (float)r64;
                 const double tr = xs_tilesum_f64(r64);
-                if (lane == 0) tau_part[it * 16 + ti] = tr;
+                const bool writes = !(share && tt == TPW - 1) || !(wave & 1);
+                if (lane == 0 && writes) tau_part[it * 16 + ti] = tr;
             }
         }
         __syncthreads();
         double tau64 = 0.0;
         for (int k = 0; k < ntiles; ++k) tau64 += tau_part[it * 16 + k];
         const float tau = (float)tau64;
+        XS_STAMP();
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
-            const int ti = wave + NW * tt;
-            if (ti >= ntiles) continue;
-            const int i = ti * 32 + l31;
-            f32x16 A[NJT];
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                xs_zero(A[jt]);
-                xs_mm_kc(Ks, 32 * jt, h[tt], A[jt], l31, hh);
-                A[jt] *= scale;
-            }
-            float asum = 0.f;
-            const float ir = xs_recip(rr[tt]);           // A = sigmoid(D / r_i * tau): one reciprocal per slot
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = xs_kidx(jt, r, hh);
-                    float v = xs_sigmoid(xs_div(A[jt][r], rr[tt], ir) * tau);   // slot_attention.py:56-57
-                    v = (i < S && j < N) ? v : 0.f;
-                    A[jt][r] = v;
-                    asum += v;
-                    if (last && i < S && j < N) a.attn[((long)b * S + i) * N + j] = v;
-                }
-            f32x16 U[2];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                xs_zero(U[ct]);
-                xs_mm_tr<NJT>(Xs, 32 * ct, A, U[ct], l31, hh);
-                U[ct] *= (1.f / XS_D);                                    // slot_attention.py:59
-            }
-            if (last) {
-                const float us = xs_rowsum<2>(U);
-                if (hh == 0 && i < S) usum[i] = us;
-                asum = wave_sum(asum);
-                if (lane == 0) area_s[ti] = asum;
+            if (tl[tt].ti < 0) continue;
+            if (share && tt == TPW - 1) {
+                if (last) { if (!(wave & 1)) xs_tile_shared_a<NJT, true>(m, h[tt], tl[tt], tau, o, it_row); }
+                else xs_tile_shared_a<NJT, false>(m, h[tt], tl[tt], tau, o, it_row);
             } else {
-                // ---- GRU cell, gate order r, z, n (slot_attention.py:60-66)
-                f32x16 hn[2];
-#pragma unroll
-                for (int gt = 0; gt < 2; ++gt) {
-                    f32x16 ar, az, ain, ahn;
-                    xs_zero(ar); xs_zero(az); xs_zero(ain); xs_zero(ahn);
-                    xs_mm_kc(Wih, 32 * gt, U, ar, l31, hh);
-                    xs_mm_kc(Whh, 32 * gt, h[tt], ar, l31, hh);
-                    xs_mm_kc(Wih, 64 + 32 * gt, U, az, l31, hh);
-                    xs_mm_kc(Whh, 64 + 32 * gt, h[tt], az, l31, hh);
-                    xs_mm_kc(Wih, 128 + 32 * gt, U, ain, l31, hh);
-                    xs_mm_kc(Whh, 128 + 32 * gt, h[tt], ahn, l31, hh);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int g = xs_kidx(gt, r, hh);
-                        const float rg = xs_sigmoid(ar[r] + bias[g]);
-                        const float zg = xs_sigmoid(az[r] + bias[64 + g]);
-                        const float ng = xs_tanh(ain[r] + bias[128 + g] + rg * (ahn[r] + bias[192 + g]));
-                        hn[gt][r] = i < S ? (1.f - zg) * ng + zg * h[tt][gt][r] : 0.f;   // padded slots stay 0 (tau!)
-                    }
-                }
-                h[tt][0] = hn[0];
-                h[tt][1] = hn[1];
-                if (i < S) {
-                    float* sp = a.states + (((long)it * a.B + b) * S + i) * XS_D;
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = h[tt][t][4 * q + e];
-                            *(f32x4*)(sp + 32 * t + 8 * q + 4 * hh) = v;
-                        }
-                }
+                if (last) xs_tile_own<NJT, true>(m, h[tt], tl[tt], tau, o, it_row);
+                else xs_tile_own<NJT, false>(m, h[tt], tl[tt], tau, o, it_row);
             }
+            XS_STAMP();
+        }
+        if (share && !last) {
+            __syncthreads();
+            if (tl[TPW - 1].ti >= 0) xs_tile_shared_b(h[TPW - 1], o);
         }
     }
     __syncthreads();
+    XS_STAMP();
     // ---- class aggregation (slot_attention.py:87-91,96): logits_c = ls * sum_{s in c} sum_k U[s][k]
-    for (int c = tid; c < a.C; c += nthr) {
+    for (int c = tid; c < a.C; c += NTHR) {
         float v = 0.f;
         for (int k = 0; k < a.spc; ++k) v += usum[c * a.spc + k];
         a.logits[(long)b * a.C + c] = a.loss_status * v;
@@ -227,9 +473,13 @@ __global__ __launch_bounds__(256) void xslot_fwd_kernel(XsFwdArgs a) {
         for (int k = 0; k < ntiles; ++k) s += area_s[k];
         a.area_part[b] = s;
     }
+    XS_STAMP();
 }
 
-static size_t xs_fwd_lds_bytes(int NJT) { return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 128) + 16 + 512) * sizeof(float); }
+static size_t xs_fwd_lds_bytes(int NJT) {
+    return (size_t)(XS_XT_FLOATS(32 * NJT) + 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 128) + 16 + 512 +
+                    (NJT <= 2 ? 4096 : 0)) * sizeof(float);
+}
 
 extern "C" int scouter_xslot_fwd_f32(const float* X, const float* PE, const float* const* tok_w,
                                      const float* const* tok_b, const float* slots0, const float* w_ih, const float* w_hh, const float* b_ih,
@@ -251,7 +501,7 @@ extern "C" int scouter_xslot_fwd_f32(const float* X, const float* PE, const floa
         a.tok_b[l] = tok_b[l];
     }
     const int ntiles = (S + 31) / 32, NJT = (N + 31) / 32;
-    const int NW = 4, TPW = (ntiles + NW - 1) / NW;
+    const int NW = XS_FWD_WAVES, TPW = (ntiles + NW - 1) / NW;
     const size_t lds = xs_fwd_lds_bytes(NJT);
     hipStream_t st = (hipStream_t)stream;
     const double flops = (double)B * (2.0 * L * N * d * d + (double)T * 4.0 * S * N * d + (T - 1) * 12.0 * S * d * d);
@@ -269,9 +519,13 @@ extern "C" int scouter_xslot_fwd_f32(const float* X, const float* PE, const floa
         else if (TPW == 3) XS_LAUNCH(NJT_, 3);         \
         else XS_LAUNCH(NJT_, 4);                       \
     } while (0)
+#ifdef XS_DEV_SINGLE_INST
+    XS_LAUNCH(2, XS_FWD_WAVES == 4 ? 3 : 2);      // dev builds (tools_dev/xs_phase_timing.hip): one instantiation compiles much faster
+#else
     if (NJT == 1) XS_TPW(1);
     else if (NJT == 2) XS_TPW(2);
     else XS_TPW(3);
+#endif
 #undef XS_TPW
 #undef XS_LAUNCH
     return sc_check_launch("xslot_fwd");
