@@ -114,17 +114,39 @@ __device__ __forceinline__ float xs_rowsum(const f32x16 (&m)[NT]) {
 // ill-conditioned (mixed-sign terms cancel), so it is evaluated in fp64 from the fp32 operands -- by linearity this
 // is the same quantity as the row sum of D, without the fp32 cancellation noise.  ksum: [64] doubles in LDS.
 __device__ __forceinline__ double xs_rowdot_f64(const f32x16 (&s)[2], const double* __restrict__ ksum, int hh) {
-    double acc = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;            // four chains: the DFMAs pipeline instead of waiting
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc += (double)s[t][r] * ksum[xs_kidx(t, r, hh)];
+        for (int q = 0; q < 4; ++q) {
+            const double2 k01 = *(const double2*)(ksum + 32 * t + 8 * q + 4 * hh);
+            const double2 k23 = *(const double2*)(ksum + 32 * t + 8 * q + 4 * hh + 2);
+            a0 += (double)s[t][4 * q] * k01.x;
+            a1 += (double)s[t][4 * q + 1] * k01.y;
+            a2 += (double)s[t][4 * q + 2] * k23.x;
+            a3 += (double)s[t][4 * q + 3] * k23.y;
+        }
+    const double acc = (a0 + a1) + (a2 + a3);
     return acc + __shfl_xor(acc, 32, 64);
 }
+// sum over the 32 slots of a tile of a per-slot fp64 value (both half-waves hold it): data-parallel-primitive row
+// reductions (quad swaps, half-row and row mirrors: ~10 cycles each) + two scalar lane reads, instead of five
+// ds_bpermute round trips through the LDS crossbar.  Result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double xs_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double xs_tilesum_f64(double v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += xs_dpp_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += xs_dpp_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += xs_dpp_f64<0x141>(v);         // row_half_mirror
+    v += xs_dpp_f64<0x140>(v);         // row_mirror: every lane of a 16-lane row holds the row sum
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    return r0 + r1;
 }
 // column sums of K (rows < NP of an [NP][XS_LD] LDS matrix; rows >= N are zero) in fp64, by threads 0..63
 __device__ __forceinline__ void xs_colsum_f64(const float* __restrict__ Ks, int NP, double* __restrict__ ksum, int tid) {

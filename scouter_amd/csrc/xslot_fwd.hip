@@ -46,78 +46,92 @@ struct XsFwdArgs {
 #define XS_XT_FLOATS(NP_) ((NP_) * XS_LD > 64 * ((NP_) + 4) ? (NP_) * XS_LD : 64 * ((NP_) + 4))
 #define XS_SB() __builtin_amdgcn_sched_barrier(0)
 struct XsLds { const float* Xs; const float* Ks; const float* Wih; const float* Whh; const float* bias; };
-struct XsNoPiece { __device__ __forceinline__ void operator()(int) const {} };
 
-// NFRAG operand fragments (one ds_read_b128 = the A operands of 4 consecutive MFMAs), read two fragments ahead of use
-template <int NFRAG, typename AddrF, typename MmaF, typename PieceF>
-__device__ __forceinline__ void xs_stream(const AddrF& addr, const MmaF& mma, const PieceF& piece) {
+// An S block = NFRAG operand fragments (one ds_read_b128 = the A operands of 4 consecutive MFMAs).  Fragments are
+// read two ahead of use; the first two are requested by `*_pre` -- which callers issue BEFORE the VALU block that
+// precedes the stream, so the LDS latency (and, for the gate streams, the bias reads that initialise the
+// accumulators) is covered by that arithmetic instead of being exposed at every block boundary.
+struct XsFrag { f32x4 f0, f1; };
+template <typename AddrF>
+__device__ __forceinline__ XsFrag xs_pre(const AddrF& addr) {
+    return XsFrag{*(const f32x4*)addr(0), *(const f32x4*)addr(1)};
+}
+template <int NFRAG, typename AddrF, typename MmaF>
+__device__ __forceinline__ void xs_stream(const AddrF& addr, const MmaF& mma, const XsFrag& pre) {
     f32x4 fr[3];
-    fr[0] = *(const f32x4*)addr(0);
-    if (NFRAG > 1) fr[1] = *(const f32x4*)addr(1);
-    XS_SB();
+    fr[0] = pre.f0;
+    fr[1] = pre.f1;
 #pragma unroll
     for (int f = 0; f < NFRAG; ++f) {
+        XS_SB();
         if (f + 2 < NFRAG) fr[(f + 2) % 3] = *(const f32x4*)addr(f + 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            mma(f, e, fr[f % 3][e]);
-            piece(4 * f + e);
-            XS_SB();
-        }
+        for (int e = 0; e < 4; ++e) mma(f, e, fr[f % 3][e]);
     }
+    XS_SB();
 }
 
-template <int NJT, typename PieceF>
-__device__ __forceinline__ void xs_s1(const XsLds& m, const f32x16 (&h)[2], f32x16 (&D)[NJT], int l31, int hh,
-                                      const PieceF& piece) {
+// S1: D^T = (K/8) s^T
+template <int NJT>
+struct XsS1 {
+    const float* base;
+    __device__ __forceinline__ XsS1(const XsLds& m, int l31, int hh) : base(m.Ks + l31 * XS_LD + 4 * hh) {}
+    __device__ __forceinline__ const float* operator()(int f) const {
+        return base + (32 * (f >> 3)) * XS_LD + 32 * ((f >> 2) & 1) + 8 * (f & 3);
+    }
+    __device__ __forceinline__ void run(const f32x16 (&h)[2], f32x16 (&D)[NJT], const XsFrag& pre) const {
 #pragma unroll
-    for (int jt = 0; jt < NJT; ++jt) xs_zero(D[jt]);
-    const float* base = m.Ks + l31 * XS_LD + 4 * hh;
-    xs_stream<8 * NJT>(
-        [&](int f) { return base + (32 * (f >> 3)) * XS_LD + 32 * ((f >> 2) & 1) + 8 * (f & 3); },
-        [&](int f, int e, float a) { D[f >> 3] = mfma32(a, h[(f >> 2) & 1][4 * (f & 3) + e], D[f >> 3]); }, piece);
-}
-// X is staged TRANSPOSED (Xt[c][j], row stride 32*NJT+4): the contraction index j is contiguous, one ds_read_b128
-// feeds four MFMAs like in the other blocks
-template <int NJT, typename PieceF>
-__device__ __forceinline__ void xs_s2(const XsLds& m, const f32x16 (&A)[NJT], f32x16 (&U)[2], int l31, int hh,
-                                      const PieceF& piece) {
-    constexpr int LDT = 32 * NJT + 4;
-    xs_zero(U[0]); xs_zero(U[1]);
-    const float* base = m.Xs + l31 * LDT + 4 * hh;
-    xs_stream<8 * NJT>(
-        [&](int f) { return base + (32 * (f / (4 * NJT))) * LDT + 8 * (f % (4 * NJT)); },
-        [&](int f, int e, float a) {
+        for (int jt = 0; jt < NJT; ++jt) xs_zero(D[jt]);
+        xs_stream<8 * NJT>(*this, [&](int f, int e, float a) {
+            D[f >> 3] = mfma32(a, h[(f >> 2) & 1][4 * (f & 3) + e], D[f >> 3]); }, pre);
+    }
+};
+// S2: U^T = (X/64)^T A^T.  X is staged TRANSPOSED (Xt[c][j], row stride 32*NJT+4): the contraction index j is
+// contiguous, so one ds_read_b128 feeds four MFMAs like in the other blocks
+template <int NJT>
+struct XsS2 {
+    static constexpr int LDT = 32 * NJT + 4;
+    const float* base;
+    __device__ __forceinline__ XsS2(const XsLds& m, int l31, int hh) : base(m.Xs + l31 * LDT + 4 * hh) {}
+    __device__ __forceinline__ const float* operator()(int f) const {
+        return base + (32 * (f / (4 * NJT))) * LDT + 8 * (f % (4 * NJT));
+    }
+    __device__ __forceinline__ void run(const f32x16 (&A)[NJT], f32x16 (&U)[2], const XsFrag& pre) const {
+        xs_zero(U[0]); xs_zero(U[1]);
+        xs_stream<8 * NJT>(*this, [&](int f, int e, float a) {
             const int ct = f / (4 * NJT), g = f % (4 * NJT);
-            U[ct] = mfma32(a, A[g >> 2][4 * (g & 3) + e], U[ct]);       // slot_attention.py:59
-        }, piece);
-}
-// six 64-deep chains: (W_ir U + W_hr h), (W_iz U + W_hz h), W_in U, W_hn h; the accumulators start from the biases
-// (b_ir+b_hr | b_iz+b_hz | b_in | b_hn), so the gate block has no bias operands
-template <typename PieceF>
-__device__ __forceinline__ void xs_s3(const XsLds& m, int gt, const f32x16 (&U)[2], const f32x16 (&h)[2],
-                                      f32x16 (&G)[4], int l31, int hh, const PieceF& piece) {
+            U[ct] = mfma32(a, A[g >> 2][4 * (g & 3) + e], U[ct]); }, pre);               // slot_attention.py:59
+    }
+};
+// S3(gt): six 64-deep chains (W_ir U + W_hr h), (W_iz U + W_hz h), W_in U, W_hn h for hidden units 32gt..32gt+31;
+// the accumulators start from the biases (b_ir+b_hr | b_iz+b_hz | b_in | b_hn): the gate block has no bias operands
+struct XsS3 {
+    const float* bi; const float* bh; const float* bias;
+    __device__ __forceinline__ XsS3(const XsLds& m, int gt, int l31, int hh)
+        : bi(m.Wih + (32 * gt + l31) * XS_LD + 4 * hh), bh(m.Whh + (32 * gt + l31) * XS_LD + 4 * hh),
+          bias(m.bias + 32 * gt + 4 * hh) {}
+    __device__ __forceinline__ const float* operator()(int f) const {
+        const int c = f >> 3, g = f & 7;
+        return ((c & 1) ? bh : bi) + (64 * (c >> 1)) * XS_LD + 32 * (g >> 2) + 8 * (g & 3);
+    }
+    __device__ __forceinline__ void init(f32x16 (&G)[4]) const {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *(const f32x4*)(m.bias + 64 * k + 32 * gt + 8 * q + 4 * hh);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4*)(bias + 64 * k + 8 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) G[k][4 * q + e] = bv[e];
-        }
-    const float* bi = m.Wih + (32 * gt + l31) * XS_LD + 4 * hh;
-    const float* bh = m.Whh + (32 * gt + l31) * XS_LD + 4 * hh;
-    xs_stream<48>(
-        [&](int f) {
-            const int c = f >> 3, g = f & 7;
-            return ((c & 1) ? bh : bi) + (64 * (c >> 1)) * XS_LD + 32 * (g >> 2) + 8 * (g & 3);
-        },
-        [&](int f, int e, float a) {
+                for (int e = 0; e < 4; ++e) G[k][4 * q + e] = bv[e];
+            }
+    }
+    __device__ __forceinline__ void run(const f32x16 (&U)[2], const f32x16 (&h)[2], f32x16 (&G)[4],
+                                        const XsFrag& pre) const {
+        xs_stream<48>(*this, [&](int f, int e, float a) {
             const int c = f >> 3, g = f & 7, k = c < 4 ? (c >> 1) : c - 2;
             const float bop = (c & 1) ? h[g >> 2][4 * (g & 3) + e] : U[g >> 2][4 * (g & 3) + e];
-            G[k] = mfma32(a, bop, G[k]);
-        }, piece);
-}
+            G[k] = mfma32(a, bop, G[k]); }, pre);
+    }
+};
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define XS_LOG2E 1.4426950408889634f
@@ -177,21 +191,29 @@ struct XsTile { int ti; int i; bool iok; float r; };
 struct XsOut {
     float* states; float* attn; float* usum; float* area_s; float* stage; float* exch;
     int S, N, lane, l31, hh, wave;
+    bool vec4;
 };
 
 // One slot tile, one iteration.  MODE 0: the wave owns the tile.  MODE 1: the tile is SHARED by the wave pair
 // (2p, 2p+1) -- both run S1 / V1 / S2 redundantly (bit-identical), each computes the GRU for 32 of the 64 hidden
 // units and they swap halves through LDS: the ntiles % 4 leftover tiles cost 0.6 instead of 1.0 tile of the critical
 // wave's time.  (The caller issues the workgroup barrier between xs_tile_shared_a and _b.)
+// S1 -> V1 -> S2 of one tile; `next` (if given) is the gate stream that follows: its first fragments and bias
+// accumulators are requested before V1 as well.  LAST (+ writer): attention map, logit partial sums, area.
 template <int NJT, bool LAST>
 __device__ __forceinline__ void xs_tile_head(const XsLds& m, const f32x16 (&h)[2], const XsTile& t, float tau,
-                                             const XsOut& o, f32x16 (&U)[2], bool writer) {
+                                             const XsOut& o, f32x16 (&U)[2], bool writer, const XsS3* next,
+                                             f32x16 (&G)[4], XsFrag& next_pre) {
     f32x16 A[NJT];
-    xs_s1<NJT>(m, h, A, o.l31, o.hh, XsNoPiece{});
+    const XsS1<NJT> s1(m, o.l31, o.hh);
+    const XsS2<NJT> s2(m, o.l31, o.hh);
+    s1.run(h, A, xs_pre(s1));
+    const XsFrag pre2 = xs_pre(s2);
+    if (!LAST) { next->init(G); next_pre = xs_pre(*next); }
+    XS_SB();
     const float c = t.iok ? -XS_LOG2E * (tau * xs_recip(t.r)) : 0.f;
     xs_v1<NJT>(A, c);
-    XS_SB();
-    xs_s2<NJT>(m, A, U, o.l31, o.hh, XsNoPiece{});
+    s2.run(A, U, pre2);
     if (LAST && writer) {
         // attention map rows of this tile are one contiguous [rows][N] block in global memory: stage the tile in this
         // wave's LDS scratch (the GRU weights are dead in the last iteration) and copy it out with coalesced stores
@@ -207,7 +229,19 @@ __device__ __forceinline__ void xs_tile_head(const XsLds& m, const f32x16 (&h)[2
         asum = wave_sum(t.iok ? asum : 0.f);
         const int rows = min(32, o.S - 32 * t.ti), cnt = rows * o.N;
         float* dst = o.attn + (long)32 * t.ti * o.N;
-        for (int k = o.lane; k < cnt; k += 64) dst[k] = st[k];
+        if (o.vec4) {                   // 16-byte aligned block: all loads first, then all stores
+            const int cnt4 = cnt >> 2;
+            f32x4 buf[(32 * NJT * 32 / 4 + 63) / 64];
+#pragma unroll
+            for (int k = 0; k < (32 * NJT * 32 / 4 + 63) / 64; ++k)
+                if (o.lane + 64 * k < cnt4) buf[k] = *(const f32x4*)(st + 4 * (o.lane + 64 * k));
+#pragma unroll
+            for (int k = 0; k < (32 * NJT * 32 / 4 + 63) / 64; ++k)
+                if (o.lane + 64 * k < cnt4) *(f32x4*)(dst + 4 * (o.lane + 64 * k)) = buf[k];
+            for (int k = 4 * cnt4 + o.lane; k < cnt; k += 64) dst[k] = st[k];
+        } else {
+            for (int k = o.lane; k < cnt; k += 64) dst[k] = st[k];
+        }
         const float us = xs_rowsum<2>(U);
         if (o.hh == 0 && t.iok) o.usum[t.i] = us;
         if (o.lane == 0) o.area_s[t.ti] = asum;
@@ -216,14 +250,19 @@ __device__ __forceinline__ void xs_tile_head(const XsLds& m, const f32x16 (&h)[2
 template <int NJT, bool LAST>
 __device__ __forceinline__ void xs_tile_own(const XsLds& m, f32x16 (&h)[2], const XsTile& t, float tau, const XsOut& o,
                                             long it_row) {
-    f32x16 U[2];
-    xs_tile_head<NJT, LAST>(m, h, t, tau, o, U, true);
+    f32x16 U[2], G0[4], G1[4];
+    const XsS3 s3a(m, 0, o.l31, o.hh), s3b(m, 1, o.l31, o.hh);
+    XsFrag pa;
+    xs_tile_head<NJT, LAST>(m, h, t, tau, o, U, true, &s3a, G0, pa);
     if (!LAST) {
-        f32x16 G[4], hn0, hn1;
-        xs_s3(m, 0, U, h, G, o.l31, o.hh, XsNoPiece{});
-        xs_v2(G, h[0], hn0); XS_SB();
-        xs_s3(m, 1, U, h, G, o.l31, o.hh, XsNoPiece{});
-        xs_v2(G, h[1], hn1); XS_SB();
+        f32x16 hn0, hn1;
+        s3a.run(U, h, G0, pa);
+        s3b.init(G1);
+        const XsFrag pb = xs_pre(s3b);
+        XS_SB();
+        xs_v2(G0, h[0], hn0);
+        s3b.run(U, h, G1, pb);
+        xs_v2(G1, h[1], hn1); XS_SB();
         h[0] = hn0; h[1] = hn1;
         if (t.iok) {
             float* sp = o.states + (it_row + t.i) * XS_D;
@@ -236,12 +275,14 @@ __device__ __forceinline__ void xs_tile_own(const XsLds& m, f32x16 (&h)[2], cons
 template <int NJT, bool LAST>
 __device__ __forceinline__ void xs_tile_shared_a(const XsLds& m, f32x16 (&h)[2], const XsTile& t, float tau,
                                                  const XsOut& o, long it_row) {
-    f32x16 U[2];
+    f32x16 U[2], G[4];
     const int gt = o.wave & 1;
-    xs_tile_head<NJT, LAST>(m, h, t, tau, o, U, gt == 0);
+    const XsS3 s3(m, gt, o.l31, o.hh);
+    XsFrag pg;
+    xs_tile_head<NJT, LAST>(m, h, t, tau, o, U, gt == 0, &s3, G, pg);
     if (!LAST) {
-        f32x16 G[4], hn;
-        xs_s3(m, gt, U, h, G, o.l31, o.hh, XsNoPiece{});
+        f32x16 hn;
+        s3.run(U, h, G, pg);
         if (gt) xs_v2(G, h[1], hn); else xs_v2(G, h[0], hn);
         XS_SB();
         if (gt) h[1] = hn; else h[0] = hn;
@@ -318,10 +359,13 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
     }
 #pragma unroll
     for (int k = 0; k < TQ; ++k) wtr[k] = *(const f32x4*)(a.tok_w[0] + (tid + k * NTHR) * 4);
+    // (all workgroups want the same 98 KB at the same moment: each starts at a different 4 KB chunk so that the
+    // requests spread over the L2 channels instead of queueing on one line after the other)
+    const int rot = b % WQ;
 #pragma unroll
-    for (int k = 0; k < WQ; ++k) wir[k] = *(const f32x4*)(a.w_ih + (tid + k * NTHR) * 4);
+    for (int k = 0; k < WQ; ++k) wir[k] = *(const f32x4*)(a.w_ih + (tid + ((k + rot) % WQ) * NTHR) * 4);
 #pragma unroll
-    for (int k = 0; k < WQ; ++k) whr[k] = *(const f32x4*)(a.w_hh + (tid + k * NTHR) * 4);
+    for (int k = 0; k < WQ; ++k) whr[k] = *(const f32x4*)(a.w_hh + (tid + ((k + rot) % WQ) * NTHR) * 4);
     // slot tiles: wave w owns tiles w, w+4, ...; the ntiles % 4 leftover tiles go to waves 0.. as whole tiles, or --
     // when there are one or two of them and the exchange buffer fits (NJT <= 2) -- each is SHARED by a wave pair
     const int ntiles = (S + 31) >> 5, nfull4 = ntiles >> 2, rem = ntiles & 3;
@@ -406,7 +450,7 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
     xs_colsum_f64(Ks, NP, ksum, tid);
 #pragma unroll
     for (int k = 0; k < WQ; ++k) {
-        const int c = tid + k * NTHR;
+        const int c = tid + ((k + rot) % WQ) * NTHR;
         *(f32x4*)(Wih + (c >> 4) * XS_LD + (c & 15) * 4) = wir[k];
         *(f32x4*)(Whh + (c >> 4) * XS_LD + (c & 15) * 4) = whr[k];
     }
@@ -417,7 +461,7 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
     const XsLds m{Xs, Ks, Wih, Whh, bias};
     float* exch = usum + 512;                                   // [4 waves][4][64][4] (only when NJT <= 2)
     const XsOut o{a.states, a.attn + (long)b * S * N, usum, area_s, Wih + wave * (32 * XS_MAX_N), exch,
-                  S, N, lane, l31, hh, wave};
+                  S, N, lane, l31, hh, wave, ((S * N) & 3) == 0 && ((size_t)a.attn & 15) == 0};
     for (int it = 0; it < a.T; ++it) {
         const bool last = it == a.T - 1;
         const long it_row = ((long)it * a.B + b) * S;
@@ -438,7 +482,9 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
                 if (lane == 0 && writes) tau_part[it * 16 + ti] = tr;
             }
         }
+        XS_STAMP();
         __syncthreads();
+        XS_STAMP();
         double tau64 = 0.0;
         for (int k = 0; k < ntiles; ++k) tau64 += tau_part[it * 16 + k];
         const float tau = (float)tau64;

@@ -17,14 +17,29 @@ w_ih, w_hh, b_ih, b_hh = r(3 * d, d) * 0.1, r(3 * d, d) * 0.1, r(3 * d) * 0.1, r
 args = (X, PE, tok_w, tok_b, slots0, w_ih, w_hh, b_ih, b_hh, spc, T, 1)
 
 
+import ctypes
+from scouter_amd import _native
+
+
 def timeit(fn, n=20):
+    """kernel time from the library's own hipEvents around each launch (host / Python launch overhead excluded)"""
     fn(); fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    torch.cuda.synchronize()
+    L = _native.lib()
+    buf = ctypes.create_string_buffer(1 << 14)
+    L.scouter_prof_collect(buf, len(buf))
+    L.scouter_prof_enable(1)
     for _ in range(n):
         fn()
-    e1.record(); e1.synchronize()
-    return e0.elapsed_time(e1) / n * 1e-3
+    torch.cuda.synchronize()
+    L.scouter_prof_enable(0)
+    L.scouter_prof_collect(buf, len(buf))
+    tot = 0.0
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split("\t")[:3]
+        if name.startswith("xslot"):
+            tot += float(ms) / float(cnt)
+    return tot * 1e-3
 
 
 out = K.xslot_fwd(*args)
