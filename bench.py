@@ -68,6 +68,47 @@ def cpu_baseline(cfg, sample_b=16, steps=1):
                                                                cfg["img_size"], cores)}
 
 
+def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, layers=1):
+    """north_star target: the fused xSlot forward at batch 256 (BASELINE configs[4]'s head: 100 classes x 3 slots, 7x7
+    grid) against the fp32 MFMA roofline.  Kernel time = the library's hipEvents around each launch, median of 8
+    batches of 20 launches after 60 warm-up launches (the clock settles); FLOPs are algorithmic (no padding counted)."""
+    from scouter_amd import _native, kernels as K
+    g = torch.Generator(device=device).manual_seed(0)
+    r = lambda *sh: torch.randn(*sh, device=device, generator=g)
+    d = 64
+    X, PE = r(batch, tokens, d).relu_(), r(tokens, d) * 0.3
+    tw, tb = [r(d, d) * 0.1 for _ in range(layers)], [r(d) * 0.1 for _ in range(layers)]
+    s0 = r(slots, d).abs() * 0.5
+    wih, whh, bih, bhh = r(3 * d, d) * 0.1, r(3 * d, d) * 0.1, r(3 * d) * 0.1, r(3 * d) * 0.1
+    fn = lambda: K.xslot_fwd(X, PE, tw, tb, s0, wih, whh, bih, bhh, spc, iters, 1)
+    L = _native.lib()
+    buf = ctypes.create_string_buffer(1 << 14)
+    for _ in range(60):
+        fn()
+    torch.cuda.synchronize()
+    L.scouter_prof_collect(buf, len(buf))
+    times = []
+    for _ in range(8):
+        L.scouter_prof_enable(1)
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        L.scouter_prof_enable(0)
+        L.scouter_prof_collect(buf, len(buf))
+        for row in buf.value.decode().splitlines():
+            name, n, ms = row.split("\t")[:3]
+            if name == "xslot_fwd":
+                times.append(float(ms) / float(n) * 1e-3)
+    t = sorted(times)[len(times) // 2]
+    qk = 2.0 * slots * tokens * d
+    fl = batch * (2.0 * layers * tokens * d * d + iters * 2 * qk + (iters - 1) * 12.0 * slots * d * d)
+    return {"kernel": "xslot_fwd_kernel (to_k MLP + 3 x [QK^T, sigmoid, AV, GRU] fused, v_mfma_f32_32x32x2_f32)",
+            "batch": batch, "slots": slots, "tokens": tokens, "avg_launch_us": round(t * 1e6, 1),
+            "achieved": round(fl / t / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "bound": "mfma",
+            "measured": "hipEvents around each launch, median of 8 batches x 20 launches after 60 warm-up launches"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +238,8 @@ def main():
                            "global_batch": world * cfg["batch"], "parallelism": "dp%d" % world,
                            "step": "zero_grad+fwd+loss+bwd(+allreduce)+adamw", "final_loss": round(loss_val, 5)},
                 "roofline": roofline, "kernels": kern}
+        if world == 1 and not a.no_prof:
+            line["xslot_roofline"] = xslot_roofline(device)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

@@ -22,6 +22,14 @@
 // (everything is unrolled) and runs out of the 512-entry register file.
 #define XS_REGION_END() __builtin_amdgcn_sched_barrier(0)
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt(0)), not for its outstanding
+// global stores -- __syncthreads() would also drain those (vmcnt(0)), i.e. stall every iteration on the write
+// acknowledgements of the slot states just stored.
+__device__ __forceinline__ void xs_lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+}
+
 __device__ __forceinline__ int xs_kidx(int t, int r, int hh) { return 32 * t + 8 * (r >> 2) + 4 * hh + (r & 3); }
 
 // acc[rows row0..row0+31][i] += sum_{k<64} M[row0 + l31][k] * B^T[k][i] ; M row-major in LDS (k contiguous)
@@ -100,6 +108,34 @@ __device__ __forceinline__ float xs_tanh(float x) {        // 1 - 2 / (1 + e^{2x
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
 }
 
+// x(lane) + x(lane ^ 32) in every lane: one v_permlane32_swap per 32-bit word (rows 2,3 of the first operand are
+// exchanged with rows 0,1 of the second) instead of a ds_bpermute round trip
+__device__ __forceinline__ float xs_halfsum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ double xs_halfsum_f64(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+}
+// sum over all 64 lanes, wave-uniform result: DPP row reductions + four scalar lane reads
+template <int CTRL>
+__device__ __forceinline__ float xs_dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float xs_wave_sum(float v) {
+    v += xs_dpp_f32<0xB1>(v);
+    v += xs_dpp_f32<0x4E>(v);
+    v += xs_dpp_f32<0x141>(v);
+    v += xs_dpp_f32<0x140>(v);
+    const int b = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+
 // in-lane sum of an NT-tile register set + the partner half-wave: sum over all 32*NT k of M[i][k]
 template <int NT>
 __device__ __forceinline__ float xs_rowsum(const f32x16 (&m)[NT]) {
@@ -108,7 +144,7 @@ __device__ __forceinline__ float xs_rowsum(const f32x16 (&m)[NT]) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += m[t][r];
-    return s + __shfl_xor(s, 32, 64);
+    return xs_halfsum(s);
 }
 // r_i = sum_j D_ij = d^-1/2 * s_i . (sum_j K_j): the normaliser the reference divides by (slot_attention.py:56) is
 // ill-conditioned (mixed-sign terms cancel), so it is evaluated in fp64 from the fp32 operands -- by linearity this
@@ -126,8 +162,7 @@ __device__ __forceinline__ double xs_rowdot_f64(const f32x16 (&s)[2], const doub
             a2 += (double)s[t][4 * q + 2] * k23.x;
             a3 += (double)s[t][4 * q + 3] * k23.y;
         }
-    const double acc = (a0 + a1) + (a2 + a3);
-    return acc + __shfl_xor(acc, 32, 64);
+    return xs_halfsum_f64((a0 + a1) + (a2 + a3));
 }
 // sum over the 32 slots of a tile of a per-slot fp64 value (both half-waves hold it): data-parallel-primitive row
 // reductions (quad swaps, half-row and row mirrors: ~10 cycles each) + two scalar lane reads, instead of five

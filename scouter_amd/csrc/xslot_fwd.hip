@@ -192,7 +192,15 @@ struct XsOut {
     float* states; float* attn; float* usum; float* area_s; float* stage; float* exch;
     int S, N, lane, l31, hh, wave;
     bool vec4;
+#ifdef XS_TIMING
+    long long* stamps; int* nst;
+#endif
 };
+#ifdef XS_TIMING
+#define XS_STAMP_O(o) do { if (threadIdx.x == 0) (o).stamps[blockIdx.x * 64 + *(o).nst] = __builtin_readcyclecounter(); ++*(o).nst; } while (0)
+#else
+#define XS_STAMP_O(o) do { } while (0)
+#endif
 
 // One slot tile, one iteration.  MODE 0: the wave owns the tile.  MODE 1: the tile is SHARED by the wave pair
 // (2p, 2p+1) -- both run S1 / V1 / S2 redundantly (bit-identical), each computes the GRU for 32 of the 64 hidden
@@ -208,12 +216,15 @@ __device__ __forceinline__ void xs_tile_head(const XsLds& m, const f32x16 (&h)[2
     const XsS1<NJT> s1(m, o.l31, o.hh);
     const XsS2<NJT> s2(m, o.l31, o.hh);
     s1.run(h, A, xs_pre(s1));
+    if (LAST) XS_STAMP_O(o);
     const XsFrag pre2 = xs_pre(s2);
     if (!LAST) { next->init(G); next_pre = xs_pre(*next); }
     XS_SB();
     const float c = t.iok ? -XS_LOG2E * (tau * xs_recip(t.r)) : 0.f;
     xs_v1<NJT>(A, c);
+    if (LAST) XS_STAMP_O(o);
     s2.run(A, U, pre2);
+    if (LAST) XS_STAMP_O(o);
     if (LAST && writer) {
         // attention map rows of this tile are one contiguous [rows][N] block in global memory: stage the tile in this
         // wave's LDS scratch (the GRU weights are dead in the last iteration) and copy it out with coalesced stores
@@ -226,7 +237,7 @@ __device__ __forceinline__ void xs_tile_head(const XsLds& m, const f32x16 (&h)[2
                 const int j = xs_kidx(jt, e, o.hh);
                 if (j < o.N) { st[o.l31 * o.N + j] = A[jt][e]; asum += A[jt][e]; }
             }
-        asum = wave_sum(t.iok ? asum : 0.f);
+        asum = xs_wave_sum(t.iok ? asum : 0.f);
         const int rows = min(32, o.S - 32 * t.ti), cnt = rows * o.N;
         float* dst = o.attn + (long)32 * t.ti * o.N;
         if (o.vec4) {                   // 16-byte aligned block: all loads first, then all stores
@@ -242,6 +253,7 @@ __device__ __forceinline__ void xs_tile_head(const XsLds& m, const f32x16 (&h)[2
         } else {
             for (int k = o.lane; k < cnt; k += 64) dst[k] = st[k];
         }
+        XS_STAMP_O(o);
         const float us = xs_rowsum<2>(U);
         if (o.hh == 0 && t.iok) o.usum[t.i] = us;
         if (o.lane == 0) o.area_s[t.ti] = asum;
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
     float* H0 = Wih;                        // [NP][68]
     float* H1 = H0 + NP * XS_LD;            // [NP][68]
     float* Wt = H1 + NP * XS_LD;            // [64][68]
-    static_assert(2 * NP + 64 <= 384, "MLP scratch fits in the GRU weight region");
+    static_assert(2 * NP + 64 + 4 * 32 <= 384, "MLP scratch + slot transpose scratch fit in the GRU weight region");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
@@ -359,35 +371,31 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
     }
 #pragma unroll
     for (int k = 0; k < TQ; ++k) wtr[k] = *(const f32x4*)(a.tok_w[0] + (tid + k * NTHR) * 4);
-    // (all workgroups want the same 98 KB at the same moment: each starts at a different 4 KB chunk so that the
-    // requests spread over the L2 channels instead of queueing on one line after the other)
-    const int rot = b % WQ;
 #pragma unroll
-    for (int k = 0; k < WQ; ++k) wir[k] = *(const f32x4*)(a.w_ih + (tid + ((k + rot) % WQ) * NTHR) * 4);
+    for (int k = 0; k < WQ; ++k) wir[k] = *(const f32x4*)(a.w_ih + (tid + k * NTHR) * 4);
 #pragma unroll
-    for (int k = 0; k < WQ; ++k) whr[k] = *(const f32x4*)(a.w_hh + (tid + ((k + rot) % WQ) * NTHR) * 4);
+    for (int k = 0; k < WQ; ++k) whr[k] = *(const f32x4*)(a.w_hh + (tid + k * NTHR) * 4);
     // slot tiles: wave w owns tiles w, w+4, ...; the ntiles % 4 leftover tiles go to waves 0.. as whole tiles, or --
     // when there are one or two of them and the exchange buffer fits (NJT <= 2) -- each is SHARED by a wave pair
     const int ntiles = (S + 31) >> 5, nfull4 = ntiles >> 2, rem = ntiles & 3;
     const bool share = NJT <= 2 && (rem == 1 || rem == 2);
     int tile_id[TPW];
     f32x16 h[TPW][2];
+    // initial slots: each wave fetches its tiles as whole 256-byte rows (coalesced; a register-layout gather straight
+    // from global memory would touch 4x the cache lines) and transposes them through a private LDS scratch below
+    f32x4 sr[TPW][8];
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
         int ti = wave + NW * tt;
         if (tt >= nfull4) ti = share ? ((wave >> 1) < rem ? 4 * nfull4 + (wave >> 1) : -1)
                                      : (tt == nfull4 && wave < rem ? 4 * nfull4 + wave : -1);
         tile_id[tt] = ti;
-        const int i = ti * 32 + l31;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ti >= 0 && i < S) v = *(const f32x4*)(a.slots0 + i * XS_D + 32 * t + 8 * q + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[tt][t][4 * q + e] = v[e];
-            }
+        for (int k = 0; k < 8; ++k) {
+            const int row = ti * 32 + 4 * k + (lane >> 4);
+            sr[tt][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ti >= 0 && row < S) sr[tt][k] = *(const f32x4*)(a.slots0 + row * XS_D + (lane & 15) * 4);
+        }
     }
 #pragma unroll
     for (int k = 0; k < XQ; ++k) {
@@ -400,6 +408,22 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
 #pragma unroll
     for (int k = 0; k < TQ; ++k) { const int c = tid + k * NTHR; *(f32x4*)(Wt + (c >> 4) * XS_LD + (c & 15) * 4) = wtr[k]; }
     if (tid < 256) bias[tid] = bias_v;
+    {
+        float* tsc = Wt + 64 * XS_LD + wave * (32 * XS_LD);          // private [32][68] scratch behind the MLP buffers
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *(f32x4*)(tsc + (4 * k + (lane >> 4)) * XS_LD + (lane & 15) * 4) = sr[tt][k];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *(const f32x4*)(tsc + l31 * XS_LD + 32 * t + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[tt][t][4 * q + e] = v[e];
+                }
+        }
+    }
     XS_STAMP();
     // ---- phase 1: to_k MLP (Linear, then (ReLU, Linear)*), output tiles (jt, ot) spread over the waves
     float* Hin = H0;
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
     xs_colsum_f64(Ks, NP, ksum, tid);
 #pragma unroll
     for (int k = 0; k < WQ; ++k) {
-        const int c = tid + ((k + rot) % WQ) * NTHR;
+        const int c = tid + k * NTHR;
         *(f32x4*)(Wih + (c >> 4) * XS_LD + (c & 15) * 4) = wir[k];
         *(f32x4*)(Whh + (c >> 4) * XS_LD + (c & 15) * 4) = whr[k];
     }
@@ -461,7 +485,11 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
     const XsLds m{Xs, Ks, Wih, Whh, bias};
     float* exch = usum + 512;                                   // [4 waves][4][64][4] (only when NJT <= 2)
     const XsOut o{a.states, a.attn + (long)b * S * N, usum, area_s, Wih + wave * (32 * XS_MAX_N), exch,
-                  S, N, lane, l31, hh, wave, ((S * N) & 3) == 0 && ((size_t)a.attn & 15) == 0};
+                  S, N, lane, l31, hh, wave, ((S * N) & 3) == 0 && ((size_t)a.attn & 15) == 0
+#ifdef XS_TIMING
+                  , a.stamps, &nstamp
+#endif
+    };
     for (int it = 0; it < a.T; ++it) {
         const bool last = it == a.T - 1;
         const long it_row = ((long)it * a.B + b) * S;
@@ -483,7 +511,7 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
             }
         }
         XS_STAMP();
-        __syncthreads();
+        xs_lds_barrier();
         XS_STAMP();
         double tau64 = 0.0;
         for (int k = 0; k < ntiles; ++k) tau64 += tau_part[it * 16 + k];
@@ -502,7 +530,7 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
             XS_STAMP();
         }
         if (share && !last) {
-            __syncthreads();
+            xs_lds_barrier();
             if (tl[TPW - 1].ti >= 0) xs_tile_shared_b(h[TPW - 1], o);
         }
     }

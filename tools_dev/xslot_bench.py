@@ -45,7 +45,10 @@ def timeit(fn, n=20):
 out = K.xslot_fwd(*args)
 dlog, garea = r(B, S // spc) * 0.01, torch.full((1,), 1e-4, device='cuda')
 bw = lambda: K.xslot_bwd(X, PE, tok_w, slots0, w_ih, w_hh, b_ih, b_hh, out, dlog, garea, spc, T, 1)
-tf, tb = timeit(lambda: K.xslot_fwd(*args)), timeit(bw)
+tfs = [timeit(lambda: K.xslot_fwd(*args)) for _ in range(8)]
+tbs = [timeit(bw) for _ in range(4)]
+print('fwd batches (us):', ' '.join('%.1f' % (t * 1e6) for t in tfs), '| bwd:', ' '.join('%.1f' % (t * 1e6) for t in tbs))
+tf, tb = sorted(tfs)[len(tfs) // 2], sorted(tbs)[len(tbs) // 2]      # median batch of 20 launches
 qk = 2.0 * S * N * d                      # one QK^T (or A.X) contraction per image
 fwd_fl = B * (2.0 * L * N * d * d + T * 2 * qk + (T - 1) * 12.0 * S * d * d)
 print('B=%d S=%d N=%d T=%d L=%d' % (B, S, N, T, L))
