@@ -11,10 +11,17 @@ sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 cols = [r[1] for r in cur.execute("pragma table_info(%s)" % disp)]
 scols = [r[1] for r in cur.execute("pragma table_info(%s)" % sym)]
 namecol = "display_name" if "display_name" in scols else "kernel_name"
-q = "select s.%s, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) from %s d join %s s on d.kernel_id=s.id group by s.%s order by 3 desc" % (namecol, disp, sym, namecol)
+# optional 2nd argument "kernel_substring:K": only dispatches that start after the K-th launch of that kernel (e.g.
+# "adamw_kernel:2" = after two optimizer steps, i.e. without the warm-up steps and the first-call tile autotuning)
+t_min = 0
+if len(sys.argv) > 2 and ":" in sys.argv[2]:
+    kname, kth = sys.argv[2].rsplit(":", 1)
+    ends = [r[0] for r in cur.execute("select d.end from %s d join %s s on d.kernel_id=s.id where s.%s like ? order by d.start"
+                                      % (disp, sym, namecol), ("%" + kname + "%",))]
+    t_min = ends[int(kth) - 1]
+q = "select s.%s, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) from %s d join %s s on d.kernel_id=s.id where d.start >= %d group by s.%s order by 3 desc" % (namecol, disp, sym, t_min, namecol)
 rows = list(cur.execute(q))
 total = sum(r[2] for r in rows)
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 print("%-90s %8s %12s %10s %7s" % ("kernel", "calls", "total_ms", "avg_us", "pct"))
 for name, n, tot, mn, mx in rows:
     name = re.sub(r"\(.*", "", name)[:90]
