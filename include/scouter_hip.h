@@ -29,6 +29,18 @@ extern "C" {
 int scouter_abi_version(void);
 const char* scouter_last_error(void);
 
+/* ---- input pipeline on the GPU: the reference's make_transform
+ * (dataset/transform_func.py:101-124) = Resize((S,S)) [:19-31, torchvision F.resize -> PIL Image.resize BILINEAR with
+ * antialiasing] -> ToTensor [:51-66] -> Normalize [:91-99], for a batch of decoded uint8 HWC images of different sizes.
+ * The resize is bit-identical to Pillow's 8-bit resampler (Resample.c); ToTensor+Normalize is a [C][256] float table
+ * the caller fills exactly as the reference computes it (float64, then float32).
+ * srcs: device array of B image pointers; hw: device [B][2] (height, width); tmp: device scratch for the horizontal
+ * pass, image b at tmp + tmp_off[b], size h_b*out_w*C bytes; max_h/max_w: largest height/width in the batch (grid
+ * sizing); out: float32 [B][C][out_h][out_w].  Down-scaling factors above 47 are refused. */
+int scouter_resize_normalize_u8_f32(const unsigned char* const* srcs, const int* hw, unsigned char* tmp,
+                                    const long* tmp_off, const float* lut, float* out, int B, int C, int max_h, int max_w,
+                                    int out_h, int out_w, void* stream);
+
 /* optional per-kernel hipEvent timing used by bench.py's roofline leg: when enabled, every launch of the conv / BN /
  * xSlot kernels is bracketed by two hipEvents on ITS stream and aggregated by kernel-instance name.
  * scouter_prof_collect writes "name\tlaunches\ttotal_ms\talgorithmic_flops\talgorithmic_bytes\n" lines into buf

@@ -34,6 +34,29 @@ def _stub(name, **attrs):
     return mod
 
 
+def _importable(name):
+    import importlib.util
+    try:
+        return importlib.util.find_spec(name) is not None
+    except (ImportError, ValueError):
+        return False
+
+
+def _tv_resize(img, size, interpolation=2):
+    """torchvision.transforms.functional.resize for a PIL image and an (h, w) size: `img.resize((w, h), interp)` --
+    the work is Pillow's (torchvision/transforms/functional_pil.py `resize`)."""
+    if isinstance(size, int):
+        raise NotImplementedError("the reference only passes (h, w) tuples (transform_func.py:115,122)")
+    return img.resize((size[1], size[0]), interpolation)
+
+
+def _tv_normalize(tensor, mean, std, inplace=False):
+    """torchvision.transforms.functional.normalize: (x - mean[:, None, None]) / std[:, None, None] in x's dtype."""
+    mean = torch.as_tensor(mean, dtype=tensor.dtype)[:, None, None]
+    std = torch.as_tensor(std, dtype=tensor.dtype)[:, None, None]
+    return tensor.clone().sub_(mean).div_(std)
+
+
 def install_shims():
     """Idempotent: registers the stub modules and puts the reference on sys.path."""
     if "torchvision" not in sys.modules:
@@ -44,9 +67,12 @@ def install_shims():
                  "RandomVerticalFlip", "ColorJitter", "RandomResizedCrop"]
         tv = _stub("torchvision")
         tr = _stub("torchvision.transforms", **{n: _Dummy for n in names})
-        trf = _stub("torchvision.transforms.functional")
+        trf = _stub("torchvision.transforms.functional", resize=_tv_resize, normalize=_tv_normalize)
         tv.transforms = tr
         tr.functional = trf
+    if "tools.image_aug" not in sys.modules and not _importable("imgaug"):
+        # dataset/transform_func.py:2 imports the imgaug pipeline at module level; only `--aug true` would use it
+        _stub("tools.image_aug", ImageAugment=None)
     if "torch._six" not in sys.modules:
         _stub("torch._six", container_abcs=collections.abc, string_classes=(str, bytes), int_classes=int)
     sys.dont_write_bytecode = True  # the reference tree is read-only

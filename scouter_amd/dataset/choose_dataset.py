@@ -1,7 +1,9 @@
-"""Dataset selection.  The reference's readers (dataset/*.py: CUB200, ConText, MNIST, ImageNet folders + imgaug) are
-host-side data plumbing outside the xSlot hot path; the hot path only depends on the
-batch contract {"image": float [B,c,H,W], "label": int64 [B]} (dataset/mnist.py:102, CUB200.py:76).  This module
-provides that contract over seeded synthetic data (the benchmark input of BASELINE.md section 3)."""
+"""Dataset selection (reference dataset/choose_dataset.py:7-28).  `--synthetic_data true` (default): seeded synthetic
+batches {"image": float [B,c,H,W], "label": int64 [B]} -- the benchmark input of BASELINE.md section 3.
+`--synthetic_data false`: the reference's readers (MNIST, CUB200, ConText, ImageNet folders); their samples carry the
+DECODED uint8 image, and the loader applies Resize + ToTensor + Normalize on the GPU (dataset/transform_func.py)."""
+import os
+
 import numpy as np
 import torch
 from torch.utils.data import Dataset
@@ -24,11 +26,33 @@ def select_dataset(args):
     if getattr(args, "dataset", "") not in ("synthetic", "MNIST", "ImageNet", "CUB200", "ConText"):
         raise ValueError("unknown dataset %s" % args.dataset)
     if args.dataset != "synthetic" and not getattr(args, "synthetic_data", True):
-        raise NotImplementedError("real-data readers are outside the xSlot hot path (SURVEY.md section 8f item 4); "
-                                  "pass --synthetic_data true")
+        return select_real_dataset(args)
     c = 1 if args.dataset == "MNIST" else 3
     size = int(args.img_size)
     n_train = int(getattr(args, "synthetic_len", 4 * args.batch_size))
     n_cls = int(args.num_classes)
     return SyntheticImages(n_train, c, size, n_cls, 1234), SyntheticImages(max(args.batch_size, n_train // 4), c, size,
                                                                            n_cls, 987654)
+
+
+def select_real_dataset(args):
+    from .transform_func import make_transform
+    if args.dataset == "MNIST":
+        from .mnist import MNIST
+        root = getattr(args, "dataset_dir", None) or "./data/mnist"
+        if not os.path.isdir(os.path.join(root, "MNIST")):
+            root = "./data/mnist"                               # the reference hard-codes this location
+        return (MNIST(root, train=True, transform=make_transform(args, "train")),
+                MNIST(root, train=False, transform=make_transform(args, "val")))
+    if args.dataset == "CUB200":
+        from .CUB200 import CUB_200
+        return (CUB_200(args, train=True, transform=make_transform(args, "train")),
+                CUB_200(args, train=False, transform=make_transform(args, "val")))
+    from .ConText import ConText, MakeList, MakeListImage
+    if args.dataset == "ConText":
+        train, val = MakeList(args).get_data()
+    elif args.dataset == "ImageNet":
+        train, val = MakeListImage(args).get_data()
+    else:
+        raise ValueError(f"unknown {args.dataset}")
+    return ConText(train, transform=make_transform(args, "train")), ConText(val, transform=make_transform(args, "val"))

@@ -48,7 +48,11 @@ def calculation(model, mode, data_loader, device, record, epoch, optimizer=None)
     print("start " + mode + " :" + str(epoch))
     steps = 0
     for batch in _progress(data_loader):
-        images = batch["image"].to(device, dtype=torch.float32)
+        images = batch["image"]
+        if isinstance(images, (list, tuple)):         # decoded uint8 images: Resize + ToTensor + Normalize on the GPU
+            images = data_loader.gpu_transform(images, device)
+        else:
+            images = images.to(device, dtype=torch.float32)
         labels = batch["label"].to(device, dtype=torch.int64)
         if training:
             optimizer.zero_grad()

@@ -512,3 +512,31 @@ def linear_small_bwd(dy, x, w, dw=None, db=None, need_dx=True):
     _native.check(_native.lib().scouter_linear_small_bwd_f32(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, Kd, C,
                                                              _stream()), "linear_small_bwd")
     return dx
+
+
+# ---- input pipeline (dataset/transform_func.py:101-124 on the GPU)
+def resize_normalize(images_u8, out_size, lut, out=None):
+    """images_u8: list of B uint8 device tensors [h, w, C] (any sizes, same C) -> float32 [B, C, S, S]:
+    PIL-exact bilinear resize + ToTensor + Normalize (`lut` = [C, 256] float32 table).  Two launches per batch."""
+    B = len(images_u8)
+    dev = images_u8[0].device
+    C = images_u8[0].shape[2]
+    for t in images_u8:
+        assert t.is_cuda and t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == C and t.is_contiguous(), \
+            "resize_normalize: dense uint8 [h, w, C] device tensors expected"
+    hs, ws = [int(t.shape[0]) for t in images_u8], [int(t.shape[1]) for t in images_u8]
+    offs, tot = [], 0
+    for h in hs:
+        offs.append(tot)
+        tot += (h * out_size * C + 15) // 16 * 16
+    meta = torch.tensor([t.data_ptr() for t in images_u8] + offs + [v for hw in zip(hs, ws) for v in hw],
+                        dtype=torch.int64)
+    meta = meta.to(dev, non_blocking=True)                    # [B ptrs | B offsets | B x (h, w)]
+    hw32 = meta[2 * B:].to(torch.int32)
+    tmp = workspace(tot + 16, dev)
+    if out is None:
+        out = torch.empty((B, C, out_size, out_size), dtype=F32, device=dev)
+    _native.check(_native.lib().scouter_resize_normalize_u8_f32(
+        _p(meta), _p(hw32), _p(tmp), _p(meta[B:]), _p(lut), _p(out), B, C, max(hs), max(ws), out_size, out_size,
+        _stream()), "resize_normalize")
+    return out

@@ -77,6 +77,15 @@ def save_on_master(obj, path, **kwargs):
         torch.save(obj, path, **kwargs)
 
 
+def get_name(root, mode_folder=True):
+    """Sorted sub-directory names (mode_folder) or file names of `root` itself (reference prepare_things.py:145-150)."""
+    for _, dirs, files in os.walk(root):
+        return sorted(dirs) if mode_folder else sorted(files)
+    return None
+
+
 class DataLoaderX(DataLoader):
-    """Plain DataLoader (the reference adds a prefetch_generator background thread; the DataLoader's own worker
-    prefetching is used here -- the benchmark input is resident synthetic data anyway)."""
+    """DataLoader whose batches may carry raw decoded images: `gpu_transform` (dataset.transform_func.GpuTransform),
+    when set, is applied by the engine on the device.  (The reference adds a prefetch_generator background thread;
+    the DataLoader's own worker prefetching is used here.)"""
+    gpu_transform = None

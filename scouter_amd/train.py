@@ -19,6 +19,7 @@ import torch
 from torch.utils.data import BatchSampler, DistributedSampler, RandomSampler, SequentialSampler
 
 from .dataset.choose_dataset import select_dataset
+from .dataset.transform_func import collate_raw, make_gpu_transform
 from .engine import evaluate, train_one_epoch
 from .optim import FusedAdamW
 from .parallel import DistributedDataParallel
@@ -94,9 +95,13 @@ def _build_loaders(args):
         train_sampler, val_sampler = DistributedSampler(train_set), DistributedSampler(val_set, shuffle=False)
     else:
         train_sampler, val_sampler = RandomSampler(train_set), SequentialSampler(val_set)
+    raw = not getattr(args, "synthetic_data", True)     # real data: samples are decoded uint8 images of any size
+    extra = {"collate_fn": collate_raw} if raw else {}
     train_loader = prt.DataLoaderX(train_set, batch_sampler=BatchSampler(train_sampler, args.batch_size, drop_last=True),
-                                   num_workers=args.num_workers)
-    val_loader = prt.DataLoaderX(val_set, args.batch_size, sampler=val_sampler, num_workers=args.num_workers)
+                                   num_workers=args.num_workers, **extra)
+    val_loader = prt.DataLoaderX(val_set, args.batch_size, sampler=val_sampler, num_workers=args.num_workers, **extra)
+    if raw:
+        train_loader.gpu_transform = val_loader.gpu_transform = make_gpu_transform(args)
     return train_loader, val_loader, train_sampler
 
 

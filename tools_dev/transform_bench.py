@@ -1,0 +1,55 @@
+"""GPU input transform (Resize 224 + ToTensor + Normalize) on a batch of 70 ImageNet-sized uint8 images vs the
+reference's CPU path (PIL resize + float64 ToTensor/Normalize, one core).  usage: python tools_dev/transform_bench.py"""
+import ctypes
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+from scouter_amd import _native, kernels as K
+from scouter_amd.dataset.transform_func import GpuTransform
+
+B, S = 70, 224
+rng = np.random.default_rng(0)
+sizes = [(int(rng.integers(300, 520)), int(rng.integers(330, 640))) for _ in range(B)]       # typical ImageNet frames
+host = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in sizes]
+dev = [t.cuda() for t in host]
+tf = GpuTransform("ImageNet", S)
+lut = tf.table.cuda()
+L = _native.lib()
+buf = ctypes.create_string_buffer(1 << 14)
+for _ in range(5):
+    K.resize_normalize(dev, S, lut)
+torch.cuda.synchronize()
+L.scouter_prof_collect(buf, len(buf)); L.scouter_prof_enable(1)
+for _ in range(20):
+    K.resize_normalize(dev, S, lut)
+torch.cuda.synchronize()
+L.scouter_prof_enable(0); L.scouter_prof_collect(buf, len(buf))
+name, n, ms = buf.value.decode().splitlines()[0].split("\t")[:3]
+t_gpu = float(ms) / float(n) * 1e-3
+in_bytes = sum(h * w * 3 for h, w in sizes)
+tmp_bytes = sum(h * S * 3 for h, w in sizes)
+alg = in_bytes + 2 * tmp_bytes + B * 3 * S * S * 4
+print("GPU kernels: %.1f us per batch of %d -> %.0f images/s, %.0f GB/s algorithmic (in %.1f MB, intermediate %.1f MB x2, out %.1f MB)"
+      % (t_gpu * 1e6, B, B / t_gpu, alg / t_gpu / 1e9, in_bytes / 1e6, tmp_bytes / 1e6, B * 3 * S * S * 4 / 1e6))
+# whole call incl. H2D of the decoded images (pageable host memory)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5):
+    tf(host, torch.device("cuda"))
+torch.cuda.synchronize(); t1 = (time.perf_counter() - t0) / 5
+print("with H2D copies of the decoded images: %.2f ms per batch -> %.0f images/s" % (t1 * 1e3, B / t1))
+try:
+    from PIL import Image
+    mean, std = np.array([0.485, 0.456, 0.406])[:, None, None], np.array([0.229, 0.224, 0.225])[:, None, None]
+    t0 = time.perf_counter()
+    for a in host[:20]:
+        r = np.array(Image.fromarray(a.numpy()).resize((S, S), Image.BILINEAR))
+        x = ((r / 255).transpose(2, 0, 1) - mean) / std
+        x = torch.from_numpy(x).float()
+    t_cpu = (time.perf_counter() - t0) / 20
+    print("reference CPU path (PIL + float64 numpy, 1 core): %.2f ms per image -> %.0f images/s per core" % (t_cpu * 1e3, 1 / t_cpu))
+except ImportError:
+    print("PIL not importable: no CPU comparison")
