@@ -84,3 +84,23 @@ def test_engine_consumes_raw_batches():
     x = loader.gpu_transform(batch["image"], torch.device("cuda")).cpu().numpy()
     for b in range(4):
         assert np.array_equal(x[b], P.transform(batch["image"][b][:, :, 0].numpy(), 64, "MNIST"))
+
+
+def test_train_main_on_image_folders(tmp_path):
+    """`python -m scouter_amd.train --synthetic_data false --dataset ImageNet --dataset_dir <folders>` end to end"""
+    Image = pytest.importorskip("PIL.Image")
+    from scouter_amd import train
+    rng = np.random.default_rng(9)
+    for phase, n in (("train", 4), ("val", 2)):
+        for wnid in ("n001", "n002"):
+            d = tmp_path / "data" / phase / wnid
+            d.mkdir(parents=True)
+            for k in range(n):
+                h, w = int(rng.integers(40, 90)), int(rng.integers(40, 90))
+                Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(d / ("%d.jpg" % k), quality=90)
+    args = train.get_args_parser().parse_args([
+        "--dataset", "ImageNet", "--model", "resnet18", "--channel", "512", "--img_size", "64", "--num_classes", "2",
+        "--slots_per_class", "1", "--pre_trained", "false", "--batch_size", "4", "--epochs", "1", "--num_workers", "0",
+        "--synthetic_data", "false", "--dataset_dir", str(tmp_path / "data") + "/", "--output_dir", ""])
+    accs = train.param_translation(args)
+    assert len(accs) == 2 and all(0.0 <= a <= 1.0 for a in accs)
