@@ -64,10 +64,14 @@ int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, co
 int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
                              int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
                              void* stream);
+/* plan_hint: -1 = built-in plan; otherwise bits 0-1 = block budget {512,1024,2048,4096} (sets the split-K count),
+ * bit 4 / bit 5 = halve the ci / co tile edge.  Every plan is deterministic; different plans sum the pixels in a
+ * different order (results differ in the last bits), so a caller that autotunes keeps its choice for the whole run. */
 size_t scouter_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
-                                            int groups);
+                                            int groups, int plan_hint);
 int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
-                             int kw, int stride, int pad, int groups, void* ws, size_t ws_bytes, void* stream);
+                             int kw, int stride, int pad, int groups, int plan_hint, void* ws, size_t ws_bytes,
+                             void* stream);
 /* stem (Cin < 32): im2col of the NCHW image into [M][Kpad] rows so the stem runs as a 1x1 conv on the same path */
 int scouter_im2col_nchw_f32(const float* x, float* col, int B, int Cin, int H, int W, int k, int stride, int pad,
                             int Kpad, void* stream);

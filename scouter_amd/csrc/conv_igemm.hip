@@ -615,16 +615,25 @@ extern "C" int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const f
 
 struct WgradPlan { int bm, bn, ci_tiles, co_tiles, splits; long pix_per_split, tiles; };
 
-static WgradPlan wgrad_plan(const ConvGeom& g) {
+// plan_hint < 0: the static plan below.  Otherwise (autotuned by the caller, include/scouter_hip.h) bits 0-1 select the
+// block budget {512, 1024, 2048, 4096} that sets the split count and bits 4-5 halve the ci / co tile edge -- smaller
+// output tiles give more parallelism without split-K slabs, which pays for the short-K (7x7, 14x14) layers.
+static WgradPlan wgrad_plan(const ConvGeom& g, int plan_hint) {
     WgradPlan p;
     p.bm = (g.Cg % 128 == 0) ? 128 : (g.Cg % 64 == 0 ? 64 : 32);
     p.bn = (g.Ng % 128 == 0) ? 128 : (g.Ng % 64 == 0 ? 64 : 32);
+    long budget = 1024;
+    if (plan_hint >= 0) {
+        budget = 512L << (plan_hint & 3);
+        if ((plan_hint & 16) && p.bm > 32) p.bm >>= 1;
+        if ((plan_hint & 32) && p.bn > 32) p.bn >>= 1;
+    }
     p.ci_tiles = g.Cg / p.bm;
     p.co_tiles = g.Ng / p.bn;
     p.tiles = (long)p.ci_tiles * p.co_tiles * g.groups * g.R * g.S;
     // enough blocks to fill 256 CUs x 2 blocks twice over, but few splits for big weight tensors: every split costs a
     // full-size slab write + read in the reduction kernel
-    long want = 1024 / p.tiles;
+    long want = budget / p.tiles;
     if (want < 1) want = 1;
     long chunks = (g.M + BK - 1) / BK;
     long cps = (chunks + want - 1) / want;               // K-chunks (of 32 pixels) per split
@@ -643,22 +652,22 @@ static ConvGeom wgrad_geom(int B, int H, int W, int Cin, int Cout, int kh, int k
 }
 
 extern "C" size_t scouter_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw,
-                                                       int stride, int pad, int groups) {
+                                                       int stride, int pad, int groups, int plan_hint) {
     if (groups <= 0 || Cin % groups || Cout % groups) return 0;
     ConvGeom g = wgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
-    WgradPlan p = wgrad_plan(g);
+    WgradPlan p = wgrad_plan(g, plan_hint);
     if (p.splits <= 1) return 0;
     return (size_t)p.splits * kh * kw * g.Cg * Cout * sizeof(float);
 }
 
 extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin,
-                                        int Cout, int kh, int kw, int stride, int pad, int groups, void* ws,
-                                        size_t ws_bytes, void* stream) {
+                                        int Cout, int kh, int kw, int stride, int pad, int groups, int plan_hint,
+                                        void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(x && dy && dw && B > 0, "conv2d_wgrad: null pointer or empty shape");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_wgrad: channels not divisible by groups");
     ConvGeom g = wgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
     SC_UNSUPPORTED(g.Cg % 32 == 0 && g.Ng % 32 == 0, "conv2d_wgrad: per-group channels must be multiples of 32");
-    WgradPlan p = wgrad_plan(g);
+    WgradPlan p = wgrad_plan(g, plan_hint);
     const long slab = (long)kh * kw * g.Cg * Cout;
     const size_t need = p.splits > 1 ? (size_t)p.splits * slab * sizeof(float) : 0;
     if (need > ws_bytes || (need && !ws)) {

@@ -71,7 +71,7 @@ AUTOTUNE = os.environ.get("SCOUTER_AUTOTUNE", "1") != "0"
 _tile_cache = {}
 
 
-def _pick_tile(key, launch):
+def _pick_tile(key, launch, candidates=(0, 1, 2, 3)):
     """Block-tile choice per (mode, layer shape): time the four tile shapes once (hipEvents on the current stream, first
     call only) and cache the winner.  Every tile gives bit-identical results, so tuning never changes numerics."""
     t = _tile_cache.get(key)
@@ -82,7 +82,8 @@ def _pick_tile(key, launch):
         return -1
     best, best_ms = -1, None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for cand in (0, 1, 2, 3):
+    torch.cuda.synchronize()          # nothing else on the device while the candidates are timed (side-stream callers!)
+    for cand in candidates:
         if not launch(cand, dry=True):
             continue
         launch(cand)
@@ -187,16 +188,33 @@ def join_side_stream(device):
         torch.cuda.current_stream(device).wait_stream(st)
 
 
+# wgrad plans (library default, or tile-halving bits | block budget, include/scouter_hip.h).  Autotuning them gains 5 %
+# on the kernels timed alone but nothing inside the step, where they share the GPU with the main stream's dgrad /
+# BatchNorm kernels -- and plans differ in summation order -- so the static plan is the default: bit-reproducible runs.
+_WGRAD_PLANS = (-1,)
+if os.environ.get("SCOUTER_WGRAD_TUNE", "0") == "1":
+    _WGRAD_PLANS += tuple(t | b for t in (0, 16, 32, 48) for b in (0, 1, 2, 3))
+
+
 def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1):
-    """Writes dW (HWIO, contiguous, e.g. a slice of the flat gradient arena)."""
+    """Writes dW (HWIO, contiguous, e.g. a slice of the flat gradient arena).  SCOUTER_WGRAD_TUNE=1 autotunes the
+    (tile, split-K) plan once per layer shape and keeps it for the run (see _WGRAD_PLANS)."""
     _chk(x, "x"); _chk(dy, "dy"); _chk(dw_hwio, "dw")
     B, H, W, Cin = x.shape
     kh, kw, cg, Cout = dw_hwio.shape
     L = _native.lib()
-    need = L.scouter_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, groups)
-    ws = workspace(need, x.device)
-    _native.check(L.scouter_conv2d_wgrad_f32(_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, stride, pad,
-                                             groups, _p(ws), ws.numel(), _stream()), "conv2d_wgrad")
+    st = _stream()
+
+    def launch(plan, dry=False):
+        if dry:
+            return True
+        need = L.scouter_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, plan)
+        ws = workspace(need, x.device)
+        _native.check(L.scouter_conv2d_wgrad_f32(_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, stride, pad,
+                                                 groups, plan, _p(ws), ws.numel(), st), "conv2d_wgrad")
+        return True
+
+    launch(_pick_tile(("wgrad", B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, _WGRAD_PLANS))
     return dw_hwio
 
 
