@@ -102,6 +102,30 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     }
     const float* wbase = wgt + (long)grp * (DGRAD ? g.Cg : g.Ng);   // group offset along the contiguous Cout axis
 
+    // ---- buffer addressing.  fp32 MFMA runs on the vector FP32 lanes (its peak IS the vector peak), so every VALU
+    // instruction in the K loop is matrix throughput lost -- unlike SALU and memory-instruction issue, which are free.
+    // Loads therefore go through buffer descriptors: address = base (SGPR) + per-row byte offset (VGPR, fixed for the
+    // whole loop) + wave-uniform tap/channel offset (SGPR, scalar arithmetic); a padding row gets an offset beyond
+    // num_records for that tap and the hardware returns zeros -- no exec masking, zero fills or 64-bit VALU adds.
+    // The base is block-relative (image of the block's first pixel, shifted down so that every tap offset is >= 0; it
+    // may precede the allocation, only valid taps are ever dereferenced), so offsets fit 31 bits for any tensor size.
+    constexpr unsigned OOB = 0x80000000u;
+    const long img_elems = (long)g.H * g.W * g.C;
+    const int b0 = (int)(m0 / ((long)g.Ho * g.Wo));
+    const long shift = DGRAD ? ((long)(g.R - 1) * g.W + (g.S - 1)) * g.C : ((long)g.pad * g.W + g.pad) * g.C;
+    const __amdgpu_buffer_rsrc_t rs_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)b0 * img_elems - shift), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7fffffff, 0x00020000);
+    unsigned a_voff[AI], a_veff[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const long rel = a_base[i] - (long)b0 * g.H * g.W;          // pixels from the base image
+        const long e = DGRAD ? (rel + (long)a_y[i] * g.W + a_x[i]) * g.C
+                             : (rel + (long)(a_y[i] + g.pad) * g.W + (a_x[i] + g.pad)) * g.C;
+        a_voff[i] = (unsigned)((e + grp * g.Cg + a_col) * 4);
+        a_veff[i] = OOB;
+    }
+
     // ---- software pipeline (per wave; the MFMA stream never waits for memory inside a K-tile):
     //   global -> registers G   two tiles ahead        (issued in the shadow of tile k's MFMAs, phase 1)
     //   G -> LDS[(k+1)&1]        one tile ahead         (phase 1)                       -> barrier
@@ -114,17 +138,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
         const int r = tap / g.S, q = tap - r * g.S;
         // wave-uniform element offset of this (tap, channel chunk) relative to tap (0,0)
         const long toff = (DGRAD ? -((long)r * g.W + q) : ((long)r * g.W + q)) * g.C + c0;
+        if (lin) {
+            if (c0 == 0) {                             // new filter tap (wave-uniform): which rows are padding now
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const bool ok = (a_mask[i] >> tap) & 1u;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (lin) {
-                if (ok) v = *(const f32x4*)(a_ptr[i] + toff);
-            } else if (ok) {                            // strided dgrad (resnet18 only): general addressing
-                const int iy = (a_y[i] - r) / g.stride, ix = (a_x[i] - q) / g.stride;
-                v = *(const f32x4*)(src + (a_base[i] + (long)iy * g.W + ix) * g.C + grp * g.Cg + c0 + a_col);
+                for (int i = 0; i < AI; ++i) a_veff[i] = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB;
             }
-            ra[i] = v;
+            const int soff = (int)((DGRAD ? shift + toff : toff) * 4);
+#pragma unroll
+            for (int i = 0; i < AI; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_veff[i], soff, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {             // strided dgrad (resnet18 only): general addressing
+                const bool ok = (a_mask[i] >> tap) & 1u;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    const int iy = (a_y[i] - r) / g.stride, ix = (a_x[i] - q) / g.stride;
+                    v = *(const f32x4*)(src + (a_base[i] + (long)iy * g.W + ix) * g.C + grp * g.Cg + c0 + a_col);
+                }
+                ra[i] = v;
+            }
         }
     };
     const float* b_ptr[BI];
@@ -133,11 +166,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
         if (B_KC) b_ptr[i] = wbase + (long)(n0 + (tid >> 3) + 32 * i) * g.wrow + a_col;
         else { const int c = tid + 256 * i, krow = c / (BN / 4), col4 = c % (BN / 4); b_ptr[i] = wbase + (long)krow * g.wrow + n0 + col4 * 4; }
     }
+    unsigned b_voff[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) b_voff[i] = (unsigned)((b_ptr[i] - wbase) * 4);
     auto load_b = [&](int kt) {
         const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
         const long woff = (long)tap * g.wtap + (B_KC ? (long)c0 : (long)c0 * g.wrow);     // wave-uniform
 #pragma unroll
-        for (int i = 0; i < BI; ++i) rb[i] = *(const f32x4*)(b_ptr[i] + woff);
+        for (int i = 0; i < BI; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff[i], (int)(woff * 4), 0));
     };
     auto store_a = [&](int buf) {
         float* As = lds + buf * T::STAGE;
@@ -211,8 +248,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     if (KT > 1) { load_a(1); load_b(1); }
     __syncthreads();
     frag_a(0, P0{}); frag_b(0, P0{});
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1, nxt = cur ^ 1;
+    // one K-tile; the LDS buffer index is a compile-time constant (the loop is unrolled by two) so that every LDS
+    // address is a register + immediate -- no per-tile VALU address arithmetic
+    auto tile = [&](int kt, auto CUR) {
+        constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
         const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
         // ---- phase 1: MFMAs of F0(kt); in their shadow: F1(kt) <- LDS[cur], G(kt+1) -> LDS[nxt], G(kt+2) <- global
         SB();
@@ -235,6 +274,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
         mma(P1{}, 0, 1); SB();
         if (has1) frag_b(nxt, P0{});
         mma(P1{}, 1, 8); SB();
+    };
+    for (int kt = 0; kt < KT; kt += 2) {
+        tile(kt, P0{});
+        if (kt + 1 < KT) tile(kt + 1, P1{});
     }
 #undef SB
 
