@@ -354,7 +354,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 // ----------------------------------------------------------------------------------------------------------------
 // wgrad: C[tap][ci][co] partial sums over a pixel range; both operands are "reduction-row, channel-contiguous"
 // ----------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+// MODE 0: general addressing (strided / shrinking convolutions, tiny maps).
+// MODE 1/2: "same" convolutions (stride 1, Ho = H, Wo = W): the source pixel of filter tap (r, q) is m + const, so both
+// operands are affine in the pixel index m and go through buffer descriptors rebuilt per chunk with SCALAR arithmetic
+// (base = first pixel of the chunk, num_records = bytes up to the end of the block's pixel range: rows beyond it
+// read zeros); 2 = 1x1 (no padding, no per-thread state at all), 1 = padded taps (branch-free x/y walk for the
+// validity bit only).  The general path spent 223 VALU instructions per 64 MFMAs in the loop; fp32 MFMA shares the
+// vector FP32 lanes, so that was a quarter of the kernel.
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__ act, const float* __restrict__ dy,
                                                        float* __restrict__ out, ConvGeom g, int ci_tiles,
                                                        int co_tiles, long pix_per_split, long slab) {
@@ -397,7 +404,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     const float* dyg = dy + grp * g.Ng + co0 + b_c4;
     f32x4 ra[AI], rb[BI];
     long a_m = mbeg;                    // first pixel of the chunk the next load_a fetches
+    // affine modes: fixed per-thread byte offsets inside a chunk
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned a_voff[AI], b_voff[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_voff[i] = (unsigned)((((tid + 256 * i) / (BM / 4)) * (long)g.C + grp * g.Cg + ci0 + a_c4) * 4);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) b_voff[i] = (unsigned)((((tid + 256 * i) / (BN / 4)) * (long)g.N + grp * g.Ng + co0 + b_c4) * 4);
+    const long tapoff = (long)(r - g.pad) * g.W + (q - g.pad);           // source pixel = m + tapoff
+    const int adv_x = BK % g.Wo, adv_y = BK / g.Wo;
+    auto records = [&](long m_chunk, int row_elems) {                    // bytes of the rows m_chunk .. mend-1
+        long n = (mend - m_chunk) * (long)row_elems * 4;
+        return (unsigned)(n < 0 ? 0 : (n > 0x7fffffffL ? 0x7fffffffL : n));
+    };
     auto load_a = [&]() {
+        if (MODE != 0) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(act + (a_m + tapoff) * g.C), 0, records(a_m, g.C), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                unsigned vo = a_voff[i];
+                if (MODE == 1) {
+                    const int iy = py[i] - g.pad + r, ix = px[i] - g.pad + q;
+                    vo = (iy >= 0 && ix >= 0 && iy < g.H && ix < g.W) ? vo : OOB;
+                    px[i] += adv_x;                              // advance by one chunk of BK pixels, branch-free
+                    const int wrap = px[i] >= g.Wo ? 1 : 0;
+                    px[i] -= wrap ? g.Wo : 0;
+                    py[i] += adv_y + wrap;
+                    py[i] -= py[i] >= g.Ho ? g.Ho : 0;
+                }
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+            }
+            a_m += BK;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int c = tid + 256 * i, prow = c / (BM / 4);
@@ -414,6 +454,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     };
     long b_m = mbeg;
     auto load_b = [&]() {
+        if (MODE != 0) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(dy + b_m * g.N), 0, records(b_m, g.N), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, b_voff[i], 0, 0));
+            b_m += BK;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const int c = tid + 256 * i, prow = c / (BN / 4);
@@ -476,8 +525,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     }
     __syncthreads();
     if (KT > 0) frag(0, P0{});
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1, nxt = cur ^ 1;
+    auto chunk = [&](int kt, auto CUR) {              // LDS buffer index is a compile-time constant (loop unrolled by 2)
+        constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
         const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
         SB();
         frag(cur, P1{});
@@ -490,6 +539,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
         SB();
         if (has1) frag(nxt, P0{});
         mma(P1{}, 0, HS); SB();
+    };
+    for (int kt = 0; kt < KT; kt += 2) {
+        chunk(kt, P0{});
+        if (kt + 1 < KT) chunk(kt + 1, P1{});
     }
 #undef SB
     float* o = out + (long)blockIdx.y * slab + (long)tap * g.Cg * g.N;
@@ -729,9 +782,22 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
     {
     ScProfScope prof(wname[wi], st, 2.0 * g.M * Cout * g.Cg * kh * kw,
                      4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
+    // "same" stride-1 convolutions take the scalar-addressed paths (see wgrad_kernel); the branch-free pixel walk of
+    // mode 1 needs at most one row wrap and one image wrap per 32-pixel chunk
+    const bool same = stride == 1 && g.Ho == H && g.Wo == W;
+    const int mode = !same ? 0 : (kh == 1 && kw == 1 && pad == 0) ? 2 : (BK / g.Wo + 1 < g.Ho ? 1 : 0);
 #define WG(BM_, BN_, WM_, WN_)                                                                                      \
-    hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_>), grid, dim3(256), 0, st, x, dy, out, g, p.ci_tiles,     \
-                       p.co_tiles, p.pix_per_split, slab)
+    do {                                                                                                            \
+        if (mode == 2)                                                                                              \
+            hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_, 2>), grid, dim3(256), 0, st, x, dy, out, g,       \
+                               p.ci_tiles, p.co_tiles, p.pix_per_split, slab);                                     \
+        else if (mode == 1)                                                                                         \
+            hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(256), 0, st, x, dy, out, g,       \
+                               p.ci_tiles, p.co_tiles, p.pix_per_split, slab);                                     \
+        else                                                                                                        \
+            hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_, 0>), grid, dim3(256), 0, st, x, dy, out, g,       \
+                               p.ci_tiles, p.co_tiles, p.pix_per_split, slab);                                     \
+    } while (0)
     if (p.bm == 128 && p.bn == 128) WG(128, 128, 64, 64);
     else if (p.bm == 128 && p.bn == 64) WG(128, 64, 64, 32);
     else if (p.bm == 128 && p.bn == 32) WG(128, 32, 32, 32);
