@@ -23,7 +23,14 @@ struct ConvGeom {
     int Cg, Ng;       // per-group channels on the K side / the column side
     long M;           // B*Ho*Wo
     int wrow, wtap;   // weight strides (elements): fwd row=k -> N, tap -> Cg*N ; dgrad row=n -> C, tap -> Ng*C
+    // reciprocals for the division-free pixel unflattening in the kernels (filled by launch_igemm_s)
+    double inv_hw;    // 1 / (Ho*Wo)
+    float inv_wo, inv_ho;
 };
+
+// floor(n / d) for 0 <= n < 2^20 with inv = 1/d: (n + 0.5) / d is at least 0.5/d away from every integer, far more
+// than the float rounding error at these magnitudes, so truncation is exact (3 VALU instead of ~40 for a division)
+__device__ __forceinline__ int fast_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;   // k-contiguous tiles: 36-float rows -> conflict-free ds_read_b128, 16B aligned
@@ -66,39 +73,50 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     // ---- per-thread A rows (fixed for the whole K loop): pointer of filter tap (0,0) + a validity bit per tap, so
     // the in-loop address work is one 64-bit add of a wave-uniform tap offset and a bit test (the general
     // bounds/stride arithmetic per load cost ~25 VALU issues each and measurably starved the MFMA issue)
-    const float* a_ptr[AI];
     unsigned a_mask[AI];
     int a_y[AI], a_x[AI];
     long a_base[AI];
+    int a_rel[AI];
     const int a_col = (tid & 7) * 4;
     constexpr bool lin = !(DGRAD && STRIDED);          // source pixel is linear in the tap index
+    // pixel (b, y, x) of each row without integer division: the block's first pixel once (fp64 reciprocal, exact for
+    // M < 2^31), then small carries per row; tap validity is separable (row bits x column bits).  The first version
+    // spent ~780 VALU instructions per block here (64-bit div/mod per row, R*S compares) -- fp32 MFMA time.
+    const int hw = g.Ho * g.Wo;
+    const int blk_b = (int)(((double)(unsigned)m0 + 0.5) * g.inv_hw);
+    const int blk_rem = (int)((unsigned)m0 - (unsigned)blk_b * (unsigned)hw);
+    const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
+    const int rows_valid = (int)(g.M - m0 < BM ? g.M - m0 : BM);
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const long m = m0 + (tid >> 3) + 32 * i;
-        const bool okm = m < g.M;
-        const long mm = okm ? m : 0;
-        const int hw = g.Ho * g.Wo;
-        const int b = (int)(mm / hw), rem = (int)(mm % hw);
-        const int y = rem / g.Wo, x = rem % g.Wo;
+        const int rowoff = (tid >> 3) + 32 * i;
+        const bool okm = rowoff < rows_valid;
+        const int tx = blk_x + rowoff, qx = fast_div(tx, g.inv_wo), x = tx - qx * g.Wo;
+        const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho), y = ty - qy * g.Ho;
+        const int b = okm ? blk_b + qy : 0;
         a_base[i] = (long)b * g.H * g.W;
+        a_rel[i] = okm ? qy * g.H * g.W : 0;                      // pixels from the block's base image
         if (DGRAD) { a_y[i] = y + g.pad; a_x[i] = x + g.pad; }
         else       { a_y[i] = y * g.stride - g.pad; a_x[i] = x * g.stride - g.pad; }
         unsigned mask = 0;
-        for (int r = 0; r < g.R; ++r)
-            for (int q = 0; q < g.S; ++q) {
-                int iy, ix;
-                bool ok = okm;
-                if (DGRAD) {
-                    const int ty = a_y[i] - r, tx = a_x[i] - q;
-                    ok = ok && ty >= 0 && tx >= 0;
-                    iy = ty / g.stride; ix = tx / g.stride;
-                    ok = ok && (iy * g.stride == ty) && (ix * g.stride == tx);
-                } else { iy = a_y[i] + r; ix = a_x[i] + q; ok = ok && iy >= 0 && ix >= 0; }
-                ok = ok && iy < g.H && ix < g.W;
-                mask |= (ok ? 1u : 0u) << (r * g.S + q);
-            }
+        if (DGRAD && STRIDED) {
+            for (int r = 0; r < g.R; ++r)
+                for (int q = 0; q < g.S; ++q) {
+                    const int ty2 = a_y[i] - r, tx2 = a_x[i] - q;
+                    bool ok = okm && ty2 >= 0 && tx2 >= 0;
+                    const int iy = ty2 / g.stride, ix = tx2 / g.stride;
+                    ok = ok && (iy * g.stride == ty2) && (ix * g.stride == tx2) && iy < g.H && ix < g.W;
+                    mask |= (ok ? 1u : 0u) << (r * g.S + q);
+                }
+        } else {
+            unsigned colbits = 0;
+            for (int q = 0; q < g.S; ++q)
+                colbits |= ((unsigned)(DGRAD ? a_x[i] - q : a_x[i] + q) < (unsigned)g.W ? 1u : 0u) << q;
+            for (int r = 0; r < g.R; ++r)
+                mask |= ((unsigned)(DGRAD ? a_y[i] - r : a_y[i] + r) < (unsigned)g.H ? colbits : 0u) << (r * g.S);
+            mask = okm ? mask : 0u;
+        }
         a_mask[i] = mask;
-        a_ptr[i] = src + (a_base[i] + (long)a_y[i] * g.W + a_x[i]) * g.C + grp * g.Cg + a_col;
     }
     const float* wbase = wgt + (long)grp * (DGRAD ? g.Cg : g.Ng);   // group offset along the contiguous Cout axis
 
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     // may precede the allocation, only valid taps are ever dereferenced), so offsets fit 31 bits for any tensor size.
     constexpr unsigned OOB = 0x80000000u;
     const long img_elems = (long)g.H * g.W * g.C;
-    const int b0 = (int)(m0 / ((long)g.Ho * g.Wo));
+    const int b0 = blk_b;
     const long shift = DGRAD ? ((long)(g.R - 1) * g.W + (g.S - 1)) * g.C : ((long)g.pad * g.W + g.pad) * g.C;
     const __amdgpu_buffer_rsrc_t rs_a =
         __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)b0 * img_elems - shift), 0, 0x7fffffff, 0x00020000);
@@ -119,9 +137,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     unsigned a_voff[AI], a_veff[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const long rel = a_base[i] - (long)b0 * g.H * g.W;          // pixels from the base image
-        const long e = DGRAD ? (rel + (long)a_y[i] * g.W + a_x[i]) * g.C
-                             : (rel + (long)(a_y[i] + g.pad) * g.W + (a_x[i] + g.pad)) * g.C;
+        const int e = DGRAD ? (a_rel[i] + a_y[i] * g.W + a_x[i]) * g.C
+                            : (a_rel[i] + (a_y[i] + g.pad) * g.W + (a_x[i] + g.pad)) * g.C;
         a_voff[i] = (unsigned)((e + grp * g.Cg + a_col) * 4);
         a_veff[i] = OOB;
     }
@@ -613,8 +630,12 @@ static void launch_igemm_s(const float* src, const float* w, const float* bias, 
                            double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
     const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
     dim3 grid(mtiles * ntiles * g.groups);
+    ConvGeom gg = g;
+    gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
+    gg.inv_wo = 1.0f / (float)g.Wo;
+    gg.inv_ho = 1.0f / (float)g.Ho;
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED>), grid, dim3(256), 0, st, src, w, bias, addend,
-                       dst, bn_part, g, relu, mtiles, ntiles);
+                       dst, bn_part, gg, relu, mtiles, ntiles);
 }
 template <int BM, int BN, int WM, int WN, bool DGRAD>
 static void launch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
@@ -641,6 +662,8 @@ static int igemm_tile(const ConvGeom& g, int hint = -1) {     // 0: 128x128  1: 
 template <bool DGRAD>
 static int dispatch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
                           double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st) {
+    SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 27),
+                   "conv2d: more than 2^31 output pixels or an image above 2^27 elements is not supported");
     switch (tile) {
         case 0: launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
         case 1: launch_igemm<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
