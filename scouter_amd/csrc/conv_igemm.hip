@@ -407,14 +407,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
 
     // per-thread pixel state of its A rows, advanced by BK pixels per chunk without divisions
     int pb[AI], py[AI], px[AI];
+    if (MODE != 2) {                    // (the 1x1 path needs no pixel coordinates at all)
+        // block's first pixel once (fp64 reciprocal, exact below 2^31), then carries per row -- no integer division
+        const int blk_b = (int)(((double)(unsigned long)mbeg + 0.5) * g.inv_hw);
+        const int blk_rem = (int)(mbeg - (long)blk_b * hw);
+        const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int c = tid + 256 * i, prow = c / (BM / 4);
-        const long m = mbeg + prow;
-        pb[i] = (int)(m / hw);
-        const int rem = (int)(m % hw);
-        py[i] = rem / g.Wo;
-        px[i] = rem - py[i] * g.Wo;
+        for (int i = 0; i < AI; ++i) {
+            const int c = tid + 256 * i, prow = c / (BM / 4);
+            const int tx = blk_x + prow, qx = fast_div(tx, g.inv_wo);
+            const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho);
+            px[i] = tx - qx * g.Wo;
+            py[i] = ty - qy * g.Ho;
+            pb[i] = blk_b + qy;
+        }
     }
     const int a_c4 = ((tid % (BM / 4)) * 4), b_c4 = ((tid % (BN / 4)) * 4);
     const float* actg = act + grp * g.Cg + ci0 + a_c4;
@@ -767,6 +773,9 @@ static ConvGeom wgrad_geom(int B, int H, int W, int Cin, int Cout, int kh, int k
     ConvGeom g{B, H, W, Cin, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout, kh, kw, stride, pad,
                groups, Cg, Ng, 0, Cout, Cg * Cout};
     g.M = (long)B * g.Ho * g.Wo;
+    g.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
+    g.inv_wo = 1.0f / (float)g.Wo;
+    g.inv_ho = 1.0f / (float)g.Ho;
     return g;
 }
 
