@@ -407,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
 
     // per-thread pixel state of its A rows, advanced by BK pixels per chunk without divisions
     int pb[AI], py[AI], px[AI];
+    int qy1 = 0, qx1 = 0;               // MODE 1: coordinates of chunk pixel (lane & 31), one per lane
     if (MODE != 2) {                    // (the 1x1 path needs no pixel coordinates at all)
         // block's first pixel once (fp64 reciprocal, exact below 2^31), then carries per row -- no integer division
         const int blk_b = (int)(((double)(unsigned long)mbeg + 0.5) * g.inv_hw);
@@ -414,13 +415,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
         const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int c = tid + 256 * i, prow = c / (BM / 4);
+            const int c = tid + 256 * i, prow = MODE == 1 ? l31 : c / (BM / 4);
             const int tx = blk_x + prow, qx = fast_div(tx, g.inv_wo);
             const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho);
             px[i] = tx - qx * g.Wo;
             py[i] = ty - qy * g.Ho;
             pb[i] = blk_b + qy;
         }
+        qx1 = px[0]; qy1 = py[0];
     }
     const int a_c4 = ((tid % (BM / 4)) * 4), b_c4 = ((tid % (BN / 4)) * 4);
     const float* actg = act + grp * g.Cg + ci0 + a_c4;
@@ -429,7 +431,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     long a_m = mbeg;                    // first pixel of the chunk the next load_a fetches
     // affine modes: fixed per-thread byte offsets inside a chunk
     constexpr unsigned OOB = 0x80000000u;
-    unsigned a_voff[AI], b_voff[BI];
+    unsigned a_voff[AI], b_voff[BI], a_bit[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_bit[i] = 1u << ((tid + 256 * i) / (BM / 4));
 #pragma unroll
     for (int i = 0; i < AI; ++i) a_voff[i] = (unsigned)((((tid + 256 * i) / (BM / 4)) * (long)g.C + grp * g.Cg + ci0 + a_c4) * 4);
 #pragma unroll
@@ -444,18 +448,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
         if (MODE != 0) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(act + (a_m + tapoff) * g.C), 0, records(a_m, g.C), 0x00020000);
+            unsigned vmask = 0xffffffffu;              // bit p: the tap's source of chunk pixel p is inside the image
+            if (MODE == 1) {
+                // every lane tests ONE pixel of the chunk (p = lane & 31); the ballot makes the 32 validity bits a
+                // scalar, so a load costs a bit test instead of its own coordinate walk (was 84 VALU per chunk)
+                const int iy = qy1 - g.pad + r, ix = qx1 - g.pad + q;
+                vmask = (unsigned)__ballot((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W);
+                qx1 += adv_x;                                  // advance by one chunk of BK pixels, branch-free
+                const int wrap = qx1 >= g.Wo ? 1 : 0;
+                qx1 -= wrap ? g.Wo : 0;
+                qy1 += adv_y + wrap;
+                qy1 -= qy1 >= g.Ho ? g.Ho : 0;
+            }
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 unsigned vo = a_voff[i];
-                if (MODE == 1) {
-                    const int iy = py[i] - g.pad + r, ix = px[i] - g.pad + q;
-                    vo = (iy >= 0 && ix >= 0 && iy < g.H && ix < g.W) ? vo : OOB;
-                    px[i] += adv_x;                              // advance by one chunk of BK pixels, branch-free
-                    const int wrap = px[i] >= g.Wo ? 1 : 0;
-                    px[i] -= wrap ? g.Wo : 0;
-                    py[i] += adv_y + wrap;
-                    py[i] -= py[i] >= g.Ho ? g.Ho : 0;
-                }
+                if (MODE == 1) vo = (vmask & a_bit[i]) ? vo : OOB;
                 ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
             }
             a_m += BK;
