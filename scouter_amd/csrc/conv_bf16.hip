@@ -1,0 +1,296 @@
+// bf16-input / fp32-accumulate implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the
+// fp32-MFMA rate) -- the mixed-precision mode of BASELINE configs[4] ("bf16").  Tensors stay fp32 in HBM (activations,
+// gradients, master weights): operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way from the global
+// loads into LDS, so every other kernel of the step (BatchNorm, xSlot, optimizer) is shared with the fp32 path and
+// only the matrix inputs lose precision -- what torch.autocast(bfloat16) does to nn.Conv2d.
+//
+//   forward : Y = X (*) W      A = X rows (pixel, k = (tap, ci) contiguous in ci), B = W^T as bf16 [tap][co][ci]
+//                              (scouter_conv2d_weight_bf16t, one small launch per layer and step)
+//   dgrad   : dX = dY (*) W^T  A = dY rows (k = co), B = W rows (n = ci, k = co contiguous: the HWIO layout itself)
+//   wgrad   : dW = X^T dY      both operands have the contraction index (pixel) as the slow axis: they are written
+//                              TRANSPOSED into LDS ([channel][pixel] bf16) so that fragments are 16-byte reads
+//
+// With bf16 MFMA the matrix pipe is no longer the bound: a 128x128x64 block tile needs 64 KB of fp32 operands for
+// 2.1 MFLOP (32 FLOP per L2 byte), so these kernels run at the operand-delivery rate.  Same scalar addressing
+// (buffer descriptors), block epilogue and BatchNorm-statistics fusion as conv_igemm.hip (conv_common.h).
+#include "conv_common.h"
+
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    // A[i = l&31][k = 8*(l>>5) + 0..7], B[k = 8*(l>>5) + 0..7][j = l&31]; D as the fp32 32x32 form
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
+    bf16x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (__bf16)v[e];
+    return r;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// forward / dgrad.  Block = 4 waves, tile BM x BN x KT (KT = 64, or 32 for 32-channel groups), 2 LDS stages,
+// LDS rows of KT+8 bf16 (16-byte aligned, conflict-free 16-byte fragment reads).
+// ----------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int KT_, bool DGRAD>
+__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restrict__ src, const void* __restrict__ wgt,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ addend, float* __restrict__ dst,
+                                                            double* __restrict__ bn_part, ConvGeom g, int relu,
+                                                            int mtiles, int ntiles) {
+    constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
+    constexpr int LDH = KT_ + 8;                          // LDS row stride in bf16
+    constexpr int A_H = BM * LDH, B_H = BN * LDH, STAGE_H = A_H + B_H;
+    constexpr int TPR = KT_ / 4;                          // threads per operand row when loading fp32 float4 along k
+    constexpr int RPI = 256 / TPR;                        // rows per load instruction
+    constexpr int AI = BM / RPI, BI = BN / RPI;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) __bf16 ldsh[];      // max(2 stages, epilogue staging) bytes
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nblk = mtiles * ntiles * g.groups;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int grp = bid % g.groups;
+    const int nt_id = (bid / g.groups) % ntiles;
+    const int mt_id = bid / (g.groups * ntiles);
+    const long m0 = (long)mt_id * BM;
+    const int n0 = nt_id * BN;
+    const int cpt = g.Cg / KT_;                // K chunks per filter tap
+    const int KT = g.R * g.S * cpt;
+
+    // ---- A rows: block-relative buffer offsets + separable tap masks (see conv_igemm.hip)
+    constexpr unsigned OOB = 0x80000000u;
+    const int hw = g.Ho * g.Wo;
+    const int blk_b = (int)(((double)(unsigned)m0 + 0.5) * g.inv_hw);
+    const int blk_rem = (int)((unsigned)m0 - (unsigned)blk_b * (unsigned)hw);
+    const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
+    const int rows_valid = (int)(g.M - m0 < BM ? g.M - m0 : BM);
+    const int a_col = (tid % TPR) * 4;
+    unsigned a_mask[AI], a_voff[AI], a_veff[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int rowoff = tid / TPR + RPI * i;
+        const bool okm = rowoff < rows_valid;
+        const int tx = blk_x + rowoff, qx = fast_div(tx, g.inv_wo), x = tx - qx * g.Wo;
+        const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho), y = ty - qy * g.Ho;
+        const int ay = DGRAD ? y + g.pad : y * g.stride - g.pad, ax = DGRAD ? x + g.pad : x * g.stride - g.pad;
+        unsigned colbits = 0, mask = 0;
+        for (int q = 0; q < g.S; ++q) colbits |= ((unsigned)(DGRAD ? ax - q : ax + q) < (unsigned)g.W ? 1u : 0u) << q;
+        for (int r = 0; r < g.R; ++r) mask |= ((unsigned)(DGRAD ? ay - r : ay + r) < (unsigned)g.H ? colbits : 0u) << (r * g.S);
+        a_mask[i] = okm ? mask : 0u;
+        const int rel = okm ? qy * g.H * g.W : 0;
+        const int e = DGRAD ? (rel + ay * g.W + ax) * g.C : (rel + (ay + g.pad) * g.W + (ax + g.pad)) * g.C;
+        a_voff[i] = (unsigned)((e + grp * g.Cg + a_col) * 4);
+        a_veff[i] = OOB;
+    }
+    const long img_elems = (long)g.H * g.W * g.C;
+    const long shift = DGRAD ? ((long)(g.R - 1) * g.W + (g.S - 1)) * g.C : ((long)g.pad * g.W + g.pad) * g.C;
+    const __amdgpu_buffer_rsrc_t rs_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)blk_b * img_elems - shift), 0, 0x7fffffff, 0x00020000);
+    // ---- B rows (n = output column of the GEMM, k contiguous)
+    //   fwd  : bf16 W^T [tap][co][Cg]      : 8 bf16 (16 B) per load, KT/8 threads per row
+    //   dgrad: fp32 W   [tap][ci][Cout]    : rows n = ci, k = co within the group, float4 per load
+    constexpr int BTPR = DGRAD ? TPR : KT_ / 8, BRPI = 256 / BTPR, BBI = (BN + BRPI - 1) / BRPI;
+    const int b_col = (tid % BTPR) * (DGRAD ? 4 : 8);
+    const char* wbase = DGRAD ? (const char*)((const float*)wgt + (long)grp * g.Cg)
+                              : (const char*)((const __bf16*)wgt + (long)grp * g.Ng * g.Cg);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7fffffff, 0x00020000);
+    unsigned b_voff[BBI];
+#pragma unroll
+    for (int i = 0; i < BBI; ++i) {
+        const int n = n0 + tid / BTPR + BRPI * i;
+        b_voff[i] = DGRAD ? (unsigned)(((long)n * g.wrow + b_col) * 4) : (unsigned)(((long)n * g.Cg + b_col) * 2);
+        if (tid / BTPR + BRPI * i >= BN) b_voff[i] = OOB;          // (tiles narrower than one load instruction)
+    }
+    const long wtap_bytes = DGRAD ? (long)g.wtap * 4 : (long)g.N * g.Cg * 2;     // fwd: [tap][Cout_total][Cg] bf16
+
+    f32x4 ra[AI];
+    f32x4 rbf[DGRAD ? BBI : 1];
+    bf16x8 rbh[DGRAD ? 1 : BBI];
+    auto load_a = [&](int kt) {
+        const int tap = kt / cpt, c0 = (kt - tap * cpt) * KT_;
+        const int r = tap / g.S, q = tap - r * g.S;
+        const long toff = (DGRAD ? -((long)r * g.W + q) : ((long)r * g.W + q)) * g.C + c0;
+        if (c0 == 0) {
+#pragma unroll
+            for (int i = 0; i < AI; ++i) a_veff[i] = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB;
+        }
+        const int soff = (int)((DGRAD ? shift + toff : toff) * 4);
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_veff[i], soff, 0));
+    };
+    auto load_b = [&](int kt) {
+        const int tap = kt / cpt, c0 = (kt - tap * cpt) * KT_;
+        const int soff = (int)(tap * wtap_bytes + (long)c0 * (DGRAD ? 4 : 2));
+#pragma unroll
+        for (int i = 0; i < BBI; ++i) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff[i], soff, 0);
+            if (DGRAD) rbf[i] = __builtin_bit_cast(f32x4, v);
+            else rbh[i] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    auto store_a = [&](int buf) {
+        __bf16* As = ldsh + buf * STAGE_H;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *(bf16x4*)(As + (tid / TPR + RPI * i) * LDH + a_col) = to_bf16x4(ra[i]);
+    };
+    auto store_b = [&](int buf) {
+        __bf16* Bs = ldsh + buf * STAGE_H + A_H;
+#pragma unroll
+        for (int i = 0; i < BBI; ++i) {
+            if (BN % BRPI != 0 && tid / BTPR + BRPI * i >= BN) continue;
+            if (DGRAD) *(bf16x4*)(Bs + (tid / BTPR + BRPI * i) * LDH + b_col) = to_bf16x4(rbf[i]);
+            else *(bf16x8*)(Bs + (tid / BTPR + BRPI * i) * LDH + b_col) = rbh[i];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int buf) {
+        const __bf16* As = ldsh + buf * STAGE_H;
+        const __bf16* Bs = As + A_H;
+#pragma unroll
+        for (int s = 0; s < KT_ / 16; ++s) {
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *(const bf16x8*)(As + (wm * WM + i * 32 + l31) * LDH + 16 * s + 8 * h);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *(const bf16x8*)(Bs + (wn * WN + j * 32 + l31) * LDH + 16 * s + 8 * h);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    // ---- pipeline: registers hold tile kt+1 while LDS[cur] feeds the MFMAs; two blocks per CU hide the rest
+    load_a(0); load_b(0);
+    store_a(0); store_b(0);
+    if (KT > 1) { load_a(1); load_b(1); }
+    __syncthreads();
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    auto tile = [&](int kt, auto CUR) {
+        constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
+        if (kt + 1 < KT) { store_a(nxt); store_b(nxt); }
+        if (kt + 2 < KT) { load_a(kt + 2); load_b(kt + 2); }
+        compute(cur);
+        __syncthreads();
+    };
+    for (int kt = 0; kt < KT; kt += 2) {
+        tile(kt, P0{});
+        if (kt + 1 < KT) tile(kt + 1, P1{});
+    }
+    igemm_epilogue<BM, BN, WM, WN>(acc, (float*)ldsh, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id);
+}
+
+// W (HWIO fp32 [taps][Cin/groups][Cout]) -> bf16 W^T [taps][Cout][Cin/groups]
+__global__ __launch_bounds__(256) void weight_bf16t_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int taps,
+                                                           int Cg, int Cout) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((long)tap * Cg + k0 + r) * Cout + n0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) wt[((long)tap * Cout + n0 + r) * Cg + k0 + tx] = (__bf16)tile[tx][r];
+}
+
+template <int BM, int BN, int WM, int WN, bool DGRAD>
+static void launch_bf16(const float* src, const void* w, const float* bias, const float* addend, float* dst,
+                        double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
+    const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
+    dim3 grid(mtiles * ntiles * g.groups);
+    ConvGeom gg = g;
+    gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
+    gg.inv_wo = 1.0f / (float)g.Wo;
+    gg.inv_ho = 1.0f / (float)g.Ho;
+    const size_t epi = (size_t)4 * WM * (WN + 4) * sizeof(float);
+    auto go = [&](auto kern, int kt) {
+        size_t lds = (size_t)2 * (BM + BN) * (kt + 8) * 2;
+        if (lds < epi) lds = epi;
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, src, w, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles);
+    };
+    if (g.Cg % 64 == 0) go(igemm_bf16_kernel<BM, BN, WM, WN, 64, DGRAD>, 64);
+    else go(igemm_bf16_kernel<BM, BN, WM, WN, 32, DGRAD>, 32);
+}
+template <bool DGRAD>
+static int dispatch_bf16(const float* src, const void* w, const float* bias, const float* addend, float* dst,
+                         double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st) {
+    SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 27),
+                   "conv2d_bf16: more than 2^31 output pixels or an image above 2^27 elements is not supported");
+    switch (tile) {
+        case 0: launch_bf16<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+        case 1: launch_bf16<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+        case 2: launch_bf16<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+        default: launch_bf16<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+    }
+    return sc_check_launch(DGRAD ? "conv2d_dgrad_bf16" : "conv2d_fwd_bf16");
+}
+static int bf16_tile(const ConvGeom& g, int hint) {       // 0: 128x128  1: 128x64  2: 64x64  3: 128x32
+    auto ok = [&](int t) { return (t == 0 && g.Ng % 128 == 0) || ((t == 1 || t == 2) && g.Ng % 64 == 0) || t == 3; };
+    if (hint >= 0 && hint <= 3 && ok(hint)) return hint;
+    auto blocks = [&](int bm, int bn) { return (long)sc_cdiv(g.M, bm) * (g.Ng / bn) * g.groups; };
+    if (g.Ng % 128 == 0 && blocks(128, 128) >= 768) return 0;
+    if (g.Ng % 64 == 0 && blocks(128, 64) >= 768) return 1;
+    if (g.Ng % 64 == 0) return 2;
+    return 3;
+}
+static int conv_out_b(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+extern "C" int scouter_conv2d_weight_bf16t(const float* w, void* wt, int kh, int kw, int Cin, int Cout, int groups,
+                                           void* stream) {
+    SC_REQUIRE(w && wt && groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_weight_bf16t: bad arguments");
+    const int Cg = Cin / groups;
+    SC_UNSUPPORTED(Cg % 32 == 0 && Cout % 32 == 0, "conv2d_weight_bf16t: channels must be multiples of 32");
+    hipLaunchKernelGGL(weight_bf16t_kernel, dim3(Cout / 32, Cg / 32, kh * kw), dim3(256), 0, (hipStream_t)stream, w,
+                       (__bf16*)wt, kh * kw, Cg, Cout);
+    return sc_check_launch("conv2d_weight_bf16t");
+}
+
+extern "C" int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, const float* bias, const float* addend,
+                                       float* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh,
+                                       int kw, int stride, int pad, int groups, int relu, int tile_hint, void* stream) {
+    SC_REQUIRE(x && wt_bf16 && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_bf16: null pointer or empty shape");
+    SC_REQUIRE(!(bn_partial && relu), "conv2d_fwd_bf16: fused BatchNorm statistics are taken before any activation");
+    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_fwd_bf16: channels not divisible by groups");
+    const int Cg = Cin / groups, Ng = Cout / groups;
+    SC_UNSUPPORTED(Cg % 32 == 0 && Ng % 32 == 0, "conv2d_fwd_bf16: per-group channels must be multiples of 32");
+    ConvGeom g{B, H, W, Cin, conv_out_b(H, kh, stride, pad), conv_out_b(W, kw, stride, pad), Cout, kh, kw, stride, pad,
+               groups, Cg, Ng, 0, Cout, Cg * Cout};
+    g.M = (long)B * g.Ho * g.Wo;
+    static const char* names[4] = {"igemm_fwd_bf16<128x128>", "igemm_fwd_bf16<128x64>", "igemm_fwd_bf16<64x64>", "igemm_fwd_bf16<128x32>"};
+    const int tile = bf16_tile(g, tile_hint);
+    ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
+                     4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
+    return dispatch_bf16<false>(x, wt_bf16, bias, addend, y, bn_partial, g, relu, tile, (hipStream_t)stream);
+}
+
+extern "C" int scouter_conv2d_dgrad_bf16(const float* dy, const float* w, const float* addend, float* dx, int B, int H,
+                                         int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups,
+                                         int tile_hint, void* stream) {
+    SC_REQUIRE(dy && w && dx && B > 0, "conv2d_dgrad_bf16: null pointer or empty shape");
+    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad_bf16: channels not divisible by groups");
+    SC_UNSUPPORTED(stride == 1, "conv2d_dgrad_bf16: strided input gradients use the fp32 kernel");
+    const int Cig = Cin / groups, Cog = Cout / groups;
+    SC_UNSUPPORTED(Cig % 32 == 0 && Cog % 32 == 0, "conv2d_dgrad_bf16: per-group channels must be multiples of 32");
+    const int Ho = conv_out_b(H, kh, stride, pad), Wo = conv_out_b(W, kw, stride, pad);
+    ConvGeom g{B, Ho, Wo, Cout, H, W, Cin, kh, kw, stride, pad, groups, Cog, Cig, 0, Cout, Cig * Cout};
+    g.M = (long)B * H * W;
+    static const char* names[4] = {"igemm_dgrad_bf16<128x128>", "igemm_dgrad_bf16<128x64>", "igemm_dgrad_bf16<64x64>", "igemm_dgrad_bf16<128x32>"};
+    const int tile = bf16_tile(g, tile_hint);
+    ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw,
+                     4.0 * ((double)B * Ho * Wo * Cout + (double)g.M * Cin));
+    return dispatch_bf16<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream);
+}

@@ -1,0 +1,102 @@
+// Pieces shared by the fp32 (conv_igemm.hip) and bf16 (conv_bf16.hip) implicit-GEMM convolution kernels: problem
+// geometry, division-free pixel unflattening, and the block epilogue (LDS-staged 16-byte stores with fused bias /
+// addend / ReLU and the fused fp64 BatchNorm statistics).
+#pragma once
+#include "common.h"
+
+struct ConvGeom {
+    int B, H, W, C;   // tensor feeding the A operand, NHWC, C = all channels
+    int Ho, Wo;       // pixel grid of the GEMM rows
+    int N;            // channels (all groups) of the GEMM-column tensor
+    int R, S, stride, pad, groups;
+    int Cg, Ng;       // per-group channels on the K side / the column side
+    long M;           // B*Ho*Wo
+    int wrow, wtap;   // weight strides (elements): fwd row=k -> N, tap -> Cg*N ; dgrad row=n -> C, tap -> Ng*C
+    // reciprocals for the division-free pixel unflattening in the kernels (filled by launch_igemm_s)
+    double inv_hw;    // 1 / (Ho*Wo)
+    float inv_wo, inv_ho;
+};
+
+// floor(n / d) for 0 <= n < 2^20 with inv = 1/d: (n + 0.5) / d is at least 0.5/d away from every integer, far more
+// than the float rounding error at these magnitudes, so truncation is exact (3 VALU instead of ~40 for a division)
+__device__ __forceinline__ int fast_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
+
+// Block epilogue.  acc: this wave's (WM x WN) accumulator tiles in MFMA layout; lds: the block's K-loop LDS (free now,
+// at least 4*WM*(WN+4) floats); rows m0.., columns grp*Ng + n0.. of the [M][N] output.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], float* lds, const ConvGeom& g,
+                                               const float* __restrict__ bias, const float* __restrict__ addend,
+                                               float* __restrict__ dst, double* __restrict__ bn_part, int relu,
+                                               long m0, int n0, int grp, int mt_id) {
+    constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    // ---- epilogue: stage each wave's WMxWN accumulator tile through LDS (the K-loop buffers are free now) and write
+    // whole 16-byte row segments: 16 dwordx4 stores (+16 vector addend loads) per lane instead of 64 scalar ones --
+    // for the short-K 1x1 layers the scalar epilogue was a quarter of the block's lifetime.
+    __syncthreads();
+    constexpr int LDE = WN + 4;                               // padded row (16B aligned, breaks the 32-bank stride)
+    float* Es = lds + wave * (WM * LDE);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Es[(i * 32 + mfma32_row(e, lane)) * LDE + j * 32 + l31] = acc[i][j][e];
+    // each wave reads back its own tile only: no block barrier needed, just this wave's LDS writes
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
+    constexpr int QPR = WN / 4;                               // float4 per tile row
+    constexpr int RPP = 64 / QPR;                             // rows covered per pass by the 64 lanes
+    const int qcol = (lane % QPR) * 4, qrow = lane / QPR;
+    const int ncol = grp * g.Ng + n0 + wn * WN + qcol;
+    f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv4 = *(const f32x4*)(bias + ncol);
+    double cs[4] = {0, 0, 0, 0}, cq[4] = {0, 0, 0, 0};        // per-column sum / sum of squares (BatchNorm statistics)
+#pragma unroll
+    for (int rr = 0; rr < WM / RPP; ++rr) {
+        const int row = rr * RPP + qrow;
+        const long m = m0 + wm * WM + row;
+        if (m >= g.M) continue;
+        f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
+        if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
+        if (bn_part) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * v[e]; }
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *(f32x4*)(dst + m * g.N + ncol) = v;
+    }
+    if (bn_part) {
+        // Fused batch statistics of the tile just written: lanes sharing a column quad (stride QPR) are combined by
+        // shuffles, the BM/WM waves sharing a column range through LDS; one fp64 (sum, sumsq) pair per column and
+        // M-tile goes to bn_part[mtile][channel][2] -- scouter_bn_fwd_f32 then skips its own read of the tensor.
+#pragma unroll
+        for (int o = QPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], o, 64); cq[e] += __shfl_xor(cq[e], o, 64); }
+        __syncthreads();                                      // every wave is done reading its staged tile
+        double* Ps = (double*)lds;                            // [4 waves][WN][2], re-uses the staging area
+        if (qrow == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { Ps[(wave * WN + qcol + e) * 2] = cs[e]; Ps[(wave * WN + qcol + e) * 2 + 1] = cq[e]; }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int wnn = tid / WN, c = tid % WN;
+            double a0 = 0, a1 = 0;
+#pragma unroll
+            for (int w = 0; w < BM / WM; ++w) {
+                const int wv = w * WAVES_N + wnn;
+                a0 += Ps[(wv * WN + c) * 2];
+                a1 += Ps[(wv * WN + c) * 2 + 1];
+            }
+            double* o = bn_part + ((long)mt_id * g.N + grp * g.Ng + n0 + tid) * 2;
+            o[0] = a0;
+            o[1] = a1;
+        }
+    }
+}

@@ -67,6 +67,9 @@ def conv_out(n, k, s, p):
 # ---------------------------------------------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------------------------------------------
+# "fp32" (exact fp32 MFMA, the parity path) or "bf16" (matrix inputs rounded to bf16, fp32 accumulation; tensors stay
+# fp32 in memory) -- set by SlotModel from args.precision; BASELINE configs[4] names bf16
+PRECISION = "fp32"
 AUTOTUNE = os.environ.get("SCOUTER_AUTOTUNE", "1") != "0"
 _tile_cache = {}
 
@@ -114,14 +117,26 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     L = _native.lib()
     st = _stream()
 
+    bf16 = PRECISION == "bf16"
+    wt = None
+    if bf16:                      # W^T as bf16 [taps][Cout][Cin/groups], rebuilt per call (weights change every step)
+        wt = torch.empty((kh * kw, Cout, cg), dtype=torch.bfloat16, device=x.device)
+        _native.check(L.scouter_conv2d_weight_bf16t(_p(w_hwio), _p(wt), kh, kw, Cin, Cout, groups, st), "weight_bf16t")
+
     def launch(tile, dry=False, part=None):
         if dry:
             return _tile_legal(Cout // groups, tile)
-        _native.check(L.scouter_conv2d_fwd_f32(_p(x), _p(w_hwio), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
-                                               Cout, kh, kw, stride, pad, groups, int(relu), tile, st), "conv2d_fwd")
+        if bf16:
+            _native.check(L.scouter_conv2d_fwd_bf16(_p(x), _p(wt), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
+                                                    Cout, kh, kw, stride, pad, groups, int(relu), tile, st),
+                          "conv2d_fwd_bf16")
+        else:
+            _native.check(L.scouter_conv2d_fwd_f32(_p(x), _p(w_hwio), _p(bias), _p(addend), _p(y), _p(part), B, H, W,
+                                                   Cin, Cout, kh, kw, stride, pad, groups, int(relu), tile, st),
+                          "conv2d_fwd")
         return True
 
-    tile = _pick_tile(("fwd", B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch)
+    tile = _pick_tile(("fwd", PRECISION, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch)
     part, rows = None, 0
     if bn_stats:
         rows = L.scouter_conv2d_fwd_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
@@ -138,14 +153,17 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1):
     L = _native.lib()
     st = _stream()
 
+    bf16 = PRECISION == "bf16" and stride == 1          # strided input gradients (resnet18) stay on the fp32 kernel
+
     def launch(tile, dry=False):
         if dry:
             return _tile_legal(Cin // groups, tile)
-        _native.check(L.scouter_conv2d_dgrad_f32(_p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw,
-                                                 stride, pad, groups, tile, st), "conv2d_dgrad")
+        fn = L.scouter_conv2d_dgrad_bf16 if bf16 else L.scouter_conv2d_dgrad_f32
+        _native.check(fn(_p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile,
+                         st), "conv2d_dgrad")
         return True
 
-    launch(_pick_tile(("dgrad", B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch))
+    launch(_pick_tile(("dgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch))
     return dx
 
 

@@ -288,3 +288,41 @@ def test_conv_fused_bn_statistics(case):
         outs.append((o, saved, rm, rv))
     for a, b in zip(outs[0], outs[1]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
+def _bf16_round(t):
+    return t.float().to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout, k, stride, pad, groups
+    (2, 14, 14, 64, 128, 3, 1, 1, 2), (3, 9, 7, 128, 64, 1, 1, 0, 1), (2, 12, 12, 32, 32, 3, 1, 1, 1),
+    (1, 8, 8, 256, 256, 3, 1, 1, 2), (2, 10, 10, 64, 64, 3, 2, 1, 1), (5, 7, 7, 192, 96, 1, 1, 0, 1)])
+def test_conv_bf16_inputs_fp32_accumulate(cfg):
+    """bf16 mode: the kernels must equal an exact convolution of the bf16-ROUNDED operands (fp32 accumulation error
+    only), for the forward (+ fused BN statistics) and the stride-1 input gradient."""
+    B, H, W, Cin, Cout, k, stride, pad, groups = cfg
+    rng = np.random.default_rng(sum(cfg))
+    x = torch.from_numpy(rng.standard_normal((B, Cin, H, W)))
+    w = torch.from_numpy(rng.standard_normal((Cout, Cin // groups, k, k)) * 0.1)
+    kk = K()
+    old = kk.PRECISION
+    kk.PRECISION = "bf16"
+    try:
+        y_ref = F.conv2d(_bf16_round(x), _bf16_round(w), None, stride, pad, 1, groups)
+        xd, wd = nhwc(x), w.float().permute(2, 3, 1, 0).contiguous().cuda()
+        y, (part, rows) = kk.conv2d_fwd(xd, wd, None, None, stride, pad, groups, False, bn_stats=True)
+        sc = float(y_ref.abs().max())
+        np.testing.assert_allclose(from_nhwc(y).numpy(), y_ref.numpy(), atol=2e-5 * sc, rtol=1e-5)
+        st = part.sum(0).cpu().numpy()                      # fused statistics of what was written
+        yf = y.double().reshape(-1, Cout).cpu().numpy()
+        np.testing.assert_allclose(st[:, 0], yf.sum(0), rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(st[:, 1], (yf * yf).sum(0), rtol=1e-9, atol=1e-6)
+        if stride == 1:
+            dy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
+            xr = _bf16_round(x).requires_grad_(True)        # only its shape matters for the input gradient
+            dx_ref = torch.autograd.grad(F.conv2d(xr, _bf16_round(w), None, stride, pad, 1, groups), xr, _bf16_round(dy))[0]
+            dx = kk.conv2d_dgrad(nhwc(dy), wd, tuple(xd.shape), None, stride, pad, groups)
+            np.testing.assert_allclose(from_nhwc(dx).numpy(), dx_ref.numpy(), atol=2e-5 * float(dx_ref.abs().max()), rtol=1e-5)
+    finally:
+        kk.PRECISION = old

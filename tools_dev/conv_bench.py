@@ -7,6 +7,8 @@ from scouter_amd.timm import create_model
 from scouter_amd.nn_hip import Conv2d, StemConv2d
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 70
+if len(sys.argv) > 2:
+    K.PRECISION = sys.argv[2]          # "bf16": matrix inputs rounded to bf16
 m = create_model('resnest26d', num_classes=10)
 shapes = collections.OrderedDict()
 # walk the net with shape tracking: replicate spatial sizes
