@@ -68,13 +68,18 @@ int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* adden
  * same semantics and fused epilogues as the fp32 entry points; operands are rounded to bf16 (RNE) on their way into
  * LDS and multiplied on v_mfma_f32_32x32x16_bf16.  The forward takes the weights pre-transposed to bf16
  * [kh*kw][Cout][Cin/groups] (scouter_conv2d_weight_bf16t, 2*kh*kw*Cin/groups*Cout bytes); dgrad reads the fp32 HWIO
- * weights directly (stride 1 only: strided input gradients stay on the fp32 kernel). */
+ * weights directly (stride 1 only: strided input gradients stay on the fp32 kernel).  wgrad_bf16 covers same-size
+ * stride-1 convolutions with per-group channels that are multiples of 64 and returns SC_ERR_UNSUPPORTED otherwise
+ * (callers then use scouter_conv2d_wgrad_f32); it shares that function's workspace. */
 int scouter_conv2d_weight_bf16t(const float* w, void* wt, int kh, int kw, int Cin, int Cout, int groups, void* stream);
 int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, const float* bias, const float* addend, float* y,
                             double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
                             int pad, int groups, int relu, int tile_hint, void* stream);
 int scouter_conv2d_dgrad_bf16(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
                               int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
+                              void* stream);
+int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
+                              int kw, int stride, int pad, int groups, int plan_hint, void* ws, size_t ws_bytes,
                               void* stream);
 /* plan_hint: -1 = built-in plan; otherwise bits 0-1 = block budget {512,1024,2048,4096} (sets the split-K count),
  * bit 4 / bit 5 = halve the ci / co tile edge.  Every plan is deterministic; different plans sum the pixels in a

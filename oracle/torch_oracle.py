@@ -167,6 +167,62 @@ def head_forward(P, feat, target, cfg, aux=None):
 # --------------------------------------------------------------------------------------------------------------
 # backbones
 # --------------------------------------------------------------------------------------------------------------
+# ---- mixed-precision emulation (BASELINE configs[4] "bf16"; the reference itself has no AMP).
+# CONV_INPUT_ROUNDING = "bf16" makes every BACKBONE convolution round its matrix operands to bfloat16 (round-to-nearest-
+# even) before an exact product -- what the build's precision="bf16" mode computes (fp32 accumulation, fp32 storage):
+#   forward : conv(rb(x), rb(w))                       when the layer has >= BF16_MIN_PIXELS output pixels
+#   dgrad   : conv_transpose(rb(dy), rb(w))            stride-1 layers with >= BF16_MIN_PIXELS input pixels
+#   wgrad   : wgrad(rb(x), rb(dy))                     same-size stride-1 layers, per-group channels multiples of 64
+# everything else (tiny attention FCs on the pooled vector, strided gradients, the 32-channel stem's weight gradient,
+# the xSlot head) stays exact.
+CONV_INPUT_ROUNDING = None
+BF16_MIN_PIXELS = 1024
+
+
+def _rb(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundedConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, groups):
+        B, _, H, W = x.shape
+        y = F.conv2d(_rb(x), _rb(w), None, stride, pad, 1, groups)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, groups)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, groups = ctx.cfg
+        B, Cin, H, W = x.shape
+        Cout, cg, kh, kw = w.shape
+        dgrad_bf16 = stride == 1 and B * H * W >= BF16_MIN_PIXELS
+        same = stride == 1 and dy.shape[2] == H and dy.shape[3] == W
+        wgrad_bf16 = (same and cg % 64 == 0 and (Cout // groups) % 64 == 0 and B * H * W >= BF16_MIN_PIXELS and
+                      ((kh == 1 and kw == 1 and pad == 0) or 64 // W + 1 < H))
+        dx = torch.nn.grad.conv2d_input(x.shape, _rb(w) if dgrad_bf16 else w, _rb(dy) if dgrad_bf16 else dy, stride, pad,
+                                        1, groups)
+        dw = torch.nn.grad.conv2d_weight(_rb(x) if wgrad_bf16 else x, w.shape, _rb(dy) if wgrad_bf16 else dy, stride, pad,
+                                         1, groups)
+        return dx, dw, None, None, None
+
+
+def _conv(x, w, bias=None, stride=1, pad=0, dilation=1, groups=1):
+    """Backbone convolution: F.conv2d, or its bf16-operand emulation (see CONV_INPUT_ROUNDING)."""
+    if CONV_INPUT_ROUNDING is None:
+        return F.conv2d(x, w, bias, stride, pad, dilation, groups)
+    assert CONV_INPUT_ROUNDING == "bf16" and dilation == 1
+    Ho = (x.shape[2] + 2 * pad - w.shape[2]) // stride + 1
+    Wo = (x.shape[3] + 2 * pad - w.shape[3]) // stride + 1
+    if x.shape[0] * Ho * Wo < BF16_MIN_PIXELS:
+        return F.conv2d(x, w, bias, stride, pad, dilation, groups)
+    y = _RoundedConv.apply(x, w, stride, pad, groups)
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
+
+
+
 def _bn(P, name, x, training):
     """nn.BatchNorm2d defaults: eps 1e-5, momentum 0.1, batch statistics in training (resnet.py:383)."""
     y = F.batch_norm(x, P[name + ".running_mean"], P[name + ".running_var"], P[name + ".weight"],
@@ -178,14 +234,14 @@ def _bn(P, name, x, training):
 
 def _split_attn(P, name, x, training):
     """SplitAttnConv2d.forward, radix 2, cardinality 1 (split_attn.py:54-80, RadixSoftmax :20-28)."""
-    x = F.conv2d(x, P[name + ".conv.weight"], None, 1, 1, 1, 2)
+    x = _conv(x, P[name + ".conv.weight"], None, 1, 1, 1, 2)
     x = torch.relu(_bn(P, name + ".bn0", x, training))
     B, RC, H, W = x.shape
     x5 = x.reshape(B, 2, RC // 2, H, W)
     gap = x5.sum(dim=1).mean(dim=(2, 3), keepdim=True)
-    g = F.conv2d(gap, P[name + ".fc1.weight"], P[name + ".fc1.bias"])
+    g = _conv(gap, P[name + ".fc1.weight"], P[name + ".fc1.bias"])
     g = torch.relu(_bn(P, name + ".bn1", g, training))
-    a = F.conv2d(g, P[name + ".fc2.weight"], P[name + ".fc2.bias"])
+    a = _conv(g, P[name + ".fc2.weight"], P[name + ".fc2.bias"])
     a = a.view(B, 1, 2, -1).transpose(1, 2)
     a = F.softmax(a, dim=1).reshape(B, 2, RC // 2, 1, 1)
     return (x5 * a).sum(dim=1)
@@ -194,27 +250,27 @@ def _split_attn(P, name, x, training):
 def _resnest_block(P, name, x, stride, training):
     """ResNestBottleneck.forward with avd=True, avd_first=False (resnest.py:111-143); `is_first` is never set
     by ResNet._make_layer so avd pooling exists only when stride > 1 (:76-80)."""
-    out = torch.relu(_bn(P, name + ".bn1", F.conv2d(x, P[name + ".conv1.weight"]), training))
+    out = torch.relu(_bn(P, name + ".bn1", _conv(x, P[name + ".conv1.weight"]), training))
     out = _split_attn(P, name + ".conv2", out, training)
     if stride > 1:
         out = F.avg_pool2d(out, 3, stride, padding=1)
-    out = _bn(P, name + ".bn3", F.conv2d(out, P[name + ".conv3.weight"]), training)
+    out = _bn(P, name + ".bn3", _conv(out, P[name + ".conv3.weight"]), training)
     residual = x
     if (name + ".downsample.1.weight") in P:          # downsample_avg (resnet.py:292-306)
         if stride > 1:
             residual = F.avg_pool2d(residual, 2, stride, ceil_mode=True, count_include_pad=False)
-        residual = _bn(P, name + ".downsample.2", F.conv2d(residual, P[name + ".downsample.1.weight"]), training)
+        residual = _bn(P, name + ".downsample.2", _conv(residual, P[name + ".downsample.1.weight"]), training)
     return torch.relu(out + residual)
 
 
 def _basic_block(P, name, x, stride, training):
     """BasicBlock.forward (resnet.py:172-199) with downsample_conv (resnet.py:273-289)."""
-    out = torch.relu(_bn(P, name + ".bn1", F.conv2d(x, P[name + ".conv1.weight"], None, stride, 1), training))
-    out = _bn(P, name + ".bn2", F.conv2d(out, P[name + ".conv2.weight"], None, 1, 1), training)
+    out = torch.relu(_bn(P, name + ".bn1", _conv(x, P[name + ".conv1.weight"], None, stride, 1), training))
+    out = _bn(P, name + ".bn2", _conv(out, P[name + ".conv2.weight"], None, 1, 1), training)
     residual = x
     if (name + ".downsample.0.weight") in P:
         residual = _bn(P, name + ".downsample.1",
-                       F.conv2d(x, P[name + ".downsample.0.weight"], None, stride, 0), training)
+                       _conv(x, P[name + ".downsample.0.weight"], None, stride, 0), training)
     return torch.relu(out + residual)
 
 
@@ -222,14 +278,14 @@ def backbone_features(P, x, arch, training, prefix="backbone."):
     """ResNet.forward_features (resnet.py:491-501) -> [B, Cin, h, w]."""
     cfg = ARCHS[arch]
     if cfg["kind"] == "resnest":   # deep stem 32-32-64 (resnet.py:389-400)
-        x = F.conv2d(x, P[prefix + "conv1.0.weight"], None, 2, 1)
+        x = _conv(x, P[prefix + "conv1.0.weight"], None, 2, 1)
         x = torch.relu(_bn(P, prefix + "conv1.1", x, training))
-        x = F.conv2d(x, P[prefix + "conv1.3.weight"], None, 1, 1)
+        x = _conv(x, P[prefix + "conv1.3.weight"], None, 1, 1)
         x = torch.relu(_bn(P, prefix + "conv1.4", x, training))
-        x = F.conv2d(x, P[prefix + "conv1.6.weight"], None, 1, 1)
+        x = _conv(x, P[prefix + "conv1.6.weight"], None, 1, 1)
     else:                          # 7x7/2 stem, or the MNIST 3x3/2 1-channel stem (slot_model.py:23-24)
         w = P[prefix + "conv1.weight"]
-        x = F.conv2d(x, w, None, 2, w.shape[-1] // 2)
+        x = _conv(x, w, None, 2, w.shape[-1] // 2)
     x = torch.relu(_bn(P, prefix + "bn1", x, training))
     x = F.max_pool2d(x, 3, 2, 1)
     block = _resnest_block if cfg["kind"] == "resnest" else _basic_block

@@ -11,6 +11,7 @@
 // fp32 MFMA issues once per 64 cycles per SIMD, so the loop is matrix-pipe bound as long as the (cheap) LDS
 // reads and the global prefetch of the next K-tile hide under it -- no reshaping tricks, exact fp32 (fmaf chain).
 #include "conv_common.h"
+#include "conv_wgrad_bf16.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -669,7 +670,7 @@ struct WgradPlan { int bm, bn, ci_tiles, co_tiles, splits; long pix_per_split, t
 // plan_hint < 0: the static plan below.  Otherwise (autotuned by the caller, include/scouter_hip.h) bits 0-1 select the
 // block budget {512, 1024, 2048, 4096} that sets the split count and bits 4-5 halve the ci / co tile edge -- smaller
 // output tiles give more parallelism without split-K slabs, which pays for the short-K (7x7, 14x14) layers.
-static WgradPlan wgrad_plan(const ConvGeom& g, int plan_hint) {
+static WgradPlan wgrad_plan(const ConvGeom& g, int plan_hint, bool chunk64 = false) {
     WgradPlan p;
     p.bm = (g.Cg % 128 == 0) ? 128 : (g.Cg % 64 == 0 ? 64 : 32);
     p.bn = (g.Ng % 128 == 0) ? 128 : (g.Ng % 64 == 0 ? 64 : 32);
@@ -689,6 +690,7 @@ static WgradPlan wgrad_plan(const ConvGeom& g, int plan_hint) {
     long chunks = (g.M + BK - 1) / BK;
     long cps = (chunks + want - 1) / want;               // K-chunks (of 32 pixels) per split
     if (cps < 8) cps = 8;                                 // at least 256 pixels per block
+    if (chunk64 && (cps & 1)) ++cps;                      // bf16 kernel: whole 64-pixel chunks
     p.pix_per_split = cps * BK;
     p.splits = (int)((g.M + p.pix_per_split - 1) / p.pix_per_split);
     return p;
@@ -775,6 +777,64 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(n / 4, 8)), dim3(256), 0, st, (const float*)ws, dw, n,
                            p.splits, slab);
         rc = sc_check_launch("conv2d_wgrad_reduce");
+    }
+    return rc;
+}
+
+// bf16 matrix inputs (conv_wgrad_bf16.h).  Supported: "same" stride-1 convolutions whose per-group channel counts are
+// multiples of 64 (everything in ResNeSt except the 32-channel stem / first grouped layer); SC_ERR_UNSUPPORTED tells the
+// caller to use the fp32 kernel for that layer.  Same workspace as scouter_conv2d_wgrad_f32.
+extern "C" int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin,
+                                         int Cout, int kh, int kw, int stride, int pad, int groups, int plan_hint,
+                                         void* ws, size_t ws_bytes, void* stream) {
+    SC_REQUIRE(x && dy && dw && B > 0, "conv2d_wgrad_bf16: null pointer or empty shape");
+    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_wgrad_bf16: channels not divisible by groups");
+    ConvGeom g = wgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
+    const bool same = stride == 1 && g.Ho == H && g.Wo == W;
+    const int mode = !same ? 0 : (kh == 1 && kw == 1 && pad == 0) ? 2 : (64 / g.Wo + 1 < g.Ho ? 1 : 0);
+    SC_UNSUPPORTED(mode != 0 && g.Cg % 64 == 0 && g.Ng % 64 == 0 && g.M < (1L << 31),
+                   "conv2d_wgrad_bf16: shape not covered by the bf16 kernel");
+    WgradPlan p = wgrad_plan(g, plan_hint, true);
+    const long slab = (long)kh * kw * g.Cg * Cout;
+    const size_t need = p.splits > 1 ? (size_t)p.splits * slab * sizeof(float) : 0;
+    if (need > ws_bytes || (need && !ws)) {
+        sc_set_error("conv2d_wgrad_bf16: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+        return SC_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* out = p.splits > 1 ? (float*)ws : dw;
+    dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
+    int rc;
+    {
+    ScProfScope prof("wgrad_bf16", st, 2.0 * g.M * Cout * g.Cg * kh * kw, 4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
+#define WGH(BM_, BN_, WM_, WN_)                                                                                     \
+    do {                                                                                                            \
+        const size_t lds = (size_t)2 * (BM_ + BN_) * 72 * 2;                                                        \
+        if (mode == 2) {                                                                                            \
+            auto kern = wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 2>;                                                   \
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, dy, out, g, p.ci_tiles, p.co_tiles,              \
+                               p.pix_per_split, slab);                                                             \
+        } else {                                                                                                    \
+            auto kern = wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 1>;                                                   \
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, dy, out, g, p.ci_tiles, p.co_tiles,              \
+                               p.pix_per_split, slab);                                                             \
+        }                                                                                                           \
+    } while (0)
+    if (p.bm == 128 && p.bn == 128) WGH(128, 128, 64, 64);
+    else if (p.bm == 128 && p.bn == 64) WGH(128, 64, 64, 32);
+    else if (p.bm == 64 && p.bn == 128) WGH(64, 128, 32, 64);
+    else WGH(64, 64, 32, 32);
+#undef WGH
+    }
+    rc = sc_check_launch("conv2d_wgrad_bf16");
+    if (rc) return rc;
+    if (p.splits > 1) {
+        ScProfScope prof2("slab_reduce", st, 0, 4.0 * (double)slab * (p.splits + 1));
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(slab / 4, 8)), dim3(256), 0, st, (const float*)ws, dw, slab,
+                           p.splits, slab);
+        rc = sc_check_launch("conv2d_wgrad_bf16_reduce");
     }
     return rc;
 }

@@ -70,6 +70,7 @@ def conv_out(n, k, s, p):
 # "fp32" (exact fp32 MFMA, the parity path) or "bf16" (matrix inputs rounded to bf16, fp32 accumulation; tensors stay
 # fp32 in memory) -- set by SlotModel from args.precision; BASELINE configs[4] names bf16
 PRECISION = "fp32"
+BF16_MIN_PIXELS = 1024      # layers with fewer GEMM rows (the split-attention FCs on the pooled vector) stay in fp32
 AUTOTUNE = os.environ.get("SCOUTER_AUTOTUNE", "1") != "0"
 _tile_cache = {}
 
@@ -117,7 +118,7 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     L = _native.lib()
     st = _stream()
 
-    bf16 = PRECISION == "bf16"
+    bf16 = PRECISION == "bf16" and y.numel() // Cout >= BF16_MIN_PIXELS
     wt = None
     if bf16:                      # W^T as bf16 [taps][Cout][Cin/groups], rebuilt per call (weights change every step)
         wt = torch.empty((kh * kw, Cout, cg), dtype=torch.bfloat16, device=x.device)
@@ -136,7 +137,7 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
                           "conv2d_fwd")
         return True
 
-    tile = _pick_tile(("fwd", PRECISION, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch)
+    tile = _pick_tile(("fwd", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch)
     part, rows = None, 0
     if bn_stats:
         rows = L.scouter_conv2d_fwd_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
@@ -153,7 +154,8 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1):
     L = _native.lib()
     st = _stream()
 
-    bf16 = PRECISION == "bf16" and stride == 1          # strided input gradients (resnet18) stay on the fp32 kernel
+    # strided input gradients (resnet18) and tiny layers stay on the fp32 kernel
+    bf16 = PRECISION == "bf16" and stride == 1 and B * H * W >= BF16_MIN_PIXELS
 
     def launch(tile, dry=False):
         if dry:
@@ -223,16 +225,23 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1):
     L = _native.lib()
     st = _stream()
 
+    # bf16 matrix inputs where the bf16 kernel applies (same-size stride-1 convolutions, 64-multiples of channels per
+    # group); the remaining layers (32-channel stem, strided convolutions) keep the fp32 kernel
+    same = stride == 1 and dy.shape[1] == H and dy.shape[2] == W
+    bf16 = (PRECISION == "bf16" and same and cg % 64 == 0 and (Cout // groups) % 64 == 0 and
+            B * H * W >= BF16_MIN_PIXELS and ((kh == 1 and kw == 1 and pad == 0) or 64 // W + 1 < H))
+    fn = L.scouter_conv2d_wgrad_bf16 if bf16 else L.scouter_conv2d_wgrad_f32
+
     def launch(plan, dry=False):
         if dry:
             return True
         need = L.scouter_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, plan)
         ws = workspace(need, x.device)
-        _native.check(L.scouter_conv2d_wgrad_f32(_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, stride, pad,
-                                                 groups, plan, _p(ws), ws.numel(), st), "conv2d_wgrad")
+        _native.check(fn(_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, plan, _p(ws),
+                         ws.numel(), st), "conv2d_wgrad")
         return True
 
-    launch(_pick_tile(("wgrad", B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, _WGRAD_PLANS))
+    launch(_pick_tile(("wgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, _WGRAD_PLANS))
     return dw_hwio
 
 

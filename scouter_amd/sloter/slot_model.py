@@ -67,6 +67,10 @@ class SlotModel(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.use_slot = args.use_slot
+        # "fp32" (parity path) or "bf16": convolution matrix inputs rounded to bf16, fp32 accumulation and storage
+        self.precision = str(getattr(args, "precision", "fp32"))
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be fp32 or bf16, got %r" % self.precision)
         self.backbone = load_backbone(args)
         self._arena = None
         self._anchor = None
@@ -162,7 +166,11 @@ class SlotModel(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         tracked = []
-        feat, bctx = self.backbone.features_fwd(x, save, tracked)             # NHWC [B, h, w, channel]
+        K.PRECISION = self.precision              # backbone convolutions; the xSlot head always runs in fp32
+        try:
+            feat, bctx = self.backbone.features_fwd(x, save, tracked)         # NHWC [B, h, w, channel]
+        finally:
+            K.PRECISION = "fp32"
         logp, stats, hstate = self._head_forward(feat, target, save)
         if tracked:
             torch._foreach_add_(tracked, 1)                                   # BatchNorm num_batches_tracked
@@ -184,7 +192,11 @@ class SlotModel(nn.Module):
                     hook(arena, lo, done_hi[0])
                 done_hi[0] = lo
         if need:
-            self.backbone.features_bwd(dfeat, bctx, stage_done if self._grad_ready_hooks else None)
+            K.PRECISION = self.precision
+            try:
+                self.backbone.features_bwd(dfeat, bctx, stage_done if self._grad_ready_hooks else None)
+            finally:
+                K.PRECISION = "fp32"
         K.join_side_stream(arena.flat.device)               # all weight gradients are in the arena from here on
         if self._grad_ready_hooks and done_hi[0] > 0:
             for hook in self._grad_ready_hooks:

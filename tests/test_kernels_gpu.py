@@ -297,7 +297,9 @@ def _bf16_round(t):
 @pytest.mark.parametrize("cfg", [
     # B, H, W, Cin, Cout, k, stride, pad, groups
     (2, 14, 14, 64, 128, 3, 1, 1, 2), (3, 9, 7, 128, 64, 1, 1, 0, 1), (2, 12, 12, 32, 32, 3, 1, 1, 1),
-    (1, 8, 8, 256, 256, 3, 1, 1, 2), (2, 10, 10, 64, 64, 3, 2, 1, 1), (5, 7, 7, 192, 96, 1, 1, 0, 1)])
+    (1, 8, 8, 256, 256, 3, 1, 1, 2), (2, 10, 10, 64, 64, 3, 2, 1, 1), (5, 7, 7, 192, 96, 1, 1, 0, 1),
+    (3, 14, 14, 128, 128, 3, 1, 1, 1), (2, 28, 28, 64, 128, 3, 1, 1, 1), (7, 7, 7, 128, 256, 1, 1, 0, 1),
+    (2, 70, 70, 64, 64, 3, 1, 1, 1)])
 def test_conv_bf16_inputs_fp32_accumulate(cfg):
     """bf16 mode: the kernels must equal an exact convolution of the bf16-ROUNDED operands (fp32 accumulation error
     only), for the forward (+ fused BN statistics) and the stride-1 input gradient."""
@@ -306,8 +308,8 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
     x = torch.from_numpy(rng.standard_normal((B, Cin, H, W)))
     w = torch.from_numpy(rng.standard_normal((Cout, Cin // groups, k, k)) * 0.1)
     kk = K()
-    old = kk.PRECISION
-    kk.PRECISION = "bf16"
+    old, old_min = kk.PRECISION, kk.BF16_MIN_PIXELS
+    kk.PRECISION, kk.BF16_MIN_PIXELS = "bf16", 1          # (the model keeps layers under 1024 pixels in fp32)
     try:
         y_ref = F.conv2d(_bf16_round(x), _bf16_round(w), None, stride, pad, 1, groups)
         xd, wd = nhwc(x), w.float().permute(2, 3, 1, 0).contiguous().cuda()
@@ -324,5 +326,15 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
             dx_ref = torch.autograd.grad(F.conv2d(xr, _bf16_round(w), None, stride, pad, 1, groups), xr, _bf16_round(dy))[0]
             dx = kk.conv2d_dgrad(nhwc(dy), wd, tuple(xd.shape), None, stride, pad, groups)
             np.testing.assert_allclose(from_nhwc(dx).numpy(), dx_ref.numpy(), atol=2e-5 * float(dx_ref.abs().max()), rtol=1e-5)
+        # weight gradient: bf16 kernel where it applies (same-size, 64-multiples), fp32 kernel elsewhere
+        dy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
+        uses_bf16 = stride == 1 and (Cin // groups) % 64 == 0 and (Cout // groups) % 64 == 0 and (k == 1 or 64 // W + 1 < H)
+        xs, dys = (_bf16_round(x), _bf16_round(dy)) if uses_bf16 else (x, dy)
+        wr = w.clone().requires_grad_(True)
+        dw_ref = torch.autograd.grad(F.conv2d(xs, wr, None, stride, pad, 1, groups), wr, dys)[0]
+        dw = torch.zeros_like(wd)
+        kk.conv2d_wgrad(xd, nhwc(dy), dw, stride, pad, groups)
+        np.testing.assert_allclose(dw.permute(3, 2, 0, 1).cpu().numpy(), dw_ref.numpy(),
+                                   atol=3e-5 * float(dw_ref.abs().max()), rtol=1e-5)
     finally:
-        kk.PRECISION = old
+        kk.PRECISION, kk.BF16_MIN_PIXELS = old, old_min
