@@ -109,6 +109,28 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
             "measured": "hipEvents around each launch, median of 8 batches x 20 launches after 60 warm-up launches"}
 
 
+def pmc_traffic(kernel_class):
+    """HBM-side bytes per launch of a kernel class (e.g. 'igemm_dgrad<64x64>') from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_hbm_traffic.json, made by tools_dev/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+    correction of MI355X_MICROARCH.md) -- PMC counters cannot be collected from inside the timed process.  None if the
+    file or the kernel is missing."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+    m = __import__("re").match(r"(igemm_fwd|igemm_dgrad|wgrad)<(\d+)x(\d+)>", kernel_class)
+    if not os.path.exists(path) or not m:
+        return None, None
+    kind, bm, bn = m.group(1), int(m.group(2)), int(m.group(3))
+    want = ("wgrad_kernel<%d, %d," % (bm, bn)) if kind == "wgrad" else "igemm_kernel<%d, %d," % (bm, bn)
+    flag = None if kind == "wgrad" else (", true, false>" if kind == "igemm_dgrad" else ", false, false>")
+    tot = n = 0.0
+    for name, rec in json.load(open(path)).items():
+        if want in name and (flag is None or name.endswith(flag)):
+            tot += (rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]) * rec["launches"]
+            n += rec["launches"]
+    if not n:
+        return None, None
+    return round(tot / n), "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,6 +250,8 @@ def main():
                         "all_conv_kernels_frac": round(tot_fl / tot_ms / PEAK_FP32_MFMA_TFLOPS, 4),
                         "whole_step_frac": round(value * 3 * FWD_GFLOP_PER_IMG * 1e9 / world
                                                  / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
+        if roofline is not None:
+            roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom)
         line = {"metric": "images/sec training step (resnest26d+xSlot, 224^2, bs70)", "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
