@@ -22,6 +22,23 @@ struct ConvGeom {
 __device__ __forceinline__ int fast_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
 
 
+// Split-K weight-gradient grids are (tiles = taps x ci-tiles x co-tiles x groups, splits = pixel ranges).  All tiles of
+// one pixel range read the same activation / gradient rows; workgroups are handed to the 8 XCDs round-robin in linear
+// order, so the natural order scatters them over all eight L2s and the rows come from HBM once per tap (PMC: 1.9 GB
+// fetched per launch for the 32-channel stem, 8x its algorithmic bytes).  This bijection keeps every pixel range on ONE
+// XCD, its tiles back to back: the re-reads hit that XCD's L2.
+__device__ __forceinline__ void wgrad_block_coords(int& tile, int& split) {
+    const int T = gridDim.x, S = gridDim.y, S8 = S & ~7;
+    const int L = blockIdx.x + T * blockIdx.y;
+    tile = blockIdx.x;
+    split = blockIdx.y;
+    if (L < T * S8) {
+        const int xcd = L & 7, idx = L >> 3;
+        split = xcd + 8 * (idx / T);
+        tile = idx % T;
+    }
+}
+
 // Block epilogue.  acc: this wave's (WM x WN) accumulator tiles in MFMA layout; lds: the block's K-loop LDS (free now,
 // at least 4*WM*(WN+4) floats); rows m0.., columns grp*Ng + n0.. of the [M][N] output.
 template <int BM, int BN, int WM, int WN>

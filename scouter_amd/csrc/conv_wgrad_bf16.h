@@ -23,14 +23,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) __bf16 ldsw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    int bid = blockIdx.x;
+    int bid, split_id;
+    wgrad_block_coords(bid, split_id);
     const int co_t = bid % co_tiles; bid /= co_tiles;
     const int ci_t = bid % ci_tiles; bid /= ci_tiles;
     const int grp = bid % g.groups;
     const int tap = bid / g.groups;
     const int r = tap / g.S, q = tap - r * g.S;
     const int ci0 = ci_t * BM, co0 = co_t * BN;
-    const long mbeg = (long)blockIdx.y * pix_per_split;
+    const long mbeg = (long)split_id * pix_per_split;
     long mend = mbeg + pix_per_split;
     if (mend > g.M) mend = g.M;
     const int KT = (int)((mend - mbeg + KP - 1) / KP);
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
         chunk(kt, P0{});
         if (kt + 1 < KT) chunk(kt + 1, P1{});
     }
-    float* o = out + (long)blockIdx.y * slab + (long)tap * g.Cg * g.N;
+    float* o = out + (long)split_id * slab + (long)tap * g.Cg * g.N;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
