@@ -46,8 +46,16 @@ __device__ __forceinline__ void xs_load_tile(const float* base, int ld, f32x16 (
 // acc += sum_{r<16} Mt[row_base + kidx(0,r,hh)][col0 + l31] * b[r]     (one 32-deep k-tile, rows of Mt = k)
 __device__ __forceinline__ void xs_mm_tr_tile(const float* __restrict__ Mt, int row_base, int col0, const f32x16& b,
                                               f32x16& acc, int l31, int hh) {
+    const float* base = Mt + (long)row_base * XS_LD + col0 + l31;
+    float fr[5];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc = mfma32(Mt[(row_base + xs_kidx(0, r, hh)) * XS_LD + col0 + l31], b[r], acc);
+    for (int k = 0; k < 4; ++k) fr[k] = base[xs_kidx(0, k, hh) * XS_LD];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                       // operand reads four MFMAs ahead (see xs_mm_tr_open)
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 4 < 16) fr[(r + 4) % 5] = base[xs_kidx(0, r + 4, hh) * XS_LD];
+        acc = mfma32(fr[r % 5], b[r], acc);
+    }
     XS_REGION_END();
 }
 

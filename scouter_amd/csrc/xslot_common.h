@@ -37,14 +37,19 @@ __device__ __forceinline__ int xs_kidx(int t, int r, int hh) { return 32 * t + 8
 // MFMA shadow (xslot_fwd.hip); the plain ones close it.
 __device__ __forceinline__ void xs_mm_kc_open(const float* __restrict__ M, int row0, const f32x16 (&b)[2], f32x16& acc,
                                               int l31, int hh) {
+    // operand fragments are requested two ahead of use and the order is pinned: left to itself the compiler issues
+    // each ds_read_b128 right before its four MFMAs and the LDS latency is exposed once per fragment (~20 %)
+    const float* base = M + (row0 + l31) * XS_LD + 4 * hh;
+    f32x4 fr[3];
+    fr[0] = *(const f32x4*)(base);
+    fr[1] = *(const f32x4*)(base + 8);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int f = 0; f < 8; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (f + 2 < 8) fr[(f + 2) % 3] = *(const f32x4*)(base + 32 * ((f + 2) >> 2) + 8 * ((f + 2) & 3));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *(const f32x4*)(M + (row0 + l31) * XS_LD + 32 * t + 8 * q + 4 * hh);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], b[t][4 * q + e], acc);
-        }
+        for (int e = 0; e < 4; ++e) acc = mfma32(fr[f % 3][e], b[f >> 2][4 * (f & 3) + e], acc);
+    }
 }
 __device__ __forceinline__ void xs_mm_kc(const float* __restrict__ M, int row0, const f32x16 (&b)[2], f32x16& acc,
                                          int l31, int hh) {
@@ -55,10 +60,17 @@ __device__ __forceinline__ void xs_mm_kc(const float* __restrict__ M, int row0, 
 template <int NT>
 __device__ __forceinline__ void xs_mm_tr_open(const float* __restrict__ Mt, int col0, const f32x16 (&b)[NT],
                                               f32x16& acc, int l31, int hh) {
+    // one ds_read_b32 per MFMA, requested four MFMAs ahead
+    const float* base = Mt + col0 + l31;
+    float fr[5];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int k = 0; k < 4; ++k) fr[k] = base[xs_kidx(k >> 4, k & 15, hh) * XS_LD];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc = mfma32(Mt[xs_kidx(t, r, hh) * XS_LD + col0 + l31], b[t][r], acc);
+    for (int k = 0; k < 16 * NT; ++k) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 4 < 16 * NT) fr[(k + 4) % 5] = base[xs_kidx((k + 4) >> 4, (k + 4) & 15, hh) * XS_LD];
+        acc = mfma32(fr[k % 5], b[k >> 4][k & 15], acc);
+    }
 }
 template <int NT>
 __device__ __forceinline__ void xs_mm_tr(const float* __restrict__ Mt, int col0, const f32x16 (&b)[NT], f32x16& acc,
