@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             const double tr = xs_tilesum_f64(r64);
             if (lane == 0) red64[ti] = tr;
         }
-        __syncthreads();
+        xs_lds_barrier();        // LDS hand-off only: pending global stores keep flying
         double tau64 = 0.0;
         for (int k = 0; k < ntiles; ++k) tau64 += red64[k];
         const float tau = (float)tau64;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             const float tc = xs_tilesum(iok ? gsum / r : 0.f);
             if (lane == 0) red[16 + ti] = tc;
         }
-        __syncthreads();
+        xs_lds_barrier();        // LDS hand-off only: pending global stores keep flying
         float c0 = 0.f;
         for (int k = 0; k < ntiles; ++k) c0 += red[16 + k];
         // ================= phase B2: dD, ds_t
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             if (it > 0) xs_store_tile<2>(dsn + (long)ti * 32 * 64, 64, ds, l31, hh);
             else if (iok) xs_store_tile<2>(a.ds0 + ((long)b * S + ti * 32) * XS_D, XS_D, ds, l31, hh);
         }
-        __syncthreads();
+        xs_lds_barrier();        // LDS hand-off only: pending global stores keep flying
     }
 
     // ================= final phase: contractions over the slot index
