@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restr
         a_mask[i] = okm ? mask : 0u;
         const int rel = okm ? qy * g.H * g.W : 0;
         const int e = DGRAD ? (rel + ay * g.W + ax) * g.C : (rel + (ay + g.pad) * g.W + (ax + g.pad)) * g.C;
-        a_voff[i] = (unsigned)((e + grp * g.Cg + a_col) * 4);
+        a_voff[i] = (unsigned)(e + grp * g.Cg + a_col) * 4u;
         a_veff[i] = OOB;
     }
     const long img_elems = (long)g.H * g.W * g.C;
@@ -228,8 +228,8 @@ static void launch_bf16(const float* src, const void* w, const float* bias, cons
 template <bool DGRAD>
 static int dispatch_bf16(const float* src, const void* w, const float* bias, const float* addend, float* dst,
                          double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st) {
-    SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 27),
-                   "conv2d_bf16: more than 2^31 output pixels or an image above 2^27 elements is not supported");
+    SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 28),
+                   "conv2d_bf16: more than 2^31 output pixels or an image above 2^28 elements is not supported");
     switch (tile) {
         case 0: launch_bf16<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
         case 1: launch_bf16<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     for (int i = 0; i < AI; ++i) {
         const int e = DGRAD ? (a_rel[i] + a_y[i] * g.W + a_x[i]) * g.C
                             : (a_rel[i] + (a_y[i] + g.pad) * g.W + (a_x[i] + g.pad)) * g.C;
-        a_voff[i] = (unsigned)((e + grp * g.Cg + a_col) * 4);
+        a_voff[i] = (unsigned)(e + grp * g.Cg + a_col) * 4u;
         a_veff[i] = OOB;
     }
 
@@ -596,8 +596,8 @@ static int igemm_tile(const ConvGeom& g, int hint = -1) {     // 0: 128x128  1: 
 template <bool DGRAD>
 static int dispatch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
                           double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st) {
-    SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 27),
-                   "conv2d: more than 2^31 output pixels or an image above 2^27 elements is not supported");
+    SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 28),
+                   "conv2d: more than 2^31 output pixels or an image above 2^28 elements is not supported");
     switch (tile) {
         case 0: launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
         case 1: launch_igemm<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
