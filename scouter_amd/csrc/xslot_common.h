@@ -79,21 +79,6 @@ __device__ __forceinline__ void xs_mm_tr(const float* __restrict__ Mt, int col0,
     XS_REGION_END();
 }
 
-// Interleave recipe for one scheduling region holding an MFMA block and an independent VALU block: every MFMA is
-// followed by up to VALU_PER vector-ALU and TRANS_PER transcendental instructions (they execute in the 64-cycle
-// shadow of the MFMA), LDS operand reads are issued DS_LEAD MFMAs ahead of their use.
-template <int N_MFMA, int MFMA_PER_DS, int VALU_PER, int TRANS_PER, int DS_LEAD = 2>
-__device__ __forceinline__ void xs_interleave() {
-    __builtin_amdgcn_sched_group_barrier(0x100, DS_LEAD, 0);
-#pragma unroll
-    for (int m = 0; m < N_MFMA; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (VALU_PER > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);
-        if (TRANS_PER > 0) __builtin_amdgcn_sched_group_barrier(0x400, TRANS_PER, 0);
-        if (m % MFMA_PER_DS == MFMA_PER_DS - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-}
-
 __device__ __forceinline__ void xs_zero(f32x16& v) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = 0.f;

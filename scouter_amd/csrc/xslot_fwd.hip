@@ -28,9 +28,7 @@ struct XsFwdArgs {
 #define XS_STAMP() do { } while (0)
 #endif
 
-#ifndef XS_FWD_WAVES
-#define XS_FWD_WAVES 4
-#endif
+#define XS_FWD_WAVES 4          // one wave per SIMD: each may use the whole 512-entry register file
 
 // ---------------------------------------------------------------------------------------------------------------
 // Building blocks of one (slot tile, iteration).  "S" blocks are streams of MFMAs (+ their LDS operand reads), "V"
@@ -594,7 +592,7 @@ extern "C" int scouter_xslot_fwd_f32(const float* X, const float* PE, const floa
         else XS_LAUNCH(NJT_, 4);                       \
     } while (0)
 #ifdef XS_DEV_SINGLE_INST
-    XS_LAUNCH(2, XS_FWD_WAVES == 4 ? 3 : 2);      // dev builds (tools_dev/xs_phase_timing.hip): one instantiation compiles much faster
+    XS_LAUNCH(2, 3);      // dev builds (tools_dev/xs_phase_timing.hip): one instantiation compiles much faster
 #else
     if (NJT == 1) XS_TPW(1);
     else if (NJT == 2) XS_TPW(2);

@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
     hipMalloc(&a.stamps, (size_t)B * 64 * 8); hipMemset(a.stamps, 0, (size_t)B * 64 * 8);
     const int ntiles = (S + 31) / 32, NJT = (N + 31) / 32, TPW = (ntiles + XS_FWD_WAVES - 1) / XS_FWD_WAVES;
     const size_t lds = xs_fwd_lds_bytes(NJT);
-    constexpr int KTPW = XS_FWD_WAVES == 4 ? 3 : 2;
+    constexpr int KTPW = 3;
     if (NJT != 2 || TPW != KTPW) { printf("harness is specialised for NJT=2, TPW=%d\n", KTPW); return 1; }
     auto kern = xslot_fwd_kernel<2, KTPW>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
