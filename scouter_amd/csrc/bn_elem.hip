@@ -110,10 +110,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
-// Sums the per-block partials of FIN_CH channels per workgroup: 32 lanes split the nb partials (4 loads in flight
+// Sums the per-block partials of FIN_CH channels per workgroup: FIN_LANES lanes split the nb partials (4 loads in flight
 // each), fixed-order combine through LDS.
-#define FIN_CH 8
-#define FIN_LANES 32
+#define FIN_CH 4
+#define FIN_LANES 64
 __device__ __forceinline__ void partial_reduce(const double* __restrict__ part, int nb, int C, int c, int bl,
                                                double& s, double& t, double (*red)[FIN_CH][2]) {
     double s4[4] = {0, 0, 0, 0}, t4[4] = {0, 0, 0, 0};
@@ -136,9 +136,16 @@ __device__ __forceinline__ void partial_reduce(const double* __restrict__ part, 
     red[bl][threadIdx.x % FIN_CH][0] = s;
     red[bl][threadIdx.x % FIN_CH][1] = t;
     __syncthreads();
-    if (bl == 0) {
-        for (int k = 1; k < FIN_LANES; ++k) { s += red[k][threadIdx.x % FIN_CH][0]; t += red[k][threadIdx.x % FIN_CH][1]; }
+    // fixed-order tree over the lanes (these kernels are pure latency: a serial 128-term chain was most of their time)
+    for (int w = FIN_LANES / 2; w >= 1; w >>= 1) {
+        if (bl < w) {
+            red[bl][threadIdx.x % FIN_CH][0] += red[bl + w][threadIdx.x % FIN_CH][0];
+            red[bl][threadIdx.x % FIN_CH][1] += red[bl + w][threadIdx.x % FIN_CH][1];
+        }
+        __syncthreads();
     }
+    s = red[0][threadIdx.x % FIN_CH][0];
+    t = red[0][threadIdx.x % FIN_CH][1];
 }
 
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,

@@ -49,13 +49,14 @@ __global__ void sa_colsum_finalize_kernel(const double* __restrict__ part, float
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * Co) return;
     const int b = (int)(i / Co), c = (int)(i % Co);
-    double s = 0;
+    double acc[4] = {0, 0, 0, 0};                       // four chains: the loads of consecutive splits overlap
     for (int k = 0; k < nsplit; ++k) {
         const double* p = part + ((long)b * nsplit + k) * C2;
-        s += p[c];
-        if (fold_radix) for (int r = 1; r * Cp < C2; ++r) s += p[r * Cp + c];
+        double v = p[c];
+        if (fold_radix) for (int r = 1; r * Cp < C2; ++r) v += p[r * Cp + c];
+        acc[k & 3] += v;
     }
-    out[i] = (float)(s * alpha);
+    out[i] = (float)(((acc[0] + acc[1]) + (acc[2] + acc[3])) * alpha);
 }
 
 // radix-2 softmax over (z[b][c], z[b][Cp+c])  (RadixSoftmax with cardinality 1, split_attn.py:20-28)
