@@ -51,6 +51,8 @@ def lib():
             raise RuntimeError(
                 "scouter_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU/PyTorch fallback for the HIP path)" % LIB_PATH)
+        import torch  # noqa: F401  -- first: the library must bind to the HIP runtime PyTorch loads (its bundled
+        #                        libamdhip64), not bring a second runtime into the process ("no ROCm-capable device")
         _lib = ctypes.CDLL(LIB_PATH)
         for name, restype, argtypes in declared_symbols():
             fn = getattr(_lib, name)      # AttributeError here = header/library mismatch
