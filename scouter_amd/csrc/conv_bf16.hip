@@ -158,19 +158,25 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restr
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     auto compute = [&](int buf) {
-        const __bf16* As = ldsh + buf * STAGE_H;
-        const __bf16* Bs = As + A_H;
+        const __bf16* As = ldsh + buf * STAGE_H + (wm * WM + l31) * LDH + 8 * h;
+        const __bf16* Bs = ldsh + buf * STAGE_H + A_H + (wn * WN + l31) * LDH + 8 * h;
+        bf16x8 fa[2][MT], fb[2][NT];                     // fragments of k-step s+1 are read while step s multiplies
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[0][i] = *(const bf16x8*)(As + i * 32 * LDH);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = *(const bf16x8*)(Bs + j * 32 * LDH);
 #pragma unroll
         for (int s = 0; s < KT_ / 16; ++s) {
-            bf16x8 fa[MT], fb[NT];
+            if (s + 1 < KT_ / 16) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *(const bf16x8*)(As + (wm * WM + i * 32 + l31) * LDH + 16 * s + 8 * h);
+                for (int i = 0; i < MT; ++i) fa[(s + 1) & 1][i] = *(const bf16x8*)(As + i * 32 * LDH + 16 * (s + 1));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *(const bf16x8*)(Bs + (wn * WN + j * 32 + l31) * LDH + 16 * s + 8 * h);
+                for (int j = 0; j < NT; ++j) fb[(s + 1) & 1][j] = *(const bf16x8*)(Bs + j * 32 * LDH + 16 * (s + 1));
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
         }
     };
 

@@ -132,20 +132,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     auto compute = [&](int buf) {
-        const __bf16* As = ldsw + buf * STAGE_H;
-        const __bf16* Bs = As + A_H;
+        const __bf16* As = ldsw + buf * STAGE_H + (wm * WM + l31) * LDP + 8 * h;
+        const __bf16* Bs = ldsw + buf * STAGE_H + A_H + (wn * WN + l31) * LDP + 8 * h;
+        wg_bf16x8 fa[2][MT], fb[2][NT];                  // fragments of k-step s+1 are read while step s multiplies
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[0][i] = *(const wg_bf16x8*)(As + i * 32 * LDP);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = *(const wg_bf16x8*)(Bs + j * 32 * LDP);
 #pragma unroll
         for (int s = 0; s < KP / 16; ++s) {
-            wg_bf16x8 fa[MT], fb[NT];
+            if (s + 1 < KP / 16) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *(const wg_bf16x8*)(As + (wm * WM + i * 32 + l31) * LDP + 16 * s + 8 * h);
+                for (int i = 0; i < MT; ++i) fa[(s + 1) & 1][i] = *(const wg_bf16x8*)(As + i * 32 * LDP + 16 * (s + 1));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *(const wg_bf16x8*)(Bs + (wn * WN + j * 32 + l31) * LDP + 16 * s + 8 * h);
+                for (int j = 0; j < NT; ++j) fb[(s + 1) & 1][j] = *(const wg_bf16x8*)(Bs + j * 32 * LDP + 16 * (s + 1));
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
         }
     };
     if (KT > 0) {
