@@ -75,6 +75,9 @@ class StemConv2d(Conv2d):
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
     def fwd(self, x_nchw, save, relu=False, addend=None, bn_stats=False):
+        if x_nchw.dim() != 4 or x_nchw.shape[1] != self.in_channels:
+            raise RuntimeError("expected an NCHW image batch with %d channel(s), got shape %s"
+                               % (self.in_channels, tuple(x_nchw.shape)))
         col = K.im2col_nchw(x_nchw, self.kernel_size, self.stride, self.padding, self.kpad)
         wflat = K.hwio(self.weight).reshape(-1)
         wpad = K.pad_rows(wflat, wflat.numel(), self.kpad * self.out_channels).view(1, 1, self.kpad, self.out_channels)

@@ -178,7 +178,10 @@ def test_fc_baseline_mode_parity():
 
 
 @pytest.mark.parametrize("arch,C,spc,B,H", [("resnest26d", 200, 1, 6, 260), ("resnest50d", 100, 3, 2, 224),
-                                            ("resnet18", 10, 1, 1, 260)])
+                                            ("resnet18", 10, 1, 1, 260),
+                                            # ragged inputs: odd sizes / not multiples of 32 (odd feature maps all the
+                                            # way down, ceil-mode pooling, partial tiles in every kernel)
+                                            ("resnest26d", 10, 1, 3, 225), ("resnet18", 10, 1, 2, 200)])
 def test_other_baseline_shapes_forward_parity(arch, C, spc, B, H):
     """BASELINE configs 4 / 5 head sizes (S = 200 / 300) and the reference's default 260x260 input (9x9 = 81 tokens,
     3 token tiles in the fused kernel), batch 1 included: forward vs the fp64 oracle, backward finite + deterministic."""
@@ -275,3 +278,24 @@ def test_bf16_mode_sits_inside_the_bf16_noise_of_the_reference_arithmetic():
     # (1 - cosine) is the squared relative angle: HIP may be at most 2.5x further from the truth than the emulation
     assert 1 - med_hip <= 2.5 * (1 - med_emu) + 1e-4
     assert 1 - cos_hip[worst] <= 2.5 * (1 - min(cos_emu.values())) + 1e-3
+
+
+def test_bad_inputs_fail_loudly():
+    """empty batch, CPU tensor, wrong channel count: Python exceptions with the library's message, never a silent
+    fallback or a device fault"""
+    from scouter_amd import kernels as K
+    m, P, images, labels = build("resnet18_mnist_64")
+    m.train()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m(images, labels)                                              # CPU tensor
+    with pytest.raises((RuntimeError, AssertionError)):
+        m(images[:0].cuda(), labels[:0].cuda())                        # empty batch
+    with pytest.raises((RuntimeError, AssertionError)):
+        m(images.repeat(1, 3, 1, 1).cuda(), labels.cuda())             # 3-channel image into the 1-channel MNIST stem
+    x = torch.zeros(2, 8, 8, 48, device="cuda")                        # 48 channels: not a multiple of 32
+    w = torch.zeros(1, 1, 48, 64, device="cuda")
+    with pytest.raises(RuntimeError, match="multiples of 32"):
+        K.conv2d_fwd(x, w)
+    # non-contiguous / float64 inputs are accepted (made dense / cast like engine.py:25 does)
+    out = m(images.double().cuda().transpose(2, 3).transpose(2, 3), labels.cuda())
+    assert torch.isfinite(out[0]).all()
