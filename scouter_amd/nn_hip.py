@@ -114,6 +114,9 @@ class BatchNorm2d(nn.Module):
         stats = None
         if isinstance(x, tuple):
             x, stats = x
+        if self.training and x.numel() == x.shape[-1]:     # torch.nn.functional.batch_norm's check (batch 1 on a 1x1 map)
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                             % (tuple(x.shape),))
         out = K.bn_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
                        residual, self.momentum, self.eps, stats if self.training else None,
                        want_mask=bool(relu and save))

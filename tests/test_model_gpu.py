@@ -296,6 +296,9 @@ def test_bad_inputs_fail_loudly():
     w = torch.zeros(1, 1, 48, 64, device="cuda")
     with pytest.raises(RuntimeError, match="multiples of 32"):
         K.conv2d_fwd(x, w)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        mr, _, im_r, lb_r = build("resnest26d_96")
+        mr.train()(im_r[:1].cuda(), lb_r[:1].cuda())                  # batch 1 in train mode: like torch's BatchNorm
     # non-contiguous / float64 inputs are accepted (made dense / cast like engine.py:25 does)
     out = m(images.double().cuda().transpose(2, 3).transpose(2, 3), labels.cuda())
     assert torch.isfinite(out[0]).all()
