@@ -136,14 +136,71 @@ class SlotAttention(nn.Module):
             Image.fromarray(image, mode="L").save(os.path.join(folder, "slot_%d.png" % i))
 
     def forward(self, inputs, inputs_x):
-        """Reference signature (slot_attention.py:44): inputs = x + pe, inputs_x = x, both [B, N, d].
-        Inference helper (no autograd through this entry point -- training goes through SlotModel)."""
-        with torch.no_grad():
-            X = inputs_x.float().contiguous()
-            PE = (inputs.float() - X)[0].contiguous()     # the encoding is batch-invariant (slot_model.py:110-111)
-            out = self.fwd(X, PE)
-            B, S, N = out["attn"].shape
-            area = out["area_part"].sum() / (B * S * N)
-            if self.vis:
-                self.save_vis()
-            return out["logits"], torch.pow(area, self.power)
+        """Reference signature (slot_attention.py:44): inputs = x + pe, inputs_x = x, both [B, N, d]; returns
+        (logits [B, C], area ** power).  Differentiable on its own (training normally goes through SlotModel's fused
+        node): one autograd node around the fused kernels.  `inputs - inputs_x` must be the batch-invariant positional
+        encoding, as in slot_model.py:110-115; the gradient of both arguments is returned on `inputs_x` (their sum is
+        what reaches the common ancestor x)."""
+        if torch.is_grad_enabled() and (inputs_x.requires_grad or inputs.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            logits, term = _XSlotFn.apply(self, inputs, inputs_x, self.initial_slots)
+        else:
+            with torch.no_grad():
+                X = inputs_x.float().contiguous()
+                out = self.fwd(X, (inputs.float() - X)[0].contiguous())
+                B, S, N = out["attn"].shape
+                logits, term = out["logits"], torch.pow(out["area_part"].sum() / (B * S * N), self.power)
+        if self.vis:
+            self.save_vis()
+        return logits, term
+
+    def _named_leaves(self):
+        """(owner module, leaf name, parameter) of every parameter the backward produces a gradient for"""
+        yield self, "initial_slots", self.initial_slots
+        for leaf in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+            yield self.gru, leaf, getattr(self.gru, leaf)
+        for m in self._to_k_layers():
+            yield m, "weight", m.weight
+            yield m, "bias", m.bias
+
+
+class _XSlotFn(torch.autograd.Function):
+    """Stand-alone autograd node of SlotAttention.forward.  `anchor` (initial_slots) only ties the node to the
+    module's parameters; their gradients are written by SlotAttention.bwd into temporary buffers (or the bound arena
+    slices) and accumulated into `.grad` here."""
+
+    @staticmethod
+    def forward(ctx, mod, inputs, inputs_x, anchor):
+        X = inputs_x.detach().float().contiguous()
+        PE = (inputs.detach().float() - X)[0].contiguous()
+        out = mod.fwd(X, PE)
+        B, S, N = out["attn"].shape
+        area = out["area_part"].sum() / (B * S * N)
+        ctx.mod, ctx.saved, ctx.dims = mod, (X, PE, out, area), (B, S, N)
+        return out["logits"], torch.pow(area, mod.power)
+
+    @staticmethod
+    def backward(ctx, g_logits, g_term):
+        mod = ctx.mod
+        X, PE, out, area = ctx.saved
+        B, S, N = ctx.dims
+        dlogits = (g_logits if g_logits is not None else torch.zeros_like(out["logits"])).float().contiguous()
+        g_term = g_term if g_term is not None else torch.zeros((), device=X.device)
+        # d(area**p)/d(sum A) = p * area**(p-1) / (B S N)
+        g_area_sum = (g_term.float() * mod.power * torch.pow(area, mod.power - 1) / (B * S * N)).reshape(1).contiguous()
+        temp = []
+        for owner, leaf, p in mod._named_leaves():
+            if p.requires_grad and leaf not in owner._g:
+                buf = torch.zeros(p.numel(), dtype=torch.float32, device=X.device)
+                owner._bind_grad(leaf, buf)
+                temp.append((owner, leaf, p))
+        try:
+            dX = mod.bwd(X, PE, out, dlogits, g_area_sum)
+            K.join_side_stream(X.device)
+            for owner, leaf, p in temp:
+                g = owner._g[leaf].reshape(p.shape).clone()
+                p.grad = g if p.grad is None else p.grad + g
+        finally:
+            for owner, leaf, _ in temp:
+                del owner._g[leaf]
+        return None, None, dX, None

@@ -130,3 +130,43 @@ def test_xslot_large_batch_properties():
     lg = (A.double() * xs[:, None, :]).sum(2).view(B, C, spc).sum(2) / d
     np.testing.assert_allclose(o1["logits"].cpu().double().numpy(), lg.cpu().numpy(), atol=5e-5, rtol=1e-5)
     np.testing.assert_allclose(o1["area_part"].cpu().double().numpy(), A.double().sum((1, 2)).cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["c2_in10_pos", "c3_in10_neg", "grid9_spc3", "c5_in100_spc3"])
+def test_standalone_slot_attention_forward_is_differentiable(case):
+    """The reference's module API, `SlotAttention(...)(x + pe, x) -> (logits, area ** power)`, used outside SlotModel:
+    values and every gradient (x and all parameters but the unused to_q) against the oracle's fp64 autograd."""
+    from scouter_amd.sloter.utils.slot_attention import SlotAttention
+    C, spc, side, L, ls, power, B, Cin = HEAD_CASES[case]
+    feat, labels, P = head_inputs(case)
+    rng = np.random.default_rng(5)
+    N, d = side * side, 64
+    x = torch.from_numpy(rng.standard_normal((B, N, d)).clip(0)).float()            # post-ReLU tokens
+    pe = torch.from_numpy(rng.standard_normal((N, d)) * 0.3).float()
+    mod = SlotAttention(C, spc, d, loss_status=ls, power=power, to_k_layer=L)
+    sd = mod.state_dict()
+    sd.update({k[len("slot."):]: v for k, v in P.items() if k.startswith("slot.")})
+    mod.load_state_dict(sd)
+    mod = mod.cuda()
+    xd = x.cuda().requires_grad_(True)
+    logits, term = mod(xd + pe.cuda(), xd)
+    wl = torch.from_numpy(rng.standard_normal((B, C))).float()
+    (logits * wl.cuda()).sum().add(term * 3.0).backward()
+    torch.cuda.synchronize()
+    # oracle, fp64
+    Pd = {k: v.double().clone().requires_grad_(True) for k, v in P.items() if k.startswith("slot.")}
+    x64 = x.double().requires_grad_(True)
+    rl, rt = O.xslot_forward(Pd, x64 + pe.double(), x64, C, spc, ls, power)
+    ((rl * wl.double()).sum() + rt * 3.0).backward()
+    floor = 1e-4 if C * spc < 100 else 2e-3                                          # S >= 200: ill-conditioned (fact 10)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), rl.detach().numpy(), atol=floor, rtol=1e-4)
+    np.testing.assert_allclose(float(term.detach()), float(rt.detach()), rtol=1e-4, atol=1e-6)
+    gx = xd.grad.cpu().double()
+    assert float((gx - x64.grad).abs().max()) <= 2e-3 * float(x64.grad.abs().max()) + 10 * floor
+    for name, p in mod.named_parameters():
+        ref = Pd["slot." + name].grad
+        if name.startswith("to_q"):
+            assert p.grad is None and ref is None
+            continue
+        sc = float(ref.abs().max())
+        assert float((p.grad.cpu().double() - ref).abs().max()) <= 3e-3 * sc + 30 * floor, name
