@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
                                                               int relu) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
-        f32x4 v = *(const f32x4*)(x + i * 4);
+        f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
         const f32x4 a = *(const f32x4*)(scale + c), b = *(const f32x4*)(shift + c), mu = *(const f32x4*)(mean + c);
         v = (v - mu) * a + b;
         if (res) v += *(const f32x4*)(res + i * 4);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int C) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
-        f32x4 g = *(const f32x4*)(dy + i * 4);
+        f32x4 g = __builtin_nontemporal_load((const f32x4*)(dy + i * 4));
         if (mbits) {
             relu_mask_apply(g, mbits, i);
         } else if (ymask) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
         }
-        const f32x4 xv = *(const f32x4*)(x + i * 4);
+        const f32x4 xv = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
         const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), sc = *(const f32x4*)(scale + c);
         const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c);
         const f32x4 xh = (xv - mu) * rs;
