@@ -10,6 +10,7 @@ import struct
 import torch
 
 from . import _native
+from . import kernels as K
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -92,7 +93,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                                    st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                    float(group["weight_decay"]), int(st["step"]),
-                                                   torch.cuda.current_stream().cuda_stream), "adamw_step")
+                                                   K._stream()), "adamw_step")
         return loss
 
     def zero_grad(self, set_to_none=False):
