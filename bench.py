@@ -236,7 +236,7 @@ def main():
             kern[name] = {"launches_per_step": n / prof_steps, "ms_per_step": round(ms / prof_steps, 4),
                           "avg_us": round(1e3 * ms / n, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None,
                           "gbps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1) if by else None}
-        conv = [k for k in kern if k.startswith(("igemm_", "wgrad<"))]
+        conv = [k for k in kern if k.startswith(("igemm_", "wgrad<", "wgrad_taps"))]
         roofline = None
         if conv:
             # the dominant kernel INSTANCE (most time per step); its rocprofv3 row is igemm_kernel<BM,BN,..> / wgrad_kernel<..>

@@ -12,6 +12,7 @@
 // reads and the global prefetch of the next K-tile hide under it -- no reshaping tricks, exact fp32 (fmaf chain).
 #include "conv_common.h"
 #include "conv_wgrad_bf16.h"
+#include "conv_wgrad_taps.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -713,8 +714,18 @@ extern "C" size_t scouter_conv2d_wgrad_workspace_bytes(int B, int H, int W, int 
     if (groups <= 0 || Cin % groups || Cout % groups) return 0;
     ConvGeom g = wgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
     WgradPlan p = wgrad_plan(g, plan_hint);
-    if (p.splits <= 1) return 0;
-    return (size_t)p.splits * kh * kw * g.Cg * Cout * sizeof(float);
+    size_t need = p.splits <= 1 ? 0 : (size_t)p.splits * kh * kw * g.Cg * Cout * sizeof(float);
+    if (plan_hint < 0 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && g.Cg == 32) {     // tap-fused plan (see wgrad_f32)
+        const long tiles = (long)(g.Ng / (g.Ng % 64 == 0 ? 64 : 32)) * groups;
+        long want = 1024 / tiles;
+        if (want < 1) want = 1;
+        long chunks = (g.M + BK - 1) / BK, cps = (chunks + want - 1) / want;
+        if (cps < 8) cps = 8;
+        const long splits = (g.M + cps * BK - 1) / (cps * BK);
+        const size_t nt = splits > 1 ? (size_t)splits * 9 * g.Cg * Cout * sizeof(float) : 0;
+        if (nt > need) need = nt;
+    }
+    return need;
 }
 
 extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin,
@@ -724,6 +735,50 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_wgrad: channels not divisible by groups");
     ConvGeom g = wgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
     SC_UNSUPPORTED(g.Cg % 32 == 0 && g.Ng % 32 == 0, "conv2d_wgrad: per-group channels must be multiples of 32");
+    // 3x3 / stride 1 / pad 1 with 32 input channels per group: tap-fused kernel (conv_wgrad_taps.h)
+    if (plan_hint < 0 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && g.Cg == 32 && BK / g.Wo + 1 < g.Ho &&
+        g.M < (1L << 31) && (long)(2 * g.W + 2) * g.C * 4 < (1L << 31)) {
+        const int bn = g.Ng % 64 == 0 ? 64 : 32;
+        const int co_tiles = g.Ng / bn;
+        const long tiles = (long)co_tiles * groups;
+        long want = 1024 / tiles;
+        if (want < 1) want = 1;
+        long chunks = (g.M + BK - 1) / BK, cps = (chunks + want - 1) / want;
+        if (cps < 8) cps = 8;
+        const long pps = cps * BK;
+        const int splits = (int)((g.M + pps - 1) / pps);
+        const long slab_t = (long)9 * g.Cg * Cout;
+        const size_t need_t = splits > 1 ? (size_t)splits * slab_t * sizeof(float) : 0;
+        if (need_t <= ws_bytes && (!need_t || ws)) {
+            hipStream_t st = (hipStream_t)stream;
+            float* out = splits > 1 ? (float*)ws : dw;
+            const size_t lds = (size_t)(9 * 32 * 32 + 32 * bn) * sizeof(float);
+            {
+                ScProfScope prof("wgrad_taps", st, 2.0 * g.M * Cout * g.Cg * 9,
+                                 4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
+                if (bn == 64) {
+                    auto kern = wgrad_taps_kernel<64>;
+                    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, x, dy, out, g,
+                                       co_tiles, pps, slab_t);
+                } else {
+                    auto kern = wgrad_taps_kernel<32>;
+                    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, x, dy, out, g,
+                                       co_tiles, pps, slab_t);
+                }
+            }
+            int rc = sc_check_launch("conv2d_wgrad_taps");
+            if (rc) return rc;
+            if (splits > 1) {
+                ScProfScope prof2("slab_reduce", st, 0, 4.0 * (double)slab_t * (splits + 1));
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(slab_t / 4, 8)), dim3(256), 0, st, (const float*)ws,
+                                   dw, slab_t, splits, slab_t);
+                rc = sc_check_launch("conv2d_wgrad_taps_reduce");
+            }
+            return rc;
+        }
+    }
     WgradPlan p = wgrad_plan(g, plan_hint);
     const long slab = (long)kh * kw * g.Cg * Cout;
     const size_t need = p.splits > 1 ? (size_t)p.splits * slab * sizeof(float) : 0;
