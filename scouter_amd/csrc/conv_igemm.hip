@@ -851,6 +851,7 @@ extern "C" int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float*
     SC_UNSUPPORTED(mode != 0 && g.Cg % 64 == 0 && g.Ng % 64 == 0 && g.M < (1L << 31),
                    "conv2d_wgrad_bf16: shape not covered by the bf16 kernel");
     WgradPlan p = wgrad_plan(g, plan_hint, true);
+    if (p.bm < 64 || p.bn < 64) p = wgrad_plan(g, plan_hint & 3, true);      // the bf16 kernel has no 32-wide tiles
     const long slab = (long)kh * kw * g.Cg * Cout;
     const size_t need = p.splits > 1 ? (size_t)p.splits * slab * sizeof(float) : 0;
     if (need > ws_bytes || (need && !ws)) {
