@@ -17,7 +17,16 @@ struct XsBwdArgs {
     float* dX; float* dgi; float* dgh; float* Usave; float* ds0; float* dZ; float* ws;
     int B, N, S, C, spc, T, L;
     float loss_status;
+#ifdef XS_TIMING
+    long long* stamps;      // dev build (tools_dev/xs_bwd_phase_timing.hip): [B][64] cycle stamps of wave 0
+#endif
 };
+
+#ifdef XS_TIMING
+#define XSB_STAMP() do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 64 + nstamp] = __builtin_readcyclecounter(); ++nstamp; } while (0)
+#else
+#define XSB_STAMP() do { } while (0)
+#endif
 
 template <int NT>
 __device__ __forceinline__ void xs_store_tile(float* base, int ld, const f32x16 (&m)[NT], int l31, int hh) {
@@ -83,6 +92,9 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     const int b = blockIdx.x, N = a.N, S = a.S, T = a.T;
     const int ntiles = (S + 31) >> 5, Sp = ntiles * 32, TPW = (ntiles + 3) >> 2;
     const float scale = 0.125f, inv_d = 1.f / XS_D;
+    int nstamp = 0;
+    (void)nstamp;
+    XSB_STAMP();
     // scratch of this image: dsn [Sp][64] | per t: A [Sp][NP], dD [Sp][NP], dU [Sp][64]
     const long per_img = (long)Sp * (64 + (long)T * (2 * NP + 64));
     float* dsn = a.ws + (long)b * per_img;
@@ -112,6 +124,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     __syncthreads();
     xs_colsum_f64(Ks, NP, ksum, tid);
     __syncthreads();
+    XSB_STAMP();
 
     for (int it = T - 1; it >= 0; --it) {
         const bool last = it == T - 1;
@@ -132,6 +145,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
         double tau64 = 0.0;
         for (int k = 0; k < ntiles; ++k) tau64 += red64[k];
         const float tau = (float)tau64;
+        XSB_STAMP();
         // ================= phase B1
         for (int tt = 0; tt < TPW; ++tt) {
             const int ti = wave + 4 * tt;
@@ -157,6 +171,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
                 }
                 xs_store_tile<NJT>(As_t(it) + (long)ti * 32 * NP, NP, A, l31, hh);
                 xs_store_tile<NJT>(dDs_t(it) + (long)ti * 32 * NP, NP, D, l31, hh);
+                if (tt == 0) XSB_STAMP();
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     xs_zero(U[ct]);
@@ -165,6 +180,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
                     xs_zero(dhp[ct]);
                 }
             }
+            if (tt == 0) XSB_STAMP();
             if (last) {
                 const float du = iok ? a.loss_status * a.dlogits[(long)b * a.C + i / a.spc] : 0.f;
 #pragma unroll
@@ -226,6 +242,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
                     }
                 }
             }
+            if (tt == 0) XSB_STAMP();
             if (!iok) {   // padded slots carry nothing
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) { xs_zero(dU[ct]); xs_zero(dhp[ct]); }
@@ -251,6 +268,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
                 }
                 xs_store_tile<1>(dDs_t(it) + (long)ti * 32 * NP + 32 * jt, NP, Aj, l31, hh);   // stash G over D
             }
+            if (tt == 0) XSB_STAMP();
             gsum += __shfl_xor(gsum, 32, 64);
             if (hh == 0) g_s[i] = gsum;
             const float tc = xs_tilesum(iok ? gsum / r : 0.f);
@@ -259,6 +277,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
         xs_lds_barrier();        // LDS hand-off only: pending global stores keep flying
         float c0 = 0.f;
         for (int k = 0; k < ntiles; ++k) c0 += red[16 + k];
+        XSB_STAMP();
         // ================= phase B2: dD, ds_t
         for (int tt = 0; tt < TPW; ++tt) {
             const int ti = wave + 4 * tt;
@@ -287,6 +306,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             else if (iok) xs_store_tile<2>(a.ds0 + ((long)b * S + ti * 32) * XS_D, XS_D, ds, l31, hh);
         }
         xs_lds_barrier();        // LDS hand-off only: pending global stores keep flying
+        XSB_STAMP();
     }
 
     // ================= final phase: contractions over the slot index
@@ -304,16 +324,27 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             if (prod == 1) { Q = dUs_t(t); ldq = 64; }
             else { Q = t == 0 ? a.slots0 : a.states + ((long)(t - 1) * a.B + b) * S * XS_D; ldq = XS_D; }
             Q += 32 * ct + l31;
-            for (int i0 = 0; i0 < Sp; i0 += 16) {
-                float pv[8], qv[8];
+            // operands come from the L2-resident scratch: the next 16 slots are requested before the MFMAs of the
+            // current ones (one wave per SIMD -- nothing else hides a load round trip)
+            float pv[2][8], qv[2][8];
+            auto fetch = [&](int buf, int i0) {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const int i = i0 + 2 * s + hh;
-                    pv[s] = P[(long)i * NP];
-                    qv[s] = (prod == 1 || i < S) ? Q[(long)i * ldq] : 0.f;
+                    pv[buf][s] = P[(long)i * NP];
+                    qv[buf][s] = (prod == 1 || i < S) ? Q[(long)i * ldq] : 0.f;
                 }
+            };
+            fetch(0, 0);
+            for (int i0 = 0; i0 < Sp; i0 += 32) {
+                if (i0 + 16 < Sp) fetch(1, i0 + 16);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) acc = mfma32(pv[s], qv[s], acc);
+                for (int s = 0; s < 8; ++s) acc = mfma32(pv[0][s], qv[0][s], acc);
+                if (i0 + 16 < Sp) {
+                    if (i0 + 32 < Sp) fetch(0, i0 + 32);
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) acc = mfma32(pv[1][s], qv[1][s], acc);
+                }
             }
         }
         float* dst = prod == 0 ? dZa : dXs;
@@ -321,6 +352,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) dst[(32 * jt + mfma32_row(e, lane)) * XS_LD + 32 * ct + l31] = acc[e] * sc;
     }
+    XSB_STAMP();
     // ================= to_k MLP backward: dZ_{L-1} = dK ; dH_{l-1} = dZ_l W_l ; dZ_{l-1} = dH_{l-1} * (H_{l-1} > 0)
     float* dZin = dZa;
     float* dZout = dZb;
@@ -360,6 +392,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
         }
         float* tmp = dZin; dZin = dZout; dZout = tmp;
     }
+    XSB_STAMP();
 }
 
 static size_t xs_bwd_lds_bytes(int NJT) { return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 16) + 32 + 1024) * sizeof(float); }
