@@ -68,8 +68,119 @@ __device__ __forceinline__ void xs_mm_tr_tile(const float* __restrict__ Mt, int 
     XS_REGION_END();
 }
 
+// to_k MLP backward of one image: dZ_{L-1} = dK ; dH_{l-1} = dZ_l W_l ; dZ_{l-1} = dH_{l-1} * (H_{l-1} > 0);
+// dX = dH_{-1} + dX^a.  dZa holds dK on entry; every dZ_l also goes to global (operand of the to_k weight gradients).
 template <int NJT>
-__global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
+__device__ __forceinline__ void xs_mlp_bwd(const XsBwdArgs& a, float* dZa, float* dZb, const float* dXs, float* Wt,
+                                           int tid, int wave, int lane, int l31, int hh, int b) {
+    const int N = a.N;
+    float* dZin = dZa;
+    float* dZout = dZb;
+    for (int l = a.L - 1; l >= 0; --l) {
+        __syncthreads();
+        xs_load_mat(Wt, a.tok_w[l], XS_D, tid, 256);
+        for (int c = tid; c < N * 16; c += 256) {           // dZ_l -> global (operand of the to_k weight-gradient GEMM)
+            const int r = c >> 4, q = c & 15;
+            *(f32x4*)(a.dZ + (((long)l * a.B + b) * N + r) * XS_D + q * 4) = *(const f32x4*)(dZin + r * XS_LD + q * 4);
+        }
+        __syncthreads();
+        for (int tile = wave; tile < NJT * 2; tile += 4) {
+            const int jt = tile >> 1, ct = tile & 1;
+            f32x16 acc;
+            xs_zero(acc);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 av = *(const f32x4*)(dZin + (32 * jt + l31) * XS_LD + 32 * t + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc = mfma32(av[e], Wt[(32 * t + 8 * q + 4 * hh + e) * XS_LD + 32 * ct + l31], acc);
+                }
+            const int c = 32 * ct + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = 32 * jt + mfma32_row(e, lane);
+                float v = acc[e];
+                if (l > 0) {
+                    const float hv = j < N ? a.Hsave[(((long)l * a.B + b) * N + j) * XS_D + c] : 0.f;   // H_l = input of layer l
+                    dZout[j * XS_LD + c] = hv > 0.f ? v : 0.f;
+                } else if (j < N) {
+                    a.dX[((long)b * N + j) * XS_D + c] = v + dXs[j * XS_LD + c];
+                }
+            }
+        }
+        float* tmp = dZin; dZin = dZout; dZout = tmp;
+    }
+}
+
+// GRU backward of one 32-slot tile (slots on the lanes): gates recomputed from (U, h), pre-activation gradients
+// stored as the operands of the weight-gradient GEMMs, dU += W_ih^T dgi, dh_prev += dz*ds + W_hh^T dgh.
+// `row` = row of this lane's slot in the [T][B][S] gradient buffers.
+__device__ __forceinline__ void xs_gru_bwd_tile(const XsBwdArgs& a, const float* Wih, const float* Whh, const float* bias,
+                                                const f32x16 (&h)[2], const f32x16 (&U)[2], const float* dsx_tile,
+                                                float cs, const float* ksumf, f32x16 (&dU)[2], f32x16 (&dhp)[2],
+                                                long row, bool iok, int l31, int hh) {
+    if (iok) xs_store_tile<2>(a.Usave + (row - l31) * XS_D, XS_D, U, l31, hh);   // row - l31 = tile row 0
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt) {
+        // ds of the 32 hidden units of this g-tile: the [32 slots][64] tile handed over by iteration t+1 (+ its
+        // deferred c0 term cs * colsum(K), variant B); requested here, used after the six gate GEMMs
+        f32x4 dsq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dsq[q] = *(const f32x4*)(dsx_tile + (long)l31 * 64 + 32 * gt + 8 * q + 4 * hh);
+        f32x16 ar, az, ain, ahn;
+        xs_zero(ar); xs_zero(az); xs_zero(ain); xs_zero(ahn);
+        xs_mm_kc(Wih, 32 * gt, U, ar, l31, hh);
+        xs_mm_kc(Whh, 32 * gt, h, ar, l31, hh);
+        xs_mm_kc(Wih, 64 + 32 * gt, U, az, l31, hh);
+        xs_mm_kc(Whh, 64 + 32 * gt, h, az, l31, hh);
+        xs_mm_kc(Wih, 128 + 32 * gt, U, ain, l31, hh);
+        xs_mm_kc(Whh, 128 + 32 * gt, h, ahn, l31, hh);
+        // gate values -> their pre-activation gradients, in place
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int g = xs_kidx(gt, e, hh);
+            const float rg = xs_sigmoid(ar[e] + bias[g]);
+            const float zg = xs_sigmoid(az[e] + bias[64 + g]);
+            const float hnb = ahn[e] + bias[192 + g];
+            const float ng = xs_tanh(ain[e] + bias[128 + g] + rg * hnb);
+            const float ds = dsq[e >> 2][e & 3] + cs * ksumf[g];
+            const float da_n = ds * (1.f - zg) * (1.f - ng * ng);
+            const float da_z = ds * (h[gt][e] - ng) * zg * (1.f - zg);
+            const float da_r = da_n * hnb * rg * (1.f - rg);
+            dhp[gt][e] += ds * zg;
+            ar[e] = da_r; az[e] = da_z; ain[e] = da_n; ahn[e] = da_n * rg;
+        }
+        if (iok) {
+            float* gi = a.dgi + row * 192 + 32 * gt + 4 * hh;
+            float* gh = a.dgh + row * 192 + 32 * gt + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v0, v1, v2, v3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = ar[4 * q + e]; v1[e] = az[4 * q + e]; v2[e] = ain[4 * q + e]; v3[e] = ahn[4 * q + e]; }
+                *(f32x4*)(gi + 8 * q) = v0; *(f32x4*)(gi + 64 + 8 * q) = v1; *(f32x4*)(gi + 128 + 8 * q) = v2;
+                *(f32x4*)(gh + 8 * q) = v0; *(f32x4*)(gh + 64 + 8 * q) = v1; *(f32x4*)(gh + 128 + 8 * q) = v3;
+            }
+        }
+        // dU^T += W_ih^T dgi^T ; dh_prev^T += W_hh^T dgh^T   (k = the 32 hidden units of this g-tile)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            xs_mm_tr_tile(Wih, 32 * gt, 32 * ct, ar, dU[ct], l31, hh);
+            xs_mm_tr_tile(Wih, 64 + 32 * gt, 32 * ct, az, dU[ct], l31, hh);
+            xs_mm_tr_tile(Wih, 128 + 32 * gt, 32 * ct, ain, dU[ct], l31, hh);
+            xs_mm_tr_tile(Whh, 32 * gt, 32 * ct, ar, dhp[ct], l31, hh);
+            xs_mm_tr_tile(Whh, 64 + 32 * gt, 32 * ct, az, dhp[ct], l31, hh);
+            xs_mm_tr_tile(Whh, 128 + 32 * gt, 32 * ct, ahn, dhp[ct], l31, hh);
+        }
+    }
+}
+
+// ---- variant A (N > 64 tokens: no LDS left for the transposes of variant B): A_t, dD_t, dU_t go to an L2/HBM
+// scratch and a final phase contracts them over the slot index.
+template <int NJT>
+__global__ __launch_bounds__(256) void xslot_bwd_scratch_kernel(XsBwdArgs a) {
     constexpr int NP = 32 * NJT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Xs = lds;
@@ -113,8 +224,8 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
         *(f32x4*)(Xs + r * XS_LD + q * 4) = x;
         *(f32x4*)(Ks + r * XS_LD + q * 4) = k;
     }
-    xs_load_mat(Wih, a.w_ih, 192, tid, 256);
-    xs_load_mat(Whh, a.w_hh, 192, tid, 256);
+    xs_load_mat_c<192, 256>(Wih, a.w_ih, tid);
+    xs_load_mat_c<192, 256>(Whh, a.w_hh, tid);
     {
         const int g = tid & 63, k = tid >> 6;
         bias[tid] = k == 0 ? a.b_ih[g] + a.b_hh[g] : k == 1 ? a.b_ih[64 + g] + a.b_hh[64 + g]
@@ -188,59 +299,9 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) dU[ct][e] = du;
             } else {
-                f32x16 dsx[2];
-                xs_load_tile<2>(dsn + (long)ti * 32 * 64, 64, dsx, l31, hh, true);
                 xs_zero(dU[0]); xs_zero(dU[1]);
                 const long row = ((long)it * a.B + b) * S + i;
-                if (iok) xs_store_tile<2>(a.Usave + (row - l31) * XS_D, XS_D, U, l31, hh);   // row-l31 = tile row 0
-#pragma unroll
-                for (int gt = 0; gt < 2; ++gt) {
-                    f32x16 ar, az, ain, ahn;
-                    xs_zero(ar); xs_zero(az); xs_zero(ain); xs_zero(ahn);
-                    xs_mm_kc(Wih, 32 * gt, U, ar, l31, hh);
-                    xs_mm_kc(Whh, 32 * gt, h, ar, l31, hh);
-                    xs_mm_kc(Wih, 64 + 32 * gt, U, az, l31, hh);
-                    xs_mm_kc(Whh, 64 + 32 * gt, h, az, l31, hh);
-                    xs_mm_kc(Wih, 128 + 32 * gt, U, ain, l31, hh);
-                    xs_mm_kc(Whh, 128 + 32 * gt, h, ahn, l31, hh);
-                    // gate values -> their pre-activation gradients, in place
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int g = xs_kidx(gt, e, hh);
-                        const float rg = xs_sigmoid(ar[e] + bias[g]);
-                        const float zg = xs_sigmoid(az[e] + bias[64 + g]);
-                        const float hnb = ahn[e] + bias[192 + g];
-                        const float ng = xs_tanh(ain[e] + bias[128 + g] + rg * hnb);
-                        const float ds = dsx[gt][e];
-                        const float da_n = ds * (1.f - zg) * (1.f - ng * ng);
-                        const float da_z = ds * (h[gt][e] - ng) * zg * (1.f - zg);
-                        const float da_r = da_n * hnb * rg * (1.f - rg);
-                        dhp[gt][e] += ds * zg;
-                        ar[e] = da_r; az[e] = da_z; ain[e] = da_n; ahn[e] = da_n * rg;
-                    }
-                    if (iok) {
-                        float* gi = a.dgi + row * 192 + 32 * gt + 4 * hh;
-                        float* gh = a.dgh + row * 192 + 32 * gt + 4 * hh;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 v0, v1, v2, v3;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { v0[e] = ar[4 * q + e]; v1[e] = az[4 * q + e]; v2[e] = ain[4 * q + e]; v3[e] = ahn[4 * q + e]; }
-                            *(f32x4*)(gi + 8 * q) = v0; *(f32x4*)(gi + 64 + 8 * q) = v1; *(f32x4*)(gi + 128 + 8 * q) = v2;
-                            *(f32x4*)(gh + 8 * q) = v0; *(f32x4*)(gh + 64 + 8 * q) = v1; *(f32x4*)(gh + 128 + 8 * q) = v3;
-                        }
-                    }
-                    // dU^T += W_ih^T dgi^T ; dh_prev^T += W_hh^T dgh^T   (k = the 32 hidden units of this g-tile)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        xs_mm_tr_tile(Wih, 32 * gt, 32 * ct, ar, dU[ct], l31, hh);
-                        xs_mm_tr_tile(Wih, 64 + 32 * gt, 32 * ct, az, dU[ct], l31, hh);
-                        xs_mm_tr_tile(Wih, 128 + 32 * gt, 32 * ct, ain, dU[ct], l31, hh);
-                        xs_mm_tr_tile(Whh, 32 * gt, 32 * ct, ar, dhp[ct], l31, hh);
-                        xs_mm_tr_tile(Whh, 64 + 32 * gt, 32 * ct, az, dhp[ct], l31, hh);
-                        xs_mm_tr_tile(Whh, 128 + 32 * gt, 32 * ct, ahn, dhp[ct], l31, hh);
-                    }
-                }
+                xs_gru_bwd_tile(a, Wih, Whh, bias, h, U, dsn + (long)ti * 32 * 64, 0.f, bias, dU, dhp, row, iok, l31, hh);
             }
             if (tt == 0) XSB_STAMP();
             if (!iok) {   // padded slots carry nothing
@@ -353,54 +414,378 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
         for (int e = 0; e < 16; ++e) dst[(32 * jt + mfma32_row(e, lane)) * XS_LD + 32 * ct + l31] = acc[e] * sc;
     }
     XSB_STAMP();
-    // ================= to_k MLP backward: dZ_{L-1} = dK ; dH_{l-1} = dZ_l W_l ; dZ_{l-1} = dH_{l-1} * (H_{l-1} > 0)
-    float* dZin = dZa;
-    float* dZout = dZb;
-    for (int l = a.L - 1; l >= 0; --l) {
-        __syncthreads();
-        xs_load_mat(Wt, a.tok_w[l], XS_D, tid, 256);
-        for (int c = tid; c < N * 16; c += 256) {           // dZ_l -> global (operand of the to_k weight-gradient GEMM)
-            const int r = c >> 4, q = c & 15;
-            *(f32x4*)(a.dZ + (((long)l * a.B + b) * N + r) * XS_D + q * 4) = *(const f32x4*)(dZin + r * XS_LD + q * 4);
-        }
-        __syncthreads();
-        for (int tile = wave; tile < NJT * 2; tile += 4) {
-            const int jt = tile >> 1, ct = tile & 1;
-            f32x16 acc;
-            xs_zero(acc);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 av = *(const f32x4*)(dZin + (32 * jt + l31) * XS_LD + 32 * t + 8 * q + 4 * hh);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc = mfma32(av[e], Wt[(32 * t + 8 * q + 4 * hh + e) * XS_LD + 32 * ct + l31], acc);
-                }
-            const int c = 32 * ct + l31;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int j = 32 * jt + mfma32_row(e, lane);
-                float v = acc[e];
-                if (l > 0) {
-                    const float hv = j < N ? a.Hsave[(((long)l * a.B + b) * N + j) * XS_D + c] : 0.f;   // H_l = input of layer l
-                    dZout[j * XS_LD + c] = hv > 0.f ? v : 0.f;
-                } else if (j < N) {
-                    a.dX[((long)b * N + j) * XS_D + c] = v + dXs[j * XS_LD + c];
-                }
-            }
-        }
-        float* tmp = dZin; dZin = dZout; dZout = tmp;
-    }
+    xs_mlp_bwd<NJT>(a, dZa, dZb, dXs, Wt, tid, wave, lane, l31, hh, b);
     XSB_STAMP();
 }
 
-static size_t xs_bwd_lds_bytes(int NJT) { return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 16) + 32 + 1024) * sizeof(float); }
+// ---- variant B (N <= 64): no scratch, one barrier per iteration.
+//  * the slot-index contractions run inside the loop: each wave bounces its tiles through a private 32x36 LDS
+//    buffer to get them with the slot index on the MFMA k axis, and keeps its partial dK / dX^a sums in registers
+//    (reduced over the four waves in a fixed order at the end);
+//  * the two workgroup-wide scalars do not need their own barriers: tau_t depends on the saved slot states only, so
+//    it is computed one iteration ahead; c0_t enters dD_t, ds_t and dK linearly (dD = dD' + c0), so the wave works
+//    with dD' and the c0 terms are added where the values are next read:
+//        ds_t = ds'_t + d^-1/2 c0_t colsum(K),      dK += d^-1/2 c0_t (1 (x) colsum(s_t)).
+#define XS_LDB 36           // row stride of the transpose buffer (floats): 16B rows, conflict-free b128 reads
+
+// t^T: the register tile [row(e,hh)][i = l31] comes back as 16 values per lane, lane (l31, hh) holding
+// [row = l31][i = 16 hh + r], r = 0..15 -- the operand order of the contraction MFMAs (k-step r <-> i = 16 hh + r)
+__device__ __forceinline__ void xs_transpose_tile(float* __restrict__ buf, const f32x16& v, f32x16& out, int l31, int hh) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) buf[xs_kidx(0, e, hh) * XS_LDB + l31] = v[e];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 x = *(const f32x4*)(buf + l31 * XS_LDB + 16 * hh + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[4 * q + e] = x[e];
+    }
+}
+
+template <int NJT>
+__global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
+    constexpr int NP = 32 * NJT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bias = lds;                          // [256] br | bz | b_in | b_hn
+    double* ksum = (double*)(bias + 256);       // [64] column sums of K (fp64)
+    double* red64 = ksum + 64;                  // [2][16] tau partials, double-buffered over the iterations
+    float* redc = (float*)(red64 + 32);         // [2][16] c0 partials
+    float* ksumf = redc + 32;                   // [64] colsum(K) in fp32
+    float* spart = ksumf + 64;                  // [2][4][64] colsum(s_t) of each wave's tiles, double-buffered
+    float* corr = spart + 512;                  // [64] sum_t c0_t colsum(s_t): the c0 terms of dK
+    float* Xs = corr + 64;
+    float* Ks = Xs + NP * XS_LD;
+    float* Wih = Ks + NP * XS_LD;
+    float* Whh = Wih + 192 * XS_LD;
+    float* bounce = Whh + 192 * XS_LD;          // [4][32][XS_LDB] per-wave transpose buffers
+    // after the loop the pool is re-used: wave-reduction buffer = dK | dX^a, then the MLP buffers
+    float* dZa = Xs;                            // [NP][68]
+    float* dXs = dZa + NP * XS_LD;              // [NP][68]
+    float* dZb = dXs + NP * XS_LD;              // [NP][68]
+    float* Wt = dZb + NP * XS_LD;               // [64][68]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x, N = a.N, S = a.S, T = a.T;
+    const int ntiles = (S + 31) >> 5, Sp = ntiles * 32, TPW = (ntiles + 3) >> 2;
+    const float scale = 0.125f, inv_d = 1.f / XS_D;
+    int nstamp = 0;
+    (void)nstamp;
+    XSB_STAMP();
+    float* dsn = a.ws + (long)b * Sp * 64;      // ds'_t of this image: [Sp][64], handed from iteration to iteration
+    float* tbuf = bounce + wave * (32 * XS_LDB);
+    auto state_t = [&](int t) { return t == 0 ? a.slots0 : a.states + ((long)(t - 1) * a.B + b) * S * XS_D; };
+
+    // ---- stage X, K, GRU weights; column sums of K and of the slot states
+    for (int c = tid; c < NP * 16; c += 256) {
+        const int r = c >> 4, q = c & 15;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f}, k = x;
+        if (r < N) {
+            x = *(const f32x4*)(a.X + ((long)b * N + r) * XS_D + q * 4);
+            k = *(const f32x4*)(a.Ksave + ((long)b * N + r) * XS_D + q * 4);
+        }
+        *(f32x4*)(Xs + r * XS_LD + q * 4) = x;
+        *(f32x4*)(Ks + r * XS_LD + q * 4) = k;
+    }
+    xs_load_mat_c<192, 256>(Wih, a.w_ih, tid);
+    xs_load_mat_c<192, 256>(Whh, a.w_hh, tid);
+    {
+        const int g = tid & 63, k = tid >> 6;
+        bias[tid] = k == 0 ? a.b_ih[g] + a.b_hh[g] : k == 1 ? a.b_ih[64 + g] + a.b_hh[64 + g]
+                  : k == 2 ? a.b_ih[128 + g] : a.b_hh[128 + g];
+    }
+    const float g_area = a.g_area_sum ? a.g_area_sum[0] : 0.f;
+    __syncthreads();
+    XSB_STAMP();
+    xs_colsum_f64(Ks, NP, ksum, tid);
+    if (tid < 64) ksumf[tid] = (float)ksum[tid];
+    __syncthreads();                            // ksum is read by every wave below
+    XSB_STAMP();
+
+    // r_i of the wave's tiles for iteration `it` (registers; every tile belongs to one wave throughout) and the
+    // tile partials of tau into red64[buf]
+    // ... and colsum(s_t) over the wave's tiles into spart[buf][wave] (the c0 term of dK needs it)
+    float rcur[4] = {0.f, 0.f, 0.f, 0.f};
+    auto phase_a = [&](int it, int buf) {
+        const float* sbase = state_t(it);
+        f32x16 hs[2], h[4][2];
+        xs_zero(hs[0]); xs_zero(hs[1]);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)          // per-lane predicates, no branch: the tiles are in flight together
+            xs_load_tile<2>(sbase + (long)(wave + 4 * tt) * 32 * XS_D, XS_D, h[tt], l31, hh, (wave + 4 * tt) * 32 + l31 < S);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int ti = wave + 4 * tt;
+            if (ti < ntiles) {
+                const double r64 = xs_rowdot_f64(h[tt], ksum, hh) * (double)scale;   // same fp64 normaliser as the forward
+                rcur[tt] = (float)r64;
+                const double tr = xs_tilesum_f64(r64);
+                if (lane == 0) red64[buf * 16 + ti] = tr;
+                hs[0] += h[tt][0]; hs[1] += h[tt][1];
+            }
+        }
+        // sum over the slots (lanes): bounce the two tiles through the wave's transpose buffer -- lane (c, hh) gets
+        // the 16 slots of its half in registers -- then add the halves
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 hT;
+            xs_transpose_tile(tbuf, hs[t], hT, l31, hh);
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v += hT[e];
+            v = xs_halfsum(v);
+            if (hh == 0) spart[(buf * 4 + wave) * 64 + 32 * t + l31] = v;
+        }
+    };
+    phase_a(T - 1, 0);
+    __syncthreads();
+    XSB_STAMP();
+
+    // this wave's share of dK' and dX^a (rows = tokens, cols = channels): 8 NJT x 16 registers that live in a
+    // wave-private, lane-contiguous global buffer between two contractions (re-read while the dA / ds' GEMMs of the
+    // next tile run) -- kept in registers throughout they push the GRU section over the 512-register budget
+    f32x4* accpark = (f32x4*)(a.ws + (long)a.B * Sp * 64) + ((long)b * 4 + wave) * (4 * NJT * 4 * 64) + lane;
+    bool have_acc = false;
+
+    int pb = 0;
+    float ssum_c = 0.f, corr_c = 0.f;
+    for (int it = T - 1; it >= 0; --it) {
+        const bool last = it == T - 1;
+        const float* sbase = state_t(it);
+        double tau64 = 0.0;
+        for (int k = 0; k < ntiles; ++k) tau64 += red64[pb * 16 + k];
+        const float tau = (float)tau64;
+        float cs_prev = 0.f;                    // d^-1/2 c0_{it+1}: completes the ds' handed over by that iteration
+        if (!last) {
+            float c0 = 0.f;
+            for (int k = 0; k < ntiles; ++k) c0 += redc[pb * 16 + k];
+            corr_c += c0 * ssum_c;              // (threads 0..63: channel tid) c0_{it+1} colsum(s_{it+1})
+            cs_prev = c0 * scale;
+        }
+        if (tid < 64)
+            ssum_c = (spart[(pb * 4 + 0) * 64 + tid] + spart[(pb * 4 + 1) * 64 + tid]) +
+                     (spart[(pb * 4 + 2) * 64 + tid] + spart[(pb * 4 + 3) * 64 + tid]);
+        XSB_STAMP();
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int ti = wave + 4 * tt;
+            if (ti >= ntiles) continue;
+            const int i = ti * 32 + l31;
+            const bool iok = i < S;
+            f32x16 h[2], A[NJT], D[NJT], U[2], dU[2], dhp[2];
+            xs_load_tile<2>(sbase + (long)ti * 32 * XS_D, XS_D, h, l31, hh, iok);
+            const float r = tt == 0 ? rcur[0] : tt == 1 ? rcur[1] : tt == 2 ? rcur[2] : rcur[3];
+            const float ir = xs_recip(r);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {          // D, A = sigmoid(D / r * tau)
+                xs_zero(D[jt]);
+                xs_mm_kc(Ks, 32 * jt, h, D[jt], l31, hh);
+                D[jt] *= scale;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = xs_sigmoid(xs_div(D[jt][e], r, ir) * tau);
+                    A[jt][e] = (iok && xs_kidx(jt, e, hh) < N) ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                xs_zero(U[ct]);
+                xs_mm_tr<NJT>(Xs, 32 * ct, A, U[ct], l31, hh);
+                U[ct] *= inv_d;
+                xs_zero(dhp[ct]);
+            }
+            if (tt == 0) XSB_STAMP();
+            if (last) {
+                const float du = iok ? a.loss_status * a.dlogits[(long)b * a.C + i / a.spc] : 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dU[ct][e] = du;
+            } else {
+                xs_zero(dU[0]); xs_zero(dU[1]);
+                const long row = ((long)it * a.B + b) * S + i;
+                xs_gru_bwd_tile(a, Wih, Whh, bias, h, U, dsn + (long)ti * 32 * 64, iok ? cs_prev : 0.f, ksumf, dU, dhp, row,
+                                iok, l31, hh);
+            }
+            if (tt == 0) XSB_STAMP();
+            if (!iok) {   // padded slots carry nothing
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) { xs_zero(dU[ct]); xs_zero(dhp[ct]); }
+            }
+            f32x16 accK[NJT][2], accX[NJT][2];
+            auto acc_load = [&](f32x16 (&acc)[NJT][2], int base) {
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        xs_zero(acc[jt][ct]);
+                        if (have_acc) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = accpark[((base + jt * 2 + ct) * 4 + q) * 64];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[jt][ct][4 * q + e] = v[e];
+                            }
+                        }
+                    }
+            };
+            auto acc_store = [&](const f32x16 (&acc)[NJT][2], int base) {
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[jt][ct][4 * q + e];
+                            accpark[((base + jt * 2 + ct) * 4 + q) * 64] = v;
+                        }
+            };
+            acc_load(accK, 0);
+            // dA^T = X dU^T / d (+ area term), G = dA * A (1 - A), g_i = sum_j G_ij D_ij ; G replaces D
+            float gsum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                f32x16 dA;
+                xs_zero(dA);
+                xs_mm_kc(Xs, 32 * jt, dU, dA, l31, hh);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float av = A[jt][e];
+                    float v = dA[e] * inv_d + (last ? g_area : 0.f);
+                    v = (iok && xs_kidx(jt, e, hh) < N) ? v * av * (1.f - av) : 0.f;
+                    gsum += v * D[jt][e];
+                    D[jt][e] = v;
+                }
+            }
+            gsum = xs_halfsum(gsum);
+            const float tc = xs_tilesum(iok ? gsum / r : 0.f);
+            if (lane == 0) redc[(pb ^ 1) * 16 + ti] = tc;
+            // dD' = G tau / r - g tau / r^2  (the + c0 is added by the readers), ds' = d^-1/2 dD' K + dh_prev
+            const float k1 = tau / r, k2 = gsum * tau / (r * r);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    D[jt][e] = (iok && xs_kidx(jt, e, hh) < N) ? D[jt][e] * k1 - k2 : 0.f;
+            {
+                f32x16 ds[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    xs_zero(ds[ct]);
+                    xs_mm_tr<NJT>(Ks, 32 * ct, D, ds[ct], l31, hh);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ds[ct][e] = iok ? ds[ct][e] * scale + dhp[ct][e] : 0.f;
+                }
+                xs_store_tile<2>(dsn + (long)ti * 32 * 64, 64, ds, l31, hh);
+            }
+            if (tt == 0) XSB_STAMP();
+            acc_load(accX, 2 * NJT);            // in flight while dK' is contracted
+            // contractions over the slots of this tile:  dK'[j][c] += dD'[i][j] s[i][c],  dX^a[j][c] += A[i][j] dU[i][c]
+            {
+                f32x16 qT[2], pT;
+                xs_transpose_tile(tbuf, h[0], qT[0], l31, hh);
+                xs_transpose_tile(tbuf, h[1], qT[1], l31, hh);
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    xs_transpose_tile(tbuf, D[jt], pT, l31, hh);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r16 = 0; r16 < 16; ++r16) accK[jt][ct] = mfma32(pT[r16], qT[ct][r16], accK[jt][ct]);
+                    XS_REGION_END();
+                }
+                acc_store(accK, 0);
+                xs_transpose_tile(tbuf, dU[0], qT[0], l31, hh);
+                xs_transpose_tile(tbuf, dU[1], qT[1], l31, hh);
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    xs_transpose_tile(tbuf, A[jt], pT, l31, hh);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r16 = 0; r16 < 16; ++r16) accX[jt][ct] = mfma32(pT[r16], qT[ct][r16], accX[jt][ct]);
+                    XS_REGION_END();
+                }
+            }
+            acc_store(accX, 2 * NJT);
+            have_acc = true;
+            if (tt == 0) XSB_STAMP();
+        }
+        if (it > 0) phase_a(it - 1, pb ^ 1);
+        xs_lds_barrier();        // LDS hand-off only: pending global stores keep flying
+        pb ^= 1;
+        XSB_STAMP();
+    }
+    // c0 of iteration 0 completes ds_0 (the gradient of the initial slots); same lanes re-read their ds' tiles
+    float c00 = 0.f;
+    for (int k = 0; k < ntiles; ++k) c00 += redc[pb * 16 + k];
+    if (tid < 64) corr[tid] = (corr_c + c00 * ssum_c) * scale;
+    {
+        f32x16 ds[4][2];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)          // (tiles beyond the wave's last one re-read tile 0: no branch, the
+            xs_load_tile<2>(dsn + (long)(wave + 4 * tt < ntiles ? wave + 4 * tt : 0) * 32 * 64, 64, ds[tt], l31, hh,
+                            true);              //  loads of all tiles are in flight together)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int ti = wave + 4 * tt;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 kq = *(const f32x4*)(ksumf + 32 * ct + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ds[tt][ct][4 * q + e] += c00 * scale * kq[e];
+                }
+            if (ti < ntiles && ti * 32 + l31 < S)
+                xs_store_tile<2>(a.ds0 + ((long)b * S + ti * 32) * XS_D, XS_D, ds[tt], l31, hh);
+        }
+    }
+    XSB_STAMP();
+    // ---- dK' and dX^a: sum the four waves' parks (fixed order) into the LDS pool
+    __threadfence_block();
+    __syncthreads();
+    {
+        const f32x4* parks = (const f32x4*)(a.ws + (long)a.B * Sp * 64) + (long)b * 4 * (4 * NJT * 4 * 64);
+#pragma unroll
+        for (int u = 0; u < NJT * 4; ++u) {                 // item = (tile, q): 4 NJT tiles x 4 quads = 256 * NJT * 4 / 64
+            const int item = u * 4 + wave;                  // every wave takes whole (tile, q) rows: lanes stay lanes
+            const int tile = item >> 2, q = item & 3;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {                   // (a wave without tiles never wrote its park: wave 0's is
+                const bool has = w < ntiles;                //  read instead and dropped -- no branch between the loads)
+                const f32x4 x = parks[(long)(has ? w : 0) * (4 * NJT * 4 * 64) + (tile * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += has ? x[e] : 0.f;
+            }
+            const int prod = tile / (2 * NJT), jt = (tile >> 1) % NJT, ct = tile & 1;
+            float* dst = prod == 0 ? dZa : dXs;
+            const float sc = prod == 0 ? scale : inv_d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dst[(32 * jt + mfma32_row(4 * q + e, lane)) * XS_LD + 32 * ct + l31] = v[e] * sc;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < N * 64; idx += 256) {         // the c0 terms of dK
+        dZa[(idx >> 6) * XS_LD + (idx & 63)] += corr[idx & 63];
+    }
+    XSB_STAMP();
+    xs_mlp_bwd<NJT>(a, dZa, dZb, dXs, Wt, tid, wave, lane, l31, hh, b);
+    XSB_STAMP();
+}
+
+static size_t xs_bwd_lds_bytes(int NJT) {
+    if (NJT > 2) return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 16) + 32 + 1024) * sizeof(float);
+    return (size_t)(256 + 2 * 64 + 2 * 32 + 32 + 64 + 512 + 64 + 2 * 32 * NJT * XS_LD + 384 * XS_LD + 4 * 32 * XS_LDB) *
+           sizeof(float);
+}
 
 extern "C" size_t scouter_xslot_bwd_workspace_bytes(int B, int N, int d, int S, int T) {
     (void)d;
     const long Sp = (S + 31) / 32 * 32, NP = (N + 31) / 32 * 32;
-    return (size_t)B * Sp * (64 + (long)T * (2 * NP + 64)) * sizeof(float);
+    if (NP <= 64) return (size_t)B * (Sp * 64 + 4 * (NP / 32) * 4 * 16 * 64) * sizeof(float);     // ds' hand-off + accumulator parks
+    return (size_t)B * Sp * (64 + (long)T * (2 * NP + 64)) * sizeof(float);    // + A_t, dD_t, dU_t of every iteration
 }
 
 extern "C" int scouter_xslot_bwd_f32(const float* X, const float* PE, const float* const* tok_w, const float* slots0,
@@ -432,15 +817,15 @@ extern "C" int scouter_xslot_bwd_f32(const float* X, const float* PE, const floa
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * (double)B * (2.0 * L * N * d * d + (double)T * 4.0 * S * N * d + (T - 1) * 12.0 * S * d * d);
     ScProfScope prof("xslot_bwd", st, flops, 4.0 * B * (3.0 * N * d + (double)S * d));
-#define XSB_LAUNCH(NJT_)                                                                                   \
+#define XSB_LAUNCH(KERN)                                                                                   \
     do {                                                                                                   \
-        auto kern = xslot_bwd_kernel<NJT_>;                                                                \
+        auto kern = KERN;                                                                                  \
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, a);                                          \
     } while (0)
-    if (NJT == 1) XSB_LAUNCH(1);
-    else if (NJT == 2) XSB_LAUNCH(2);
-    else XSB_LAUNCH(3);
+    if (NJT == 1) XSB_LAUNCH(xslot_bwd_kernel<1>);
+    else if (NJT == 2) XSB_LAUNCH(xslot_bwd_kernel<2>);
+    else XSB_LAUNCH(xslot_bwd_scratch_kernel<3>);
 #undef XSB_LAUNCH
     return sc_check_launch("xslot_bwd");
 }

@@ -204,3 +204,20 @@ __device__ __forceinline__ void xs_load_mat(float* __restrict__ dst, const float
         *(f32x4*)(dst + r * XS_LD + q * 4) = *(const f32x4*)(src + r * XS_D + q * 4);
     }
 }
+// the same with a compile-time shape: every 16-byte load of the thread is in flight before the first LDS store (the
+// loop above leaves one load per round trip -- 12 round trips for a GRU weight matrix)
+template <int ROWS, int NTHR>
+__device__ __forceinline__ void xs_load_mat_c(float* __restrict__ dst, const float* __restrict__ src, int tid) {
+    constexpr int IT = (ROWS * 16 + NTHR - 1) / NTHR;
+    f32x4 v[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int c = tid + k * NTHR;
+        if (ROWS * 16 % NTHR == 0 || c < ROWS * 16) v[k] = *(const f32x4*)(src + (c >> 4) * XS_D + (c & 15) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int c = tid + k * NTHR;
+        if (ROWS * 16 % NTHR == 0 || c < ROWS * 16) *(f32x4*)(dst + (c >> 4) * XS_LD + (c & 15) * 4) = v[k];
+    }
+}
