@@ -83,26 +83,38 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
     fn = lambda: K.xslot_fwd(X, PE, tw, tb, s0, wih, whh, bih, bhh, spc, iters, 1)
     L = _native.lib()
     buf = ctypes.create_string_buffer(1 << 14)
-    for _ in range(60):
-        fn()
-    torch.cuda.synchronize()
-    L.scouter_prof_collect(buf, len(buf))
-    times = []
-    for _ in range(8):
-        L.scouter_prof_enable(1)
-        for _ in range(20):
+
+    def median_launch(fn, kernel):
+        for _ in range(60):
             fn()
         torch.cuda.synchronize()
-        L.scouter_prof_enable(0)
         L.scouter_prof_collect(buf, len(buf))
-        for row in buf.value.decode().splitlines():
-            name, n, ms = row.split("\t")[:3]
-            if name == "xslot_fwd":
-                times.append(float(ms) / float(n) * 1e-3)
-    t = sorted(times)[len(times) // 2]
+        times = []
+        for _ in range(8):
+            L.scouter_prof_enable(1)
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            L.scouter_prof_enable(0)
+            L.scouter_prof_collect(buf, len(buf))
+            for row in buf.value.decode().splitlines():
+                name, n, ms = row.split("\t")[:3]
+                if name == kernel:
+                    times.append(float(ms) / float(n) * 1e-3)
+        return sorted(times)[len(times) // 2]
+
+    t = median_launch(fn, "xslot_fwd")
     qk = 2.0 * slots * tokens * d
     fl = batch * (2.0 * layers * tokens * d * d + iters * 2 * qk + (iters - 1) * 12.0 * slots * d * d)
-    return {"kernel": "xslot_fwd_kernel (to_k MLP + 3 x [QK^T, sigmoid, AV, GRU] fused, v_mfma_f32_32x32x2_f32)",
+    saved = fn()
+    dlog, g_area = r(batch, slots // spc), torch.full((1,), 1e-3, device=device)
+    tb_ = median_launch(lambda: K.xslot_bwd(X, PE, tw, s0, wih, whh, bih, bhh, saved, dlog, g_area, spc, iters, 1),
+                        "xslot_bwd")
+    backward = {"kernel": "xslot_bwd_kernel (per-iteration forward recomputation + GRU / normaliser / attention backward + "
+                          "slot-index contractions + to_k MLP backward, fused)", "avg_launch_us": round(tb_ * 1e6, 1),
+                "flop_model": "3 x forward (recomputation + two GEMMs per forward GEMM)",
+                "achieved": round(3 * fl / tb_ / 1e12, 2), "frac": round(3 * fl / tb_ / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    return {"backward": backward, "kernel": "xslot_fwd_kernel (to_k MLP + 3 x [QK^T, sigmoid, AV, GRU] fused, v_mfma_f32_32x32x2_f32)",
             "batch": batch, "slots": slots, "tokens": tokens, "avg_launch_us": round(t * 1e6, 1),
             "achieved": round(fl / t / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "bound": "mfma",
@@ -220,7 +232,7 @@ def main():
         L.scouter_prof_enable(0)
         L.scouter_prof_collect(prof_buf, len(prof_buf))
         Kmod.SIDE_STREAM_ENABLED = True
-    loss_val = float(losses[0])
+    loss_val = float(losses[0].detach())
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
