@@ -132,6 +132,68 @@ def test_xslot_large_batch_properties():
     np.testing.assert_allclose(o1["area_part"].cpu().double().numpy(), A.double().sum((1, 2)).cpu().numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,S,N,T,L,spc", [(2, 512, 64, 8, 2, 1),      # S, T at the kernel limits, 16 slot tiles
+                                            (2, 512, 96, 3, 8, 2),      # N, L at the limits (scratch variant)
+                                            (3, 33, 20, 1, 1, 3),       # a single iteration (no GRU), ragged tiles
+                                            (1, 96, 32, 2, 1, 1)])      # one image, N = one token tile exactly
+def test_xslot_kernels_at_their_limits_match_the_oracle(B, S, N, T, L, spc):
+    """The fused forward / backward kernels straight through the C ABI at the supported maxima (S <= 512 slots, N <= 96
+    tokens, T <= 8 iterations, L <= 8 to_k layers) and at degenerate sizes, against the fp64 oracle and its autograd.
+    Yardstick as everywhere for many-slot heads: what plain fp32 PyTorch loses on the same inputs."""
+    from scouter_amd import kernels as Kk
+    d, C = 64, S // spc
+    g = torch.Generator().manual_seed(S * 7 + N)
+    r = lambda *sh: torch.randn(*sh, generator=g)
+    P = {"slot.initial_slots": (r(1, S, d).abs() * 0.5), "slot.gru.weight_ih_l0": r(3 * d, d) * 0.1,
+         "slot.gru.weight_hh_l0": r(3 * d, d) * 0.1, "slot.gru.bias_ih_l0": r(3 * d) * 0.1,
+         "slot.gru.bias_hh_l0": r(3 * d) * 0.1}
+    for l in range(L):
+        P["slot.to_k.%d.weight" % (2 * l)] = r(d, d) * (0.2 if L > 2 else 0.1)
+        P["slot.to_k.%d.bias" % (2 * l)] = r(d) * 0.1
+    X, PE = r(B, N, d).relu(), r(N, d) * 0.3
+    wl, ga = r(B, C), 0.01
+
+    def oracle(dtype):
+        Q = {k: v.to(dtype).clone().requires_grad_(True) for k, v in P.items()}
+        x = X.to(dtype).clone().requires_grad_(True)
+        aux = {}
+        lg, _ = O.xslot_forward(Q, x + PE.to(dtype), x, C, spc, 1, 1, iters=T, aux=aux)
+        ((lg * wl.to(dtype)).sum() + ga * aux["attn"].sum()).backward()
+        return lg.detach(), aux["attn"].detach(), x.grad, Q
+
+    lg64, at64, gx64, Q64 = oracle(torch.float64)
+    lg32, at32, gx32, Q32 = oracle(torch.float32)
+    floor = float((lg32.double() - lg64).abs().max())
+    tol = max(1e-4, 3 * floor)
+    dev = torch.device("cuda")
+    cu = lambda t: t.float().contiguous().to(dev)
+    tw = [cu(P["slot.to_k.%d.weight" % (2 * l)]) for l in range(L)]
+    tb = [cu(P["slot.to_k.%d.bias" % (2 * l)]) for l in range(L)]
+    gru = [cu(P["slot.gru." + n]) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    s0 = cu(P["slot.initial_slots"][0])
+    fwd = Kk.xslot_fwd(cu(X), cu(PE), tw, tb, s0, *gru, spc, T, 1)
+    np.testing.assert_allclose(fwd["logits"].cpu().numpy(), lg64.numpy(), atol=tol, rtol=1e-4)
+    np.testing.assert_allclose(fwd["attn"].cpu().numpy(), at64.numpy(), atol=max(tol, 1e-4), rtol=0)
+    bwd = Kk.xslot_bwd(cu(X), cu(PE), tw, s0, *gru, fwd, cu(wl), torch.full((1,), ga, device=dev), spc, T, 1)
+    torch.cuda.synchronize()
+
+    def close(mine, ref, ref32, name):
+        sc = float(ref.abs().max())
+        noise = float((ref32.double() - ref).abs().max())                      # fp32 autograd's own deviation
+        assert float((mine.cpu().double() - ref).abs().max()) <= 3e-3 * sc + 3 * noise + 1e-6, name
+
+    close(bwd["dX"], gx64, gx32, "dX")
+    close(bwd["ds0"].sum(0), Q64["slot.initial_slots"].grad[0], Q32["slot.initial_slots"].grad[0], "d initial_slots")
+    if T > 1:       # GRU weight gradients are GEMMs over the rows the kernel emits: dW_ih = dgi^T U, db_ih = colsum(dgi)
+        dgi, U = bwd["dgi"].double().cpu().reshape(-1, 3 * d), bwd["U"].double().cpu().reshape(-1, d)
+        close(dgi.t() @ U, Q64["slot.gru.weight_ih_l0"].grad, Q32["slot.gru.weight_ih_l0"].grad, "dW_ih")
+        close(bwd["dgh"].double().cpu().reshape(-1, 3 * d).sum(0), Q64["slot.gru.bias_hh_l0"].grad,
+              Q32["slot.gru.bias_hh_l0"].grad, "db_hh")
+    # first to_k layer: dW_0 = dZ_0^T (X + PE), db_0 = colsum(dZ_0)
+    dz0 = bwd["dZ"][0].double().cpu().reshape(-1, d)
+    close(dz0.t() @ (X + PE).double().reshape(-1, d), Q64["slot.to_k.0.weight"].grad, Q32["slot.to_k.0.weight"].grad, "dW_to_k0")
+
+
 @pytest.mark.parametrize("B,S,N,T", [(3, 300, 49, 3), (2, 64, 49, 2), (3, 160, 25, 3), (2, 96, 81, 3)])
 def test_xslot_backward_is_reproducible_and_ignores_stale_workspace(B, S, N, T):
     """Several slot tiles per image (S > 32: the four waves of a workgroup exchange tau / c0 / partial sums): launches
