@@ -118,3 +118,45 @@ def test_xslot_forward_is_reproducible():
             o = K.xslot_fwd(X, PE, tw, tb, s0, *gru, 1, T, 1)
             return o["logits"], o["attn"], o["area_part"], o["K"], o["H"], o["states"]
         _repeat(fwd, dev)
+
+
+@pytest.mark.parametrize("arch,chan,img", [("resnest26d", 2048, 96), ("resnet18", 512, 64)])
+def test_whole_training_steps_are_reproducible(arch, chan, img):
+    """Four optimizer steps (forward, loss, backward with the weight gradients on the side stream, fused AdamW) from the
+    same seed, twice, with differently poisoned allocator / workspace contents: every parameter, BatchNorm buffer and
+    loss value must be bit-identical -- the step has no cross-stream race and no dependence on stale memory."""
+    from scouter_amd.optim import FusedAdamW
+    from scouter_amd.sloter.slot_model import SlotModel
+    from scouter_amd.train import get_args_parser
+    dev = torch.device("cuda")
+
+    def run(fill):
+        args = get_args_parser().parse_args(["--dataset", "ImageNet", "--model", arch, "--channel", str(chan), "--img_size",
+                                             str(img), "--num_classes", "6", "--slots_per_class", "2", "--pre_trained",
+                                             "false", "--lambda_value", "1"])
+        for name, typ in (("num_classes", int), ("lambda_value", float), ("power", int), ("slots_per_class", int)):
+            setattr(args, name, typ(getattr(args, name)))
+        torch.manual_seed(11)
+        model = SlotModel(args).cuda().train()
+        opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+        g = torch.Generator().manual_seed(5)
+        losses = []
+        for it in range(4):
+            x = torch.randn(6, 3, img, img, generator=g).cuda()
+            y = torch.randint(0, 6, (6,), generator=g).cuda()
+            _poison(fill if it % 2 == 0 else -fill, dev)
+            opt.zero_grad()
+            out, ls = model(x, y)
+            ls[0].backward()
+            opt.step()
+            losses.append(ls[0].detach().clone())
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in model.state_dict().items()}, torch.stack(losses)
+
+    sd0, l0 = run(0.0)
+    sd1, l1 = run(float("nan"))
+    sd2, l2 = run(1.0e30)
+    assert torch.isfinite(l0).all()
+    assert torch.equal(l0, l1) and torch.equal(l0, l2), (l0, l1, l2)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]) and torch.equal(sd0[k], sd2[k]), k
