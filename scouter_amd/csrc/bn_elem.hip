@@ -412,6 +412,57 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     }
 }
 
+// Backward gathers for stride 1 / 2 (every pool of the three backbones): one workgroup row per input pixel row
+// (blockIdx.y = b * H + iy: scalar), threads along (ix, channel quad), the contributing output windows enumerated
+// directly -- oy in [ceil((iy + pad - k + 1) / S), floor((iy + pad) / S)] -- instead of testing k x k taps with a
+// modulo and a division each.  The generic kernels above spent ~900 VALU instructions per 16-byte result on 64-bit
+// index arithmetic, tap tests and 16 divisions (3.0 TB/s); these are memory-bound.  avg: dy * (1 / divisor), the
+// reciprocal taken once per window (within 1 ulp of PyTorch's dy / divisor).
+template <int S, bool MAXP>
+__global__ __launch_bounds__(256) void pool_bwd_rows_kernel(const float* __restrict__ dy,
+                                                            const unsigned char* __restrict__ arg,
+                                                            float* __restrict__ dx, PoolGeom g, float inv_c4n) {
+    const int c4n = g.C / 4;
+    const int xid = blockIdx.x * 256 + threadIdx.x;
+    if (xid >= g.W * c4n) return;
+    const int ix = (int)(((float)xid + 0.5f) * inv_c4n), cq = xid - ix * c4n;      // xid < 2^20: exact
+    const int row = blockIdx.y, b = row / g.H, iy = row - b * g.H;
+    const int ty = iy + g.pad, tx = ix + g.pad;
+    const int oy_hi = min(ty / S, g.Ho - 1), ox_hi = min(tx / S, g.Wo - 1);
+    const int oy_lo = max((ty - g.k + S) / S, 0), ox_lo = max((tx - g.k + S) / S, 0);    // ceil((t - k + 1) / S), t - k + S >= 0 or result clamps
+    f32x4 acc = {0, 0, 0, 0};
+    for (int oy = ty - g.k + S < 0 ? 0 : oy_lo; oy <= oy_hi; ++oy) {
+        const int ky = ty - oy * S;
+        for (int ox = tx - g.k + S < 0 ? 0 : ox_lo; ox <= ox_hi; ++ox) {
+            const int kx = tx - ox * S;
+            const long o = (((long)b * g.Ho + oy) * g.Wo + ox) * g.C + cq * 4;
+            const f32x4 d = *(const f32x4*)(dy + o);
+            if (MAXP) {
+                const uchar4 a = *(const uchar4*)(arg + o);
+                const int tap = ky * g.k + kx;
+                if (a.x == tap) acc[0] += d[0];
+                if (a.y == tap) acc[1] += d[1];
+                if (a.z == tap) acc[2] += d[2];
+                if (a.w == tap) acc[3] += d[3];
+            } else {
+                acc += d * (1.0f / avg_div(g, oy, ox));
+            }
+        }
+    }
+    *(f32x4*)(dx + ((long)row * g.W + ix) * g.C + cq * 4) = acc;
+}
+
+template <bool MAXP>
+static bool pool_bwd_rows(const float* dy, const unsigned char* arg, float* dx, const PoolGeom& g, hipStream_t st) {
+    const long xw = (long)g.W * (g.C / 4), rows = (long)g.B * g.H;
+    if ((g.stride != 1 && g.stride != 2) || xw >= (1 << 20) || rows > 65535) return false;
+    dim3 grid((unsigned)((xw + 255) / 256), (unsigned)rows);
+    const float inv = 1.0f / (float)(g.C / 4);
+    if (g.stride == 1) hipLaunchKernelGGL((pool_bwd_rows_kernel<1, MAXP>), grid, dim3(256), 0, st, dy, arg, dx, g, inv);
+    else hipLaunchKernelGGL((pool_bwd_rows_kernel<2, MAXP>), grid, dim3(256), 0, st, dy, arg, dx, g, inv);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // layout: NCHW <-> NHWC (32x32 LDS tile transpose of the [C][HW] plane of every image)
 // ---------------------------------------------------------------------------------------------------------------
@@ -553,6 +604,7 @@ extern "C" int scouter_maxpool_bwd_f32(const float* dy, const unsigned char* arg
                                        int C, int k, int stride, int pad, void* stream) {
     const int ceil_mode = 0, count_include_pad = 0;
     POOL_SETUP("maxpool_bwd")
+    if (pool_bwd_rows<true>(dy, argmax, dx, g, st)) return sc_check_launch("maxpool_bwd");
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)B * H * W * C / 4)), dim3(256), 0, st, dy, argmax, dx, g);
     return sc_check_launch("maxpool_bwd");
 }
@@ -565,6 +617,7 @@ extern "C" int scouter_avgpool_fwd_f32(const float* x, float* y, int B, int H, i
 extern "C" int scouter_avgpool_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, int k, int stride,
                                        int pad, int ceil_mode, int count_include_pad, void* stream) {
     POOL_SETUP("avgpool_bwd")
+    if (pool_bwd_rows<false>(dy, nullptr, dx, g, st)) return sc_check_launch("avgpool_bwd");
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks((long)B * H * W * C / 4)), dim3(256), 0, st, dy, dx, g);
     return sc_check_launch("avgpool_bwd");
 }
