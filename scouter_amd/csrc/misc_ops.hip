@@ -190,6 +190,34 @@ __global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restric
         col[i] = v;
     }
 }
+// The same, one workgroup row per output pixel row (blockIdx.y = b * Ho + oy) and one 16-byte store per thread: the
+// (ci, ky, kx) decomposition of the <= 64 patch columns is tabulated once per workgroup in LDS, the thread index only
+// needs one exact float-reciprocal division.  (The element-wise kernel above: five integer divisions, two of them
+// 64-bit, per 4-byte store -- ALU-bound at 1.6 TB/s.)
+__global__ __launch_bounds__(256) void im2col_nchw_rows_kernel(const float* __restrict__ x, float* __restrict__ col, int Cin,
+                                                               int H, int W, int Ho, int Wo, int k, int stride, int pad,
+                                                               int Kpad, float inv_q) {
+    __shared__ int tab[64];                       // kk -> ci | ky << 8 | kx << 16 | valid << 24
+    const int K = k * k * Cin;
+    if (threadIdx.x < 64) {
+        const int kk = threadIdx.x, ci = kk % Cin, tap = kk / Cin;
+        tab[kk] = kk < K ? (ci | (tap / k) << 8 | (tap % k) << 16 | 1 << 24) : 0;
+    }
+    __syncthreads();
+    const int qn = Kpad / 4;                      // float4 per output pixel
+    const int xid = blockIdx.x * 256 + threadIdx.x;
+    if (xid >= Wo * qn) return;
+    const int ox = (int)(((float)xid + 0.5f) * inv_q), q = xid - ox * qn;
+    const int row = blockIdx.y, b = row / Ho, oy = row - b * Ho;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int t = tab[4 * q + e];
+        const int iy = oy * stride - pad + ((t >> 8) & 0xff), ix = ox * stride - pad + ((t >> 16) & 0xff);
+        if ((t >> 24) && iy >= 0 && iy < H && ix >= 0 && ix < W) v[e] = x[(((long)b * Cin + (t & 0xff)) * H + iy) * W + ix];
+    }
+    *(f32x4*)(col + ((long)row * Wo + ox) * Kpad + 4 * q) = v;
+}
 // wpad[Kpad][Cout] = {w[K][Cout]; 0}
 __global__ void pad_rows_kernel(const float* __restrict__ w, float* __restrict__ wpad, long nvalid, long ntotal) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,6 +228,12 @@ extern "C" int scouter_im2col_nchw_f32(const float* x, float* col, int B, int Ci
     SC_REQUIRE(x && col && Kpad >= k * k * Cin && Kpad % 32 == 0, "im2col: bad arguments");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const long n = (long)B * Ho * Wo * Kpad;
+    const long xw = (long)Wo * (Kpad / 4), rows = (long)B * Ho;
+    if (Kpad <= 64 && Cin < 256 && k < 256 && xw < (1 << 20) && rows <= 65535) {
+        hipLaunchKernelGGL(im2col_nchw_rows_kernel, dim3((unsigned)((xw + 255) / 256), (unsigned)rows), dim3(256), 0,
+                           (hipStream_t)stream, x, col, Cin, H, W, Ho, Wo, k, stride, pad, Kpad, 1.0f / (float)(Kpad / 4));
+        return sc_check_launch("im2col");
+    }
     hipLaunchKernelGGL(im2col_nchw_kernel, dim3(ew_blocks(n) * 2), dim3(256), 0, (hipStream_t)stream, x, col, B, Cin, H, W, Ho, Wo, k, stride, pad, Kpad);
     return sc_check_launch("im2col");
 }
