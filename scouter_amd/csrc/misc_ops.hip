@@ -369,16 +369,32 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
                                                     float* __restrict__ m, float* __restrict__ v, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float rsqrt_bc2) {
     const AdamChunk ch = chunks[blockIdx.x];
-    const float step = lr / bc1;
-    for (int i = threadIdx.x; i < ch.n; i += 256) {
-        const float g = grads[ch.off + i];
-        float p = ch.p[i] * (1.f - lr * wd);
-        const float mi = b1 * m[ch.off + i] + (1.f - b1) * g;
-        const float vi = b2 * v[ch.off + i] + (1.f - b2) * g * g;
+    const float step = lr / bc1, decay = 1.f - lr * wd;
+    auto upd = [&](float g, float& p, float& mi, float& vi) {
+        p *= decay;
+        mi = b1 * mi + (1.f - b1) * g;
+        vi = b2 * vi + (1.f - b2) * g * g;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        p -= step * (mi / denom);
+    };
+    // 16-byte accesses where the chunk allows it (the arena offsets are 16-byte aligned by construction; parameters
+    // are whole torch allocations), scalar tail otherwise -- same arithmetic per element either way
+    const int n4 = (((size_t)ch.p & 15) == 0 && (ch.off & 3) == 0) ? ch.n / 4 : 0;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const f32x4 g = *(const f32x4*)(grads + ch.off + 4 * i);
+        f32x4 p = *(const f32x4*)(ch.p + 4 * i), mi = *(const f32x4*)(m + ch.off + 4 * i), vi = *(const f32x4*)(v + ch.off + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) upd(g[e], p[e], mi[e], vi[e]);
+        *(f32x4*)(m + ch.off + 4 * i) = mi;
+        *(f32x4*)(v + ch.off + 4 * i) = vi;
+        *(f32x4*)(ch.p + 4 * i) = p;
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < ch.n; i += 256) {
+        float p = ch.p[i], mi = m[ch.off + i], vi = v[ch.off + i];
+        upd(grads[ch.off + i], p, mi, vi);
         m[ch.off + i] = mi;
         v[ch.off + i] = vi;
-        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
-        ch.p[i] = p - step * (mi / denom);
+        ch.p[i] = p;
     }
 }
 extern "C" int scouter_adamw_step_f32(const void* chunk_table, int nchunks, const float* grads, float* exp_avg,

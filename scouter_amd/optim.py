@@ -14,7 +14,7 @@ from . import kernels as K
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    CHUNK = 65536
+    CHUNK = 16384       # elements per workgroup: ~1000 workgroups for resnest26d (16-byte accesses, 16 per thread)
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)

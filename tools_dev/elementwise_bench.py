@@ -24,3 +24,9 @@ for H, C in ((56, 128), (28, 256), (14, 512)):       # avd pools of layers 2-4 (
 img = torch.randn(B, 3, 224, 224, device='cuda')
 col = K.im2col_nchw(img, 3, 2, 1, 32)
 report("im2col_nchw 224^2 k3 s2 -> [M][32]", t_of(lambda: K.im2col_nchw(img, 3, 2, 1, 32)), 4 * (img.numel() + col.numel()))
+from scouter_amd.optim import FusedAdamW
+ps = [torch.nn.Parameter(torch.randn(n, device='cuda')) for n in [2048 * 512 * 2] * 6 + [512 * 512 * 9] * 2 + [65536] * 20 + [2048] * 60 + [64] * 100]
+for p_ in ps: p_.grad = torch.randn_like(p_)
+opt = FusedAdamW(ps, lr=1e-4)
+ntot = sum(p_.numel() for p_ in ps)
+report("fused AdamW, %.1f M parameters in %d tensors" % (ntot / 1e6, len(ps)), t_of(lambda: opt.step()), 4 * 7 * ntot)
