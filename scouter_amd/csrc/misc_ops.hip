@@ -384,7 +384,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
         const f32x4 g = *(const f32x4*)(grads + ch.off + 4 * i);
         f32x4 p = *(const f32x4*)(ch.p + 4 * i), mi = *(const f32x4*)(m + ch.off + 4 * i), vi = *(const f32x4*)(v + ch.off + 4 * i);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) upd(g[e], p[e], mi[e], vi[e]);
+        for (int e = 0; e < 4; ++e) {
+            float pe = p[e], me = mi[e], ve = vi[e];
+            upd(g[e], pe, me, ve);
+            p[e] = pe; mi[e] = me; vi[e] = ve;
+        }
         *(f32x4*)(m + ch.off + 4 * i) = mi;
         *(f32x4*)(v + ch.off + 4 * i) = vi;
         *(f32x4*)(ch.p + 4 * i) = p;
