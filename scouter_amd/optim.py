@@ -3,7 +3,11 @@ numerics (reference train.py:146: `torch.optim.AdamW(params, lr=args.lr)` -- bet
 weight_decay 1e-2; `args.weight_decay` is ignored by the reference and therefore here too).
 
 Gradients are read from the model's flat GradArena (param.grad are views of it); exp_avg / exp_avg_sq live in two
-flat arenas with the same offsets, so `step()` is a single launch over a chunk table."""
+flat arenas with the same offsets, so `step()` is a single launch over a chunk table.
+
+Deviation from torch semantics, by design: every backward of the HIP path OVERWRITES the gradient arena (it does not
+accumulate into .grad), so `zero_grad()` has nothing to clear and two backwards before one `step()` leave only the
+second gradient -- gradient accumulation is not part of the reference's loop (engine.py:29-35) and is not supported."""
 import ctypes
 import struct
 
@@ -51,13 +55,37 @@ class FusedAdamW(torch.optim.Optimizer):
             assert len(blob) == len(rows) * _native.lib().scouter_adamw_chunk_bytes()
             table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
             state = self.state.setdefault("_flat_%d" % len(plans), {})
-            if "exp_avg" not in state or state["exp_avg"].numel() != span or state["exp_avg"].device != dev:
+            if "exp_avg" in state and state["exp_avg"].numel() == span and state["exp_avg"].device != dev:
+                # restored from a checkpoint loaded with map_location="cpu": keep the moments, move them
+                state["exp_avg"] = state["exp_avg"].to(dev, torch.float32).contiguous()
+                state["exp_avg_sq"] = state["exp_avg_sq"].to(dev, torch.float32).contiguous()
+            if "exp_avg" not in state or state["exp_avg"].numel() != span:
+                if "exp_avg" in state:
+                    raise RuntimeError("FusedAdamW: restored moment arena has %d elements, the model's gradient arena "
+                                       "spans %d -- the checkpoint belongs to another parameter set"
+                                       % (state["exp_avg"].numel(), span))
                 state["exp_avg"] = torch.zeros(span, dtype=torch.float32, device=dev)
                 state["exp_avg_sq"] = torch.zeros(span, dtype=torch.float32, device=dev)
-                state.setdefault("step", 0)
+            state.setdefault("step", 0)
             plans.append(dict(table=table, n=len(rows), base=base, span=span, ids=[id(p) for p in ps],
                               gptrs=[p.grad.data_ptr() for p in ps], pptrs=[p.data_ptr() for p in ps], state=state))
         self._plan = plans
+
+    def load_state_dict(self, state_dict):
+        """torch's Optimizer.load_state_dict casts per-PARAMETER state to the parameter's device; the flat moment
+        arenas live under string keys (`_flat_<group>`) and would stay wherever `torch.load(map_location=...)` put
+        them.  Move them next to the parameters and drop the cached launch plan (it references the old state)."""
+        super().load_state_dict(state_dict)
+        self._plan = None
+        for gi, group in enumerate(self.param_groups):
+            st = self.state.get("_flat_%d" % gi)
+            if not st or not group["params"]:
+                continue
+            dev = group["params"][0].device
+            for key in ("exp_avg", "exp_avg_sq"):
+                if key in st and torch.is_tensor(st[key]):
+                    st[key] = st[key].to(dev, torch.float32).contiguous()
+            st["step"] = int(st.get("step", 0))
 
     def _plan_valid(self):
         if self._plan is None:
@@ -70,6 +98,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 continue
             if [id(p) for p in ps] != plan["ids"] or [p.grad.data_ptr() for p in ps] != plan["gptrs"] \
                     or [p.data_ptr() for p in ps] != plan["pptrs"]:
+                return False
+            if plan["state"] is not self.state.get("_flat_%d" % self._plan.index(plan)):
                 return False
         return True
 

@@ -24,10 +24,9 @@ class Identical(nn.Module):
 
 def load_backbone(args):
     """reference slot_model.py:18-52 (resnet-family branch; the other timm families are out of scope)."""
-    in_chans = 1 if args.dataset == "MNIST" else 3
-    bone = create_model(args.model, pretrained=False, num_classes=args.num_classes, in_chans=in_chans)
-    if getattr(args, "pre_trained", False):
-        print("note: pretrained ImageNet weights cannot be downloaded here; load them with load_state_dict")
+    # slot_model.py:19-22: a 3-channel model (pretrained weights when args.pre_trained: a LOCAL file, see
+    # timm/models/helpers.py -- raises when it is absent rather than freezing random layers), then the MNIST stem swap
+    bone = create_model(args.model, pretrained=bool(getattr(args, "pre_trained", False)), num_classes=args.num_classes)
     if args.dataset == "MNIST":
         from ..nn_hip import StemConv2d
         bone.conv1 = StemConv2d(1, 64, 3, 2, 1)                 # slot_model.py:23-24

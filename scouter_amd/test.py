@@ -69,7 +69,8 @@ def main():
     channels, size = (1 if args.dataset == "MNIST" else 3), int(args.img_size)
     if args.image:
         raw, image = load_image(args.image, size, channels)
-        raw.save(os.path.join(args.vis_dir, "image.png")) if os.path.isdir(args.vis_dir) else None
+        os.makedirs(args.vis_dir, exist_ok=True)
+        raw.save(os.path.join(args.vis_dir, "image.png"))
     else:
         image = torch.from_numpy(np.random.default_rng(0).standard_normal((channels, size, size), dtype=np.float32))
     out, pred, maps, ratio = run(args, model, image, args.vis_dir, args.label)

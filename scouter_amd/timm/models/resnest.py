@@ -50,16 +50,18 @@ class ResNestBottleneck(nn.Module):
         return self.conv1.bwd(dc1, k1, need_dx, addend=dxres)
 
 
-def _resnest(layers, pretrained, num_classes, in_chans, **kwargs):
-    if pretrained:
-        raise RuntimeError("pretrained weights cannot be downloaded here; load a state_dict instead")
-    return ResNet(ResNestBottleneck, layers, num_classes=num_classes, in_chans=in_chans, stem_type="deep",
-                  stem_width=32, avg_down=True, block_args=dict(radix=2, avd=True, avd_first=False), **kwargs)
+def _resnest(name, layers, pretrained, num_classes, in_chans, **kwargs):
+    model = ResNet(ResNestBottleneck, layers, num_classes=num_classes, in_chans=in_chans, stem_type="deep",
+                   stem_width=32, avg_down=True, block_args=dict(radix=2, avd=True, avd_first=False), **kwargs)
+    if pretrained:                               # resnest.py:165-189; local file instead of a download (helpers.py)
+        from .helpers import load_pretrained
+        load_pretrained(model, name, num_classes, in_chans)
+    return model
 
 
 def resnest26d(pretrained=False, num_classes=1000, in_chans=3, **kwargs):
-    return _resnest([2, 2, 2, 2], pretrained, num_classes, in_chans, **kwargs)
+    return _resnest("resnest26d", [2, 2, 2, 2], pretrained, num_classes, in_chans, **kwargs)
 
 
 def resnest50d(pretrained=False, num_classes=1000, in_chans=3, **kwargs):
-    return _resnest([3, 4, 6, 3], pretrained, num_classes, in_chans, **kwargs)
+    return _resnest("resnest50d", [3, 4, 6, 3], pretrained, num_classes, in_chans, **kwargs)

@@ -221,6 +221,8 @@ class ResNet(nn.Module):
 
 
 def resnet18(pretrained=False, num_classes=1000, in_chans=3, **kwargs):
-    if pretrained:
-        raise RuntimeError("pretrained weights cannot be downloaded here; load a state_dict instead")
-    return ResNet(BasicBlock, [2, 2, 2, 2], num_classes=num_classes, in_chans=in_chans, **kwargs)
+    model = ResNet(BasicBlock, [2, 2, 2, 2], num_classes=num_classes, in_chans=in_chans, **kwargs)
+    if pretrained:                               # resnet.py:516-521; local file instead of a download (helpers.py)
+        from .helpers import load_pretrained
+        load_pretrained(model, "resnet18", num_classes, in_chans)
+    return model

@@ -41,6 +41,49 @@ def test_fused_adamw_matches_adamw_maths():
         np.testing.assert_allclose(p.detach().cpu().double().numpy(), r.numpy(), rtol=2e-6, atol=2e-7)
 
 
+def test_fused_adamw_state_dict_roundtrip_keeps_moments(tmp_path):
+    """--resume path (train._restore loads with map_location='cpu'): the flat moment arenas must come back on the
+    device with their contents, so the step after a resume is bit-identical to the uninterrupted run; and a
+    load_state_dict AFTER steps must replace the cached launch plan's state."""
+    from scouter_amd.optim import FusedAdamW
+    rng = np.random.default_rng(1)
+    shapes = [(32, 32, 3, 3), (5000,), (7, 3)]
+
+    def make():
+        r = np.random.default_rng(2)
+        ps = [torch.nn.Parameter(torch.from_numpy(r.standard_normal(s).astype(np.float32)).cuda()) for s in shapes]
+        flat = torch.zeros(sum((p.numel() + 3) // 4 * 4 for p in ps), device="cuda")
+        off = 0
+        for p in ps:
+            p.grad = flat[off:off + p.numel()].view(p.shape)
+            off += (p.numel() + 3) // 4 * 4
+        return ps, flat
+    gs = [torch.from_numpy(rng.standard_normal(5000 + 32 * 32 * 9 + 21 + 8).astype(np.float32)).cuda() for _ in range(3)]
+    ps_a, flat_a = make()
+    opt_a = FusedAdamW(ps_a, lr=1e-2)
+    for g in gs[:2]:
+        flat_a.copy_(g[:flat_a.numel()]); opt_a.step()
+    torch.save({"optimizer": opt_a.state_dict(), "params": [p.detach().cpu() for p in ps_a]}, tmp_path / "ck.pth")
+    flat_a.copy_(gs[2][:flat_a.numel()]); opt_a.step()                        # uninterrupted third step
+    # resumed run: fresh optimizer, one warm-up step FIRST (so a launch plan with its own zero state is cached)
+    blob = torch.load(tmp_path / "ck.pth", map_location="cpu", weights_only=False)
+    ps_b, flat_b = make()
+    opt_b = FusedAdamW(ps_b, lr=1e-2)
+    flat_b.copy_(gs[0][:flat_b.numel()]); opt_b.step()
+    with torch.no_grad():
+        for p, v in zip(ps_b, blob["params"]):
+            p.copy_(v.cuda())
+    opt_b.load_state_dict(blob["optimizer"])
+    st = opt_b.state["_flat_0"]
+    assert st["exp_avg"].is_cuda and st["step"] == 2 and float(st["exp_avg"].abs().max()) > 0
+    flat_b.copy_(gs[2][:flat_b.numel()]); opt_b.step()
+    assert opt_b.state["_flat_0"]["step"] == 3
+    assert torch.equal(opt_b.state["_flat_0"]["exp_avg"], opt_a.state["_flat_0"]["exp_avg"])
+    assert torch.equal(opt_b.state["_flat_0"]["exp_avg_sq"], opt_a.state["_flat_0"]["exp_avg_sq"])
+    for a, b in zip(ps_a, ps_b):
+        assert torch.equal(a, b)
+
+
 def _mnist_args():
     return argparse.Namespace(model="resnet18", pre_trained=False, num_classes=10, dataset="MNIST", use_slot=True,
                               use_pre=False, grad=False, channel=512, slots_per_class=1, hidden_dim=64,

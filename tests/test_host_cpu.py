@@ -61,11 +61,49 @@ def test_cpu_input_is_refused_not_emulated():
         m(torch.randn(2, 1, 64, 64), torch.tensor([0, 1]))
 
 
-def test_freeze_layers_matches_reference_rule():
+def test_freeze_layers_matches_reference_rule(pretrained_dir):
     from scouter_amd.sloter.slot_model import SlotModel
+    sd = pretrained_dir("resnest26d")
     m = SlotModel(_args("resnest26d", pre_trained=True, freeze_layers=2))
     frozen = {n.split(".")[1] for n, p in m.named_parameters() if not p.requires_grad}
     assert frozen == {"conv1", "bn1", "layer1", "layer2"}
+    # the frozen layers hold the PRETRAINED values (local file, reference helpers.py:68-101), fc discarded (10 != 1000)
+    got = m.state_dict()
+    for k, v in sd.items():
+        if k.startswith("fc."):
+            assert "backbone." + k not in got
+        else:
+            assert torch.equal(got["backbone." + k], v), k
+    assert m.backbone.layer1[0].conv1.weight.permute(2, 3, 1, 0).is_contiguous()     # HWIO physical layout kept
+
+
+def test_pre_trained_without_weights_raises_instead_of_freezing_random_layers(pretrained_dir):
+    """`--pre_trained true` (the reference default) must not silently random-initialise and freeze."""
+    from scouter_amd.sloter.slot_model import SlotModel
+    with pytest.raises(FileNotFoundError, match="SCOUTER_PRETRAINED_DIR"):
+        SlotModel(_args("resnet18", mnist=True, L=1, pre_trained=True, freeze_layers=2))
+    with pytest.raises(FileNotFoundError, match="gluon_resnest26-50eb607c.pth"):
+        SlotModel(_args("resnest26d", pre_trained=True, use_slot=False))
+
+
+def test_pre_trained_mnist_swaps_the_stem_after_loading(pretrained_dir):
+    """reference slot_model.py:19-24: 3-channel pretrained model first, THEN conv1 := fresh Conv2d(1, 64, 3, 2, 1)."""
+    from scouter_amd.sloter.slot_model import SlotModel
+    sd = pretrained_dir("resnet18")
+    assert tuple(sd["conv1.weight"].shape) == (64, 3, 7, 7)
+    m = SlotModel(_args("resnet18", mnist=True, L=1, pre_trained=True, freeze_layers=1))
+    assert tuple(m.backbone.conv1.weight.shape) == (64, 1, 3, 3)
+    assert torch.equal(m.state_dict()["backbone.layer3.1.conv2.weight"], sd["layer3.1.conv2.weight"])
+    assert not m.backbone.layer1[0].conv1.weight.requires_grad and m.backbone.layer2[0].conv1.weight.requires_grad
+
+
+def test_pretrained_first_conv_channel_sum_for_one_channel_models(pretrained_dir):
+    """helpers.py:77-81 of the reference: in_chans == 1 sums the RGB filter."""
+    from scouter_amd.timm.models import create_model
+    sd = pretrained_dir("resnet18")
+    m = create_model("resnet18", pretrained=True, num_classes=1000, in_chans=1)
+    assert torch.allclose(m.state_dict()["conv1.weight"], sd["conv1.weight"].sum(1, keepdim=True))
+    assert torch.equal(m.state_dict()["fc.weight"], sd["fc.weight"])
 
 
 def test_grad_arena_views_alias_flat_buffer():
