@@ -221,8 +221,7 @@ def main():
     prof_buf = ctypes.create_string_buffer(1 << 16)
     prof_steps = 0 if a.no_prof else max(1, a.prof_steps)
     if prof_steps:
-        from scouter_amd import kernels as Kmod
-        Kmod.SIDE_STREAM_ENABLED = False
+        model.set_side_stream(False)
         step()
         fence()
         L.scouter_prof_enable(1)
@@ -231,7 +230,7 @@ def main():
         fence()
         L.scouter_prof_enable(0)
         L.scouter_prof_collect(prof_buf, len(prof_buf))
-        Kmod.SIDE_STREAM_ENABLED = True
+        model.set_side_stream(True)
     loss_val = float(losses[0].detach())
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if dist.is_initialized():

@@ -74,9 +74,10 @@ def conv_out(n, k, s, p):
 # ---------------------------------------------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------------------------------------------
-# "fp32" (exact fp32 MFMA, the parity path) or "bf16" (matrix inputs rounded to bf16, fp32 accumulation; tensors stay
-# fp32 in memory) -- set by SlotModel from args.precision; BASELINE configs[4] names bf16
-PRECISION = "fp32"
+# precision = "fp32" (exact fp32 MFMA, the parity path) or "bf16" (matrix inputs rounded to bf16, fp32 accumulation;
+# tensors stay fp32 in memory; BASELINE configs[4] names bf16).  It is an ARGUMENT of every convolution call, carried
+# by the layer object (nn_hip.Conv2d.precision, set per model by SlotModel) -- there is no module-global switch, so
+# models of different precision, or a backward on the autograd thread next to another model's forward, cannot race.
 BF16_MIN_PIXELS = 1024      # layers with fewer GEMM rows (the split-attention FCs on the pooled vector) stay in fp32
 AUTOTUNE = os.environ.get("SCOUTER_AUTOTUNE", "1") != "0"
 _tile_cache = {}
@@ -114,7 +115,8 @@ def _tile_legal(ng, t):
     return (t == 0 and ng % 128 == 0) or (t in (1, 2) and ng % 64 == 0) or t == 3
 
 
-def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, relu=False, bn_stats=False):
+def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, relu=False, bn_stats=False,
+               precision="fp32"):
     """bn_stats=True: the epilogue also produces the per-tile fp64 channel sums BatchNorm needs; returns
     (y, (partial, rows)) and `bn_fwd(..., stats=(partial, rows))` then skips its own statistics pass."""
     _chk(x, "x"); _chk(w_hwio, "weight"); _chk(bias, "bias"); _chk(addend, "addend")
@@ -125,7 +127,7 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     L = _native.lib()
     st = _stream()
 
-    bf16 = PRECISION == "bf16" and y.numel() // Cout >= BF16_MIN_PIXELS
+    bf16 = precision == "bf16" and y.numel() // Cout >= BF16_MIN_PIXELS
     wt = None
     if bf16:                      # W^T as bf16 [taps][Cout][Cin/groups], rebuilt per call (weights change every step)
         wt = torch.empty((kh * kw, Cout, cg), dtype=torch.bfloat16, device=x.device)
@@ -153,7 +155,7 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     return (y, (part, rows)) if bn_stats else y
 
 
-def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1):
+def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, precision="fp32"):
     _chk(dy, "dy"); _chk(w_hwio, "weight"); _chk(addend, "addend")
     B, H, W, Cin = x_shape
     kh, kw, cg, Cout = w_hwio.shape
@@ -162,7 +164,7 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1):
     st = _stream()
 
     # strided input gradients (resnet18) and tiny layers stay on the fp32 kernel
-    bf16 = PRECISION == "bf16" and stride == 1 and B * H * W >= BF16_MIN_PIXELS
+    bf16 = precision == "bf16" and stride == 1 and B * H * W >= BF16_MIN_PIXELS
 
     def launch(tile, dry=False):
         if dry:
@@ -177,7 +179,8 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1):
 
 
 _side = {}
-SIDE_STREAM_ENABLED = os.environ.get("SCOUTER_SIDE_STREAM", "1") != "0"
+# default of nn_hip.Conv2d.use_side_stream (a per-layer / per-model setting: SlotModel.set_side_stream)
+SIDE_STREAM_DEFAULT = os.environ.get("SCOUTER_SIDE_STREAM", "1") != "0"
 
 
 class side_stream:
@@ -186,12 +189,12 @@ class side_stream:
     (MFMA-bound) is off the critical path and overlaps the HBM-bound BatchNorm-backward passes of earlier layers.
     `join_side_stream()` makes the current stream wait for it again."""
 
-    def __init__(self, device, *tensors):
-        self.device, self.tensors = device, tensors
+    def __init__(self, device, *tensors, enabled=True):
+        self.device, self.tensors, self.enabled = device, tensors, enabled
 
     def __enter__(self):
         self.ctx = None
-        if not SIDE_STREAM_ENABLED:
+        if not self.enabled:
             return None
         key = (self.device.type, self.device.index)
         st = _side.get(key)
@@ -223,7 +226,7 @@ if os.environ.get("SCOUTER_WGRAD_TUNE", "0") == "1":
     _WGRAD_PLANS += tuple(t | b for t in (0, 16, 32, 48) for b in (0, 1, 2, 3))
 
 
-def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1):
+def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
     """Writes dW (HWIO, contiguous, e.g. a slice of the flat gradient arena).  SCOUTER_WGRAD_TUNE=1 autotunes the
     (tile, split-K) plan once per layer shape and keeps it for the run (see _WGRAD_PLANS)."""
     _chk(x, "x"); _chk(dy, "dy"); _chk(dw_hwio, "dw")
@@ -235,7 +238,7 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1):
     # bf16 matrix inputs where the bf16 kernel applies (same-size stride-1 convolutions, 64-multiples of channels per
     # group); the remaining layers (32-channel stem, strided convolutions) keep the fp32 kernel
     same = stride == 1 and dy.shape[1] == H and dy.shape[2] == W
-    bf16 = (PRECISION == "bf16" and same and cg % 64 == 0 and (Cout // groups) % 64 == 0 and
+    bf16 = (precision == "bf16" and same and cg % 64 == 0 and (Cout // groups) % 64 == 0 and
             B * H * W >= BF16_MIN_PIXELS and ((kh == 1 and kw == 1 and pad == 0) or 64 // W + 1 < H))
     fn = L.scouter_conv2d_wgrad_bf16 if bf16 else L.scouter_conv2d_wgrad_f32
 

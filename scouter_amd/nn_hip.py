@@ -34,6 +34,8 @@ class Conv2d(nn.Module):
         self.weight = nn.Parameter(w.permute(3, 2, 0, 1))          # logical OIHW, physical HWIO
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self._dw = self._db = None                                  # arena slices, set by GradArena
+        self.precision = "fp32"                                     # per layer; SlotModel.set_precision (no global)
+        self.use_side_stream = K.SIDE_STREAM_DEFAULT                # weight gradient on the side stream
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # timm resnet.py:447-448
         if bias:
             bound = 1.0 / math.sqrt(in_channels // groups * k * k)
@@ -42,20 +44,22 @@ class Conv2d(nn.Module):
     def fwd(self, x, save, relu=False, addend=None, bn_stats=False):
         """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd."""
         y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
-                         bn_stats)
+                         bn_stats, precision=self.precision)
         return y, (x if save else None)
 
     def bwd(self, dy, ctx, need_dx=True, addend=None):
         x = ctx
         if self._dw is not None or self._db is not None:
-            with K.side_stream(dy.device, x, dy):           # weight / bias gradients: off the critical path
+            # weight / bias gradients: off the critical path
+            with K.side_stream(dy.device, x, dy, enabled=self.use_side_stream):
                 if self._dw is not None:
-                    K.conv2d_wgrad(x, dy, self._dw, self.stride, self.padding, self.groups)
+                    K.conv2d_wgrad(x, dy, self._dw, self.stride, self.padding, self.groups, precision=self.precision)
                 if self._db is not None:
                     K.colsum(dy, self._db)
         if not need_dx:
             return None
-        return K.conv2d_dgrad(dy, K.hwio(self.weight), tuple(x.shape), addend, self.stride, self.padding, self.groups)
+        return K.conv2d_dgrad(dy, K.hwio(self.weight), tuple(x.shape), addend, self.stride, self.padding, self.groups,
+                              precision=self.precision)
 
 
 class StemConv2d(Conv2d):
@@ -72,6 +76,8 @@ class StemConv2d(Conv2d):
         self.weight = nn.Parameter(torch.empty(k, k, in_channels, out_channels).permute(3, 2, 0, 1))
         self.bias = None
         self._dw = self._db = None
+        self.precision = "fp32"
+        self.use_side_stream = K.SIDE_STREAM_DEFAULT
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
     def fwd(self, x_nchw, save, relu=False, addend=None, bn_stats=False):
@@ -81,16 +87,16 @@ class StemConv2d(Conv2d):
         col = K.im2col_nchw(x_nchw, self.kernel_size, self.stride, self.padding, self.kpad)
         wflat = K.hwio(self.weight).reshape(-1)
         wpad = K.pad_rows(wflat, wflat.numel(), self.kpad * self.out_channels).view(1, 1, self.kpad, self.out_channels)
-        y = K.conv2d_fwd(col, wpad, None, addend, 1, 0, 1, relu, bn_stats)
+        y = K.conv2d_fwd(col, wpad, None, addend, 1, 0, 1, relu, bn_stats, precision=self.precision)
         return y, (col if save else None)
 
     def bwd(self, dy, ctx, need_dx=False, addend=None):
         if need_dx:
             raise NotImplementedError("gradient w.r.t. the input image is not part of the training hot path")
         if self._dw is not None:
-            with K.side_stream(dy.device, ctx, dy):
+            with K.side_stream(dy.device, ctx, dy, enabled=self.use_side_stream):
                 dwpad = torch.empty((1, 1, self.kpad, self.out_channels), dtype=torch.float32, device=dy.device)
-                K.conv2d_wgrad(ctx, dy, dwpad)
+                K.conv2d_wgrad(ctx, dy, dwpad, precision=self.precision)
                 n = self.kdim * self.out_channels
                 K.axpby(dwpad.view(-1)[:n], None, 1.0, 0.0, out=self._dw.reshape(-1))
         return None

@@ -71,6 +71,7 @@ class SlotModel(nn.Module):
         if self.precision not in ("fp32", "bf16"):
             raise ValueError("precision must be fp32 or bf16, got %r" % self.precision)
         self.backbone = load_backbone(args)
+        self.set_precision(self.precision)
         self._arena = None
         self._anchor = None
         self._post_backward_hooks = []       # called with the GradArena after every backward (data-parallel reduce)
@@ -91,6 +92,22 @@ class SlotModel(nn.Module):
                                   to_k_layer=args.to_k_layer)
         self.position_emb = build_position_encoding("sine", hidden_dim=args.hidden_dim)
         self.lambda_value = float(args.lambda_value)
+
+    def set_precision(self, precision):
+        """Matrix-input precision of the BACKBONE convolutions (the xSlot head incl. conv1x1 always runs in fp32).
+        Stored on each layer object, so two models of different precision never share a switch."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be fp32 or bf16, got %r" % precision)
+        self.precision = precision
+        for mod in self.backbone.modules():
+            if isinstance(mod, Conv2d):
+                mod.precision = precision
+
+    def set_side_stream(self, enabled):
+        """Weight gradients on the side stream (default) or serially on the compute stream (per-kernel timing)."""
+        for mod in self.modules():
+            if isinstance(mod, Conv2d):
+                mod.use_side_stream = bool(enabled)
 
     def dfs_freeze(self, model, freeze_layer_num):
         """reference slot_model.py:79-94"""
@@ -165,11 +182,7 @@ class SlotModel(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         tracked = []
-        K.PRECISION = self.precision              # backbone convolutions; the xSlot head always runs in fp32
-        try:
-            feat, bctx = self.backbone.features_fwd(x, save, tracked)         # NHWC [B, h, w, channel]
-        finally:
-            K.PRECISION = "fp32"
+        feat, bctx = self.backbone.features_fwd(x, save, tracked)             # NHWC [B, h, w, channel]
         logp, stats, hstate = self._head_forward(feat, target, save)
         if tracked:
             torch._foreach_add_(tracked, 1)                                   # BatchNorm num_batches_tracked
@@ -191,11 +204,7 @@ class SlotModel(nn.Module):
                     hook(arena, lo, done_hi[0])
                 done_hi[0] = lo
         if need:
-            K.PRECISION = self.precision
-            try:
-                self.backbone.features_bwd(dfeat, bctx, stage_done if self._grad_ready_hooks else None)
-            finally:
-                K.PRECISION = "fp32"
+            self.backbone.features_bwd(dfeat, bctx, stage_done if self._grad_ready_hooks else None)
         K.join_side_stream(arena.flat.device)               # all weight gradients are in the arena from here on
         if self._grad_ready_hooks and done_hi[0] > 0:
             for hook in self._grad_ready_hooks:

@@ -283,3 +283,36 @@ def test_training_learns_a_separable_task(precision):
             acc.append(float((out.argmax(1) == y).float().mean()))
     assert np.mean(last[-10:]) < 0.7 * np.mean(first), (np.mean(first), np.mean(last[-10:]))
     assert np.mean(acc) > 0.6, np.mean(acc)
+
+
+def test_two_stage_recipe_fc_baseline_then_use_pre_xslot(tmp_path, monkeypatch):
+    """SURVEY section 8 f3 / reference README.md:84-97: stage 1 trains the FC baseline through train.main (checkpoint
+    `saved_model/MNIST_no_slot_checkpoint.pth`, written by save_on_master), stage 2 builds the xSlot model with
+    --use_pre true (+ --pre_trained false), which must start from exactly the stage-1 backbone and train."""
+    from scouter_amd import train as T
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SLURM_PROCID"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.chdir(tmp_path)
+    base = ["--model", "resnet18", "--dataset", "MNIST", "--channel", "512", "--num_classes", "10", "--slots_per_class", "1",
+            "--power", "1", "--to_k_layer", "1", "--pre_trained", "false", "--img_size", "64", "--batch_size", "8",
+            "--synthetic_len", "16", "--epochs", "1", "--num_workers", "0", "--output_dir", "saved_model/"]
+    parser = argparse.ArgumentParser(parents=[T.get_args_parser()])
+    (tmp_path / "saved_model").mkdir()
+    T.param_translation(parser.parse_args(base + ["--use_slot", "false"]))
+    ck = tmp_path / "saved_model" / "MNIST_no_slot_checkpoint.pth"
+    assert ck.exists()
+    stage1 = torch.load(ck, map_location="cpu", weights_only=False)["model"]
+    assert "backbone.fc.weight" in stage1
+    # stage 2: construction alone must reproduce the stage-1 backbone ...
+    from scouter_amd.sloter.slot_model import SlotModel
+    a2 = parser.parse_args(base + ["--use_slot", "true", "--use_pre", "true"])
+    for name, typ in (("num_classes", int), ("lambda_value", float), ("power", int), ("slots_per_class", int)):
+        setattr(a2, name, typ(getattr(a2, name)))
+    m = SlotModel(a2)
+    sd = m.state_dict()
+    for k, v in stage1.items():
+        if not k.startswith("backbone.fc."):
+            assert torch.equal(sd[k].cpu(), v.cpu()), k
+    # ... and the recipe's second command runs end to end from it
+    accs = T.param_translation(parser.parse_args(base + ["--use_slot", "true", "--use_pre", "true"]))
+    assert len(accs) == 2 and (tmp_path / "saved_model" / "MNIST_use_slot_checkpoint.pth").exists()

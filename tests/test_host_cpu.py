@@ -119,3 +119,41 @@ def test_grad_arena_views_alias_flat_buffer():
     assert a.views[name].shape == p.shape and a.views[name].stride() == p.stride()
     hw = a.views[name].permute(2, 3, 1, 0).reshape(-1)
     assert torch.equal(hw, a.flat[off:off + n])
+
+
+def test_use_pre_stage2_handoff_loads_fc_baseline_checkpoint(tmp_path, monkeypatch):
+    """README two-stage recipe (reference README.md:84-97, sloter/slot_model.py:26-33): the FC baseline (use_slot
+    false) is saved under `saved_model/{dataset}_no_slot_checkpoint.pth`; the xSlot model built with use_pre=True
+    strips `backbone.` (incl. the `backbone.fc.*` keys, which must exist at load time) and THEN replaces
+    global_pool / fc by Identical."""
+    from scouter_amd.sloter.slot_model import Identical, SlotModel
+    from scouter_amd.tools import prepare_things as prt
+    from scouter_amd.train import checkpoint_name
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "saved_model").mkdir()
+    a1 = _args("resnet18", mnist=True, L=1, use_slot=False)
+    a1.cal_area_size = False
+    fc = SlotModel(a1)
+    with torch.no_grad():                                    # make every tensor distinguishable from a fresh init
+        for i, p in enumerate(fc.parameters()):
+            p.add_(0.01 * (i + 1))
+        fc.backbone.bn1.running_mean.fill_(0.25)
+    assert checkpoint_name(a1) == "MNIST_no_slot_checkpoint.pth"
+    prt.save_on_master({"model": fc.state_dict(), "epoch": 0}, tmp_path / "saved_model" / checkpoint_name(a1))
+    assert "backbone.fc.weight" in fc.state_dict()
+    m = SlotModel(_args("resnet18", mnist=True, L=1, use_slot=True, use_pre=True))
+    assert isinstance(m.backbone.fc, Identical) and isinstance(m.backbone.global_pool, Identical)
+    got, src = m.state_dict(), fc.state_dict()
+    assert not any(k.startswith("backbone.fc.") for k in got)
+    n = 0
+    for k, v in src.items():
+        if not k.startswith("backbone.fc."):
+            assert torch.equal(got[k], v), k
+            n += 1
+    assert n == len(src) - 2
+    assert m.backbone.layer1[0].conv1.weight.permute(2, 3, 1, 0).is_contiguous()
+    # a checkpoint of another class count does not fit (strict load, like the reference)
+    bad = SlotModel(_args("resnet18", C=7, mnist=True, L=1, use_slot=False))
+    prt.save_on_master({"model": bad.state_dict()}, tmp_path / "saved_model" / "MNIST_no_slot_checkpoint.pth")
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        SlotModel(_args("resnet18", mnist=True, L=1, use_slot=True, use_pre=True))

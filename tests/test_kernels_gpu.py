@@ -308,12 +308,12 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
     x = torch.from_numpy(rng.standard_normal((B, Cin, H, W)))
     w = torch.from_numpy(rng.standard_normal((Cout, Cin // groups, k, k)) * 0.1)
     kk = K()
-    old, old_min = kk.PRECISION, kk.BF16_MIN_PIXELS
-    kk.PRECISION, kk.BF16_MIN_PIXELS = "bf16", 1          # (the model keeps layers under 1024 pixels in fp32)
+    old_min = kk.BF16_MIN_PIXELS
+    kk.BF16_MIN_PIXELS = 1                                # (the model keeps layers under 1024 pixels in fp32)
     try:
         y_ref = F.conv2d(_bf16_round(x), _bf16_round(w), None, stride, pad, 1, groups)
         xd, wd = nhwc(x), w.float().permute(2, 3, 1, 0).contiguous().cuda()
-        y, (part, rows) = kk.conv2d_fwd(xd, wd, None, None, stride, pad, groups, False, bn_stats=True)
+        y, (part, rows) = kk.conv2d_fwd(xd, wd, None, None, stride, pad, groups, False, bn_stats=True, precision="bf16")
         sc = float(y_ref.abs().max())
         np.testing.assert_allclose(from_nhwc(y).numpy(), y_ref.numpy(), atol=2e-5 * sc, rtol=1e-5)
         st = part.sum(0).cpu().numpy()                      # fused statistics of what was written
@@ -324,7 +324,7 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
             dy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
             xr = _bf16_round(x).requires_grad_(True)        # only its shape matters for the input gradient
             dx_ref = torch.autograd.grad(F.conv2d(xr, _bf16_round(w), None, stride, pad, 1, groups), xr, _bf16_round(dy))[0]
-            dx = kk.conv2d_dgrad(nhwc(dy), wd, tuple(xd.shape), None, stride, pad, groups)
+            dx = kk.conv2d_dgrad(nhwc(dy), wd, tuple(xd.shape), None, stride, pad, groups, precision="bf16")
             np.testing.assert_allclose(from_nhwc(dx).numpy(), dx_ref.numpy(), atol=2e-5 * float(dx_ref.abs().max()), rtol=1e-5)
         # weight gradient: bf16 kernel where it applies (same-size, 64-multiples), fp32 kernel elsewhere
         dy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
@@ -333,8 +333,8 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
         wr = w.clone().requires_grad_(True)
         dw_ref = torch.autograd.grad(F.conv2d(xs, wr, None, stride, pad, 1, groups), wr, dys)[0]
         dw = torch.zeros_like(wd)
-        kk.conv2d_wgrad(xd, nhwc(dy), dw, stride, pad, groups)
+        kk.conv2d_wgrad(xd, nhwc(dy), dw, stride, pad, groups, precision="bf16")
         np.testing.assert_allclose(dw.permute(3, 2, 0, 1).cpu().numpy(), dw_ref.numpy(),
                                    atol=3e-5 * float(dw_ref.abs().max()), rtol=1e-5)
     finally:
-        kk.PRECISION, kk.BF16_MIN_PIXELS = old, old_min
+        kk.BF16_MIN_PIXELS = old_min

@@ -243,7 +243,7 @@ def test_bf16_mode_sits_inside_the_bf16_noise_of_the_reference_arithmetic():
     case = "resnest26d_224"
     g = np.load(os.path.join(GOLD, "model_%s.npz" % case))
     mb, _, images, labels = build(case)
-    mb.precision = "bf16"
+    mb.set_precision("bf16")
     mb.train()
     out, (loss, nll, area) = mb(images.cuda(), labels.cuda())
     loss.backward()

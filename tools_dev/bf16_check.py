@@ -7,12 +7,9 @@ g = np.load(os.path.join(GOLD, "model_%s.npz" % case))
 res = {}
 for prec in ("fp32", "bf16"):
     m, P, images, labels = build(case)
-    m.precision = prec
+    m.set_precision(prec)
     m.train()
-    from scouter_amd import kernels as K
-    K.PRECISION = prec
     feat, _ = m.backbone.features_fwd(images.cuda().float(), False, [])
-    K.PRECISION = "fp32"
     out, (loss, nll, area) = m(images.cuda(), labels.cuda())
     loss.backward()
     res[prec] = (feat.double().cpu(), out.detach().double().cpu(), float(loss), {k: p.grad.double().cpu() for k, p in m.named_parameters() if p.grad is not None})

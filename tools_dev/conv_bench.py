@@ -7,8 +7,7 @@ from scouter_amd.timm import create_model
 from scouter_amd.nn_hip import Conv2d, StemConv2d
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 70
-if len(sys.argv) > 2:
-    K.PRECISION = sys.argv[2]          # "bf16": matrix inputs rounded to bf16
+PREC = sys.argv[2] if len(sys.argv) > 2 else "fp32"   # "bf16": matrix inputs rounded to bf16
 m = create_model('resnest26d', num_classes=10)
 shapes = collections.OrderedDict()
 # walk the net with shape tracking: replicate spatial sizes
@@ -41,13 +40,13 @@ print('%-40s %5s %9s | %8s %6s | %8s %6s | %8s %6s' % ('cin,cout,k,s,p,g,H', 'cn
 for (cin, cout, k, s, p, g, H), cnt in shapes.items():
     x = torch.randn(B, H, H, cin, device='cuda')
     w = torch.randn(k, k, cin // g, cout, device='cuda') * 0.05
-    y = K.conv2d_fwd(x, w, None, None, s, p, g)
+    y = K.conv2d_fwd(x, w, None, None, s, p, g, precision=PREC)
     dy = torch.randn_like(y)
     dw = torch.empty_like(w)
     fl = 2.0 * y.numel() * (cin // g) * k * k
-    tf = timeit(lambda: K.conv2d_fwd(x, w, None, None, s, p, g))
-    td = timeit(lambda: K.conv2d_dgrad(dy, w, tuple(x.shape), None, s, p, g))
-    tw = timeit(lambda: K.conv2d_wgrad(x, dy, dw, s, p, g))
+    tf = timeit(lambda: K.conv2d_fwd(x, w, None, None, s, p, g, precision=PREC))
+    td = timeit(lambda: K.conv2d_dgrad(dy, w, tuple(x.shape), None, s, p, g, precision=PREC))
+    tw = timeit(lambda: K.conv2d_wgrad(x, dy, dw, s, p, g, precision=PREC))
     print('%-40s %5d %9.2f | %8.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f' % (str((cin, cout, k, s, p, g, H)), cnt, fl / 1e9, tf * 1e6, fl / tf / 1e12, td * 1e6, fl / td / 1e12, tw * 1e6, fl / tw / 1e12))
     tot['fwd'] += tf * cnt; tot['dgrad'] += td * cnt; tot['wgrad'] += tw * cnt; totf += fl * cnt
 print('TOTAL ms  fwd %.2f dgrad %.2f wgrad %.2f | GFLOP/pass %.1f  => TF fwd %.1f dgrad %.1f wgrad %.1f' % (tot['fwd'] * 1e3, tot['dgrad'] * 1e3, tot['wgrad'] * 1e3, totf / 1e9, totf / tot['fwd'] / 1e12, totf / tot['dgrad'] / 1e12, totf / tot['wgrad'] / 1e12))
