@@ -5,6 +5,9 @@ xSlot, 10 classes, channel 2048, to_k_layer 3, power 2, T=3, 224x224, per-GPU ba
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W            (one rank per GPU, gradients all-reduced over RCCL/xGMI)
+  python bench.py --config {1,2,3,4,5} [--precision fp32|bf16]   the other BASELINE configs at their per-GPU batch
+         (1-based, SURVEY.md section 8 table: 1 = MNIST resnet18, 2 = the headline, 3 = negative xSlot, 4 = CUB200,
+         5 = ImageNet-100 resnest50d 100x3 slots -- the config that names bf16, its default precision); same JSON schema
 
 A step = zero_grad -> forward -> loss -> backward (+ gradient all-reduce) -> AdamW, on a synthetic batch already
 resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects on that line:
@@ -26,51 +29,109 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CFG = dict(model="resnest26d", num_classes=10, slots_per_class=1, channel=2048, to_k_layer=3, power=2, loss_status=1,
-           lambda_value="1", hidden_dim=64, img_size=224, batch=70)
-FWD_GFLOP_PER_IMG = 7.243 + 0.0159          # backbone conv + head, SURVEY.md section 8d / Appendix B
-PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md chip table
+           lambda_value="1", hidden_dim=64, img_size=224, batch=70, dataset="ImageNet", precision="fp32",
+           fwd_gflop=7.243 + 0.0159,
+           name="BASELINE configs[1]: ImageNet-10 resnest26d + positive xSlot, channel 2048, T=3, to_k_layer 3, power 2",
+           metric="images/sec training step (resnest26d+xSlot, 224^2, bs70)")
+# BASELINE.json configs, 1-based as in SURVEY.md section 8 (head recipes from the reference README, FLOPs per image
+# = backbone conv + head forward); --config 2 is the headline (the default)
+CONFIGS = {
+    1: dict(CFG, model="resnet18", channel=512, to_k_layer=1, power=1, batch=64, dataset="MNIST",
+            fwd_gflop=3.406 + 0.0054,
+            name="BASELINE configs[0]: MNIST-shaped resnet18 (1-channel 3x3 stem) + xSlot, 10 classes, T=3, to_k_layer 1, power 1",
+            metric="images/sec training step (resnet18+xSlot MNIST stem, 224^2, bs64)"),
+    2: CFG,
+    3: dict(CFG, loss_status=-1,
+            name="BASELINE configs[2]: ImageNet-10 resnest26d + NEGATIVE xSlot (loss_status=-1), channel 2048, T=3, to_k_layer 3, power 2",
+            metric="images/sec training step (resnest26d+negative xSlot, 224^2, bs70)"),
+    4: dict(CFG, num_classes=200, batch=128, fwd_gflop=7.243 + 0.0511,
+            name="BASELINE configs[3]: CUB200 resnest26d + xSlot, 200 classes x 1 slot, channel 2048, T=3, to_k_layer 3, power 2",
+            metric="images/sec training step (resnest26d+xSlot 200 slots, 224^2, bs128)"),
+    5: dict(CFG, model="resnest50d", num_classes=100, slots_per_class=3, batch=256, precision="bf16",
+            fwd_gflop=10.738 + 0.0696,
+            name="BASELINE configs[4]: ImageNet-100 resnest50d + xSlot, 100 classes x 3 slots (wide-slot stress), channel 2048, T=3, to_k_layer 3, power 2",
+            metric="images/sec training step (resnest50d+xSlot 300 slots, 224^2, bs256)"),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0              # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), same table
 
 
 def make_args(cfg):
-    return argparse.Namespace(model=cfg["model"], pre_trained=False, num_classes=cfg["num_classes"], dataset="ImageNet",
+    return argparse.Namespace(model=cfg["model"], pre_trained=False, num_classes=cfg["num_classes"],
+                              dataset=cfg.get("dataset", "ImageNet"),
                               use_slot=True, use_pre=False, grad=False, channel=cfg["channel"],
                               slots_per_class=cfg["slots_per_class"], hidden_dim=cfg["hidden_dim"], freeze_layers=0,
                               vis=False, vis_id=0, loss_status=cfg["loss_status"], power=cfg["power"],
-                              to_k_layer=cfg["to_k_layer"], lambda_value=cfg["lambda_value"])
+                              to_k_layer=cfg["to_k_layer"], lambda_value=cfg["lambda_value"],
+                              precision=cfg.get("precision", "fp32"))
 
 
-def synth_batch(B, size, C, rank, device):
+def synth_batch(B, size, C, rank, device, in_chans=3):
     rng = np.random.default_rng(1234 + rank)
-    x = torch.from_numpy(rng.standard_normal((B, 3, size, size), dtype=np.float32)).to(device)
+    x = torch.from_numpy(rng.standard_normal((B, in_chans, size, size), dtype=np.float32)).to(device)
     y = torch.from_numpy(rng.integers(0, C, B).astype(np.int64)).to(device)
     return x, y
 
 
-def cpu_baseline(cfg, sample_b=16, steps=1):
-    """The CPU oracle's train step (the port of the reference's PyTorch-CPU path) on a bounded sample."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, budget_s=25.0, steps=3):
+    """The CPU oracle's train step (the port of the reference's PyTorch-CPU path) beside the GPU number: SURVEY.md
+    section 8d asks for the config's own batch, 1 warm-up + 3 timed steps, all host cores, CPU model and core count in
+    the object.  The sample is bounded to ~`budget_s` of CPU work: a probe step at batch 8 sizes the sample batch (the
+    config batch when 4 steps of it fit the budget, else the largest batch that does -- said in `sample`)."""
     from oracle import torch_oracle as O
-    cores = min(os.cpu_count() or 1, 32)           # beyond ~32 threads torch-CPU convolution on a small batch slows down
-    torch.set_num_threads(cores)
-    spec = O.state_dict_spec(cfg["model"], cfg["num_classes"], cfg["slots_per_class"], cfg["to_k_layer"])
+    ncpu = os.cpu_count() or 1
+    mnist = cfg.get("dataset") == "MNIST"
+    spec = O.state_dict_spec(cfg["model"], cfg["num_classes"], cfg["slots_per_class"], cfg["to_k_layer"],
+                             in_chans=1 if mnist else 3, mnist_stem=mnist)
     P = O.synth_state(spec, 0)
     ocfg = dict(model=cfg["model"], num_classes=cfg["num_classes"], slots_per_class=cfg["slots_per_class"],
                 loss_status=cfg["loss_status"], power=cfg["power"], lambda_value=float(cfg["lambda_value"]))
     tr = O.OracleTrainer(P, ocfg, lr=1e-4)
-    img, lab = O.synth_batch(sample_b, 3, cfg["img_size"], cfg["num_classes"], 1234)
-    tr.step(img, lab)                                   # warm-up
-    t0 = time.time()
-    for _ in range(steps):
-        tr.step(img, lab)
-    dt = (time.time() - t0) / steps
+
+    def timed(b, n):
+        img, lab = O.synth_batch(b, 1 if mnist else 3, cfg["img_size"], cfg["num_classes"], 1234)
+        t0 = time.time()
+        for _ in range(n):
+            tr.step(img, lab)
+        return (time.time() - t0) / n
+    # thread count: all host cores (SURVEY 8d) unless a smaller pool is measurably faster on this box (torch-CPU
+    # convolutions on a small batch slow down beyond a few dozen threads) -- the CPU gets its best setting
+    probe, cores = None, ncpu
+    for c in sorted({min(32, ncpu), min(64, ncpu), ncpu}):
+        torch.set_num_threads(c)
+        timed(8, 1)                                      # thread pool / allocator warm-up
+        t = timed(8, 1) / 8                              # seconds per image
+        if probe is None or t < probe:
+            probe, cores = t, c
+    torch.set_num_threads(cores)
+    full = cfg["batch"]
+    sample_b = full if probe * full * (steps + 1) <= budget_s else max(8, int(budget_s / (probe * (steps + 1))) // 8 * 8)
+    sample_b = min(sample_b, full)
+    timed(sample_b, 1)                                   # the warm-up step at the sample batch
+    dt = timed(sample_b, steps)
+    why = "the config's own batch" if sample_b == full else \
+        "batch %d instead of the config's %d to keep the default run within ~%d s of CPU work" % (sample_b, full, budget_s)
     return {"value": round(sample_b / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d timed train steps (+1 warm-up) of the torch-CPU oracle, batch %d of the same %s %dx%d "
-                      "workload, torch.set_num_threads(%d)" % (steps, sample_b, cfg["model"], cfg["img_size"],
-                                                               cfg["img_size"], cores)}
+            "cpu_model": cpu_model_name(), "host_logical_cpus": ncpu, "seconds_per_step": round(dt, 3),
+            "sample": "%d timed train steps (+1 warm-up) of the torch-CPU oracle (oracle/torch_oracle.py, fp32), batch %d "
+                      "of the same %s %dx%d workload (%s), torch.set_num_threads(%d) = the fastest of {32, 64, all %d} logical CPUs "
+                      "on %s" % (steps, sample_b, cfg["model"], cfg["img_size"], cfg["img_size"], why, cores, ncpu,
+                                 cpu_model_name())}
 
 
-def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, layers=1):
+def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, layers=3):
     """north_star target: the fused xSlot forward at batch 256 (BASELINE configs[4]'s head: 100 classes x 3 slots, 7x7
-    grid) against the fp32 MFMA roofline.  Kernel time = the library's hipEvents around each launch, median of 8
+    grid, to_k_layer 3) against the fp32 MFMA roofline.  Kernel time = the library's hipEvents around each launch, median of 8
     batches of 20 launches after 60 warm-up launches (the clock settles); FLOPs are algorithmic (no padding counted)."""
     from scouter_amd import _native, kernels as K
     g = torch.Generator(device=device).manual_seed(0)
@@ -115,7 +176,7 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
                 "flop_model": "3 x forward (recomputation + two GEMMs per forward GEMM)",
                 "achieved": round(3 * fl / tb_ / 1e12, 2), "frac": round(3 * fl / tb_ / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
     return {"backward": backward, "kernel": "xslot_fwd_kernel (to_k MLP + 3 x [QK^T, sigmoid, AV, GRU] fused, v_mfma_f32_32x32x2_f32)",
-            "batch": batch, "slots": slots, "tokens": tokens, "avg_launch_us": round(t * 1e6, 1),
+            "batch": batch, "slots": slots, "tokens": tokens, "to_k_layers": layers, "avg_launch_us": round(t * 1e6, 1),
             "achieved": round(fl / t / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "bound": "mfma",
             "measured": "hipEvents around each launch, median of 8 batches x 20 launches after 60 warm-up launches"}
@@ -148,7 +209,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=CFG["batch"], help="per-GPU batch (weak scaling)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE config, 1-based (SURVEY.md section 8 table); 2 = the headline metric")
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default=None,
+                    help="backbone matrix-input precision (default: fp32; bf16 for --config 5, the config that names it)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's; weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel hipEvent pass (no roofline object)")
     ap.add_argument("--prof-steps", type=int, default=5, help="steps of the serial per-kernel timing pass")
@@ -178,7 +243,13 @@ def main():
     from scouter_amd.parallel import DistributedDataParallel
     from scouter_amd.sloter.slot_model import SlotModel
 
-    cfg = dict(CFG, batch=a.batch)
+    cfg = dict(CONFIGS[a.config])
+    if a.batch:
+        cfg["batch"] = a.batch
+    if a.precision:
+        cfg["precision"] = a.precision
+    bf16 = cfg["precision"] == "bf16"
+    mnist = cfg["dataset"] == "MNIST"
     torch.manual_seed(0)
     model = SlotModel(make_args(cfg))
     for m in model.modules():                          # exercise every layer: last-BN gamma = 1
@@ -187,7 +258,7 @@ def main():
     model = model.to(device).train()
     net = DistributedDataParallel(model, device_ids=[local_rank]) if (world > 1 or dist.is_initialized()) else model
     opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
-    x, y = synth_batch(cfg["batch"], cfg["img_size"], cfg["num_classes"], rank, device)
+    x, y = synth_batch(cfg["batch"], cfg["img_size"], cfg["num_classes"], rank, device, 1 if mnist else 3)
 
     def step():
         opt.zero_grad()
@@ -247,7 +318,9 @@ def main():
             kern[name] = {"launches_per_step": n / prof_steps, "ms_per_step": round(ms / prof_steps, 4),
                           "avg_us": round(1e3 * ms / n, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None,
                           "gbps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1) if by else None}
-        conv = [k for k in kern if k.startswith(("igemm_", "wgrad<", "wgrad_taps"))]
+        conv = [k for k in kern if k.startswith(("igemm_", "wgrad<", "wgrad_taps", "wgrad_bf16"))]
+        is_bf16_kernel = lambda k: "bf16" in k
+        kpeak = lambda k: PEAK_BF16_MFMA_TFLOPS if is_bf16_kernel(k) else PEAK_FP32_MFMA_TFLOPS
         roofline = None
         if conv:
             # the dominant kernel INSTANCE (most time per step); its rocprofv3 row is igemm_kernel<BM,BN,..> / wgrad_kernel<..>
@@ -255,25 +328,34 @@ def main():
             ach = kern[dom]["tflops"]
             tot_ms = sum(kern[k]["ms_per_step"] for k in conv)
             tot_fl = sum(kern[k]["tflops"] * kern[k]["ms_per_step"] for k in conv)
-            roofline = {"bound": "mfma", "kernel": dom + " (fp32 implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)",
-                        "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            # time-weighted fraction of each kernel's OWN matrix peak (fp32-MFMA kernels vs 157.3, bf16-MFMA kernels vs
+            # 2500 TFLOP/s): in bf16 mode the small / strided layers stay on the fp32 kernels
+            frac_all = sum(kern[k]["tflops"] * kern[k]["ms_per_step"] / kpeak(k) for k in conv) / tot_ms
+            step_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+            roofline = {"bound": "mfma",
+                        "kernel": dom + (" (bf16-input implicit-GEMM convolution, v_mfma_f32_32x32x16_bf16, fp32 accumulate)"
+                                         if is_bf16_kernel(dom) else
+                                         " (fp32 implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)"),
+                        "achieved": ach, "peak": kpeak(dom), "unit": "TFLOP/s",
+                        "frac": round(ach / kpeak(dom), 4), "traffic": None,
                         "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches_per_step"],
                         "measured": "hipEvents on the launch stream over %d serial steps (weight-gradient side stream "
                                     "off) right after the timed region" % prof_steps,
                         "all_conv_kernels_tflops": round(tot_fl / tot_ms, 2),
-                        "all_conv_kernels_frac": round(tot_fl / tot_ms / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "whole_step_frac": round(value * 3 * FWD_GFLOP_PER_IMG * 1e9 / world
-                                                 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
+                        "all_conv_kernels_frac": round(frac_all, 4),
+                        "whole_step_frac": round(value * 3 * cfg["fwd_gflop"] * 1e9 / world / (step_peak * 1e12), 4)}
         if roofline is not None:
-            roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom)
-        line = {"metric": "images/sec training step (resnest26d+xSlot, 224^2, bs70)", "value": round(value, 2),
+            roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom) if a.config == 2 and not bf16 else (None, None)
+        line = {"metric": cfg["metric"] if cfg["batch"] == CONFIGS[a.config]["batch"] else
+                cfg["metric"].rsplit(", bs", 1)[0] + ", bs%d)" % cfg["batch"], "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "BASELINE configs[1]: ImageNet-10 resnest26d + positive xSlot, channel 2048, "
-                                       "T=3, to_k_layer 3, power 2, 224x224, per-GPU batch %d, random init, AdamW "
-                                       "lr 1e-4" % cfg["batch"],
+                "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+                "config": {"workload": "%s, 224x224, per-GPU batch %d, random init, AdamW lr 1e-4%s"
+                                       % (cfg["name"], cfg["batch"],
+                                          "; backbone convolution matrix inputs in bf16 (fp32 accumulate, fp32 storage, "
+                                          "fp32 head)" if bf16 else ""),
+                           "baseline_config": a.config, "precision": cfg["precision"],
                            "global_batch": world * cfg["batch"], "parallelism": "dp%d" % world,
                            "step": "zero_grad+fwd+loss+bwd(+allreduce)+adamw", "final_loss": round(loss_val, 5)},
                 "roofline": roofline, "kernels": kern}

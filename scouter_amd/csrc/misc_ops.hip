@@ -265,7 +265,9 @@ extern "C" int scouter_posenc_sine_f32(float* pe, int h, int w, int d, void* str
 
 // ---------------------------------------------------------------------------------------------------------------
 // loss head: log_softmax + NLL(mean) + lambda * area**power, top-1 count; and its backward.
-//   stats[0]=loss  [1]=nll  [2]=area**power  [3]=#correct/B  [4]=area (mean of A_T)
+//   stats[0]=loss  [1]=nll  [2]=area**power  [3]=#correct/B  [4]=area (mean of A_T)  [5]=#labels outside [0, C)
+// A label outside [0, C) (num_classes / dataset mismatch) is never dereferenced: it makes loss and nll NaN, its row of
+// dlogits NaN, and is counted in stats[5] so the host can raise like F.nll_loss does (engine.calculation checks it).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void slot_loss_fwd_kernel(const float* __restrict__ logits,
                                                             const long* __restrict__ labels,
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(256) void slot_loss_fwd_kernel(const float* __restr
                                                             int B, int C, double area_count, float lambda,
                                                             float power,
                                                             float* __restrict__ logp, float* __restrict__ stats) {
-    __shared__ float red[2][256];
-    float nll = 0.f, corr = 0.f;
+    __shared__ float red[3][256];
+    float nll = 0.f, corr = 0.f, bad = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
         const float* row = logits + (long)b * C;
         float m = -INFINITY;
@@ -285,15 +287,24 @@ __global__ __launch_bounds__(256) void slot_loss_fwd_kernel(const float* __restr
         const float lse = m + logf(s);
         for (int c = 0; c < C; ++c) logp[(long)b * C + c] = row[c] - lse;
         if (labels) {
-            const int y = (int)labels[b];
-            nll -= row[y] - lse;
-            corr += (am == y) ? 1.f : 0.f;
+            const long y = labels[b];
+            if (y >= 0 && y < C) {
+                nll -= row[y] - lse;
+                corr += (am == (int)y) ? 1.f : 0.f;
+            } else {
+                nll = __builtin_nanf("");
+                bad += 1.f;
+            }
         }
     }
-    red[0][threadIdx.x] = nll; red[1][threadIdx.x] = corr;
+    red[0][threadIdx.x] = nll; red[1][threadIdx.x] = corr; red[2][threadIdx.x] = bad;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        if (threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+            red[2][threadIdx.x] += red[2][threadIdx.x + o];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0 && stats) {
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(256) void slot_loss_fwd_kernel(const float* __restr
         stats[2] = term;
         stats[3] = labels ? red[1][0] / B : 0.f;
         stats[4] = area;
+        stats[5] = red[2][0];
     }
 }
 // upstream grads (device scalars, NULL = 0): g_loss, g_nll, g_term ; g_logp [B][C] or NULL
@@ -325,7 +337,12 @@ __global__ __launch_bounds__(256) void slot_loss_bwd_kernel(const float* __restr
     const float wn = labels ? (gl + gn) / B : 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
         float rs = 0.f;
-        const int y = labels ? (int)labels[b] : -1;
+        const long yl = labels ? labels[b] : -1;
+        const int y = (yl >= 0 && yl < C) ? (int)yl : -1;
+        if (labels && y < 0) {                  // out-of-range label: poisoned row, nothing dereferenced
+            for (int c = 0; c < C; ++c) dlogits[(long)b * C + c] = __builtin_nanf("");
+            continue;
+        }
         for (int c = 0; c < C; ++c) {
             float d = g_logp ? g_logp[(long)b * C + c] : 0.f;
             if (c == y) d -= wn;

@@ -34,8 +34,11 @@ class _DeviceMeter:
             self.host[i] += v
 
     def read(self):
-        dev = self.total[:4].tolist() if self.total is not None else [0.0] * 4      # the only host sync of the epoch
-        return [d + h for d, h in zip(dev, self.host)]
+        dev = self.total[:6].tolist() if self.total is not None else [0.0] * 6      # the only host sync of the epoch
+        if dev[5] > 0:                 # stats[5]: labels outside [0, num_classes) seen by the loss kernel this epoch
+            raise IndexError("%d target label(s) out of bounds for num_classes (F.nll_loss raises the same way; check "
+                             "--num_classes against the dataset)" % int(dev[5]))
+        return [d + h for d, h in zip(dev[:4], self.host)]
 
 
 def _unwrap(model):

@@ -259,6 +259,28 @@ def test_loss_fwd_bwd():
     dl, ga = kk.slot_loss_bwd(lp, y.cuda(), stats, one, None, None, None, B * S * N, lam, power)
     np.testing.assert_allclose(dl.cpu().numpy(), lr.grad.numpy(), atol=1e-6)
     np.testing.assert_allclose(float(ga), float(ar.grad[0]), rtol=1e-5)
+    assert float(stats[5]) == 0.0
+
+
+def test_loss_label_out_of_range_is_flagged_not_dereferenced():
+    """F.nll_loss raises on a target outside [0, C) (reference slot_model.py:121); here the kernels never index with
+    it: loss / nll become NaN, the row's dlogits NaN, stats[5] counts the offenders and engine.calculation raises."""
+    kk = K()
+    B, C = 6, 5
+    logits = torch.randn(B, C, device="cuda")
+    y = torch.tensor([0, 4, 5, 2, -1, 1], device="cuda")
+    lp, stats = kk.slot_loss_fwd(logits, y, None, 1.0, 0.0, 1.0)
+    assert float(stats[5]) == 2.0 and bool(torch.isnan(stats[0])) and bool(torch.isnan(stats[1]))
+    np.testing.assert_allclose(lp.cpu().numpy(), F.log_softmax(logits.cpu(), 1).numpy(), atol=2e-6)
+    one = torch.ones(1, dtype=torch.float32, device="cuda")
+    dl, _ = kk.slot_loss_bwd(lp, y, stats, one, None, None, None, 1.0, 0.0, 1.0)
+    bad = torch.isnan(dl).all(dim=1).cpu().tolist()
+    assert bad == [False, False, True, False, True, False]
+    from scouter_amd.engine import _DeviceMeter
+    meter = _DeviceMeter()
+    meter.add_device(stats)
+    with pytest.raises(IndexError, match="out of bounds"):
+        meter.read()
 
 
 @pytest.mark.parametrize("case", [(3, 14, 14, 64, 128, 3, 1, 1, 2), (2, 9, 9, 256, 64, 1, 1, 0, 1), (5, 1, 1, 64, 32, 1, 1, 0, 1),
