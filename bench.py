@@ -83,7 +83,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cfg, budget_s=25.0, steps=3):
+def cpu_baseline(cfg, budget_s=20.0, steps=3):
     """The CPU oracle's train step (the port of the reference's PyTorch-CPU path) beside the GPU number: SURVEY.md
     section 8d asks for the config's own batch, 1 warm-up + 3 timed steps, all host cores, CPU model and core count in
     the object.  The sample is bounded to ~`budget_s` of CPU work: a probe step at batch 8 sizes the sample batch (the
@@ -104,16 +104,13 @@ def cpu_baseline(cfg, budget_s=25.0, steps=3):
         for _ in range(n):
             tr.step(img, lab)
         return (time.time() - t0) / n
-    # thread count: all host cores unless a smaller pool is measurably faster on this box (torch-CPU
-    # convolutions on a small batch slow down beyond a few dozen threads) -- the CPU gets its best setting
-    probe, cores = None, ncpu
-    for c in sorted({min(32, ncpu), min(64, ncpu), ncpu}):
-        torch.set_num_threads(c)
-        timed(8, 1)                                      # thread pool / allocator warm-up
-        t = timed(8, 1) / 8                              # seconds per image
-        if probe is None or t < probe:
-            probe, cores = t, c
+    # thread count: 32.  SURVEY 8d asks for all host cores, but on the GPU box (2 x EPYC 9575F, 256 logical CPUs) torch-CPU
+    # convolutions at these batch sizes are SLOWER beyond a few dozen threads: the round-2 probe timed {32, 64, 256}
+    # threads on configs 1-4 and 32 won every time (256 threads: minutes per step) -- the CPU gets its best setting.
+    cores = min(32, ncpu)
     torch.set_num_threads(cores)
+    timed(8, 1)                                          # thread pool / allocator warm-up
+    probe = timed(8, 1) / 8                              # seconds per image
     full = cfg["batch"]
     sample_b = full if probe * full * (steps + 1) <= budget_s else max(8, int(budget_s / (probe * (steps + 1))) // 8 * 8)
     sample_b = min(sample_b, full)
@@ -124,7 +121,7 @@ def cpu_baseline(cfg, budget_s=25.0, steps=3):
     return {"value": round(sample_b / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "cpu_model": cpu_model_name(), "host_logical_cpus": ncpu, "seconds_per_step": round(dt, 3),
             "sample": "%d timed train steps (+1 warm-up) of the torch-CPU oracle (oracle/torch_oracle.py, fp32), batch %d "
-                      "of the same %s %dx%d workload (%s), torch.set_num_threads(%d) = the fastest of {32, 64, all %d} logical CPUs "
+                      "of the same %s %dx%d workload (%s), torch.set_num_threads(%d) of %d logical CPUs (32 measured faster than 64 / all) "
                       "on %s" % (steps, sample_b, cfg["model"], cfg["img_size"], cfg["img_size"], why, cores, ncpu,
                                  cpu_model_name())}
 

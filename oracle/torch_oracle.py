@@ -142,10 +142,34 @@ def vis_maps(attn, num_classes, slots_per_class, vis_id=0):
     return a.detach().cpu().numpy().astype(np.uint8)
 
 
+# Test instrumentation: callable(name, pre_activation) -> activation, applied at every ReLU that follows a BatchNorm /
+# closes a residual block / follows conv1x1 (name = the state_dict prefix of that layer, e.g. "backbone.layer2.0.bn1",
+# "conv1x1").  None = torch.relu.  tests/test_model_gpu.py uses it to capture the sign pattern, and to evaluate the
+# oracle UNDER THE HIP PATH'S sign pattern so that gradient comparisons are not dominated by a ReLU flipping on a ~0
+# pre-activation (one flip moves every upstream gradient by ~1/samples in either implementation).
+RELU_HOOK = None
+
+
+def _relu(name, x):
+    return torch.relu(x) if RELU_HOOK is None else RELU_HOOK(name, x)
+
+
+# Same idea for the stem's MaxPool2d(3, 2, 1): callable(x) -> pooled, e.g. maxpool_with_indices under the HIP path's
+# window choice (after a ReLU most windows hold several exact zeros, and one flipped sign re-routes the gradient).
+MAXPOOL_HOOK = None
+
+
+def maxpool_with_indices(x, arg):
+    """3x3 / stride 2 / pad 1 pooling that takes element `arg` (= ky * 3 + kx, [B, C, Ho, Wo]) of every window."""
+    B, C, H, W = x.shape
+    cols = F.unfold(F.pad(x, (1, 1, 1, 1), value=float("-inf")), 3, stride=2).view(B, C, 9, -1)
+    return cols.gather(2, arg.reshape(B, C, 1, -1).long()).view(B, C, arg.shape[2], arg.shape[3])
+
+
 def head_forward(P, feat, target, cfg, aux=None):
     """SlotModel.forward after the backbone (slot_model.py:108-127).  feat: [B, Cin, h, w]."""
     x = F.conv2d(feat, P["conv1x1.weight"], P["conv1x1.bias"])
-    x = torch.relu(x)
+    x = _relu("conv1x1", x)
     b, d, h, w = x.shape
     pe = posenc_sine(h, w, d, x.dtype)
     x_pe = x + pe
@@ -235,12 +259,12 @@ def _bn(P, name, x, training):
 def _split_attn(P, name, x, training):
     """SplitAttnConv2d.forward, radix 2, cardinality 1 (split_attn.py:54-80, RadixSoftmax :20-28)."""
     x = _conv(x, P[name + ".conv.weight"], None, 1, 1, 1, 2)
-    x = torch.relu(_bn(P, name + ".bn0", x, training))
+    x = _relu(name + ".bn0", _bn(P, name + ".bn0", x, training))
     B, RC, H, W = x.shape
     x5 = x.reshape(B, 2, RC // 2, H, W)
     gap = x5.sum(dim=1).mean(dim=(2, 3), keepdim=True)
     g = _conv(gap, P[name + ".fc1.weight"], P[name + ".fc1.bias"])
-    g = torch.relu(_bn(P, name + ".bn1", g, training))
+    g = _relu(name + ".bn1", _bn(P, name + ".bn1", g, training))
     a = _conv(g, P[name + ".fc2.weight"], P[name + ".fc2.bias"])
     a = a.view(B, 1, 2, -1).transpose(1, 2)
     a = F.softmax(a, dim=1).reshape(B, 2, RC // 2, 1, 1)
@@ -250,7 +274,7 @@ def _split_attn(P, name, x, training):
 def _resnest_block(P, name, x, stride, training):
     """ResNestBottleneck.forward with avd=True, avd_first=False (resnest.py:111-143); `is_first` is never set
     by ResNet._make_layer so avd pooling exists only when stride > 1 (:76-80)."""
-    out = torch.relu(_bn(P, name + ".bn1", _conv(x, P[name + ".conv1.weight"]), training))
+    out = _relu(name + ".bn1", _bn(P, name + ".bn1", _conv(x, P[name + ".conv1.weight"]), training))
     out = _split_attn(P, name + ".conv2", out, training)
     if stride > 1:
         out = F.avg_pool2d(out, 3, stride, padding=1)
@@ -260,18 +284,18 @@ def _resnest_block(P, name, x, stride, training):
         if stride > 1:
             residual = F.avg_pool2d(residual, 2, stride, ceil_mode=True, count_include_pad=False)
         residual = _bn(P, name + ".downsample.2", _conv(residual, P[name + ".downsample.1.weight"]), training)
-    return torch.relu(out + residual)
+    return _relu(name + ".bn3", out + residual)
 
 
 def _basic_block(P, name, x, stride, training):
     """BasicBlock.forward (resnet.py:172-199) with downsample_conv (resnet.py:273-289)."""
-    out = torch.relu(_bn(P, name + ".bn1", _conv(x, P[name + ".conv1.weight"], None, stride, 1), training))
+    out = _relu(name + ".bn1", _bn(P, name + ".bn1", _conv(x, P[name + ".conv1.weight"], None, stride, 1), training))
     out = _bn(P, name + ".bn2", _conv(out, P[name + ".conv2.weight"], None, 1, 1), training)
     residual = x
     if (name + ".downsample.0.weight") in P:
         residual = _bn(P, name + ".downsample.1",
                        _conv(x, P[name + ".downsample.0.weight"], None, stride, 0), training)
-    return torch.relu(out + residual)
+    return _relu(name + ".bn2", out + residual)
 
 
 def backbone_features(P, x, arch, training, prefix="backbone."):
@@ -279,15 +303,15 @@ def backbone_features(P, x, arch, training, prefix="backbone."):
     cfg = ARCHS[arch]
     if cfg["kind"] == "resnest":   # deep stem 32-32-64 (resnet.py:389-400)
         x = _conv(x, P[prefix + "conv1.0.weight"], None, 2, 1)
-        x = torch.relu(_bn(P, prefix + "conv1.1", x, training))
+        x = _relu(prefix + "conv1.1", _bn(P, prefix + "conv1.1", x, training))
         x = _conv(x, P[prefix + "conv1.3.weight"], None, 1, 1)
-        x = torch.relu(_bn(P, prefix + "conv1.4", x, training))
+        x = _relu(prefix + "conv1.4", _bn(P, prefix + "conv1.4", x, training))
         x = _conv(x, P[prefix + "conv1.6.weight"], None, 1, 1)
     else:                          # 7x7/2 stem, or the MNIST 3x3/2 1-channel stem (slot_model.py:23-24)
         w = P[prefix + "conv1.weight"]
         x = _conv(x, w, None, 2, w.shape[-1] // 2)
-    x = torch.relu(_bn(P, prefix + "bn1", x, training))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _relu(prefix + "bn1", _bn(P, prefix + "bn1", x, training))
+    x = F.max_pool2d(x, 3, 2, 1) if MAXPOOL_HOOK is None else MAXPOOL_HOOK(x)
     block = _resnest_block if cfg["kind"] == "resnest" else _basic_block
     for li, nblocks in enumerate(cfg["layers"]):
         for bi in range(nblocks):

@@ -36,6 +36,7 @@ class Conv2d(nn.Module):
         self._dw = self._db = None                                  # arena slices, set by GradArena
         self.precision = "fp32"                                     # per layer; SlotModel.set_precision (no global)
         self.use_side_stream = K.SIDE_STREAM_DEFAULT                # weight gradient on the side stream
+        self._capture = None                                        # test instrumentation, see BatchNorm2d
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # timm resnet.py:447-448
         if bias:
             bound = 1.0 / math.sqrt(in_channels // groups * k * k)
@@ -45,6 +46,8 @@ class Conv2d(nn.Module):
         """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd."""
         y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
                          bn_stats, precision=self.precision)
+        if self._capture is not None and relu:
+            self._capture[0][self._capture[1]] = y
         return y, (x if save else None)
 
     def bwd(self, dy, ctx, need_dx=True, addend=None):
@@ -114,6 +117,7 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._dg = self._db = None
+        self._capture = None                 # test instrumentation: (dict, key) -> the ReLU'd output is stored there
 
     def fwd(self, x, save, relu=False, residual=None, tracked=None):
         """x may be the (tensor, stats) pair a conv produced with bn_stats=True."""
@@ -128,6 +132,8 @@ class BatchNorm2d(nn.Module):
                        want_mask=bool(relu and save))
         if self.training and tracked is not None:
             tracked.append(self.num_batches_tracked)
+        if self._capture is not None and relu:
+            self._capture[0][self._capture[1]] = out[0]
         # the backward takes the ReLU sign from a 1-bit/element mask, not from the 4-byte activation
         return out[0], ((x, out[2] if relu else None, out[1], self.training) if save else None)
 

@@ -103,6 +103,7 @@ class ResNet(nn.Module):
         self.bn1 = BatchNorm2d(self.inplanes)
         self.act1 = Act()
         self.maxpool = Identity()      # MaxPool2d(3, 2, 1) runs in scouter_maxpool_*_f32
+        self._capture = None           # test instrumentation: (dict, key) -> the max-pool window indices go there
         chans, strides = [64, 128, 256, 512], [1, 2, 2, 2]
         for i in range(4):
             setattr(self, "layer%d" % (i + 1), self._make_layer(block, chans[i], layers[i], strides[i], avg_down,
@@ -145,6 +146,8 @@ class ResNet(nn.Module):
             ctx.append((k0,))
         h, bb = self.bn1.fwd(c, save, relu=True, tracked=tracked)
         p, arg = K.maxpool_fwd(h, 3, 2, 1, want_argmax=save)
+        if self._capture is not None and arg is not None:
+            self._capture[0][self._capture[1]] = arg
         ctx.append((bb, arg, tuple(h.shape)))
         x = p
         for li in range(1, 5):

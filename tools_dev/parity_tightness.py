@@ -4,11 +4,12 @@ oracle fp64) -- the numbers behind the assertions of tests/test_model_gpu.py."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
-from test_model_gpu import build, oracle_run, GOLD
+from test_model_gpu import build, oracle_run, capture_relu_signs, GOLD
 for case in sys.argv[1:] or ["resnet18_mnist_64", "resnest26d_96", "resnest50d_64_spc3", "resnest26d_224"]:
     g = np.load(os.path.join(GOLD, "model_%s.npz" % case))
     m, P, images, labels = build(case)
     m.train()
+    signs = capture_relu_signs(m)
     out, (loss, nll, area) = m(images.cuda(), labels.cuda())
     loss.backward(); torch.cuda.synchronize()
     floor = float(np.abs(g["f32_log_probs"] - g["f64_log_probs"]).max())
@@ -18,8 +19,12 @@ for case in sys.argv[1:] or ["resnet18_mnist_64", "resnest26d_96", "resnest50d_6
     print("%-22s log_probs: HIP %.3g torch32 %.3g ratio %.2f | attn: HIP %.3g torch32 %.3g" % (case, err, floor, err / max(floor, 1e-12), ea, fa))
     if case == "resnest26d_224":
         continue
-    _, _, _, leaves, _ = oracle_run(case, torch.float64)
-    _, _, _, leaves32, _ = oracle_run(case, torch.float32)
+    pool_arg = signs.pop("maxpool").permute(0, 3, 1, 2).cpu()
+    masks = {k: (v > 0).permute(0, 3, 1, 2).cpu() for k, v in signs.items()}
+    own = {}
+    _, _, _, leaves, _ = oracle_run(case, torch.float64, relu_masks=masks, sign_log=own, pool_arg=pool_arg)
+    _, _, _, leaves32, _ = oracle_run(case, torch.float32, relu_masks=masks, pool_arg=pool_arg)
+    print("   ReLU flips HIP vs oracle fp64:", {k: int((own[k] != masks[k]).sum()) for k in masks if int((own[k] != masks[k]).sum())})
     named = dict(m.named_parameters())
     viol = []
     for k, ref in leaves.items():
