@@ -69,6 +69,32 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
     const int ncol = grp * g.Ng + n0 + wn * WN + qcol;
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv4 = *(const f32x4*)(bias + ncol);
+    // BatchNorm statistics straight from the accumulators when the stored value IS the accumulator (no bias / addend --
+    // every convolution in front of a BatchNorm except the split-attention fc1): in the MFMA layout a lane holds 16 rows
+    // of ONE column per 32x32 block, so the column partials are lane-local: 16 fp64 adds + 16 fp64 fmas per block and ONE
+    // cross-lane step (the other lane half), instead of the row-major path's fp64 accumulation per element PLUS three
+    // 64-bit shuffle rounds over eight values (~170 VALU per thread -- matrix time on these short-K layers).  fp64 from
+    // the first addition on: 16-term fp32 partials were tried and cost accuracy END TO END (a rounding error in a batch
+    // mean shifts a whole channel coherently; log-probs moved from 5e-5 to 1.2e-4 off the fp64 reference on the 224x224
+    // fixture).  Rows beyond M contribute exact zeros (their A rows read zeros).
+    const bool acc_stats = bn_part && !bias && !addend;
+    double as[NT], aq[NT];
+    if (acc_stats) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            as[j] = 0.0; aq[j] = 0.0;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const double v = (double)acc[i][j][e];
+                    as[j] += v;
+                    aq[j] = fma(v, v, aq[j]);
+                }
+            as[j] += __shfl_xor(as[j], 32, 64);               // the other 16 rows of the column (lane half h)
+            aq[j] += __shfl_xor(aq[j], 32, 64);
+        }
+    }
     double cs[4] = {0, 0, 0, 0}, cq[4] = {0, 0, 0, 0};        // per-column sum / sum of squares (BatchNorm statistics)
 #pragma unroll
     for (int rr = 0; rr < WM / RPP; ++rr) {
@@ -77,7 +103,7 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
         if (m >= g.M) continue;
         f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
         if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
-        if (bn_part) {
+        if (bn_part && !acc_stats) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * v[e]; }
         }
@@ -91,13 +117,20 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
         // Fused batch statistics of the tile just written: lanes sharing a column quad (stride QPR) are combined by
         // shuffles, the BM/WM waves sharing a column range through LDS; one fp64 (sum, sumsq) pair per column and
         // M-tile goes to bn_part[mtile][channel][2] -- scouter_bn_fwd_f32 then skips its own read of the tensor.
+        if (!acc_stats) {
 #pragma unroll
-        for (int o = QPR; o < 64; o <<= 1)
+            for (int o = QPR; o < 64; o <<= 1)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], o, 64); cq[e] += __shfl_xor(cq[e], o, 64); }
+                for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], o, 64); cq[e] += __shfl_xor(cq[e], o, 64); }
+        }
         __syncthreads();                                      // every wave is done reading its staged tile
         double* Ps = (double*)lds;                            // [4 waves][WN][2], re-uses the staging area
-        if (qrow == 0) {
+        if (acc_stats) {
+            if (lane < 32) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { Ps[(wave * WN + j * 32 + l31) * 2] = as[j]; Ps[(wave * WN + j * 32 + l31) * 2 + 1] = aq[j]; }
+            }
+        } else if (qrow == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { Ps[(wave * WN + qcol + e) * 2] = cs[e]; Ps[(wave * WN + qcol + e) * 2 + 1] = cq[e]; }
         }

@@ -30,7 +30,12 @@ struct TileCfg {
 // ----------------------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ----------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED>
+// PW ("pointwise"): 1x1 / stride 1 / pad 0 -- GEMM row m IS pixel m, so the block prologue needs no (b, y, x)
+// decomposition, no tap masks and no per-tap offset switch: the A descriptor covers exactly the block's valid rows
+// (rows beyond M read zeros through num_records).  36 of resnest26d's 48 convolutions are pointwise and they have the
+// SHORTEST K loops (Cin/32 = 2..64 tiles), where the general prologue's ~300 VALU instructions per thread -- fp32 MFMA
+// shares the vector lanes -- were a tenth to a third of the block's matrix time (tools_dev/isa_phases.py).
+template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED, bool PW>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ addend, float* __restrict__ dst,
@@ -55,77 +60,89 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     const int cpt = g.Cg / BK;                 // K chunks per filter tap
     const int KT = g.R * g.S * cpt;
 
-    // ---- per-thread A rows (fixed for the whole K loop): pointer of filter tap (0,0) + a validity bit per tap, so
-    // the in-loop address work is one 64-bit add of a wave-uniform tap offset and a bit test (the general
-    // bounds/stride arithmetic per load cost ~25 VALU issues each and measurably starved the MFMA issue)
     unsigned a_mask[AI];
     int a_y[AI], a_x[AI];
     long a_base[AI];
-    int a_rel[AI];
     const int a_col = (tid & 7) * 4;
     constexpr bool lin = !(DGRAD && STRIDED);          // source pixel is linear in the tap index
-    // pixel (b, y, x) of each row without integer division: the block's first pixel once (fp64 reciprocal, exact for
-    // M < 2^31), then small carries per row; tap validity is separable (row bits x column bits).  The first version
-    // spent ~780 VALU instructions per block here (64-bit div/mod per row, R*S compares) -- fp32 MFMA time.
-    const int hw = g.Ho * g.Wo;
-    const int blk_b = (int)(((double)(unsigned)m0 + 0.5) * g.inv_hw);
-    const int blk_rem = (int)((unsigned)m0 - (unsigned)blk_b * (unsigned)hw);
-    const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
     const int rows_valid = (int)(g.M - m0 < BM ? g.M - m0 : BM);
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int rowoff = (tid >> 3) + 32 * i;
-        const bool okm = rowoff < rows_valid;
-        const int tx = blk_x + rowoff, qx = fast_div(tx, g.inv_wo), x = tx - qx * g.Wo;
-        const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho), y = ty - qy * g.Ho;
-        const int b = okm ? blk_b + qy : 0;
-        a_base[i] = (long)b * g.H * g.W;
-        a_rel[i] = okm ? qy * g.H * g.W : 0;                      // pixels from the block's base image
-        if (DGRAD) { a_y[i] = y + g.pad; a_x[i] = x + g.pad; }
-        else       { a_y[i] = y * g.stride - g.pad; a_x[i] = x * g.stride - g.pad; }
-        unsigned mask = 0;
-        if (DGRAD && STRIDED) {
-            for (int r = 0; r < g.R; ++r)
-                for (int q = 0; q < g.S; ++q) {
-                    const int ty2 = a_y[i] - r, tx2 = a_x[i] - q;
-                    bool ok = okm && ty2 >= 0 && tx2 >= 0;
-                    const int iy = ty2 / g.stride, ix = tx2 / g.stride;
-                    ok = ok && (iy * g.stride == ty2) && (ix * g.stride == tx2) && iy < g.H && ix < g.W;
-                    mask |= (ok ? 1u : 0u) << (r * g.S + q);
-                }
-        } else {
-            unsigned colbits = 0;
-            for (int q = 0; q < g.S; ++q)
-                colbits |= ((unsigned)(DGRAD ? a_x[i] - q : a_x[i] + q) < (unsigned)g.W ? 1u : 0u) << q;
-            for (int r = 0; r < g.R; ++r)
-                mask |= ((unsigned)(DGRAD ? a_y[i] - r : a_y[i] + r) < (unsigned)g.H ? colbits : 0u) << (r * g.S);
-            mask = okm ? mask : 0u;
-        }
-        a_mask[i] = mask;
-    }
     const float* wbase = wgt + (long)grp * (DGRAD ? g.Cg : g.Ng);   // group offset along the contiguous Cout axis
-
-    // ---- buffer addressing.  fp32 MFMA runs on the vector FP32 lanes (its peak IS the vector peak), so every VALU
-    // instruction in the K loop is matrix throughput lost -- unlike SALU and memory-instruction issue, which are free.
-    // Loads therefore go through buffer descriptors: address = base (SGPR) + per-row byte offset (VGPR, fixed for the
-    // whole loop) + wave-uniform tap/channel offset (SGPR, scalar arithmetic); a padding row gets an offset beyond
-    // num_records for that tap and the hardware returns zeros -- no exec masking, zero fills or 64-bit VALU adds.
-    // The base is block-relative (image of the block's first pixel, shifted down so that every tap offset is >= 0; it
-    // may precede the allocation, only valid taps are ever dereferenced), so offsets fit 31 bits for any tensor size.
     constexpr unsigned OOB = 0x80000000u;
-    const long img_elems = (long)g.H * g.W * g.C;
-    const int b0 = blk_b;
-    const long shift = DGRAD ? ((long)(g.R - 1) * g.W + (g.S - 1)) * g.C : ((long)g.pad * g.W + g.pad) * g.C;
-    const __amdgpu_buffer_rsrc_t rs_a =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)b0 * img_elems - shift), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7fffffff, 0x00020000);
     unsigned a_voff[AI], a_veff[AI];
+    long shift = 0;
+    __amdgpu_buffer_rsrc_t rs_a;
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7fffffff, 0x00020000);
+    if constexpr (PW) {
+        // pointwise: row r of the block is pixel m0 + r; the descriptor spans the block's valid rows only, so rows
+        // beyond M read zeros without any per-row state
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + m0 * g.C), 0,
+                                                 (unsigned)rows_valid * (unsigned)g.C * 4u, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int e = DGRAD ? (a_rel[i] + a_y[i] * g.W + a_x[i]) * g.C
-                            : (a_rel[i] + (a_y[i] + g.pad) * g.W + (a_x[i] + g.pad)) * g.C;
-        a_voff[i] = (unsigned)(e + grp * g.Cg + a_col) * 4u;
-        a_veff[i] = OOB;
+        for (int i = 0; i < AI; ++i) {
+            a_voff[i] = (unsigned)(((tid >> 3) + 32 * i) * g.C + grp * g.Cg + a_col) * 4u;
+            a_veff[i] = a_voff[i];
+            a_mask[i] = 0; a_y[i] = a_x[i] = 0; a_base[i] = 0;
+        }
+    } else {
+        // ---- per-thread A rows (fixed for the whole K loop): pointer of filter tap (0,0) + a validity bit per tap, so
+        // the in-loop address work is one 64-bit add of a wave-uniform tap offset and a bit test (the general
+        // bounds/stride arithmetic per load cost ~25 VALU issues each and measurably starved the MFMA issue)
+        // pixel (b, y, x) of each row without integer division: the block's first pixel once (fp64 reciprocal, exact for
+        // M < 2^31), then small carries per row; tap validity is separable (row bits x column bits).  The first version
+        // spent ~780 VALU instructions per block here (64-bit div/mod per row, R*S compares) -- fp32 MFMA time.
+        int a_rel[AI];
+        const int hw = g.Ho * g.Wo;
+        const int blk_b = (int)(((double)(unsigned)m0 + 0.5) * g.inv_hw);
+        const int blk_rem = (int)((unsigned)m0 - (unsigned)blk_b * (unsigned)hw);
+        const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int rowoff = (tid >> 3) + 32 * i;
+            const bool okm = rowoff < rows_valid;
+            const int tx = blk_x + rowoff, qx = fast_div(tx, g.inv_wo), x = tx - qx * g.Wo;
+            const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho), y = ty - qy * g.Ho;
+            const int b = okm ? blk_b + qy : 0;
+            a_base[i] = (long)b * g.H * g.W;
+            a_rel[i] = okm ? qy * g.H * g.W : 0;                      // pixels from the block's base image
+            if (DGRAD) { a_y[i] = y + g.pad; a_x[i] = x + g.pad; }
+            else       { a_y[i] = y * g.stride - g.pad; a_x[i] = x * g.stride - g.pad; }
+            unsigned mask = 0;
+            if (DGRAD && STRIDED) {
+                for (int r = 0; r < g.R; ++r)
+                    for (int q = 0; q < g.S; ++q) {
+                        const int ty2 = a_y[i] - r, tx2 = a_x[i] - q;
+                        bool ok = okm && ty2 >= 0 && tx2 >= 0;
+                        const int iy = ty2 / g.stride, ix = tx2 / g.stride;
+                        ok = ok && (iy * g.stride == ty2) && (ix * g.stride == tx2) && iy < g.H && ix < g.W;
+                        mask |= (ok ? 1u : 0u) << (r * g.S + q);
+                    }
+            } else {
+                unsigned colbits = 0;
+                for (int q = 0; q < g.S; ++q)
+                    colbits |= ((unsigned)(DGRAD ? a_x[i] - q : a_x[i] + q) < (unsigned)g.W ? 1u : 0u) << q;
+                for (int r = 0; r < g.R; ++r)
+                    mask |= ((unsigned)(DGRAD ? a_y[i] - r : a_y[i] + r) < (unsigned)g.H ? colbits : 0u) << (r * g.S);
+                mask = okm ? mask : 0u;
+            }
+            a_mask[i] = mask;
+        }
+        // ---- buffer addressing.  fp32 MFMA runs on the vector FP32 lanes (its peak IS the vector peak), so every VALU
+        // instruction in the K loop is matrix throughput lost -- unlike SALU and memory-instruction issue, which are free.
+        // Loads therefore go through buffer descriptors: address = base (SGPR) + per-row byte offset (VGPR, fixed for the
+        // whole loop) + wave-uniform tap/channel offset (SGPR, scalar arithmetic); a padding row gets an offset beyond
+        // num_records for that tap and the hardware returns zeros -- no exec masking, zero fills or 64-bit VALU adds.
+        // The base is block-relative (image of the block's first pixel, shifted down so that every tap offset is >= 0; it
+        // may precede the allocation, only valid taps are ever dereferenced), so offsets fit 31 bits for any tensor size.
+        const long img_elems = (long)g.H * g.W * g.C;
+        shift = DGRAD ? ((long)(g.R - 1) * g.W + (g.S - 1)) * g.C : ((long)g.pad * g.W + g.pad) * g.C;
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)blk_b * img_elems - shift), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int e = DGRAD ? (a_rel[i] + a_y[i] * g.W + a_x[i]) * g.C
+                                : (a_rel[i] + (a_y[i] + g.pad) * g.W + (a_x[i] + g.pad)) * g.C;
+            a_voff[i] = (unsigned)(e + grp * g.Cg + a_col) * 4u;
+            a_veff[i] = OOB;
+        }
     }
 
     // ---- software pipeline (per wave; the MFMA stream never waits for memory inside a K-tile):
@@ -136,6 +153,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     // the two co-resident blocks convoy and sit in their LDS round trips together.
     f32x4 ra[AI], rb[BI];
     auto load_a = [&](int kt) {
+        if constexpr (PW) {                            // one tap: K-tile kt is channels [32 kt, 32 kt + 32)
+#pragma unroll
+            for (int i = 0; i < AI; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[i], kt * (BK * 4), 0));
+            return;
+        }
         const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
         const int r = tap / g.S, q = tap - r * g.S;
         // wave-uniform element offset of this (tap, channel chunk) relative to tap (0,0)
@@ -172,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < BI; ++i) b_voff[i] = (unsigned)((b_ptr[i] - wbase) * 4);
     auto load_b = [&](int kt) {
-        const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+        const int tap = PW ? 0 : kt / cpt, c0 = (kt - tap * cpt) * BK;
         const long woff = (long)tap * g.wtap + (B_KC ? (long)c0 : (long)c0 * g.wrow);     // wave-uniform
 #pragma unroll
         for (int i = 0; i < BI; ++i)
@@ -560,7 +583,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // ----------------------------------------------------------------------------------------------------------------
 // host dispatch
 // ----------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED>
+template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED, bool PW>
 static void launch_igemm_s(const float* src, const float* w, const float* bias, const float* addend, float* dst,
                            double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
     const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
@@ -569,14 +592,18 @@ static void launch_igemm_s(const float* src, const float* w, const float* bias, 
     gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
     gg.inv_wo = 1.0f / (float)g.Wo;
     gg.inv_ho = 1.0f / (float)g.Ho;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED>), grid, dim3(256), 0, st, src, w, bias, addend,
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED, PW>), grid, dim3(256), 0, st, src, w, bias, addend,
                        dst, bn_part, gg, relu, mtiles, ntiles);
 }
 template <int BM, int BN, int WM, int WN, bool DGRAD>
 static void launch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
                          double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
-    if (DGRAD && g.stride != 1) launch_igemm_s<BM, BN, WM, WN, DGRAD, true>(src, w, bias, addend, dst, bn_part, g, relu, st);
-    else launch_igemm_s<BM, BN, WM, WN, DGRAD, false>(src, w, bias, addend, dst, bn_part, g, relu, st);
+    // pointwise fast path: 1x1 / stride 1 / pad 0 (row m == pixel m on both sides), block rows within 32-bit offsets
+    const bool pw = g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.H == g.Ho && g.W == g.Wo &&
+                    (long)BM * g.C * 4 < (1L << 31);
+    if (pw) launch_igemm_s<BM, BN, WM, WN, DGRAD, false, true>(src, w, bias, addend, dst, bn_part, g, relu, st);
+    else if (DGRAD && g.stride != 1) launch_igemm_s<BM, BN, WM, WN, DGRAD, true, false>(src, w, bias, addend, dst, bn_part, g, relu, st);
+    else launch_igemm_s<BM, BN, WM, WN, DGRAD, false, false>(src, w, bias, addend, dst, bn_part, g, relu, st);
 }
 
 // tile choice: largest tile that still fills the chip (>= ~1.5 rounds of 256 CUs x 2 blocks); Ng is a multiple of 32

@@ -283,15 +283,18 @@ def test_loss_label_out_of_range_is_flagged_not_dereferenced():
         meter.read()
 
 
+@pytest.mark.parametrize("with_bias", [True, False])
 @pytest.mark.parametrize("case", [(3, 14, 14, 64, 128, 3, 1, 1, 2), (2, 9, 9, 256, 64, 1, 1, 0, 1), (5, 1, 1, 64, 32, 1, 1, 0, 1),
-                                  (2, 30, 30, 32, 32, 3, 1, 1, 1)])
-def test_conv_fused_bn_statistics(case):
-    """conv epilogue -> per-tile fp64 channel sums -> bn_fwd(stats=...) == bn_fwd computing its own statistics."""
+                                  (2, 30, 30, 32, 32, 3, 1, 1, 1), (3, 17, 13, 128, 256, 1, 1, 0, 1)])
+def test_conv_fused_bn_statistics(case, with_bias):
+    """conv epilogue -> per-tile fp64 channel sums -> bn_fwd(stats=...) == bn_fwd computing its own statistics.
+    with_bias: the row-major path; without (every conv in front of a BatchNorm in the backbones): lane-local fp64
+    column partials taken straight from the MFMA accumulators -- incl. partial last M tiles and a mean of ~6 sigma."""
     B, H, W, Cin, Cout, k, s, p, g = case
     rng = np.random.default_rng(11)
     x = nhwc(torch.from_numpy(rng.standard_normal((B, Cin, H, W)) + 0.3))
-    w = to_hwio(torch.from_numpy(rng.standard_normal((Cout, Cin // g, k, k)) / np.sqrt(Cin // g * k * k)))
-    bias = torch.from_numpy(rng.standard_normal(Cout)).float().cuda()
+    w = to_hwio(torch.from_numpy(rng.standard_normal((Cout, Cin // g, k, k)) / np.sqrt(Cin // g * k * k) + 0.02))
+    bias = torch.from_numpy(rng.standard_normal(Cout)).float().cuda() if with_bias else None
     kk = K()
     y_plain = kk.conv2d_fwd(x, w, bias, None, s, p, g)
     y, (part, rows) = kk.conv2d_fwd(x, w, bias, None, s, p, g, False, bn_stats=True)
@@ -299,7 +302,7 @@ def test_conv_fused_bn_statistics(case):
     M = y.numel() // Cout
     sums = part.sum(0).cpu().numpy()
     yd = y.double().view(M, Cout).cpu().numpy()
-    np.testing.assert_allclose(sums[:, 0], yd.sum(0), rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(sums[:, 0], yd.sum(0), rtol=1e-10, atol=1e-8)         # fp64 from the first addition on
     np.testing.assert_allclose(sums[:, 1], (yd * yd).sum(0), rtol=1e-10, atol=1e-8)
     gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cout)).float().cuda()
     beta = torch.from_numpy(rng.standard_normal(Cout)).float().cuda()

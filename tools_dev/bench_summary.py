@@ -1,5 +1,6 @@
+"""usage: python tools_dev/bench_summary.py <bench-json-file>     (or: ... < file)"""
 import json, sys
-for line in sys.stdin:
+for line in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
     line = line.strip()
     if not line.startswith("{"):
         continue

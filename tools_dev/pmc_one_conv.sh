@@ -1,0 +1,10 @@
+# SQ-side counters of ONE convolution layer: where the wave cycles go (issue stalls vs waits vs VALU vs MFMA busy).
+# usage: bash tools_dev/pmc_one_conv.sh <outfile> MODE cin cout k groups H [B] [tile]
+export TMPDIR=/tmp
+OUT=$1; shift
+D=/tmp/pmc_one_$$; rm -rf $D; mkdir -p $D
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $D -- python tools_dev/one_conv.py "$@" > $D/log 2>&1
+echo "== $@" >> $OUT
+python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) gemm >> $OUT
+python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) wgrad >> $OUT
+rm -rf $D
