@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--precision", choices=("fp32", "bf16"), default=None,
                     help="backbone matrix-input precision (default: fp32; bf16 for --config 5, the config that names it)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's; weak scaling)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured hipGraph (scouter_amd/graph.py) instead of issuing it kernel by "
+                         "kernel; measured SLOWER on ROCm 7.0 / MI355X for this GPU-bound step, hence opt-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel hipEvent pass (no roofline object)")
     ap.add_argument("--prof-steps", type=int, default=5, help="steps of the serial per-kernel timing pass")
@@ -254,10 +257,21 @@ def main():
             torch.nn.init.ones_((m.bn3 if hasattr(m, "bn3") else m.bn2).weight)
     model = model.to(device).train()
     net = DistributedDataParallel(model, device_ids=[local_rank]) if (world > 1 or dist.is_initialized()) else model
-    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    # --graph (one GPU): the whole step is replayed from a captured hipGraph (bit-identical to the eager step,
+    # tests/test_graph_gpu.py).  N > 1 stays eager -- capturing the RCCL collectives has not been validated on a
+    # multi-GPU node from here (SCOUTER_GRAPH_DP=1 opts in).
+    use_graph = a.graph and (world == 1 and not dist.is_initialized() or bool(os.environ.get("SCOUTER_GRAPH_DP")))
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=use_graph)
     x, y = synth_batch(cfg["batch"], cfg["img_size"], cfg["num_classes"], rank, device, 1 if mnist else 3)
+    graphed = None
+    if use_graph:
+        from scouter_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(net, opt)
 
-    def step():
+    def step(eager=False):
+        if graphed is not None and not eager:
+            logp, stats = graphed(x, y)
+            return [stats[0]]
         opt.zero_grad()
         out, losses = net(x, y)
         losses[0].backward()
@@ -290,11 +304,11 @@ def main():
     prof_steps = 0 if a.no_prof else max(1, a.prof_steps)
     if prof_steps:
         model.set_side_stream(False)
-        step()
+        step(eager=True)
         fence()
         L.scouter_prof_enable(1)
         for _ in range(prof_steps):
-            step()
+            step(eager=True)
         fence()
         L.scouter_prof_enable(0)
         L.scouter_prof_collect(prof_buf, len(prof_buf))
@@ -354,7 +368,9 @@ def main():
                                           "fp32 head)" if bf16 else ""),
                            "baseline_config": a.config, "precision": cfg["precision"],
                            "global_batch": world * cfg["batch"], "parallelism": "dp%d" % world,
-                           "step": "zero_grad+fwd+loss+bwd(+allreduce)+adamw", "final_loss": round(loss_val, 5)},
+                           "step": "zero_grad+fwd+loss+bwd(+allreduce)+adamw",
+                           "launch": "hipGraph replay (one captured graph per step)" if graphed is not None else "eager",
+                           "final_loss": round(loss_val, 5)},
                 "roofline": roofline, "kernels": kern}
         if world == 1 and not a.no_prof:
             line["xslot_roofline"] = xslot_roofline(device)

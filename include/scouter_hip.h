@@ -186,6 +186,12 @@ int scouter_adamw_chunk_bytes(void);
 int scouter_adamw_step_f32(const void* chunk_table, int nchunks, const float* grads, float* exp_avg,
                            float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay,
                            int step, void* stream);
+/* The same update with the step-dependent scalars read from DEVICE memory, so that the launch can live in a captured
+ * hipGraph (scouter_amd/graph.py): dyn[0] = learning rate, dyn[1] = step count t >= 1 (as a float, exact below 2^24);
+ * the bias corrections 1 - beta^t are formed in the kernel.  The host advances dyn[1] before each launch. */
+int scouter_adamw_step_dev_f32(const void* chunk_table, int nchunks, const float* grads, float* exp_avg,
+                               float* exp_avg_sq, const float* dyn, float beta1, float beta2, float eps,
+                               float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

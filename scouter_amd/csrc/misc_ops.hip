@@ -382,10 +382,18 @@ extern "C" int scouter_slot_loss_bwd_f32(const float* logp, const long* labels, 
 // chunk table entry i: param pointer, offset of the chunk inside the flat grad / moment arenas, length
 // ---------------------------------------------------------------------------------------------------------------
 struct AdamChunk { float* p; long off; int n; int pad; };
+template <bool DEV>
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ chunks, const float* __restrict__ grads,
                                                     float* __restrict__ m, float* __restrict__ v, float lr, float b1,
-                                                    float b2, float eps, float wd, float bc1, float rsqrt_bc2) {
+                                                    float b2, float eps, float wd, float bc1, float rsqrt_bc2,
+                                                    const float* __restrict__ dyn) {
     const AdamChunk ch = chunks[blockIdx.x];
+    if (DEV) {                                  // graph-captured launch: lr and the step count come from device memory
+        lr = dyn[0];
+        const double t = (double)dyn[1];
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    }
     const float step = lr / bc1, decay = 1.f - lr * wd;
     auto upd = [&](float g, float& p, float& mi, float& vi) {
         p *= decay;
@@ -423,10 +431,19 @@ extern "C" int scouter_adamw_step_f32(const void* chunk_table, int nchunks, cons
                                       float weight_decay, int step, void* stream) {
     SC_REQUIRE(chunk_table && grads && exp_avg && exp_avg_sq && nchunks > 0 && step > 0, "adamw_step: bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunk_table,
-                       grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-                       (float)(1.0 / sqrt(bc2)));
+    hipLaunchKernelGGL(adamw_kernel<false>, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                       (const AdamChunk*)chunk_table, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)(1.0 / sqrt(bc2)), (const float*)nullptr);
     return sc_check_launch("adamw_step");
+}
+extern "C" int scouter_adamw_step_dev_f32(const void* chunk_table, int nchunks, const float* grads, float* exp_avg,
+                                          float* exp_avg_sq, const float* dyn, float beta1, float beta2, float eps,
+                                          float weight_decay, void* stream) {
+    SC_REQUIRE(chunk_table && grads && exp_avg && exp_avg_sq && dyn && nchunks > 0, "adamw_step_dev: bad arguments");
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                       (const AdamChunk*)chunk_table, grads, exp_avg, exp_avg_sq, 0.f, beta1, beta2, eps, weight_decay,
+                       1.f, 1.f, dyn);
+    return sc_check_launch("adamw_step_dev");
 }
 extern "C" int scouter_adamw_chunk_bytes(void) { return (int)sizeof(AdamChunk); }
 

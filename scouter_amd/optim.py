@@ -20,10 +20,15 @@ from . import kernels as K
 class FusedAdamW(torch.optim.Optimizer):
     CHUNK = 16384       # elements per workgroup: ~1000 workgroups for resnest26d (16-byte accesses, 16 per thread)
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self._plan = None
+        # capturable (like torch.optim's flag): learning rate and step count are read by the kernel from a small device
+        # buffer, so step() contains no host-computed scalar and can be recorded into a hipGraph (scouter_amd/graph.py).
+        # The host mirror state["step"] is still advanced, so state_dict() / resume are unchanged.
+        self.capturable = bool(capturable)
+        self._dyn = {}                       # group index -> device tensor [lr, step]
 
     # ---- plan: one chunk table per param group over a private flat layout (offsets 16B-aligned)
     def _build_plan(self):
@@ -77,6 +82,8 @@ class FusedAdamW(torch.optim.Optimizer):
         them.  Move them next to the parameters and drop the cached launch plan (it references the old state)."""
         super().load_state_dict(state_dict)
         self._plan = None
+        self._dyn = {}
+        self.__dict__.pop("_lr_pushed", None)
         for gi, group in enumerate(self.param_groups):
             st = self.state.get("_flat_%d" % gi)
             if not st or not group["params"]:
@@ -119,12 +126,47 @@ class FusedAdamW(torch.optim.Optimizer):
             st["step"] += 1
             b1, b2 = group["betas"]
             grads = ctypes.c_void_p(plan["base"])
+            if self.capturable:
+                gi = self._plan.index(plan)
+                dyn = self._dyn_buffer(gi, group, st, advance=True)
+                _native.check(L.scouter_adamw_step_dev_f32(plan["table"].data_ptr(), plan["n"], grads,
+                                                           st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                                           dyn.data_ptr(), float(b1), float(b2), float(group["eps"]),
+                                                           float(group["weight_decay"]), K._stream()), "adamw_step_dev")
+                continue
             _native.check(L.scouter_adamw_step_f32(plan["table"].data_ptr(), plan["n"], grads,
                                                    st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                    float(group["weight_decay"]), int(st["step"]),
                                                    K._stream()), "adamw_step")
         return loss
+
+    def _dyn_buffer(self, gi, group, st, advance):
+        """Device scalars [lr, step] of a param group.  Created (outside any capture) with step = the host count BEFORE
+        this call's increment; `advance` adds 1 on the device (a tiny captured kernel), so replays keep counting."""
+        dyn = self._dyn.get(gi)
+        if dyn is None:
+            dev = st["exp_avg"].device
+            dyn = self._dyn[gi] = torch.tensor([float(group["lr"]), float(st["step"] - 1)], dtype=torch.float32, device=dev)
+        if advance:
+            dyn[1:2].add_(1.0)
+        return dyn
+
+    def sync_hyperparameters(self, replays=0):
+        """Before a graph replay: push a changed learning rate (lr schedulers act on param_groups on the host) into the
+        device scalars; `replays` = steps the captured graph is about to run, added to the host-side step mirror."""
+        if not self.capturable:
+            return
+        for gi, group in enumerate(self.param_groups):
+            dyn = self._dyn.get(gi)
+            if dyn is None:
+                continue
+            if getattr(self, "_lr_pushed", {}).get(gi) != float(group["lr"]):
+                dyn[0:1].fill_(float(group["lr"]))
+                self.__dict__.setdefault("_lr_pushed", {})[gi] = float(group["lr"])
+            st = self.state.get("_flat_%d" % gi)
+            if st is not None and replays:
+                st["step"] += int(replays)
 
     def zero_grad(self, set_to_none=False):
         """Gradients live in the model's flat arena and are overwritten by every backward; keeping the views in
