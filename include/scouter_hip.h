@@ -107,6 +107,9 @@ int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, 
                        int training, int relu, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
                        const double* ext_partial, int ext_rows, unsigned long long* relu_mask_out, void* ws,
                        size_t ws_bytes, void* stream);
+/* y == NULL in scouter_bn_fwd_f32: statistics / running-stat update only.  scouter_bn_apply_f32: the apply pass alone
+ * from a saved block [4][C] = {mean, rstd, scale, shift} (contiguous rows, as written through the four *_out pointers). */
+int scouter_bn_apply_f32(const float* x, const float* bn_saved, float* y, long M, int C, int relu, void* stream);
 /* g = dy * (y > 0), the sign taken from relu_mask if given, else from ymask (both may be NULL: no ReLU);
  * dgamma/dbeta may be NULL (frozen); gout (may be NULL) receives g. */
 int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean, const float* rstd,
@@ -131,13 +134,22 @@ int scouter_avgpool_bwd_f32(const float* dy, float* dx, int B, int H, int W, int
                             int ceil_mode, int count_include_pad, void* stream);
 int scouter_transpose_f32(const float* in, float* out, int batch, int rows, int cols, void* stream);
 
-/* ---- split attention glue: timm/models/layers/split_attn.py:62-80 (radix 2, cardinality 1) */
+/* ---- split attention glue: timm/models/layers/split_attn.py:62-80 (radix 2, cardinality 1).
+ * bn_saved (may be NULL) = the [4][2Cp] block {mean, rstd, scale, shift} scouter_bn_fwd_f32 wrote for bn0: x is then the
+ * RAW output of the radix convolution and relu(bn0(x)) is evaluated on the fly -- the activation is never stored
+ * (scouter_bn_fwd_f32 with y == NULL only finalises the statistics).  scouter_sa_bn_bwd_f32 is the matching backward:
+ * gradient w.r.t. the split-attention input h0 (from dout, the attention weights a and d(gap)), ReLU mask recomputed from
+ * x0, BatchNorm backward of bn0 (dgamma / dbeta may be NULL) -> dx = gradient w.r.t. the convolution output. */
 size_t scouter_sa_workspace_bytes(int B, int HW, int C2);
-int scouter_sa_reduce_f32(const float* x, const float* dout, float* out, int B, int HW, int Cp, int mode, void* ws,
+int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out, int B, int HW, int Cp,
+                          int mode, void* ws, size_t ws_bytes, void* stream);
+int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0, const float* bn_saved,
+                          int B, int HW, int Cp, int training, float* dgamma, float* dbeta, float* dx, void* ws,
                           size_t ws_bytes, void* stream);
 int scouter_radix_softmax_fwd_f32(const float* z, float* a, int B, int Cp, void* stream);
 int scouter_radix_softmax_bwd_f32(const float* a, const float* da, float* dz, int B, int Cp, void* stream);
-int scouter_sa_apply_fwd_f32(const float* x, const float* a, float* out, int B, int HW, int Cp, void* stream);
+int scouter_sa_apply_fwd_f32(const float* x, const float* a, const float* bn_saved, float* out, int B, int HW, int Cp,
+                             void* stream);
 int scouter_sa_apply_bwd_f32(const float* dout, const float* a, const float* dgap, float* dx, int B, int HW, int Cp,
                              void* stream);
 

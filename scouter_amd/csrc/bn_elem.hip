@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
         const int c = (int)((i * 4) % C);
         f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
         const f32x4 a = *(const f32x4*)(scale + c), b = *(const f32x4*)(shift + c), mu = *(const f32x4*)(mean + c);
-        v = (v - mu) * a + b;
+        v = bn_affine(v, mu, a, b);
         if (res) v += *(const f32x4*)(res + i * 4);
         if (relu) {
             if (mbits) {        // i - lane is a multiple of 64 (256-thread blocks, grid stride a multiple of 256)
@@ -506,7 +506,7 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
                                   float eps, int training, int relu, float* mean_out, float* rstd_out,
                                   float* scale_out, float* shift_out, const double* ext_partial, int ext_rows,
                                   unsigned long long* relu_mask_out, void* ws, size_t ws_bytes, void* stream) {
-    SC_REQUIRE(x && y && mean_out && rstd_out && scale_out && shift_out, "bn_fwd: null pointer");
+    SC_REQUIRE(x && mean_out && rstd_out && scale_out && shift_out, "bn_fwd: null pointer");   // y == NULL: statistics only
     SC_REQUIRE(!relu_mask_out || relu, "bn_fwd: relu_mask_out without relu");
     SC_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
     COL_CHECKS("bn_fwd")
@@ -522,9 +522,20 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
                        gamma, beta, running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out,
                        shift_out);
     const long n4 = M * C / 4;
-    hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, scale_out,
-                       shift_out, residual, y, relu_mask_out, n4, C, relu);
+    if (y)       // y == NULL: the consumer applies (x - mean) * scale + shift itself (fused split attention)
+        hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, scale_out,
+                           shift_out, residual, y, relu_mask_out, n4, C, relu);
     return sc_check_launch("bn_fwd");
+}
+
+// the apply pass alone: y = [relu]((x - mean) * scale + shift) from a saved [4][C] block (mean, rstd, scale, shift)
+extern "C" int scouter_bn_apply_f32(const float* x, const float* bn_saved, float* y, long M, int C, int relu,
+                                    void* stream) {
+    SC_REQUIRE(x && bn_saved && y && M > 0 && C > 0 && C % 4 == 0, "bn_apply: bad arguments");
+    const long n4 = M * C / 4;
+    hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, bn_saved,
+                       bn_saved + 2 * C, bn_saved + 3 * C, nullptr, y, nullptr, n4, C, relu);
+    return sc_check_launch("bn_apply");
 }
 
 extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean,
@@ -551,6 +562,109 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale, c1,
                        c2, relu_mask, dx, gout, n4, C);
     return sc_check_launch("bn_bwd");
+}
+
+// ---- split attention fused with its BatchNorm (bn0), backward (timm/models/layers/split_attn.py:62-80 + bn0/act0).
+// x0 = raw output of the radix convolution [B][HW][C2]; h0 = relu(bn0(x0)) is never stored.  One pass produces
+//   g = (dout * a_r + dgap / HW) * [bn0(x0) > 0]      (gradient w.r.t. the BatchNorm output, ReLU folded in)
+// is never stored either: pass 1 forms it and reduces g, g * xhat per block; pass 2 (after the finalize) forms it again
+// and writes dx0 = scale * (g - c1 - xhat * c2).  16 bytes per element of the [B][HW][2C'] tensor in total; the
+// unfused chain moved 26 (sa_apply_bwd writing dh0, colsum_partial<1> re-reading dh0 + x0 + mask, the apply pass).
+__device__ __forceinline__ f32x4 sa_bn_g(const float* __restrict__ dout, const float* __restrict__ a,
+                                         const float* __restrict__ dgap, long r, int b, int c, int cp, int C, int Cp,
+                                         float inv_hw, f32x4 x, f32x4 mu, f32x4 sc, f32x4 sh) {
+    const f32x4 d = *(const f32x4*)(dout + r * Cp + cp);
+    const f32x4 av = *(const f32x4*)(a + (long)b * C + c);
+    const f32x4 gp = *(const f32x4*)(dgap + (long)b * Cp + cp) * inv_hw;
+    const f32x4 v = bn_affine(x, mu, sc, sh);
+    f32x4 gg = d * av + gp;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gg[k] = v[k] > 0.f ? gg[k] : 0.f;
+    return gg;
+}
+__global__ __launch_bounds__(256) void sa_bn_bwd_partial_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                                                const float* __restrict__ dgap,
+                                                                const float* __restrict__ x0,
+                                                                const float* __restrict__ bn,   // [4][C2]
+                                                                double* __restrict__ part, ColGeom g, int HW, int Cp,
+                                                                float inv_hw) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x;
+    const int cq = tid % g.tpr, rl = tid / g.tpr;
+    const int c = blockIdx.y * g.cslab + cq * 4;
+    double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+    if (rl < g.rpb && c < g.C) {
+        const f32x4 mu = *(const f32x4*)(bn + c), rs = *(const f32x4*)(bn + g.C + c);
+        const f32x4 sc = *(const f32x4*)(bn + 2 * g.C + c), sh = *(const f32x4*)(bn + 3 * g.C + c);
+        const int cp = c >= Cp ? c - Cp : c;                      // column inside the radix half
+        const long rstep = (long)gridDim.x * g.rpb;
+        for (long r = (long)blockIdx.x * g.rpb + rl; r < g.M; r += rstep) {
+            const int b = (int)((unsigned)r / (unsigned)HW);      // M < 2^31 (host check); HBM-bound pass
+            const f32x4 x = *(const f32x4*)(x0 + r * g.C + c);
+            const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, g.C, Cp, inv_hw, x, mu, sc, sh);
+            const f32x4 xh = (x - mu) * rs;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += gg[k]; t[k] += (double)gg[k] * xh[k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = s[k]; red[tid * 8 + 4 + k] = t[k]; }
+    __syncthreads();
+    if (rl == 0 && c < g.C) {
+        for (int j = 1; j < g.rpb; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += red[(j * g.tpr + cq) * 8 + k]; t[k] += red[(j * g.tpr + cq) * 8 + 4 + k]; }
+        double* o = part + ((long)blockIdx.x * g.C + c) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k * 2] = s[k]; o[k * 2 + 1] = t[k]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                                              const float* __restrict__ dgap,
+                                                              const float* __restrict__ x0, const float* __restrict__ bn,
+                                                              const float* __restrict__ c1, const float* __restrict__ c2,
+                                                              float* __restrict__ dx, long n4, int C, int HW, int Cp,
+                                                              float inv_hw) {
+    const int c4n = C / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4n;
+        const int c = (int)(i - r * c4n) * 4, cp = c >= Cp ? c - Cp : c;
+        const int b = (int)((unsigned)r / (unsigned)HW);
+        const f32x4 mu = *(const f32x4*)(bn + c), rs = *(const f32x4*)(bn + C + c);
+        const f32x4 sc = *(const f32x4*)(bn + 2 * C + c), sh = *(const f32x4*)(bn + 3 * C + c);
+        const f32x4 x = __builtin_nontemporal_load((const f32x4*)(x0 + i * 4));
+        const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, C, Cp, inv_hw, x, mu, sc, sh);
+        const f32x4 xh = (x - mu) * rs;
+        *(f32x4*)(dx + i * 4) = sc * (gg - *(const f32x4*)(c1 + c) - xh * *(const f32x4*)(c2 + c));
+    }
+}
+
+extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0,
+                                     const float* bn_saved, int B, int HW, int Cp, int training, float* dgamma,
+                                     float* dbeta, float* dx, void* ws, size_t ws_bytes, void* stream) {
+    SC_REQUIRE(dout && a && dgap && x0 && bn_saved && dx && B > 0 && HW > 0 && Cp % 4 == 0, "sa_bn_bwd: bad arguments");
+    const long M = (long)B * HW;
+    const int C = 2 * Cp;
+    SC_UNSUPPORTED(M < (1L << 31), "sa_bn_bwd: more than 2^31 pixels per batch");
+    COL_CHECKS("sa_bn_bwd")
+    const size_t coef_off = (size_t)nb * C * 2 * sizeof(double);
+    if (ws_bytes < coef_off + 2 * (size_t)C * sizeof(float)) {
+        sc_set_error("sa_bn_bwd: workspace too small");
+        return SC_ERR_WORKSPACE;
+    }
+    float* c1 = (float*)((char*)ws + coef_off);
+    float* c2 = c1 + C;
+    hipStream_t st = (hipStream_t)stream;
+    ScProfScope prof("sa_bn_bwd(reduce+finalize+apply)", st, 0, (12.0 * C + 8.0 * Cp) * M);
+    hipLaunchKernelGGL(sa_bn_bwd_partial_kernel, pgrid, dim3(256), 0, st, dout, a, dgap, x0, bn_saved, (double*)ws, g,
+                       HW, Cp, 1.f / HW);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+                       training, dgamma, dbeta, c1, c2);
+    const long n4 = M * C / 4;
+    hipLaunchKernelGGL(sa_bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved, c1, c2,
+                       dx, n4, C, HW, Cp, 1.f / HW);
+    return sc_check_launch("sa_bn_bwd");
 }
 
 // out[c] = alpha * sum_m a[m][c] (* b[m][c] when b != NULL)

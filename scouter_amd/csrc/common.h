@@ -63,6 +63,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// BatchNorm apply, one expression for EVERY kernel that evaluates it (apply pass, fused split-attention passes and
+// their backward): (x - mean) * scale + shift as an explicit fma, so the ReLU sign of an element is the same bit
+// wherever it is recomputed.
+__device__ __forceinline__ f32x4 bn_affine(f32x4 x, f32x4 mu, f32x4 sc, f32x4 sh) {
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaf(x[k] - mu[k], sc[k], sh[k]);
+    return v;
+}
+
 // bijective XCD-aware remap of a linear workgroup id (8 XCDs; consecutive logical ids share an XCD's L2)
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;

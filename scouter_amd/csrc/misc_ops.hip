@@ -11,8 +11,11 @@ static inline int ew_blocks(long n) { long b = (n + 255) / 256; return (int)(b >
 // ---------------------------------------------------------------------------------------------------------------
 // Per-image column sums over the HW rows of x[b] ([HW][C2], C2 = radix*C'), optionally of x*w (w: [HW][C'] broadcast
 // over the radix halves).  partial: [B][nsplit][C2] doubles.
+// bn != NULL ([4][C2]: mean, rstd, scale, shift): x is the RAW convolution output and the summed quantity is
+// relu(bn(x)) -- the BatchNorm apply pass of bn0 is folded into the reductions that read the tensor anyway.
 template <bool WITH_W>
 __global__ __launch_bounds__(256) void sa_colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bn,
                                                                 double* __restrict__ part, int HW, int C2, int Cp,
                                                                 int tpr, int rpb, int rows_per_split) {
     __shared__ double red[256 * 4];
@@ -22,8 +25,15 @@ __global__ __launch_bounds__(256) void sa_colsum_partial_kernel(const float* __r
     double s[4] = {0, 0, 0, 0};
     const float* xb = x + (long)b * HW * C2;
     const float* wb = WITH_W ? w + (long)b * HW * Cp : nullptr;
+    f32x4 mu = {0, 0, 0, 0}, sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (bn) { mu = *(const f32x4*)(bn + c); sc = *(const f32x4*)(bn + 2 * C2 + c); sh = *(const f32x4*)(bn + 3 * C2 + c); }
     for (int r = r0 + rl; r < r1; r += rpb) {
         f32x4 v = *(const f32x4*)(xb + (long)r * C2 + c);
+        if (bn) {
+            v = bn_affine(v, mu, sc, sh);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
         if (WITH_W) v *= *(const f32x4*)(wb + (long)r * Cp + (c % Cp));
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] += v[k];
@@ -82,13 +92,22 @@ __global__ void radix_softmax_bwd_kernel(const float* __restrict__ a, const floa
 
 // out[b,hw,c] = x[b,hw,c]*a[b,c] + x[b,hw,Cp+c]*a[b,Cp+c]
 __global__ __launch_bounds__(256) void sa_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
-                                                           float* __restrict__ out, long n4, int HW, int Cp) {
+                                                           const float* __restrict__ bn, float* __restrict__ out,
+                                                           long n4, int HW, int Cp) {
     const int c4n = Cp / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
         const long row = i / c4n;                 // b*HW + hw
         const int b = (int)(row / HW);
-        const f32x4 x0 = *(const f32x4*)(x + row * 2 * Cp + c), x1 = *(const f32x4*)(x + row * 2 * Cp + Cp + c);
+        f32x4 x0 = *(const f32x4*)(x + row * 2 * Cp + c), x1 = *(const f32x4*)(x + row * 2 * Cp + Cp + c);
+        if (bn) {                                 // x is the raw convolution output: relu(bn0(x)) on the fly
+            const int C2 = 2 * Cp;
+            x0 = bn_affine(x0, *(const f32x4*)(bn + c), *(const f32x4*)(bn + 2 * C2 + c), *(const f32x4*)(bn + 3 * C2 + c));
+            x1 = bn_affine(x1, *(const f32x4*)(bn + Cp + c), *(const f32x4*)(bn + 2 * C2 + Cp + c),
+                           *(const f32x4*)(bn + 3 * C2 + Cp + c));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x0[k] = fmaxf(x0[k], 0.f); x1[k] = fmaxf(x1[k], 0.f); }
+        }
         const f32x4 a0 = *(const f32x4*)(a + (long)b * 2 * Cp + c), a1 = *(const f32x4*)(a + (long)b * 2 * Cp + Cp + c);
         *(f32x4*)(out + i * 4) = x0 * a0 + x1 * a1;
     }
@@ -125,8 +144,8 @@ extern "C" size_t scouter_sa_workspace_bytes(int B, int HW, int C2) { (void)HW; 
 
 // mode 0: gap[b][c]  = mean_hw (x[.,c] + x[.,Cp+c])          (out: [B][Cp])
 // mode 1: da[b][c2]  = sum_hw dout[b,hw,c2 % Cp] * x[b,hw,c2] (out: [B][2Cp])
-extern "C" int scouter_sa_reduce_f32(const float* x, const float* dout, float* out, int B, int HW, int Cp, int mode,
-                                     void* ws, size_t ws_bytes, void* stream) {
+extern "C" int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out, int B, int HW,
+                                     int Cp, int mode, void* ws, size_t ws_bytes, void* stream) {
     const int C2 = 2 * Cp;
     int tpr, rpb, ns, rps;
     SC_REQUIRE(x && out && B > 0 && HW > 0, "sa_reduce: bad arguments");
@@ -135,11 +154,11 @@ extern "C" int scouter_sa_reduce_f32(const float* x, const float* dout, float* o
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(ns, B);
     if (mode == 0) {
-        hipLaunchKernelGGL(sa_colsum_partial_kernel<false>, grid, dim3(256), 0, st, x, nullptr, (double*)ws, HW, C2, Cp, tpr, rpb, rps);
+        hipLaunchKernelGGL(sa_colsum_partial_kernel<false>, grid, dim3(256), 0, st, x, nullptr, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps);
         hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * Cp, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 1, 1.f / HW);
     } else {
         SC_REQUIRE(dout, "sa_reduce: dout missing");
-        hipLaunchKernelGGL(sa_colsum_partial_kernel<true>, grid, dim3(256), 0, st, x, dout, (double*)ws, HW, C2, Cp, tpr, rpb, rps);
+        hipLaunchKernelGGL(sa_colsum_partial_kernel<true>, grid, dim3(256), 0, st, x, dout, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps);
         hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * C2, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 0, 1.f);
     }
     return sc_check_launch("sa_reduce");
@@ -152,10 +171,11 @@ extern "C" int scouter_radix_softmax_bwd_f32(const float* a, const float* da, fl
     hipLaunchKernelGGL(radix_softmax_bwd_kernel, dim3(sc_cdiv((long)B * Cp, 256)), dim3(256), 0, (hipStream_t)stream, a, da, dz, B, Cp);
     return sc_check_launch("radix_softmax_bwd");
 }
-extern "C" int scouter_sa_apply_fwd_f32(const float* x, const float* a, float* out, int B, int HW, int Cp, void* stream) {
+extern "C" int scouter_sa_apply_fwd_f32(const float* x, const float* a, const float* bn_saved, float* out, int B, int HW,
+                                        int Cp, void* stream) {
     SC_REQUIRE(Cp % 4 == 0, "sa_apply: Cp %% 4 != 0");
     const long n4 = (long)B * HW * Cp / 4;
-    hipLaunchKernelGGL(sa_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, a, out, n4, HW, Cp);
+    hipLaunchKernelGGL(sa_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, a, bn_saved, out, n4, HW, Cp);
     return sc_check_launch("sa_apply_fwd");
 }
 extern "C" int scouter_sa_apply_bwd_f32(const float* dout, const float* a, const float* dgap, float* dx, int B, int HW,

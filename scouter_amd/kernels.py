@@ -287,6 +287,31 @@ def _col_ws(M, C, device):
     return workspace(L.scouter_colreduce_workspace_bytes(M, C) + 8 * C + 64, device)
 
 
+def bn_stats(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, stats=None):
+    """Finalises the BatchNorm statistics only (running stats updated in training): returns saved = [4, C] (mean, rstd,
+    scale, shift).  The consumer applies (x - mean) * scale + shift itself (fused split attention)."""
+    _chk(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    saved = torch.empty((4, C), dtype=F32, device=x.device)
+    ws = _col_ws(M, C, x.device)
+    _native.check(_native.lib().scouter_bn_fwd_f32(
+        _p(x), None, None, M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
+        int(training), 0, _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]),
+        _p(stats[0]) if stats else None, stats[1] if stats else 0, None, _p(ws), ws.numel(), _stream()), "bn_stats")
+    return saved
+
+
+def bn_apply(x, saved, relu):
+    """y = [relu]((x - mean) * scale + shift) with a `saved` block from bn_stats / bn_fwd: the apply pass alone (the same
+    kernel and expression the fused consumers evaluate; used by the tests to read the ReLU sign pattern)."""
+    y = torch.empty_like(x)
+    C = x.shape[-1]
+    M = x.numel() // C
+    _native.check(_native.lib().scouter_bn_apply_f32(_p(x), _p(saved), _p(y), M, C, int(relu), _stream()), "bn_apply")
+    return y
+
+
 def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=None, momentum=0.1, eps=1e-5,
            stats=None, want_mask=False):
     """x: [..., C] NHWC.  Returns (y, saved) with saved = (mean, rstd, scale, shift) packed as one [4, C] tensor.
@@ -411,24 +436,37 @@ def _sa_ws(B, HW, C2, device):
     return workspace(_native.lib().scouter_sa_workspace_bytes(B, HW, C2), device)
 
 
-def sa_gap(x):
-    """x: [B, H, W, 2C'] -> gap [B, C'] = mean_hw(x[..., :C'] + x[..., C':])"""
+def sa_gap(x, bn=None):
+    """x: [B, H, W, 2C'] -> gap [B, C'] = mean_hw(h[..., :C'] + h[..., C':]), h = x, or relu(bn(x)) on the fly when `bn`
+    (the [4, 2C'] block of bn_stats) is given and x is the raw convolution output."""
     B, H, W, C2 = x.shape
     out = torch.empty((B, C2 // 2), dtype=F32, device=x.device)
     ws = _sa_ws(B, H * W, C2, x.device)
-    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), None, _p(out), B, H * W, C2 // 2, 0, _p(ws), ws.numel(),
-                                                      _stream()), "sa_gap")
+    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), None, _p(bn), _p(out), B, H * W, C2 // 2, 0, _p(ws),
+                                                      ws.numel(), _stream()), "sa_gap")
     return out
 
 
-def sa_dattn(x, dout):
-    """da[b, r*C'+c] = sum_hw dout[b,hw,c] * x[b,hw,r*C'+c]"""
+def sa_dattn(x, dout, bn=None):
+    """da[b, r*C'+c] = sum_hw dout[b,hw,c] * h[b,hw,r*C'+c]   (h as in sa_gap)"""
     B, H, W, C2 = x.shape
     out = torch.empty((B, C2), dtype=F32, device=x.device)
     ws = _sa_ws(B, H * W, C2, x.device)
-    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), _p(dout), _p(out), B, H * W, C2 // 2, 1, _p(ws), ws.numel(),
-                                                      _stream()), "sa_dattn")
+    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), _p(dout), _p(bn), _p(out), B, H * W, C2 // 2, 1, _p(ws),
+                                                      ws.numel(), _stream()), "sa_dattn")
     return out
+
+
+def sa_bn_bwd(dout, a, dgap, x0, bn, training, dgamma=None, dbeta=None):
+    """Backward of [bn0 -> ReLU -> split-attention weighting / GAP] in one fused chain: returns the gradient w.r.t. the
+    radix convolution's raw output x0 [B, H, W, 2C'] and fills dgamma / dbeta (arena slices) of bn0."""
+    B, H, W, Cp = dout.shape
+    dx = torch.empty_like(x0)
+    ws = _col_ws(B * H * W, 2 * Cp, x0.device)
+    _native.check(_native.lib().scouter_sa_bn_bwd_f32(_p(dout), _p(a), _p(dgap), _p(x0), _p(bn), B, H * W, Cp,
+                                                      int(training), _p(dgamma), _p(dbeta), _p(dx), _p(ws), ws.numel(),
+                                                      _stream()), "sa_bn_bwd")
+    return dx
 
 
 def radix_softmax_fwd(z):
@@ -445,10 +483,10 @@ def radix_softmax_bwd(a, da):
     return dz
 
 
-def sa_apply_fwd(x, a):
+def sa_apply_fwd(x, a, bn=None):
     B, H, W, C2 = x.shape
     out = torch.empty((B, H, W, C2 // 2), dtype=F32, device=x.device)
-    _native.check(_native.lib().scouter_sa_apply_fwd_f32(_p(x), _p(a), _p(out), B, H * W, C2 // 2, _stream()),
+    _native.check(_native.lib().scouter_sa_apply_fwd_f32(_p(x), _p(a), _p(bn), _p(out), B, H * W, C2 // 2, _stream()),
                   "sa_apply_fwd")
     return out
 

@@ -137,6 +137,23 @@ class BatchNorm2d(nn.Module):
         # the backward takes the ReLU sign from a 1-bit/element mask, not from the 4-byte activation
         return out[0], ((x, out[2] if relu else None, out[1], self.training) if save else None)
 
+    def stats_only(self, x, tracked=None):
+        """Statistics / running-stat update without the apply pass -> (raw x, saved [4, C]); the consumer evaluates
+        relu((x - mean) * scale + shift) itself (fused split attention, timm/models/layers/split_attn.py)."""
+        stats = None
+        if isinstance(x, tuple):
+            x, stats = x
+        if self.training and x.numel() == x.shape[-1]:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                             % (tuple(x.shape),))
+        saved = K.bn_stats(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                           self.momentum, self.eps, stats if self.training else None)
+        if self.training and tracked is not None:
+            tracked.append(self.num_batches_tracked)
+        if self._capture is not None:                    # test instrumentation: the activation the fused kernels see
+            self._capture[0][self._capture[1]] = K.bn_apply(x, saved, True)
+        return x, saved
+
     def bwd(self, dy, ctx, want_gout=False):
         x, mask, saved, training = ctx
         return K.bn_bwd(dy, None, x, saved, training, self._dg, self._db, want_gout, mask=mask)

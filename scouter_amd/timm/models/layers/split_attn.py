@@ -26,25 +26,27 @@ class SplitAttnConv2d(nn.Module):
         self.fc2 = Conv2d(attn_chs, mid_chs, 1, bias=True)
 
     def fwd(self, x, save, tracked=None):
+        """bn0 + ReLU are folded into the two passes that read the radix convolution's output anyway (GAP and the
+        attention-weighted sum): only the batch statistics are finalised, the activation relu(bn0(x0)) is never stored --
+        one 8-byte-per-element pass less on the largest tensor of every block, forward and backward."""
         c, c_conv = self.conv.fwd(x, save, bn_stats=self.bn0.training)
-        h, c_bn0 = self.bn0.fwd(c, save, relu=True, tracked=tracked)           # [B,H,W,2C']
-        B = h.shape[0]
-        gap = K.sa_gap(h)                                                        # split_attn.py:63-68
+        x0, saved0 = self.bn0.stats_only(c, tracked)                             # x0: [B,H,W,2C'] raw conv output
+        B = x0.shape[0]
+        gap = K.sa_gap(x0, saved0)                                               # split_attn.py:63-68 (+ bn0, act0)
         z1, c_fc1 = self.fc1.fwd(gap.view(B, 1, 1, -1), save, bn_stats=self.bn1.training)
         g1, c_bn1 = self.bn1.fwd(z1, save, relu=True, tracked=tracked)
         z2, c_fc2 = self.fc2.fwd(g1, save)
         a = K.radix_softmax_fwd(z2.view(B, -1))                                  # split_attn.py:20-28,75
-        out = K.sa_apply_fwd(h, a)                                               # split_attn.py:76-79
-        return out, ((c_conv, c_bn0, c_fc1, c_bn1, c_fc2, h, a) if save else None)
+        out = K.sa_apply_fwd(x0, a, saved0)                                      # split_attn.py:76-79
+        return out, ((c_conv, x0, saved0, self.bn0.training, c_fc1, c_bn1, c_fc2, a) if save else None)
 
     def bwd(self, dout, ctx):
-        c_conv, c_bn0, c_fc1, c_bn1, c_fc2, h, a = ctx
-        B = h.shape[0]
-        da = K.sa_dattn(h, dout)
+        c_conv, x0, saved0, training0, c_fc1, c_bn1, c_fc2, a = ctx
+        B = x0.shape[0]
+        da = K.sa_dattn(x0, dout, saved0)
         dz2 = K.radix_softmax_bwd(a, da)
         dg1 = self.fc2.bwd(dz2.view(B, 1, 1, -1), c_fc2, True)
         dz1, _ = self.bn1.bwd(dg1, c_bn1)
         dgap = self.fc1.bwd(dz1, c_fc1, True)
-        dh = K.sa_apply_bwd(dout, a, dgap.view(B, -1))
-        dc, _ = self.bn0.bwd(dh, c_bn0)
+        dc = K.sa_bn_bwd(dout, a, dgap.view(B, -1), x0, saved0, training0, self.bn0._dg, self.bn0._db)
         return self.conv.bwd(dc, c_conv, True)

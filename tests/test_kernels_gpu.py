@@ -212,6 +212,50 @@ def test_split_attention_glue():
     np.testing.assert_allclose(dx.cpu().numpy(), dx_ref.numpy(), atol=1e-5)
 
 
+@pytest.mark.parametrize("shape,training", [((3, 10, 10, 64), True), ((2, 7, 9, 128), True), ((5, 4, 4, 32), False)])
+def test_split_attention_fused_with_its_batchnorm(shape, training):
+    """bn0 + ReLU folded into the split-attention passes (the activation relu(bn0(x0)) is never stored): GAP, weighted
+    radix sum, d(attention), and the fused backward [d(h0) -> ReLU mask -> BatchNorm backward] against fp64 autograd of
+    the unfused chain (timm/models/layers/split_attn.py:62-80 + bn0 / act0)."""
+    rng = np.random.default_rng(sum(shape))
+    kk = K()
+    B, H, W, Cp = shape
+    C2 = 2 * Cp
+    x0 = torch.from_numpy(rng.standard_normal((B, H, W, C2)) * 1.5 + 0.4)
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, C2)); beta = torch.from_numpy(rng.standard_normal(C2) * 0.3)
+    rm0 = torch.from_numpy(rng.standard_normal(C2) * 0.2); rv0 = torch.from_numpy(rng.uniform(0.5, 2.0, C2))
+    a = torch.softmax(torch.from_numpy(rng.standard_normal((B, 2, Cp))), 1).reshape(B, C2)
+    dout = torch.from_numpy(rng.standard_normal((B, H, W, Cp)))
+    dgap = torch.from_numpy(rng.standard_normal((B, Cp)))
+    # fp64 reference of the unfused chain
+    xr = x0.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    h = torch.relu(F.batch_norm(xr.permute(0, 3, 1, 2), rm, rv, gr, br, training, 0.1, 1e-5)).permute(0, 2, 3, 1)
+    gap_ref = (h[..., :Cp] + h[..., Cp:]).mean((1, 2))
+    out_ref = h[..., :Cp] * a[:, None, None, :Cp] + h[..., Cp:] * a[:, None, None, Cp:]
+    da_ref = torch.cat([(dout * h[..., :Cp]).sum((1, 2)), (dout * h[..., Cp:]).sum((1, 2))], 1).detach()
+    ((out_ref * dout).sum() + (gap_ref * dgap).sum()).backward()
+    # HIP: statistics only, then the fused passes
+    f = lambda t: t.float().cuda()
+    rmd, rvd = f(rm0), f(rv0)
+    xd = f(x0)
+    saved = kk.bn_stats(xd, f(gamma), f(beta), rmd, rvd, training)
+    np.testing.assert_allclose(kk.sa_gap(xd, saved).cpu().numpy(), gap_ref.detach().numpy(), atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(kk.sa_apply_fwd(xd, f(a), saved).cpu().numpy(), out_ref.detach().numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(kk.sa_dattn(xd, f(dout), saved).cpu().numpy(), da_ref.numpy(), atol=2e-4, rtol=1e-5)
+    if training:
+        np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), atol=1e-6, rtol=1e-5)
+    # the apply pass alone reproduces the activation (and thereby the sign pattern) the fused kernels see
+    np.testing.assert_allclose(kk.bn_apply(xd, saved, True).cpu().numpy(), h.detach().numpy(), atol=1e-5, rtol=1e-5)
+    dg, db = torch.zeros(C2, device="cuda"), torch.zeros(C2, device="cuda")
+    dx = kk.sa_bn_bwd(f(dout), f(a), f(dgap), xd, saved, training, dg, db)
+    sc = float(xr.grad.abs().max())
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=2e-6 * max(sc, 1.0), rtol=2e-5)
+    np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.numpy(), atol=2e-5 * float(gr.grad.abs().max()), rtol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.numpy(), atol=2e-5 * float(br.grad.abs().max()), rtol=1e-5)
+
+
 def test_colsum_relu_axpby_matmul_tn():
     rng = np.random.default_rng(7)
     kk = K()
