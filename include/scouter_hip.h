@@ -99,14 +99,16 @@ int scouter_pad_rows_f32(const float* w, float* wpad, long nvalid, long ntotal, 
  * updated with `momentum` and the unbiased variance; eval mode: running stats.
  * y = (x - mean) * scale + shift with scale = gamma*rstd, shift = beta; mean/rstd/scale are saved for the backward.
  * relu_mask_out (optional, needs relu): sign bitmask of y, scouter_relu_mask_words(M*C) 64-bit words (1 bit/element);
- * handing it to scouter_bn_bwd_f32 as relu_mask replaces the 4-byte-per-element read of ymask in both backward passes. */
+ * handing it to scouter_bn_bwd_f32 as relu_mask replaces the 4-byte-per-element read of ymask in both backward passes.
+ * planes_out (optional): the output ALSO as nplanes (1 or 3) bf16 operand planes for scouter_conv2d_fwd_planes
+ * (likewise dx_planes of scouter_sa_bn_bwd_f32 for scouter_conv2d_dgrad_planes). */
 size_t scouter_relu_mask_words(long n);
 size_t scouter_colreduce_workspace_bytes(long M, int C);
 int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                        int training, int relu, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
-                       const double* ext_partial, int ext_rows, unsigned long long* relu_mask_out, void* ws,
-                       size_t ws_bytes, void* stream);
+                       const double* ext_partial, int ext_rows, unsigned long long* relu_mask_out, void* planes_out,
+                       int nplanes, void* ws, size_t ws_bytes, void* stream);
 /* y == NULL in scouter_bn_fwd_f32: statistics / running-stat update only.  scouter_bn_apply_f32: the apply pass alone
  * from a saved block [4][C] = {mean, rstd, scale, shift} (contiguous rows, as written through the four *_out pointers). */
 int scouter_bn_apply_f32(const float* x, const float* bn_saved, float* y, long M, int C, int relu, void* stream);
@@ -144,8 +146,8 @@ size_t scouter_sa_workspace_bytes(int B, int HW, int C2);
 int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out, int B, int HW, int Cp,
                           int mode, void* ws, size_t ws_bytes, void* stream);
 int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0, const float* bn_saved,
-                          int B, int HW, int Cp, int training, float* dgamma, float* dbeta, float* dx, void* ws,
-                          size_t ws_bytes, void* stream);
+                          int B, int HW, int Cp, int training, float* dgamma, float* dbeta, float* dx, void* dx_planes,
+                          int nplanes, void* ws, size_t ws_bytes, void* stream);
 int scouter_radix_softmax_fwd_f32(const float* z, float* a, int B, int Cp, void* stream);
 int scouter_radix_softmax_bwd_f32(const float* a, const float* da, float* dz, int B, int Cp, void* stream);
 int scouter_sa_apply_fwd_f32(const float* x, const float* a, const float* bn_saved, float* out, int B, int HW, int Cp,
@@ -191,6 +193,22 @@ int scouter_linear_small_fwd_f32(const float* x, const float* w, const float* bi
                                  void* stream);
 int scouter_linear_small_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
                                  int B, int K, int C, void* stream);
+
+/* ---- convolution on pre-split bf16 operand planes (scouter_amd/csrc/conv_planes.hip; same reference call sites as
+ * scouter_conv2d_*_f32).  nplanes = 3: x = hi + mid + lo exactly, six bf16 MFMA products per fp32 product -> fp32
+ * accuracy at 2.7x the fp32-MFMA rate;  nplanes = 1: plain bf16 inputs (BASELINE configs[4]).
+ * planes: [nplanes][elements] bf16, every plane laid out like the fp32 tensor.  Weight planes (k contiguous):
+ * w_fwd [nplanes][tap][Cout][Cin/groups], w_dgrad [nplanes][tap][Cin][Cout/groups]; either may be NULL. */
+int scouter_planes_split_f32(const float* x, void* planes, long n, int nplanes, void* stream);
+int scouter_planes_split_weight_f32(const float* w_hwio, void* w_fwd, void* w_dgrad, int kh, int kw, int Cin, int Cout,
+                                    int groups, int nplanes, void* stream);
+int scouter_conv2d_fwd_planes_bn_partial_rows(int B, int H, int W, int kh, int kw, int stride, int pad);
+int scouter_conv2d_fwd_planes(const void* x_planes, const void* w_planes, const float* bias, const float* addend,
+                              float* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                              int stride, int pad, int groups, int relu, int nplanes, int tile, void* stream);
+int scouter_conv2d_dgrad_planes(const void* dy_planes, const void* w_planes, const float* addend, float* dx, int B, int H,
+                                int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int nplanes,
+                                int tile, void* stream);
 
 /* ---- optimizer: torch.optim.AdamW defaults (train.py:146).  chunk table = array of {float* param; long offset
  * into the flat grad/moment arenas; int n; int pad} built by the host (scouter_adamw_chunk_bytes() each). */

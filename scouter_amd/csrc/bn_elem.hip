@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ res, float* __restrict__ y,
                                                               unsigned long long* __restrict__ mbits, long n4, int C,
-                                                              int relu) {
+                                                              int relu, unsigned short* __restrict__ planes,
+                                                              int nplanes) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         }
         *(f32x4*)(y + i * 4) = v;
+        if (planes) store_planes4(planes, n4 * 4, nplanes, i, v);     // operand planes of the consuming plane convolution
     }
 }
 
@@ -505,8 +507,10 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
                                   const float* beta, float* running_mean, float* running_var, float momentum,
                                   float eps, int training, int relu, float* mean_out, float* rstd_out,
                                   float* scale_out, float* shift_out, const double* ext_partial, int ext_rows,
-                                  unsigned long long* relu_mask_out, void* ws, size_t ws_bytes, void* stream) {
+                                  unsigned long long* relu_mask_out, void* planes_out, int nplanes, void* ws,
+                                  size_t ws_bytes, void* stream) {
     SC_REQUIRE(x && mean_out && rstd_out && scale_out && shift_out, "bn_fwd: null pointer");   // y == NULL: statistics only
+    SC_REQUIRE(!planes_out || (y && (nplanes == 1 || nplanes == 3)), "bn_fwd: planes_out needs y and 1 or 3 planes");
     SC_REQUIRE(!relu_mask_out || relu, "bn_fwd: relu_mask_out without relu");
     SC_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
     COL_CHECKS("bn_fwd")
@@ -524,7 +528,7 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
     const long n4 = M * C / 4;
     if (y)       // y == NULL: the consumer applies (x - mean) * scale + shift itself (fused split attention)
         hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, scale_out,
-                           shift_out, residual, y, relu_mask_out, n4, C, relu);
+                               shift_out, residual, y, relu_mask_out, n4, C, relu, (unsigned short*)planes_out, nplanes);
     return sc_check_launch("bn_fwd");
 }
 
@@ -534,7 +538,7 @@ extern "C" int scouter_bn_apply_f32(const float* x, const float* bn_saved, float
     SC_REQUIRE(x && bn_saved && y && M > 0 && C > 0 && C % 4 == 0, "bn_apply: bad arguments");
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, bn_saved,
-                       bn_saved + 2 * C, bn_saved + 3 * C, nullptr, y, nullptr, n4, C, relu);
+                       bn_saved + 2 * C, bn_saved + 3 * C, nullptr, y, nullptr, n4, C, relu, nullptr, 0);
     return sc_check_launch("bn_apply");
 }
 
@@ -625,7 +629,8 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __res
                                                               const float* __restrict__ x0, const float* __restrict__ bn,
                                                               const float* __restrict__ c1, const float* __restrict__ c2,
                                                               float* __restrict__ dx, long n4, int C, int HW, int Cp,
-                                                              float inv_hw) {
+                                                              float inv_hw, unsigned short* __restrict__ planes,
+                                                              int nplanes) {
     const int c4n = C / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long r = i / c4n;
@@ -636,13 +641,16 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __res
         const f32x4 x = __builtin_nontemporal_load((const f32x4*)(x0 + i * 4));
         const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, C, Cp, inv_hw, x, mu, sc, sh);
         const f32x4 xh = (x - mu) * rs;
-        *(f32x4*)(dx + i * 4) = sc * (gg - *(const f32x4*)(c1 + c) - xh * *(const f32x4*)(c2 + c));
+        const f32x4 o = sc * (gg - *(const f32x4*)(c1 + c) - xh * *(const f32x4*)(c2 + c));
+        *(f32x4*)(dx + i * 4) = o;
+        if (planes) store_planes4(planes, n4 * 4, nplanes, i, o);      // A operand of the plane input-gradient kernel
     }
 }
 
 extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0,
                                      const float* bn_saved, int B, int HW, int Cp, int training, float* dgamma,
-                                     float* dbeta, float* dx, void* ws, size_t ws_bytes, void* stream) {
+                                     float* dbeta, float* dx, void* dx_planes, int nplanes, void* ws, size_t ws_bytes,
+                                     void* stream) {
     SC_REQUIRE(dout && a && dgap && x0 && bn_saved && dx && B > 0 && HW > 0 && Cp % 4 == 0, "sa_bn_bwd: bad arguments");
     const long M = (long)B * HW;
     const int C = 2 * Cp;
@@ -663,7 +671,7 @@ extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const fl
                        training, dgamma, dbeta, c1, c2);
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(sa_bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved, c1, c2,
-                       dx, n4, C, HW, Cp, 1.f / HW);
+                       dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);
     return sc_check_launch("sa_bn_bwd");
 }
 

@@ -63,6 +63,36 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// exact split of an fp32 value into three bf16 terms x = hi + mid + lo (RNE at each step; the residuals are exactly
+// representable): the operand format of the plane convolutions (conv_planes.hip)
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3_bf16(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 bh = (__bf16)x;
+    const float r1 = x - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;
+    const __bf16 bl = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, bh);
+    m = __builtin_bit_cast(unsigned short, bm);
+    l = __builtin_bit_cast(unsigned short, bl);
+}
+// writes the planes of four consecutive elements (element index i4 * 4) of a tensor with `plane_elems` elements
+__device__ __forceinline__ void store_planes4(unsigned short* __restrict__ planes, long plane_elems, int nplanes, long i4,
+                                              f32x4 v) {
+    u16x4 h, m, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned short a, b, c;
+        split3_bf16(v[k], a, b, c);
+        h[k] = a; m[k] = b; l[k] = c;
+    }
+    *(u16x4*)(planes + i4 * 4) = h;
+    if (nplanes == 3) {
+        *(u16x4*)(planes + plane_elems + i4 * 4) = m;
+        *(u16x4*)(planes + 2 * plane_elems + i4 * 4) = l;
+    }
+}
+
 // BatchNorm apply, one expression for EVERY kernel that evaluates it (apply pass, fused split-attention passes and
 // their backward): (x - mean) * scale + shift as an explicit fma, so the ReLU sign of an element is the same bit
 // wherever it is recomputed.

@@ -1,0 +1,422 @@
+// Implicit-GEMM convolution on the bf16 matrix cores over PRE-SPLIT operand planes, fed by LDS-DMA.
+//
+// Why.  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate, and the large 3x3 layers of the backbones already
+// sit at what the clock allows on it (~130 TFLOP/s).  An fp32 value splits EXACTLY into three bf16 terms
+//      x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)          (8 + 8 + 8 mantissa bits)
+// and a product a*b is recovered to fp32 accuracy from the six bf16 products of weight <= 2^-16
+//      a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16: 6 MFMAs at 16x the rate = 2.7x the fp32-MFMA throughput, with the
+// error of an fp32 product (relative 2^-24 per term; measured against fp64 like the fp32 kernel, tests/test_planes_gpu.py).
+// Round 1 tried this with the split done INSIDE the convolution (VALU + ds_write per loaded element, repeated for each
+// of the nine taps): 120-165 TFLOP/s-equivalent, LDS-store-bound.  Here the split is done ONCE by the producer of the
+// tensor (the BatchNorm apply pass writes planes instead of fp32, 6 instead of 4 bytes per element) and the
+// convolution moves planes global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write, no VALU):
+// per 128x128x32 block tile 48 KB of DMA and 24 ds_read_b128 per wave feed 48 MFMAs (1536 matrix cycles) per wave.
+// NP = 1 is the plain bf16 mode (BASELINE configs[4]) with bf16 activation storage: same kernel, one product.
+//
+// Layouts.  activation planes [NP][M pixels][C] bf16 (each plane an NHWC tensor); weight planes, k contiguous:
+//   forward [NP][tap][Cout][Cin/groups]      dgrad [NP][tap][Cin][Cout/groups]     (scouter_planes_split_weight_*)
+// LDS image of one (operand, plane) K-tile: rows of 32 bf16 = 64 B = four 16-byte chunks, chunk c of row r stored at
+// slot c ^ ((r >> 2) & 3): the DMA writes lane-linearly (1 KB per wave instruction = 16 rows), so the swizzle is applied
+// on the SOURCE address; fragment reads (ds_read_b128, lane = row) are then bank-conflict free.
+#include "conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// LDS-DMA of 16 bytes per lane (buffer_load_dwordx4 ... lds): LDS destination = wave-uniform `lds` + lane * 16.
+// (A NON-template helper on purpose: with the builtin inside a kernel template, hipcc's host pass silently drops the
+// kernel's launch stub -- the builtin does not exist for the host target -- and the library fails to link at load time.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds), 16, voff, soff, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16p(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+#define split3 split3_bf16
+
+// ---------------------------------------------------------------------------------------------------------------
+// producers of planes
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 [n] -> planes [NP][n]   (stand-alone split: weights, tests; activations get their planes from the BatchNorm pass)
+template <int NP>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ p,
+                                                           long n4, long plane_elems) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(x + i * 4);
+        u16x4 h, m, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned short a, b, c;
+            split3(v[k], a, b, c);
+            h[k] = a; m[k] = b; l[k] = c;
+        }
+        *(u16x4*)(p + i * 4) = h;
+        if (NP == 3) { *(u16x4*)(p + plane_elems + i * 4) = m; *(u16x4*)(p + 2 * plane_elems + i * 4) = l; }
+    }
+}
+
+// weights HWIO fp32 [tap][Cin/g][Cout] -> forward planes [NP][tap][Cout][Cg] and / or dgrad planes [NP][tap][Cin][Ng]
+// (Cin index = grp*Cg + ci ; Ng = Cout/groups).  One thread per (tap, ci, co) element; tiny tensors.
+template <int NP>
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf,
+                                                           unsigned short* __restrict__ wd, int taps, int Cg, int Cout,
+                                                           int groups) {
+    const long n = (long)taps * Cg * Cout;
+    const int Ng = Cout / groups;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        const int ci = (int)((i / Cout) % Cg);
+        const int tap = (int)(i / ((long)Cout * Cg));
+        unsigned short s[3];
+        split3(w[i], s[0], s[1], s[2]);
+        const int grp = co / Ng;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            if (wf) wf[(long)pl * n + ((long)tap * Cout + co) * Cg + ci] = s[pl];
+            if (wd) wd[(long)pl * n + ((long)tap * (Cg * groups) + grp * Cg + ci) * Ng + (co - grp * Ng)] = s[pl];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward / dgrad on planes
+// ---------------------------------------------------------------------------------------------------------------
+// g describes the GEMM exactly as in conv_igemm.hip (for DGRAD the A tensor is dY and the columns are Cin).
+// NWM waves along M x 2 along N (4 or 8 waves: 256 or 512 threads); every wave owns a 64 x (BN/2) or (BM/NWM) x (BN/2) tile.
+template <int BM, int BN, int NP, int NSTAGE, bool DGRAD, int NWM = 2>
+__global__ __launch_bounds__(NWM * 128, 1) void pconv_kernel(const unsigned short* __restrict__ a_planes, long a_plane_elems,
+                                                       const unsigned short* __restrict__ w_planes, long w_plane_elems,
+                                                       const float* __restrict__ bias, const float* __restrict__ addend,
+                                                       float* __restrict__ dst, double* __restrict__ bn_part, ConvGeom g,
+                                                       int relu, int mtiles, int ntiles) {
+    constexpr int BK = 32, NW = 2 * NWM, WM = BM / NWM, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+    constexpr int A_BYTES = NP * BM * 64, B_BYTES = NP * BN * 64, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int ARG = BM / 16 / NW, BRG = BN / 16 / NW;      // 16-row groups per wave and operand
+    constexpr int DMA_PER_TILE = (ARG + BRG) * NP;             // DMA instructions one wave issues per K-tile
+    constexpr int NPROD = NP == 3 ? 6 : 1;
+    static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
+    extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations are wave-uniform (M0)
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nblk = mtiles * ntiles * g.groups;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int grp = bid % g.groups;
+    const int nt_id = (bid / g.groups) % ntiles;
+    const int mt_id = bid / (g.groups * ntiles);
+    const long m0 = (long)mt_id * BM;
+    const int n0 = nt_id * BN;
+    const int cpt = g.Cg / BK;
+    const int KT = g.R * g.S * cpt;
+
+    // ---- DMA source addressing.  Lane = (row-in-group = lane >> 2, LDS slot = lane & 3); it fetches the chunk that the
+    // swizzle maps to its slot.  Row state as in conv_igemm.hip (block-relative offsets, separable tap masks, OOB rows
+    // read zeros -- also through the LDS path).
+    constexpr unsigned OOB = 0x80000000u;
+    const int slot = lane & 3, rin = lane >> 2;
+    const int chunk = slot ^ ((lane >> 4) & 3);                // (row >> 2) & 3 == (lane >> 4) & 3 for every row group
+    const int hw = g.Ho * g.Wo;
+    const int blk_b = (int)(((double)(unsigned)m0 + 0.5) * g.inv_hw);
+    const int blk_rem = (int)((unsigned)m0 - (unsigned)blk_b * (unsigned)hw);
+    const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
+    const int rows_valid = (int)(g.M - m0 < BM ? g.M - m0 : BM);
+    unsigned a_mask[ARG], a_voff[ARG], a_veff[ARG];
+#pragma unroll
+    for (int t = 0; t < ARG; ++t) {
+        const int rowoff = 16 * (wave + NW * t) + rin;
+        const bool okm = rowoff < rows_valid;
+        const int tx = blk_x + rowoff, qx = fast_div(tx, g.inv_wo), x = tx - qx * g.Wo;
+        const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho), y = ty - qy * g.Ho;
+        const int ay = DGRAD ? y + g.pad : y * g.stride - g.pad, ax = DGRAD ? x + g.pad : x * g.stride - g.pad;
+        unsigned colbits = 0, mask = 0;
+        for (int q = 0; q < g.S; ++q) colbits |= ((unsigned)(DGRAD ? ax - q : ax + q) < (unsigned)g.W ? 1u : 0u) << q;
+        for (int r = 0; r < g.R; ++r) mask |= ((unsigned)(DGRAD ? ay - r : ay + r) < (unsigned)g.H ? colbits : 0u) << (r * g.S);
+        a_mask[t] = okm ? mask : 0u;
+        const int rel = okm ? qy * g.H * g.W : 0;
+        const int e = DGRAD ? (rel + ay * g.W + ax) * g.C : (rel + (ay + g.pad) * g.W + (ax + g.pad)) * g.C;
+        a_voff[t] = (unsigned)(e + grp * g.Cg + chunk * 8) * 2u;
+        a_veff[t] = OOB;
+    }
+    const long img_elems = (long)g.H * g.W * g.C;
+    const long shift = DGRAD ? ((long)(g.R - 1) * g.W + (g.S - 1)) * g.C : ((long)g.pad * g.W + g.pad) * g.C;
+    // one descriptor per plane would cost SGPRs; the plane offset goes into the scalar offset instead (< 2^31 bytes per
+    // tensor is checked by the host)
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a_planes + (long)blk_b * img_elems - shift), 0, 0x7fffffff, 0x00020000);
+    // B rows: n = n0 + row; weight planes [tap][N_total][Cg(k)] with this group's rows at grp*Ng
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(w_planes + (long)grp * g.Ng * g.Cg), 0, 0x7fffffff, 0x00020000);
+    unsigned b_voff[BRG];
+#pragma unroll
+    for (int t = 0; t < BRG; ++t) b_voff[t] = (unsigned)((n0 + 16 * (wave + NW * t) + rin) * g.Cg + chunk * 8) * 2u;
+    const long wtap_bytes = (long)g.N * g.Cg * 2;
+    const long a_plane_bytes = a_plane_elems * 2, w_plane_bytes = w_plane_elems * 2;
+
+    auto issue = [&](int kt, int stage) {          // DMA of K-tile kt into LDS stage `stage`
+        const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+        const int r = tap / g.S, q = tap - r * g.S;
+        const long toff = (DGRAD ? -((long)r * g.W + q) : ((long)r * g.W + q)) * g.C + c0;
+        if (c0 == 0) {
+#pragma unroll
+            for (int t = 0; t < ARG; ++t) a_veff[t] = ((a_mask[t] >> tap) & 1u) ? a_voff[t] : OOB;
+        }
+        const long sa = (DGRAD ? shift + toff : toff) * 2;
+        const long sb = tap * wtap_bytes + (long)c0 * 2;
+        char* st = lds_raw + stage * STAGE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int t = 0; t < ARG; ++t)
+                dma16(rs_a, st + pl * (BM * 64) + (wave + NW * t) * 1024, a_veff[t], (int)(sa + pl * a_plane_bytes));
+#pragma unroll
+            for (int t = 0; t < BRG; ++t)
+                dma16(rs_b, st + A_BYTES + pl * (BN * 64) + (wave + NW * t) * 1024, b_voff[t], (int)(sb + pl * w_plane_bytes));
+        }
+    };
+
+    // Two accumulator sets for NP = 3: the hi*hi products in `acc`, the five correction products (2^-8 ... 2^-16 of it) in
+    // `accl`, added once at the end.  With ONE accumulator the small products are aligned against a large running sum
+    // inside the matrix unit and lose their low bits by truncation: measured a NEGATIVE bias of 7e-8 x mean|y| per layer
+    // (K = 1152; the exact-fp32 MFMA kernel: 1e-9) at an unchanged rms error -- harmless per layer, but a coherent error,
+    // and end to end (26 layers) it tripled the deviation from the fp64 reference.
+    constexpr int NACC = NP == 3 ? 2 : 1;
+    f32x16 acc[MT][NT], accl[NACC == 2 ? MT : 1][NACC == 2 ? NT : 1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if (NACC == 2) accl[i][j][e] = 0.f;
+            }
+
+    // fragment read offsets: lane = row l31 of a 32-row block, k-chunk 2*step + h, swizzled slot
+    const int sw = (l31 >> 2) & 3;
+    auto frag = [&](const char* base, int row0, int step) -> bf16x8 {
+        const int c = (2 * step + h) ^ sw;
+        return *(const bf16x8*)(base + (row0 + l31) * 64 + c * 16);
+    };
+
+    // ---- pipeline.  One wave per SIMD (the LDS image leaves room for one workgroup per CU), so latency must be hidden
+    // inside the wave: fragments are double-buffered per half K-tile (step), and the DMA runs NSTAGE - 1 K-tiles ahead.
+    //   A  ds_read  F[1] <- (kt, step 1)
+    //   B  24 MFMA on F[0]                                  (covers A)
+    //   C  lgkmcnt(0): F[1] there, this wave is done with stage(kt);  vmcnt: this wave's part of tile kt+1 has landed
+    //   D  ONE barrier per K-tile: tile kt+1 complete in LDS, stage(kt) free
+    //   E  DMA tile kt+NSTAGE -> stage(kt);  ds_read F[0] <- (kt+1, step 0)
+    //   F  24 MFMA on F[1]                                  (covers E)
+    // A first version (fragments read at the top of each step, two barriers per K-tile) ran the matrix pipe at 50 % with
+    // the DMA ablated: every step exposed its LDS round trip.
+    bf16x8 F[2][MT + NT][NP];
+    auto load_frags = [&](int buf, int stage, int step) {
+        const char* As = lds_raw + stage * STAGE_BYTES;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) F[buf][i][pl] = frag(As + pl * (BM * 64), wm * WM + i * 32, step);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) F[buf][MT + j][pl] = frag(Bs + pl * (BN * 64), wn * WN + j * 32, step);
+        }
+    };
+    auto mma = [&](int buf) {
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first
+#pragma unroll
+        for (int pr = (NP == 3 ? 0 : 5); pr < 6; ++pr)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (NACC == 2 && pr < 5)
+                        accl[i][j] = mfma_bf16p(F[buf][i][PA[pr]], F[buf][MT + j][PB[pr]], accl[i][j]);
+                    else
+                        acc[i][j] = mfma_bf16p(F[buf][i][NP == 3 ? PA[pr] : 0], F[buf][MT + j][NP == 3 ? PB[pr] : 0], acc[i][j]);
+                }
+    };
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
+// scheduling groups: one MFMA followed by a few of the other instruction kinds -- a wave issues in order, so everything
+// that is not placed BETWEEN two MFMAs (32 cycles apart) runs with the matrix pipe idle; PMC on the first version: 240
+// non-MFMA instructions per K-tile issued in clusters = 1100 of 3500 cycles per K-tile with the pipe empty
+#define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+    constexpr int NMMA = MT * NT * NPROD;                 // MFMAs per half K-tile
+    constexpr int NFR = (MT + NT) * NP;                   // fragment reads per half K-tile
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s) issue(s < KT ? s : KT - 1, s);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 1) * DMA_PER_TILE) : "memory");     // tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // (so that the loop header is entered with no LDS read pending on any path)
+    for (int kt = 0; kt < KT; ++kt) {
+        const int stage = kt % NSTAGE, nstage = (kt + 1) % NSTAGE;
+        SBAR();
+        load_frags(1, stage, 1);                                  // A
+        mma(0);                                                   // B
+#pragma unroll
+        for (int q = 0; q < NMMA; ++q) { SG(0x008, 1); if (q < NFR) { SG(0x100, 1); SG(0x006, 2); } }
+        SBAR();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // C: lgkmcnt(0) (the builtin: hipcc's counter tracking
+                                                                  //    sees it, an asm wait would be invisible to it)
+        // this wave's part of tile kt+1 has landed (NSTAGE - 2 younger tiles may stay in flight; past the end the
+        // pipeline re-fetches the last tile instead of branching, so the count is the same in every iteration)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DMA_PER_TILE) : "memory");
+        __builtin_amdgcn_s_barrier();                             // D
+        SBAR();
+        issue(kt + NSTAGE < KT ? kt + NSTAGE : KT - 1, stage);    // E
+        load_frags(0, nstage, 0);
+        mma(1);                                                   // F
+#pragma unroll
+        for (int q = 0; q < NMMA; ++q) {
+            SG(0x008, 1);
+            if (q < DMA_PER_TILE) { SG(0x020, 1); SG(0x006, 4); }
+            else if (q - DMA_PER_TILE < NFR) { SG(0x100, 1); SG(0x006, 2); }
+        }
+        // F[0]'s reads retired long ago; saying so stops hipcc from waiting lgkmcnt(0) behind the NEXT iteration's F[1]
+        // reads before it lets the first MFMA of step 0 go (it cannot count across the back edge)
+        SBAR();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+#undef SBAR
+#undef SG
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (NACC == 2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] += accl[i][j];
+    }
+    // epilogue shared with the fp32 kernels (LDS-staged 16-byte stores, bias / addend / ReLU, BatchNorm statistics)
+    igemm_epilogue<BM, BN, WM, WN>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static int conv_out_p(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+extern "C" int scouter_planes_split_f32(const float* x, void* planes, long n, int nplanes, void* stream) {
+    SC_REQUIRE(x && planes && n > 0 && n % 4 == 0 && (nplanes == 1 || nplanes == 3), "planes_split: bad arguments");
+    const long n4 = n / 4;
+    long nb = (n4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nplanes == 3)
+        hipLaunchKernelGGL(split_planes_kernel<3>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x,
+                           (unsigned short*)planes, n4, n);
+    else
+        hipLaunchKernelGGL(split_planes_kernel<1>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x,
+                           (unsigned short*)planes, n4, n);
+    return sc_check_launch("planes_split");
+}
+
+extern "C" int scouter_planes_split_weight_f32(const float* w_hwio, void* w_fwd, void* w_dgrad, int kh, int kw, int Cin,
+                                               int Cout, int groups, int nplanes, void* stream) {
+    SC_REQUIRE(w_hwio && (w_fwd || w_dgrad) && groups > 0 && Cin % groups == 0 && Cout % groups == 0 &&
+               (nplanes == 1 || nplanes == 3), "planes_split_weight: bad arguments");
+    const long n = (long)kh * kw * (Cin / groups) * Cout;
+    long nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nplanes == 3)
+        hipLaunchKernelGGL(split_weight_kernel<3>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_hwio,
+                           (unsigned short*)w_fwd, (unsigned short*)w_dgrad, kh * kw, Cin / groups, Cout, groups);
+    else
+        hipLaunchKernelGGL(split_weight_kernel<1>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_hwio,
+                           (unsigned short*)w_fwd, (unsigned short*)w_dgrad, kh * kw, Cin / groups, Cout, groups);
+    return sc_check_launch("planes_split_weight");
+}
+
+template <int BM, int BN, int NP, int NSTAGE, bool DGRAD, int NWM = 2>
+static void launch_pconv(const void* a, long a_pe, const void* w, long w_pe, const float* bias, const float* addend,
+                         float* dst, double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
+    const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
+    ConvGeom gg = g;
+    gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
+    gg.inv_wo = 1.0f / (float)g.Wo;
+    gg.inv_ho = 1.0f / (float)g.Ho;
+    constexpr int STAGE_BYTES = NP * (BM + BN) * 64;
+    constexpr int EPI_BYTES = 2 * NWM * (BM / NWM) * (BN / 2 + 4) * 4;
+    const size_t lds = (size_t)(NSTAGE * STAGE_BYTES > EPI_BYTES ? NSTAGE * STAGE_BYTES : EPI_BYTES);
+    auto kern = pconv_kernel<BM, BN, NP, NSTAGE, DGRAD, NWM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles * g.groups), dim3(NWM * 128), lds, st, (const unsigned short*)a, a_pe,
+                       (const unsigned short*)w, w_pe, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles);
+}
+
+// tile: 0 = 128x128, 1 = 128x64 (N per group must be a multiple of the tile's N)
+template <bool DGRAD>
+static int dispatch_pconv(const void* a, long a_pe, const void* w, long w_pe, const float* bias, const float* addend,
+                          float* dst, double* bn_part, const ConvGeom& g, int relu, int nplanes, int tile,
+                          hipStream_t st) {
+    const bool wide = g.Ng % 128 == 0 && tile != 1;
+    if (nplanes == 3 && tile == 2) {        // two workgroups per CU (2 LDS stages of 36 KB)
+        launch_pconv<128, 64, 3, 2, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+    } else if (nplanes == 3 && tile == 3) { // three workgroups per CU
+        launch_pconv<64, 64, 3, 2, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+    } else if (nplanes == 3 && tile == 4 && g.Ng % 128 == 0) {   // 256 x 128, eight waves: 25 % fewer L2 -> LDS bytes
+        launch_pconv<256, 128, 3, 2, DGRAD, 4>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+    } else if (nplanes == 3) {
+        if (wide) launch_pconv<128, 128, 3, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+        else launch_pconv<128, 64, 3, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+    } else {
+        if (wide) launch_pconv<128, 128, 1, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+        else launch_pconv<128, 64, 1, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+    }
+    return sc_check_launch(DGRAD ? "conv2d_dgrad_planes" : "conv2d_fwd_planes");
+}
+
+extern "C" int scouter_conv2d_fwd_planes_bn_partial_rows(int B, int H, int W, int kh, int kw, int stride, int pad) {
+    return sc_cdiv((long)B * conv_out_p(H, kh, stride, pad) * conv_out_p(W, kw, stride, pad), 64);     // upper bound
+}
+
+// x_planes: [nplanes][B*H*W][Cin] bf16; w_planes: scouter_planes_split_weight_f32's forward layout.
+extern "C" int scouter_conv2d_fwd_planes(const void* x_planes, const void* w_planes, const float* bias,
+                                         const float* addend, float* y, double* bn_partial, int B, int H, int W, int Cin,
+                                         int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int nplanes,
+                                         int tile, void* stream) {
+    SC_REQUIRE(x_planes && w_planes && y && B > 0 && H > 0 && W > 0 && (nplanes == 1 || nplanes == 3),
+               "conv2d_fwd_planes: bad arguments");
+    SC_REQUIRE(!(bn_partial && (relu & 1)), "conv2d_fwd_planes: fused BatchNorm statistics are taken before any activation");
+    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_fwd_planes: channels not divisible by groups");
+    const int Cg = Cin / groups, Ng = Cout / groups;
+    SC_UNSUPPORTED(Cg % 32 == 0 && Ng % 64 == 0, "conv2d_fwd_planes: needs Cin/groups %% 32 == 0 and Cout/groups %% 64 == 0");
+    ConvGeom g{B, H, W, Cin, conv_out_p(H, kh, stride, pad), conv_out_p(W, kw, stride, pad), Cout, kh, kw, stride, pad,
+               groups, Cg, Ng, 0, Cout, Cg * Cout};
+    g.M = (long)B * g.Ho * g.Wo;
+    const long a_pe = (long)B * H * W * Cin, w_pe = (long)kh * kw * Cg * Cout;
+    SC_UNSUPPORTED(g.M < (1L << 31) && (long)nplanes * a_pe * 2 < (1L << 31) + ((long)H * W * Cin * 2) &&
+                   (long)H * W * Cin < (1L << 28), "conv2d_fwd_planes: tensor too large for 32-bit plane offsets");
+    ScProfScope prof(nplanes == 3 ? "pconv_fwd<bf16x3>" : "pconv_fwd<bf16>", (hipStream_t)stream,
+                     2.0 * g.M * Cout * Cg * kh * kw, 2.0 * nplanes * ((double)a_pe) + 4.0 * (double)g.M * Cout);
+    return dispatch_pconv<false>(x_planes, a_pe, w_planes, w_pe, bias, addend, y, bn_partial, g, relu, nplanes, tile,
+                                 (hipStream_t)stream);
+}
+
+// dy_planes: [nplanes][B*Ho*Wo][Cout]; w_planes: the dgrad layout.  Stride-1 convolutions only.
+extern "C" int scouter_conv2d_dgrad_planes(const void* dy_planes, const void* w_planes, const float* addend, float* dx,
+                                           int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                           int groups, int nplanes, int tile, void* stream) {
+    SC_REQUIRE(dy_planes && w_planes && dx && B > 0 && (nplanes == 1 || nplanes == 3), "conv2d_dgrad_planes: bad arguments");
+    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad_planes: channels not divisible by groups");
+    SC_UNSUPPORTED(stride == 1, "conv2d_dgrad_planes: stride-1 convolutions only");
+    const int Cig = Cin / groups, Cog = Cout / groups;
+    SC_UNSUPPORTED(Cog % 32 == 0 && Cig % 64 == 0, "conv2d_dgrad_planes: needs Cout/groups %% 32 == 0 and Cin/groups %% 64 == 0");
+    const int Ho = conv_out_p(H, kh, stride, pad), Wo = conv_out_p(W, kw, stride, pad);
+    ConvGeom g{B, Ho, Wo, Cout, H, W, Cin, kh, kw, stride, pad, groups, Cog, Cig, 0, Cout, Cig * Cout};
+    g.M = (long)B * H * W;
+    const long a_pe = (long)B * Ho * Wo * Cout, w_pe = (long)kh * kw * Cig * Cout;
+    SC_UNSUPPORTED(g.M < (1L << 31) && (long)nplanes * a_pe * 2 < (1L << 31) + ((long)Ho * Wo * Cout * 2) &&
+                   (long)Ho * Wo * Cout < (1L << 28), "conv2d_dgrad_planes: tensor too large for 32-bit plane offsets");
+    ScProfScope prof(nplanes == 3 ? "pconv_dgrad<bf16x3>" : "pconv_dgrad<bf16>", (hipStream_t)stream,
+                     2.0 * g.M * Cin * Cog * kh * kw, 2.0 * nplanes * ((double)a_pe) + 4.0 * (double)g.M * Cin);
+    return dispatch_pconv<true>(dy_planes, a_pe, w_planes, w_pe, nullptr, addend, dx, nullptr, g, 0, nplanes, tile,
+                                (hipStream_t)stream);
+}

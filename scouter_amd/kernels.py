@@ -178,6 +178,114 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
     return dx
 
 
+# ---- convolution on pre-split bf16 operand planes (csrc/conv_planes.hip)
+BF16 = torch.bfloat16
+
+
+class PlaneTensor:
+    """An activation held twice: `f32` (NHWC fp32, what the weight-gradient kernel and the elementwise passes read) and
+    `planes` ([np, B, H, W, C] bf16, the A operand of the plane convolutions).  Produced by bn_fwd(planes=np) and
+    sa_bn_bwd(planes=np)."""
+    __slots__ = ("f32", "planes")
+
+    def __init__(self, f32, planes):
+        self.f32, self.planes = f32, planes
+
+    @property
+    def shape(self):
+        return self.f32.shape
+
+    @property
+    def device(self):
+        return self.f32.device
+
+
+def planes_split(x, nplanes=3):
+    """fp32 tensor -> [nplanes, *x.shape] bf16 planes with x == sum(planes) exactly for nplanes = 3."""
+    _chk(x, "x")
+    out = torch.empty((nplanes,) + tuple(x.shape), dtype=BF16, device=x.device)
+    _native.check(_native.lib().scouter_planes_split_f32(_p(x), _p(out), x.numel(), nplanes, _stream()), "planes_split")
+    return out
+
+
+def planes_split_weight(w_hwio, groups, nplanes=3, fwd=True, dgrad=True):
+    """HWIO fp32 weight -> (forward planes [np, taps, Cout, Cin/g], dgrad planes [np, taps, Cin, Cout/g])."""
+    kh, kw, cg, Cout = w_hwio.shape
+    Cin = cg * groups
+    wf = torch.empty((nplanes, kh * kw, Cout, cg), dtype=BF16, device=w_hwio.device) if fwd else None
+    wd = torch.empty((nplanes, kh * kw, Cin, Cout // groups), dtype=BF16, device=w_hwio.device) if dgrad else None
+    _native.check(_native.lib().scouter_planes_split_weight_f32(_p(w_hwio), _p(wf), _p(wd), kh, kw, Cin, Cout, groups,
+                                                                nplanes, _stream()), "planes_split_weight")
+    return wf, wd
+
+
+_PLANE_TILE_ROWS = {0: 128, 1: 128, 2: 128, 3: 64, 4: 256}
+
+
+def _plane_tiles(ng):
+    """Block tiles of the plane kernels (csrc/conv_planes.hip dispatch_pconv): 0 = 128x128, 2 = 128x64 (two workgroups
+    per CU), 3 = 64x64 (three), 4 = 256x128 with eight waves.  Every tile sums each output in the same order."""
+    return (0, 2, 3, 4) if ng % 128 == 0 else (2, 3)
+
+
+def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, addend=None, relu=False, bn_stats=False,
+                      tile=None):
+    """xp: activation planes [np, B, H, W, Cin]; wf: forward weight planes.  Returns y (fp32 NHWC) or (y, stats).
+    tile None: autotuned once per layer shape (bit-identical results for every tile)."""
+    nplanes, B, H, W, Cin = xp.shape
+    Cout = wf.shape[2]
+    y = torch.empty((B, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout), dtype=F32, device=xp.device)
+    L = _native.lib()
+    cands = _plane_tiles(Cout // groups)
+    M = y.numel() // Cout
+    # scratch for the statistics of the largest partial count (64-row tiles) while the tiles are being timed
+    scratch = [None]
+
+    def launch(t, dry=False, part=None):
+        if dry:
+            return t in cands
+        if bn_stats and part is None:
+            if scratch[0] is None:
+                scratch[0] = torch.empty(((M + 63) // 64, Cout, 2), dtype=torch.float64, device=xp.device)
+            part = scratch[0]
+        _native.check(L.scouter_conv2d_fwd_planes(_p(xp), _p(wf), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
+                                                  Cout, kh, kw, stride, pad, groups, int(relu), nplanes, t, _stream()),
+                      "conv2d_fwd_planes")
+        return True
+    if tile is None:
+        tile = _pick_tile(("pfwd", nplanes, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, cands)
+        if tile < 0:
+            tile = cands[0]
+    part, rows = None, 0
+    if bn_stats:
+        rows = (M + _PLANE_TILE_ROWS[tile] - 1) // _PLANE_TILE_ROWS[tile]      # one partial per M tile of the kernel
+        part = torch.empty((rows, Cout, 2), dtype=torch.float64, device=xp.device)
+    launch(tile, part=part)
+    return (y, (part, rows)) if bn_stats else y
+
+
+def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, addend=None, tile=None):
+    nplanes = dyp.shape[0]
+    B, H, W, Cin = x_shape
+    Cout = dyp.shape[-1]
+    dx = torch.empty(x_shape, dtype=F32, device=dyp.device)
+    cands = _plane_tiles(Cin // groups)
+
+    def launch(t, dry=False):
+        if dry:
+            return t in cands
+        _native.check(_native.lib().scouter_conv2d_dgrad_planes(_p(dyp), _p(wd), _p(addend), _p(dx), B, H, W, Cin, Cout,
+                                                                kh, kw, stride, pad, groups, nplanes, t, _stream()),
+                      "conv2d_dgrad_planes")
+        return True
+    if tile is None:
+        tile = _pick_tile(("pdgrad", nplanes, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, cands)
+        if tile < 0:
+            tile = cands[0]
+    launch(tile)
+    return dx
+
+
 _side = {}
 # default of nn_hip.Conv2d.use_side_stream (a per-layer / per-model setting: SlotModel.set_side_stream)
 SIDE_STREAM_DEFAULT = os.environ.get("SCOUTER_SIDE_STREAM", "1") != "0"
@@ -298,7 +406,8 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, momentum=0.1, 
     _native.check(_native.lib().scouter_bn_fwd_f32(
         _p(x), None, None, M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
         int(training), 0, _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]),
-        _p(stats[0]) if stats else None, stats[1] if stats else 0, None, _p(ws), ws.numel(), _stream()), "bn_stats")
+        _p(stats[0]) if stats else None, stats[1] if stats else 0, None, None, 0, _p(ws), ws.numel(), _stream()),
+        "bn_stats")
     return saved
 
 
@@ -313,7 +422,7 @@ def bn_apply(x, saved, relu):
 
 
 def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=None, momentum=0.1, eps=1e-5,
-           stats=None, want_mask=False):
+           stats=None, want_mask=False, planes=0):
     """x: [..., C] NHWC.  Returns (y, saved) with saved = (mean, rstd, scale, shift) packed as one [4, C] tensor.
     stats = (partial, rows) from conv2d_fwd(bn_stats=True) replaces the statistics pass over x.
     want_mask (with relu): returns (y, saved, mask) -- the 1-bit/element sign mask bn_bwd takes instead of y."""
@@ -327,10 +436,14 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=N
     if want_mask:
         assert relu
         mask = torch.empty(_native.lib().scouter_relu_mask_words(x.numel()), dtype=torch.int64, device=x.device)
+    yp = torch.empty((planes,) + tuple(x.shape), dtype=BF16, device=x.device) if planes else None
     _native.check(_native.lib().scouter_bn_fwd_f32(
         _p(x), _p(y), _p(residual), M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
         int(training), int(relu), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]),
-        _p(stats[0]) if stats else None, stats[1] if stats else 0, _p(mask), _p(ws), ws.numel(), _stream()), "bn_fwd")
+        _p(stats[0]) if stats else None, stats[1] if stats else 0, _p(mask), _p(yp), planes, _p(ws), ws.numel(),
+        _stream()), "bn_fwd")
+    if planes:
+        y = PlaneTensor(y, yp)
     return (y, saved, mask) if want_mask else (y, saved)
 
 
@@ -457,16 +570,17 @@ def sa_dattn(x, dout, bn=None):
     return out
 
 
-def sa_bn_bwd(dout, a, dgap, x0, bn, training, dgamma=None, dbeta=None):
+def sa_bn_bwd(dout, a, dgap, x0, bn, training, dgamma=None, dbeta=None, planes=0):
     """Backward of [bn0 -> ReLU -> split-attention weighting / GAP] in one fused chain: returns the gradient w.r.t. the
-    radix convolution's raw output x0 [B, H, W, 2C'] and fills dgamma / dbeta (arena slices) of bn0."""
+    radix convolution's raw output x0 [B, H, W, 2C'] (a PlaneTensor when `planes`) and fills dgamma / dbeta."""
     B, H, W, Cp = dout.shape
     dx = torch.empty_like(x0)
+    dxp = torch.empty((planes,) + tuple(x0.shape), dtype=BF16, device=x0.device) if planes else None
     ws = _col_ws(B * H * W, 2 * Cp, x0.device)
     _native.check(_native.lib().scouter_sa_bn_bwd_f32(_p(dout), _p(a), _p(dgap), _p(x0), _p(bn), B, H * W, Cp,
-                                                      int(training), _p(dgamma), _p(dbeta), _p(dx), _p(ws), ws.numel(),
-                                                      _stream()), "sa_bn_bwd")
-    return dx
+                                                      int(training), _p(dgamma), _p(dbeta), _p(dx), _p(dxp), planes,
+                                                      _p(ws), ws.numel(), _stream()), "sa_bn_bwd")
+    return PlaneTensor(dx, dxp) if planes else dx
 
 
 def radix_softmax_fwd(z):

@@ -36,14 +36,37 @@ class Conv2d(nn.Module):
         self._dw = self._db = None                                  # arena slices, set by GradArena
         self.precision = "fp32"                                     # per layer; SlotModel.set_precision (no global)
         self.use_side_stream = K.SIDE_STREAM_DEFAULT                # weight gradient on the side stream
+        self.planes = 0                                             # 3: bf16x3 plane kernels (SlotModel.set_planes)
         self._capture = None                                        # test instrumentation, see BatchNorm2d
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # timm resnet.py:447-448
         if bias:
             bound = 1.0 / math.sqrt(in_channels // groups * k * k)
             nn.init.uniform_(self.bias, -bound, bound)
 
+    # ---- bf16x3 operand planes (csrc/conv_planes.hip): the producer of this layer's input hands over a K.PlaneTensor
+    def planes_in(self):
+        """Number of operand planes this layer wants its INPUT in (0: plain fp32 tensor)."""
+        cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
+        ok = self.planes and self.precision == "fp32" and self.stride == 1 and cg % 32 == 0 and ng % 64 == 0
+        return self.planes if ok else 0
+
+    def planes_dy(self):
+        """Number of planes this layer wants its OUTPUT GRADIENT in (input-gradient kernel on planes)."""
+        cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
+        ok = self.planes and self.precision == "fp32" and self.stride == 1 and ng % 32 == 0 and cg % 64 == 0
+        return self.planes if ok else 0
+
     def fwd(self, x, save, relu=False, addend=None, bn_stats=False):
         """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd."""
+        if isinstance(x, K.PlaneTensor):
+            k = self.kernel_size
+            want_wd = save and self.planes_dy() > 0
+            wf, wd = K.planes_split_weight(K.hwio(self.weight), self.groups, x.planes.shape[0], fwd=True, dgrad=want_wd)
+            y = K.conv2d_fwd_planes(x.planes, wf, k, k, self.stride, self.padding, self.groups, self.bias, addend, relu,
+                                    bn_stats)
+            if self._capture is not None and relu:
+                self._capture[0][self._capture[1]] = y
+            return y, ((x.f32, wd) if save else None)
         y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
                          bn_stats, precision=self.precision)
         if self._capture is not None and relu:
@@ -51,7 +74,20 @@ class Conv2d(nn.Module):
         return y, (x if save else None)
 
     def bwd(self, dy, ctx, need_dx=True, addend=None):
-        x = ctx
+        wd = None
+        if isinstance(ctx, tuple):
+            x, wd = ctx
+        else:
+            x = ctx
+        dyp = None
+        if isinstance(dy, K.PlaneTensor):
+            dy, dyp = dy.f32, dy.planes
+        if need_dx and dyp is not None and wd is not None:
+            k = self.kernel_size
+            dx = K.conv2d_dgrad_planes(dyp, wd, tuple(x.shape), k, k, self.stride, self.padding, self.groups, addend)
+            need_dx = False
+        else:
+            dx = None
         if self._dw is not None or self._db is not None:
             # weight / bias gradients: off the critical path
             with K.side_stream(dy.device, x, dy, enabled=self.use_side_stream):
@@ -60,7 +96,7 @@ class Conv2d(nn.Module):
                 if self._db is not None:
                     K.colsum(dy, self._db)
         if not need_dx:
-            return None
+            return dx
         return K.conv2d_dgrad(dy, K.hwio(self.weight), tuple(x.shape), addend, self.stride, self.padding, self.groups,
                               precision=self.precision)
 
@@ -81,6 +117,7 @@ class StemConv2d(Conv2d):
         self._dw = self._db = None
         self.precision = "fp32"
         self.use_side_stream = K.SIDE_STREAM_DEFAULT
+        self.planes = 0
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
     def fwd(self, x_nchw, save, relu=False, addend=None, bn_stats=False):
@@ -119,8 +156,9 @@ class BatchNorm2d(nn.Module):
         self._dg = self._db = None
         self._capture = None                 # test instrumentation: (dict, key) -> the ReLU'd output is stored there
 
-    def fwd(self, x, save, relu=False, residual=None, tracked=None):
-        """x may be the (tensor, stats) pair a conv produced with bn_stats=True."""
+    def fwd(self, x, save, relu=False, residual=None, tracked=None, planes=0):
+        """x may be the (tensor, stats) pair a conv produced with bn_stats=True.  planes = 1 / 3: the output is a
+        K.PlaneTensor (fp32 + bf16 operand planes for the plane convolution that consumes it)."""
         stats = None
         if isinstance(x, tuple):
             x, stats = x
@@ -129,11 +167,11 @@ class BatchNorm2d(nn.Module):
                              % (tuple(x.shape),))
         out = K.bn_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
                        residual, self.momentum, self.eps, stats if self.training else None,
-                       want_mask=bool(relu and save))
+                       want_mask=bool(relu and save), planes=planes)
         if self.training and tracked is not None:
             tracked.append(self.num_batches_tracked)
         if self._capture is not None and relu:
-            self._capture[0][self._capture[1]] = out[0]
+            self._capture[0][self._capture[1]] = out[0].f32 if isinstance(out[0], K.PlaneTensor) else out[0]
         # the backward takes the ReLU sign from a 1-bit/element mask, not from the 4-byte activation
         return out[0], ((x, out[2] if relu else None, out[1], self.training) if save else None)
 

@@ -31,7 +31,7 @@ class ResNestBottleneck(nn.Module):
 
     def fwd(self, x, save, tracked):
         c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
-        h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked)
+        h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked, planes=self.conv2.conv.planes_in())
         sa, ksa = self.conv2.fwd(h1, save, tracked)
         p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
         c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training)

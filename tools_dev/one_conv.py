@@ -14,8 +14,12 @@ if tile is not None:
     K._tile_cache[("fwd", False, B, H, H, cin, cout, k, k, 1, p, g)] = tile
     K._tile_cache[("dgrad", False, B, H, H, cin, cout, k, k, 1, p, g)] = tile
 y = K.conv2d_fwd(x, w, None, None, 1, p, g); dy = torch.randn_like(y); dw = torch.empty_like(w)
+if mode.startswith('pfwd'):                      # plane convolution: pfwd3 / pfwd1
+    npl = int(mode[4:] or 3)
+    xp = K.planes_split(x, npl); wf, _ = K.planes_split_weight(w, g, npl)
 for _ in range(10):
-    if mode == 'fwd': K.conv2d_fwd(x, w, None, None, 1, p, g, bn_stats=True)
+    if mode.startswith('pfwd'): K.conv2d_fwd_planes(xp, wf, k, k, 1, p, g, bn_stats=True, tile=tile or 0)
+    elif mode == 'fwd': K.conv2d_fwd(x, w, None, None, 1, p, g, bn_stats=True)
     elif mode == 'dgrad': K.conv2d_dgrad(dy, w, tuple(x.shape), None, 1, p, g)
     else: K.conv2d_wgrad(x, dy, dw, 1, p, g)
 torch.cuda.synchronize()
