@@ -210,6 +210,14 @@ int scouter_conv2d_dgrad_planes(const void* dy_planes, const void* w_planes, con
                                 int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int nplanes,
                                 int tile, void* stream);
 
+/* weight gradient on planes: same-size stride-1 convolutions (2 * pad == k - 1), 64-multiples of channels per group;
+ * x_planes [nplanes][B*H*W][Cin], dy_planes [nplanes][B*H*W][Cout]; dw HWIO fp32; split-K slabs in ws, summed in a
+ * fixed order. */
+size_t scouter_conv2d_wgrad_planes_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int groups);
+int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_planes, float* dw, int B, int H, int W, int Cin,
+                                int Cout, int kh, int kw, int pad, int groups, int nplanes, void* ws, size_t ws_bytes,
+                                void* stream);
+
 /* ---- optimizer: torch.optim.AdamW defaults (train.py:146).  chunk table = array of {float* param; long offset
  * into the flat grad/moment arenas; int n; int pad} built by the host (scouter_adamw_chunk_bytes() each). */
 int scouter_adamw_chunk_bytes(void);

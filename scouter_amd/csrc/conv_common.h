@@ -39,6 +39,9 @@ __device__ __forceinline__ void wgrad_block_coords(int& tile, int& split) {
     }
 }
 
+// deterministic sum of split-K slabs (conv_igemm.hip)
+void sc_launch_slab_reduce(const float* part, float* dst, long n, int splits, long slab, hipStream_t st);
+
 // Block epilogue.  acc: this wave's (WM x WN) accumulator tiles in MFMA layout; lds: the block's K-loop LDS (free now,
 // at least 4*WM*(WN+4) floats); rows m0.., columns grp*Ng + n0.. of the [M][N] output.
 template <int BM, int BN, int WM, int WN>

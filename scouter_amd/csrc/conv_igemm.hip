@@ -580,6 +580,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+// (also used by the plane weight-gradient kernel, conv_planes.hip)
+void sc_launch_slab_reduce(const float* part, float* dst, long n, int splits, long slab, hipStream_t st) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(n / 4, 8)), dim3(256), 0, st, part, dst, n, splits, slab);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // host dispatch
 // ----------------------------------------------------------------------------------------------------------------

@@ -420,3 +420,323 @@ extern "C" int scouter_conv2d_dgrad_planes(const void* dy_planes, const void* w_
     return dispatch_pconv<true>(dy_planes, a_pe, w_planes, w_pe, nullptr, addend, dx, nullptr, g, 0, nplanes, tile,
                                 (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient on planes:  dW[tap][ci][co] = sum_m X[m + tapoff][ci] * dY[m][co]   ("same" stride-1 convolutions)
+// ---------------------------------------------------------------------------------------------------------------
+// The contraction index is the PIXEL, but both operands are stored pixel-major / channel-contiguous, while a bf16 MFMA
+// lane wants 8 consecutive k of one row.  ds_read_b64_tr_b16 does that transpose in the LDS read: the 16 lanes of a group
+// each point at 4 contiguous bf16 of a [4 rows][16 columns] block (lane t: row t >> 2, columns 4 (t & 3) ..) and lane t
+// RECEIVES column t of the four rows (measured with tools_dev/tr_b16_probe.hip).  So the LDS image stays the natural one
+// -- [32 pixels][BM channels] per operand plane, filled by LDS-DMA exactly like the forward kernel -- and a fragment
+// (row = channel l & 31, k = pixels 8 (l >> 5) .. + 7) is two transposing reads.  Bank conflicts: the four pixel rows a
+// 32-lane half touches are BM * 2 bytes apart (a multiple of 256 for BM = 128): the 16-byte slot s of pixel row r is
+// stored at slot s ^ 4 (r & 3) [BM = 128] resp. s ^ 4 ((r >> 1) & 1) [BM = 64], again applied on the DMA's source side.
+__device__ __forceinline__ unsigned long long ds_read_tr16(unsigned addr) {
+    unsigned long long v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+template <int CH>   // channels per LDS row (BM or BN): slot swizzle of pixel row r
+__device__ __forceinline__ int px_swz(int r) { return CH == 128 ? 4 * (r & 3) : 4 * ((r >> 1) & 1); }
+
+template <int BM, int BN, int NP, int NSTAGE>
+__global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __restrict__ x_planes, long x_pe,
+                                                        const unsigned short* __restrict__ dy_planes, long dy_pe,
+                                                        float* __restrict__ out, ConvGeom g, int ci_tiles, int co_tiles,
+                                                        long pix_per_split, long slab) {
+    constexpr int BK = 32, WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+    constexpr int A_BYTES = NP * BK * BM * 2, B_BYTES = NP * BK * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int APX = 512 / BM, BPX = 512 / BN;               // pixel rows one DMA instruction covers (1 KB)
+    constexpr int AQ = BK / APX / 4, BQ = BK / BPX / 4;         // DMA instructions per wave, operand and plane
+    constexpr int DMA_PER_TILE = (AQ + BQ) * NP;
+    constexpr int NACC = NP == 3 ? 2 : 1;
+    static_assert((BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile");
+    extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid, split_id;
+    wgrad_block_coords(bid, split_id);
+    const int co_t = bid % co_tiles; bid /= co_tiles;
+    const int ci_t = bid % ci_tiles; bid /= ci_tiles;
+    const int grp = bid % g.groups;
+    const int tap = bid / g.groups;
+    const int r = tap / g.S, q = tap - r * g.S;
+    const int ci0 = ci_t * BM, co0 = co_t * BN;
+    const long mbeg = (long)split_id * pix_per_split;
+    long mend = mbeg + pix_per_split;
+    if (mend > g.M) mend = g.M;
+    const int KT = (int)((mend - mbeg + BK - 1) / BK);
+    const long tapoff = (long)(r - g.pad) * g.W + (q - g.pad);           // source pixel = m + tapoff
+
+    // ---- tap validity of the chunk's pixels: lane l tests pixel (l & 31) of the chunk, a ballot makes it scalar
+    // (branch-free walk over (y, x): at most one row wrap and one image wrap per 32-pixel chunk, checked by the host)
+    const int hw = g.Ho * g.Wo;
+    const int blk_b = (int)(((double)(unsigned long)mbeg + 0.5) * g.inv_hw);
+    const int blk_rem = (int)(mbeg - (long)blk_b * hw);
+    const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
+    int qx1, qy1;
+    {
+        const int tx = blk_x + l31, qx = fast_div(tx, g.inv_wo);
+        const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho);
+        qx1 = tx - qx * g.Wo;
+        qy1 = ty - qy * g.Ho;
+    }
+    const int adv_x = BK % g.Wo, adv_y = BK / g.Wo;
+
+    // ---- DMA lane geometry: instruction iq of this wave covers pixel rows APX * (wave + 4 iq) .. of the chunk
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int ASL = BM / 8, BSL = BN / 8;                    // 16-byte slots per pixel row
+    unsigned a_voff[AQ], a_bit[AQ], b_voff[BQ];
+#pragma unroll
+    for (int iq = 0; iq < AQ; ++iq) {
+        const int rq = APX * (wave + 4 * iq) + lane / ASL, sl = lane % ASL;
+        const int c = sl ^ px_swz<BM>(rq);                       // channel chunk this lane fetches for its slot
+        a_voff[iq] = (unsigned)(((long)rq * g.C + grp * g.Cg + ci0 + 8 * c) * 2);
+        a_bit[iq] = 1u << rq;
+    }
+#pragma unroll
+    for (int iq = 0; iq < BQ; ++iq) {
+        const int rq = BPX * (wave + 4 * iq) + lane / BSL, sl = lane % BSL;
+        const int c = sl ^ px_swz<BN>(rq);
+        b_voff[iq] = (unsigned)(((long)rq * g.N + grp * g.Ng + co0 + 8 * c) * 2);
+    }
+    auto records = [&](long m_chunk, int row_elems) {            // bytes of the rows m_chunk .. mend-1
+        long n = (mend - m_chunk) * (long)row_elems * 2;
+        return (unsigned)(n < 0 ? 0 : (n > 0x7fffffffL ? 0x7fffffffL : n));
+    };
+    long next_m = mbeg;                                           // first pixel of the chunk the next issue() fetches
+    auto issue = [&](int stage) {
+        const long m = next_m;
+        const unsigned rec_a = records(m, g.C), rec_b = records(m, g.N);
+        const int iy = qy1 - g.pad + r, ix = qx1 - g.pad + q;
+        const unsigned vmask = (unsigned)__ballot((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W);
+        qx1 += adv_x;
+        const int wrap = qx1 >= g.Wo ? 1 : 0;
+        qx1 -= wrap ? g.Wo : 0;
+        qy1 += adv_y + wrap;
+        qy1 -= qy1 >= g.Ho ? g.Ho : 0;
+        char* st = lds_raw + stage * STAGE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            // one descriptor per plane (scalar work): num_records clips the chunk at the end of the pixel range, and the
+            // range check covers the scalar offset too -- a plane offset passed there read zeros for planes 1 and 2
+            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(x_planes + pl * x_pe + (m + tapoff) * g.C), 0, rec_a, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(dy_planes + pl * dy_pe + m * g.N), 0, rec_b, 0x00020000);
+#pragma unroll
+            for (int iq = 0; iq < AQ; ++iq)
+                dma16(rs_a, st + pl * (BK * BM * 2) + (wave + 4 * iq) * 1024, (vmask & a_bit[iq]) ? a_voff[iq] : OOB, 0);
+#pragma unroll
+            for (int iq = 0; iq < BQ; ++iq)
+                dma16(rs_b, st + A_BYTES + pl * (BK * BN * 2) + (wave + 4 * iq) * 1024, b_voff[iq], 0);
+        }
+        next_m += BK;
+    };
+
+    f32x16 acc[MT][NT], accl[NACC == 2 ? MT : 1][NACC == 2 ? NT : 1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if (NACC == 2) accl[i][j][e] = 0.f;
+            }
+
+    // ---- transposing fragment reads.  Lane l, read u (k sub-block of 4): pixel row 16 step + 8 h + 4 u + ((l >> 2) & 3),
+    // columns blockbase + 16 ((l >> 4) & 1) + 4 (l & 3) .. + 3
+    const int r2 = (lane >> 2) & 3, g1 = (lane >> 4) & 1, c4 = 4 * (lane & 3);
+    unsigned fa_off[MT], fb_off[NT];                              // lane's byte offset inside an operand plane image
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int col = wm * WM + 32 * i + 16 * g1 + c4, row0 = 8 * h + r2;
+        fa_off[i] = (unsigned)(row0 * (BM * 2) + (((col >> 3) ^ px_swz<BM>(row0)) << 4) + (col & 7) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = wn * WN + 32 * j + 16 * g1 + c4, row0 = 8 * h + r2;
+        fb_off[j] = (unsigned)(row0 * (BN * 2) + (((col >> 3) ^ px_swz<BN>(row0)) << 4) + (col & 7) * 2);
+    }
+    // (rows 16 step + 4 u further down keep (row & 3) and, for 64-channel rows, flip ((row >> 1) & 1) only with u -> the
+    // swizzle term is folded per u below)
+    bf16x8 F[2][MT + NT][NP];
+    auto load_frags = [&](int buf, int stage, int step) {
+        const unsigned sbase = lds_base + stage * STAGE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                u64x2 v;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    // 4 u rows further: (row & 3) unchanged; for 64-channel rows ((row >> 1) & 1) flips when u = ... never:
+                    // 4 u changes bit 2 only, so both swizzles are unchanged by u and by 16 step
+                    v[u] = ds_read_tr16(sbase + pl * (BK * BM * 2) + fa_off[i] + (16 * step + 4 * u) * (BM * 2));
+                }
+                F[buf][i][pl] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                u64x2 v;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    v[u] = ds_read_tr16(sbase + A_BYTES + pl * (BK * BN * 2) + fb_off[j] + (16 * step + 4 * u) * (BN * 2));
+                F[buf][MT + j][pl] = __builtin_bit_cast(bf16x8, v);
+            }
+        }
+    };
+    auto mma = [&](int buf) {
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int pr = (NP == 3 ? 0 : 5); pr < 6; ++pr)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (NACC == 2 && pr < 5)
+                        accl[i][j] = mfma_bf16p(F[buf][i][PA[pr]], F[buf][MT + j][PB[pr]], accl[i][j]);
+                    else
+                        acc[i][j] = mfma_bf16p(F[buf][i][NP == 3 ? PA[pr] : 0], F[buf][MT + j][NP == 3 ? PB[pr] : 0], acc[i][j]);
+                }
+    };
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
+    // (the transposing reads are inline asm: hipcc does not count them, every wait is explicit)
+#define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    if (KT > 0) {
+#pragma unroll
+        for (int s = 0; s < NSTAGE; ++s) issue(s);               // chunks past the end read zeros (num_records = 0)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 1) * DMA_PER_TILE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, 0, 0);
+        LGKM0();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int stage = kt % NSTAGE, nstage = (kt + 1) % NSTAGE;
+            SBAR();
+            load_frags(1, stage, 1);
+            SBAR();
+            mma(0);
+            SBAR();
+            LGKM0();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DMA_PER_TILE) : "memory");
+            __builtin_amdgcn_s_barrier();
+            SBAR();
+            issue(stage);
+            load_frags(0, nstage, 0);
+            SBAR();
+            mma(1);
+            SBAR();
+            LGKM0();
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+#undef SBAR
+#undef LGKM0
+    float* o = out + (long)split_id * slab + (long)tap * g.Cg * g.N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ci = ci0 + wm * WM + i * 32 + mfma32_row(e, lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = grp * g.Ng + co0 + wn * WN + j * 32 + l31;
+                o[(long)ci * g.N + co] = NACC == 2 ? acc[i][j][e] + accl[i][j][e] : acc[i][j][e];
+            }
+        }
+}
+
+extern "C" size_t scouter_conv2d_wgrad_planes_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                                                              int groups) {
+    if (groups <= 0 || Cin % groups || Cout % groups) return 0;
+    const long M = (long)B * H * W;
+    const int Cg = Cin / groups, Ng = Cout / groups;
+    const int bm = Cg % 128 == 0 ? 128 : 64, bn = Ng % 128 == 0 ? 128 : 64;
+    const long tiles = (long)(Cg / bm) * (Ng / bn) * groups * kh * kw;
+    long want = 1024 / tiles;
+    if (want < 1) want = 1;
+    const long chunks = (M + 31) / 32;
+    long cps = (chunks + want - 1) / want;
+    if (cps < 8) cps = 8;
+    const long splits = (M + cps * 32 - 1) / (cps * 32);
+    return splits > 1 ? (size_t)splits * kh * kw * Cg * Cout * sizeof(float) : 0;
+}
+
+// x_planes [np][B*H*W][Cin], dy_planes [np][B*H*W][Cout] (stride 1, output size == input size); dw: HWIO fp32.
+extern "C" int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_planes, float* dw, int B, int H, int W,
+                                           int Cin, int Cout, int kh, int kw, int pad, int groups, int nplanes, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    SC_REQUIRE(x_planes && dy_planes && dw && B > 0 && (nplanes == 1 || nplanes == 3), "conv2d_wgrad_planes: bad arguments");
+    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_wgrad_planes: channels not divisible by groups");
+    const int Cg = Cin / groups, Ng = Cout / groups;
+    SC_UNSUPPORTED(kh == kw && 2 * pad == kh - 1 && Cg % 64 == 0 && Ng % 64 == 0 && 32 / W + 1 < H,
+                   "conv2d_wgrad_planes: same-size convolutions with 64-multiples of channels per group only");
+    ConvGeom g{B, H, W, Cin, H, W, Cout, kh, kw, 1, pad, groups, Cg, Ng, 0, Cout, Cg * Cout};
+    g.M = (long)B * H * W;
+    g.inv_hw = 1.0 / ((double)H * W);
+    g.inv_wo = 1.0f / (float)W;
+    g.inv_ho = 1.0f / (float)H;
+    const long x_pe = g.M * Cin, dy_pe = g.M * Cout;
+    SC_UNSUPPORTED(g.M < (1L << 31) && (long)nplanes * x_pe * 2 < (1L << 32) && (long)nplanes * dy_pe * 2 < (1L << 32),
+                   "conv2d_wgrad_planes: tensor too large for 32-bit plane offsets");
+    const int bm = Cg % 128 == 0 ? 128 : 64, bn = Ng % 128 == 0 ? 128 : 64;
+    const int ci_tiles = Cg / bm, co_tiles = Ng / bn;
+    const long tiles = (long)ci_tiles * co_tiles * groups * kh * kw;
+    long want = 1024 / tiles;
+    if (want < 1) want = 1;
+    const long chunks = (g.M + 31) / 32;
+    long cps = (chunks + want - 1) / want;
+    if (cps < 8) cps = 8;
+    const long pps = cps * 32;
+    const int splits = (int)((g.M + pps - 1) / pps);
+    const long slab = (long)kh * kw * Cg * Cout;
+    const size_t need = splits > 1 ? (size_t)splits * slab * sizeof(float) : 0;
+    if (need > ws_bytes || (need && !ws)) {
+        sc_set_error("conv2d_wgrad_planes: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+        return SC_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* out = splits > 1 ? (float*)ws : dw;
+    dim3 grid((unsigned)tiles, (unsigned)splits);
+    {
+        ScProfScope prof(nplanes == 3 ? "pwgrad<bf16x3>" : "pwgrad<bf16>", st, 2.0 * g.M * Cout * Cg * kh * kw,
+                         2.0 * nplanes * ((double)x_pe + (double)dy_pe));
+#define PWG(BM_, BN_, NP_)                                                                                          \
+    do {                                                                                                            \
+        constexpr int NST = 3;                                                                                      \
+        const size_t lds = (size_t)NST * NP_ * 32 * (BM_ + BN_) * 2;                                                \
+        auto kern = pwgrad_kernel<BM_, BN_, NP_, NST>;                                                              \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned short*)x_planes, x_pe,                   \
+                           (const unsigned short*)dy_planes, dy_pe, out, g, ci_tiles, co_tiles, pps, slab);         \
+    } while (0)
+        if (nplanes == 3) {
+            if (bm == 128 && bn == 128) PWG(128, 128, 3);
+            else if (bm == 128) PWG(128, 64, 3);
+            else if (bn == 128) PWG(64, 128, 3);
+            else PWG(64, 64, 3);
+        } else {
+            if (bm == 128 && bn == 128) PWG(128, 128, 1);
+            else if (bm == 128) PWG(128, 64, 1);
+            else if (bn == 128) PWG(64, 128, 1);
+            else PWG(64, 64, 1);
+        }
+#undef PWG
+    }
+    int rc = sc_check_launch("conv2d_wgrad_planes");
+    if (rc) return rc;
+    if (splits > 1) {
+        ScProfScope prof2("slab_reduce", st, 0, 4.0 * (double)slab * (splits + 1));
+        sc_launch_slab_reduce((const float*)ws, dw, slab, splits, slab, st);
+        rc = sc_check_launch("conv2d_wgrad_planes_reduce");
+    }
+    return rc;
+}

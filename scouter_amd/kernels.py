@@ -286,6 +286,17 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
     return dx
 
 
+def conv2d_wgrad_planes(xp, dyp, dw_hwio, pad, groups=1):
+    """xp [np, B, H, W, Cin], dyp [np, B, H, W, Cout] -> dw (HWIO fp32, written in place)."""
+    nplanes, B, H, W, Cin = xp.shape
+    kh, kw, cg, Cout = dw_hwio.shape
+    L = _native.lib()
+    ws = workspace(L.scouter_conv2d_wgrad_planes_workspace_bytes(B, H, W, Cin, Cout, kh, kw, groups), xp.device)
+    _native.check(L.scouter_conv2d_wgrad_planes(_p(xp), _p(dyp), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, pad, groups,
+                                                nplanes, _p(ws), ws.numel(), _stream()), "conv2d_wgrad_planes")
+    return dw_hwio
+
+
 _side = {}
 # default of nn_hip.Conv2d.use_side_stream (a per-layer / per-model setting: SlotModel.set_side_stream)
 SIDE_STREAM_DEFAULT = os.environ.get("SCOUTER_SIDE_STREAM", "1") != "0"

@@ -56,6 +56,12 @@ class Conv2d(nn.Module):
         ok = self.planes and self.precision == "fp32" and self.stride == 1 and ng % 32 == 0 and cg % 64 == 0
         return self.planes if ok else 0
 
+    def planes_wgrad(self):
+        """Weight gradient on planes too (same-size convolution, 64-multiples of channels per group)."""
+        cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
+        return bool(self.planes_in() and self.planes_dy() and cg % 64 == 0 and ng % 64 == 0
+                    and 2 * self.padding == self.kernel_size - 1)
+
     def fwd(self, x, save, relu=False, addend=None, bn_stats=False):
         """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd."""
         if isinstance(x, K.PlaneTensor):
@@ -66,7 +72,7 @@ class Conv2d(nn.Module):
                                     bn_stats)
             if self._capture is not None and relu:
                 self._capture[0][self._capture[1]] = y
-            return y, ((x.f32, wd) if save else None)
+            return y, ((x.f32, wd, x.planes if self.planes_wgrad() else None) if save else None)
         y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
                          bn_stats, precision=self.precision)
         if self._capture is not None and relu:
@@ -74,9 +80,9 @@ class Conv2d(nn.Module):
         return y, (x if save else None)
 
     def bwd(self, dy, ctx, need_dx=True, addend=None):
-        wd = None
+        wd = xp = None
         if isinstance(ctx, tuple):
-            x, wd = ctx
+            x, wd, xp = ctx
         else:
             x = ctx
         dyp = None
@@ -90,8 +96,11 @@ class Conv2d(nn.Module):
             dx = None
         if self._dw is not None or self._db is not None:
             # weight / bias gradients: off the critical path
-            with K.side_stream(dy.device, x, dy, enabled=self.use_side_stream):
-                if self._dw is not None:
+            with K.side_stream(dy.device, x, dy, xp, dyp, enabled=self.use_side_stream):
+                # (the plane kernel's branch-free pixel walk needs maps that are not tiny: 32 // W + 1 < H)
+                if self._dw is not None and xp is not None and dyp is not None and 32 // x.shape[2] + 1 < x.shape[1]:
+                    K.conv2d_wgrad_planes(xp, dyp, self._dw, self.padding, self.groups)
+                elif self._dw is not None:
                     K.conv2d_wgrad(x, dy, self._dw, self.stride, self.padding, self.groups, precision=self.precision)
                 if self._db is not None:
                     K.colsum(dy, self._db)

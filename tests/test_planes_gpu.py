@@ -88,3 +88,31 @@ def test_plane_convolution_matches_fp64(cfg):
         ed3 = float((dx3.permute(0, 3, 1, 2).cpu().double() - dx_true).abs().max())
         print("dgrad %s: |bf16x3 - fp64| %.3g  |fp32 MFMA - fp64| %.3g" % (cfg, ed3, ed32))
         assert ed3 <= max(2.0 * ed32, 4e-7 * float(dx_true.abs().max())), (ed3, ed32)
+
+
+@pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 128, 3, 1, 1), (3, 9, 7, 128, 256, 3, 1, 2), (1, 8, 8, 256, 256, 1, 0, 1),
+                                 (2, 20, 20, 128, 128, 3, 1, 2), (1, 30, 30, 64, 64, 3, 1, 1), (5, 7, 7, 128, 128, 3, 1, 1),
+                                 (3, 28, 28, 128, 256, 3, 1, 2)])
+def test_plane_weight_gradient_matches_fp64(cfg):
+    """dW on planes: transposing LDS reads (ds_read_b64_tr_b16), split-K slabs, padded taps, ragged last chunk."""
+    B, H, W, Cin, Cout, k, pad, groups = cfg
+    kk = K()
+    rng = np.random.default_rng(sum(cfg) + 1)
+    x = torch.from_numpy(rng.standard_normal((B, Cin, H, W)) + 0.2)
+    dy = torch.from_numpy(rng.standard_normal((B, Cout, H, W)))
+    xd, dyd = nhwc(x), nhwc(dy)
+    w = torch.zeros(Cout, Cin // groups, k, k, dtype=torch.float64, requires_grad=True)
+    dw_true = torch.autograd.grad(F.conv2d(xd.permute(0, 3, 1, 2).cpu().double(), w, None, 1, pad, 1, groups), w,
+                                  dyd.permute(0, 3, 1, 2).cpu().double())[0]
+    dw32 = torch.zeros(k, k, Cin // groups, Cout, device="cuda")
+    kk.conv2d_wgrad(xd, dyd, dw32, 1, pad, groups)
+    dw3 = torch.full((k, k, Cin // groups, Cout), float("nan"), device="cuda")
+    kk.conv2d_wgrad_planes(kk.planes_split(xd, 3), kk.planes_split(dyd, 3), dw3, pad, groups)
+    e32 = float((dw32.permute(3, 2, 0, 1).cpu().double() - dw_true).abs().max())
+    e3 = float((dw3.permute(3, 2, 0, 1).cpu().double() - dw_true).abs().max())
+    sc = float(dw_true.abs().max())
+    print("wgrad %s: |bf16x3 - fp64| %.3g  |fp32 MFMA - fp64| %.3g  (scale %.3g)" % (cfg, e3, e32, sc))
+    assert e3 <= max(2.0 * e32, 4e-7 * sc), (e3, e32, sc)
+    dw3b = torch.zeros_like(dw3)
+    kk.conv2d_wgrad_planes(kk.planes_split(xd, 3), kk.planes_split(dyd, 3), dw3b, pad, groups)
+    assert torch.equal(dw3, dw3b)                                   # deterministic

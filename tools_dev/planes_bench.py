@@ -26,5 +26,11 @@ for cin, cout, k, g, H in shapes:
     if (cin // g) % 64 == 0:
         y = K.conv2d_fwd(x, w, None, None, 1, p, g); dyp = K.planes_split(torch.randn_like(y), 3)
         td = min(timeit(lambda: K.conv2d_dgrad_planes(dyp, wd3, tuple(x.shape), k, k, 1, p, g, tile=t)) for t in ((0, 2, 4) if (cin // g) % 128 == 0 else (2, 3)))
+    tw32 = tw3 = float('nan')
+    if (cin // g) % 64 == 0 and (cout // g) % 64 == 0:
+        y = K.conv2d_fwd(x, w, None, None, 1, p, g); dyt = torch.randn_like(y); dwb = torch.empty_like(w)
+        dyp3 = K.planes_split(dyt, 3)
+        tw32 = timeit(lambda: K.conv2d_wgrad(x, dyt, dwb, 1, p, g)); tw3 = timeit(lambda: K.conv2d_wgrad_planes(xp3, dyp3, dwb, p, g))
+    print("   wgrad fp32 %.1f us, bf16x3 %.1f us (%.1f TF/s)" % (tw32, tw3, fl / tw3 / 1e6))
     print("%-28s %8.2f | %9.1f %9.1f %9.1f | %9.1f %9.1f" % (str((cin, cout, k, g, H)), fl / 1e9, t32, best3, best1, fl / best3 / 1e6, fl / td / 1e6), ["%.0f" % v for v in t3])
 
