@@ -179,26 +179,41 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
             "measured": "hipEvents around each launch, median of 8 batches x 20 launches after 60 warm-up launches"}
 
 
+PMC_TRAFFIC_FILE = "r02_pmc_hbm_traffic.json"
+
+
 def pmc_traffic(kernel_class):
-    """HBM-side bytes per launch of a kernel class (e.g. 'igemm_dgrad<64x64>') from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_hbm_traffic.json, made by tools_dev/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950
-    correction of MI355X_MICROARCH.md) -- PMC counters cannot be collected from inside the timed process.  None if the
-    file or the kernel is missing."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
-    m = __import__("re").match(r"(igemm_fwd|igemm_dgrad|wgrad)<(\d+)x(\d+)>", kernel_class)
-    if not os.path.exists(path) or not m:
+    """HBM-side bytes per launch of a kernel class (e.g. 'igemm_dgrad<64x64>', 'pconv_fwd<bf16x3>') from the committed
+    rocprofv3 PMC passes (profiles/r02_pmc_hbm_traffic.json, made by tools_dev/pmc_traffic.py: 2 x FETCH_SIZE +
+    WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md) -- PMC counters cannot be collected from inside the timed
+    process.  None if the file or the kernel is missing."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
+    if not os.path.exists(path):
         return None, None
-    kind, bm, bn = m.group(1), int(m.group(2)), int(m.group(3))
-    want = ("wgrad_kernel<%d, %d," % (bm, bn)) if kind == "wgrad" else "igemm_kernel<%d, %d," % (bm, bn)
-    flag = None if kind == "wgrad" else (", true, false>" if kind == "igemm_dgrad" else ", false, false>")
+    m = re.match(r"(igemm_fwd|igemm_dgrad|wgrad)<(\d+)x(\d+)>", kernel_class)
+    if m:
+        kind, bm, bn = m.group(1), int(m.group(2)), int(m.group(3))
+        want = ("wgrad_kernel<%d, %d," % (bm, bn)) if kind == "wgrad" else "igemm_kernel<%d, %d," % (bm, bn)
+        # igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED, PW>
+        match = (lambda name: want in name) if kind == "wgrad" else \
+            (lambda name: want in name and (", true, " if kind == "igemm_dgrad" else ", false, ") in name.split(want)[1][:24])
+    elif kernel_class.startswith("pconv_fwd"):
+        match = lambda name: "pconv_kernel<" in name and ", false" in name
+    elif kernel_class.startswith("pconv_dgrad"):
+        match = lambda name: "pconv_kernel<" in name and ", true" in name
+    elif kernel_class.startswith("pwgrad"):
+        match = lambda name: "pwgrad_kernel<" in name
+    else:
+        return None, None
     tot = n = 0.0
     for name, rec in json.load(open(path)).items():
-        if want in name and (flag is None or name.endswith(flag)):
+        if match(name):
             tot += (rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]) * rec["launches"]
             n += rec["launches"]
     if not n:
         return None, None
-    return round(tot / n), "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+    return round(tot / n), "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % PMC_TRAFFIC_FILE
 
 
 def main():
@@ -329,9 +344,16 @@ def main():
             kern[name] = {"launches_per_step": n / prof_steps, "ms_per_step": round(ms / prof_steps, 4),
                           "avg_us": round(1e3 * ms / n, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None,
                           "gbps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1) if by else None}
-        conv = [k for k in kern if k.startswith(("igemm_", "wgrad<", "wgrad_taps", "wgrad_bf16"))]
+        conv = [k for k in kern if k.startswith(("igemm_", "wgrad<", "wgrad_taps", "wgrad_bf16", "pconv_", "pwgrad"))]
         is_bf16_kernel = lambda k: "bf16" in k
-        kpeak = lambda k: PEAK_BF16_MFMA_TFLOPS if is_bf16_kernel(k) else PEAK_FP32_MFMA_TFLOPS
+        # peaks per kernel family: exact-fp32 MFMA 157.3; plain bf16 MFMA 2500; "bf16x3" = fp32-accurate products rebuilt
+        # from SIX bf16 MFMA products each, so its algorithmic-FLOP ceiling is 2500 / 6 = 416.7 TFLOP/s
+        kpeak = lambda k: (PEAK_BF16_MFMA_TFLOPS / 6.0 if "bf16x3" in k else PEAK_BF16_MFMA_TFLOPS) if is_bf16_kernel(k) \
+            else PEAK_FP32_MFMA_TFLOPS
+        kdesc = lambda k: (" (convolution on exact three-way bf16 operand splits: 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, "
+                           "fp32 accumulate; peak = 2500 / 6 TFLOP/s of algorithmic work)" if "bf16x3" in k else
+                           " (bf16-input implicit-GEMM convolution, v_mfma_f32_32x32x16_bf16, fp32 accumulate)"
+                           if is_bf16_kernel(k) else " (fp32 implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)")
         roofline = None
         if conv:
             # the dominant kernel INSTANCE (most time per step); its rocprofv3 row is igemm_kernel<BM,BN,..> / wgrad_kernel<..>
@@ -344,10 +366,8 @@ def main():
             frac_all = sum(kern[k]["tflops"] * kern[k]["ms_per_step"] / kpeak(k) for k in conv) / tot_ms
             step_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
             roofline = {"bound": "mfma",
-                        "kernel": dom + (" (bf16-input implicit-GEMM convolution, v_mfma_f32_32x32x16_bf16, fp32 accumulate)"
-                                         if is_bf16_kernel(dom) else
-                                         " (fp32 implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)"),
-                        "achieved": ach, "peak": kpeak(dom), "unit": "TFLOP/s",
+                        "kernel": dom + kdesc(dom),
+                        "achieved": ach, "peak": round(kpeak(dom), 1), "unit": "TFLOP/s",
                         "frac": round(ach / kpeak(dom), 4), "traffic": None,
                         "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches_per_step"],
                         "measured": "hipEvents on the launch stream over %d serial steps (weight-gradient side stream "

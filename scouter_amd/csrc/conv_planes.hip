@@ -21,6 +21,8 @@
 // on the SOURCE address; fragment reads (ds_read_b128, lane = row) are then bank-conflict free.
 #include "conv_common.h"
 
+#include <type_traits>
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -157,14 +159,21 @@ __global__ __launch_bounds__(NWM * 128, 1) void pconv_kernel(const unsigned shor
     const long wtap_bytes = (long)g.N * g.Cg * 2;
     const long a_plane_bytes = a_plane_elems * 2, w_plane_bytes = w_plane_elems * 2;
 
+    // K order of the input-gradient kernel: channel chunk outer, filter tap INNER.  The nine taps of one 32-channel
+    // chunk re-read (shifted) the same pixel rows right away -- 64 bytes per row stay cache-resident -- whereas tap-major
+    // order comes back to a pixel row only after sweeping all Cg channels of every row of the tile: 128 KB per workgroup
+    // x 32 workgroups per XCD = the whole 4 MB L2 for the wide dY rows (PMC: 1.2 GB fetched per launch against 168 MB
+    // of operands; 118 -> 152 TFLOP/s-equivalent on the 56x56 layer).  The forward kernel (narrower rows, and weight
+    // tiles whose two 64-byte halves are then used back to back) measured 5 % faster tap-major and keeps that order.
+    constexpr bool TAP_INNER = DGRAD;
+    const int ntaps = g.R * g.S;
     auto issue = [&](int kt, int stage) {          // DMA of K-tile kt into LDS stage `stage`
-        const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+        const int chunk_i = TAP_INNER ? kt / ntaps : kt % cpt, tap = TAP_INNER ? kt - chunk_i * ntaps : kt / cpt;
+        const int c0 = chunk_i * BK;
         const int r = tap / g.S, q = tap - r * g.S;
         const long toff = (DGRAD ? -((long)r * g.W + q) : ((long)r * g.W + q)) * g.C + c0;
-        if (c0 == 0) {
 #pragma unroll
-            for (int t = 0; t < ARG; ++t) a_veff[t] = ((a_mask[t] >> tap) & 1u) ? a_voff[t] : OOB;
-        }
+        for (int t = 0; t < ARG; ++t) a_veff[t] = ((a_mask[t] >> tap) & 1u) ? a_voff[t] : OOB;
         const long sa = (DGRAD ? shift + toff : toff) * 2;
         const long sb = tap * wtap_bytes + (long)c0 * 2;
         char* st = lds_raw + stage * STAGE_BYTES;
@@ -432,9 +441,10 @@ extern "C" int scouter_conv2d_dgrad_planes(const void* dy_planes, const void* w_
 // (row = channel l & 31, k = pixels 8 (l >> 5) .. + 7) is two transposing reads.  Bank conflicts: the four pixel rows a
 // 32-lane half touches are BM * 2 bytes apart (a multiple of 256 for BM = 128): the 16-byte slot s of pixel row r is
 // stored at slot s ^ 4 (r & 3) [BM = 128] resp. s ^ 4 ((r >> 1) & 1) [BM = 64], again applied on the DMA's source side.
+template <int OFF>    // OFF: compile-time byte offset (the instruction's 16-bit offset field): no address VALU per read
 __device__ __forceinline__ unsigned long long ds_read_tr16(unsigned addr) {
     unsigned long long v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -522,6 +532,9 @@ __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __
         qy1 += adv_y + wrap;
         qy1 -= qy1 >= g.Ho ? g.Ho : 0;
         char* st = lds_raw + stage * STAGE_BYTES;
+        unsigned a_veff[AQ];
+#pragma unroll
+        for (int iq = 0; iq < AQ; ++iq) a_veff[iq] = (vmask & a_bit[iq]) ? a_voff[iq] : OOB;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
             // one descriptor per plane (scalar work): num_records clips the chunk at the end of the pixel range, and the
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __
                 (void*)(dy_planes + pl * dy_pe + m * g.N), 0, rec_b, 0x00020000);
 #pragma unroll
             for (int iq = 0; iq < AQ; ++iq)
-                dma16(rs_a, st + pl * (BK * BM * 2) + (wave + 4 * iq) * 1024, (vmask & a_bit[iq]) ? a_voff[iq] : OOB, 0);
+                dma16(rs_a, st + pl * (BK * BM * 2) + (wave + 4 * iq) * 1024, a_veff[iq], 0);
 #pragma unroll
             for (int iq = 0; iq < BQ; ++iq)
                 dma16(rs_b, st + A_BYTES + pl * (BK * BN * 2) + (wave + 4 * iq) * 1024, b_voff[iq], 0);
@@ -568,31 +581,38 @@ __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __
     // (rows 16 step + 4 u further down keep (row & 3) and, for 64-channel rows, flip ((row >> 1) & 1) only with u -> the
     // swizzle term is folded per u below)
     bf16x8 F[2][MT + NT][NP];
-    auto load_frags = [&](int buf, int stage, int step) {
+    // (4 u or 16 step rows further down change neither (row & 3) nor ((row >> 1) & 1): the swizzle term of a lane is fixed,
+    // and plane / step / u offsets are instruction immediates -- one address VGPR per 32-channel block and stage)
+    auto load_frags = [&](int buf, int stage, auto STEP) {
+        constexpr int step = decltype(STEP)::value;
         const unsigned sbase = lds_base + stage * STAGE_BYTES;
+        unsigned ab[MT], bb[NT];
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
+        for (int i = 0; i < MT; ++i) ab[i] = sbase + fa_off[i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bb[j] = sbase + fb_off[j];
+        auto rd = [&](auto PL) {
+            constexpr int pl = decltype(PL)::value;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 u64x2 v;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    // 4 u rows further: (row & 3) unchanged; for 64-channel rows ((row >> 1) & 1) flips when u = ... never:
-                    // 4 u changes bit 2 only, so both swizzles are unchanged by u and by 16 step
-                    v[u] = ds_read_tr16(sbase + pl * (BK * BM * 2) + fa_off[i] + (16 * step + 4 * u) * (BM * 2));
-                }
+                v[0] = ds_read_tr16<pl * (BK * BM * 2) + (16 * step) * (BM * 2)>(ab[i]);
+                v[1] = ds_read_tr16<pl * (BK * BM * 2) + (16 * step + 4) * (BM * 2)>(ab[i]);
                 F[buf][i][pl] = __builtin_bit_cast(bf16x8, v);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 u64x2 v;
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    v[u] = ds_read_tr16(sbase + A_BYTES + pl * (BK * BN * 2) + fb_off[j] + (16 * step + 4 * u) * (BN * 2));
+                v[0] = ds_read_tr16<A_BYTES + pl * (BK * BN * 2) + (16 * step) * (BN * 2)>(bb[j]);
+                v[1] = ds_read_tr16<A_BYTES + pl * (BK * BN * 2) + (16 * step + 4) * (BN * 2)>(bb[j]);
                 F[buf][MT + j][pl] = __builtin_bit_cast(bf16x8, v);
             }
-        }
+        };
+        rd(std::integral_constant<int, 0>{});
+        if constexpr (NP == 3) { rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{}); }
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
     auto mma = [&](int buf) {
         constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -615,12 +635,12 @@ __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __
         for (int s = 0; s < NSTAGE; ++s) issue(s);               // chunks past the end read zeros (num_records = 0)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 1) * DMA_PER_TILE) : "memory");
         __builtin_amdgcn_s_barrier();
-        load_frags(0, 0, 0);
+        load_frags(0, 0, S0{});
         LGKM0();
         for (int kt = 0; kt < KT; ++kt) {
             const int stage = kt % NSTAGE, nstage = (kt + 1) % NSTAGE;
             SBAR();
-            load_frags(1, stage, 1);
+            load_frags(1, stage, S1{});
             SBAR();
             mma(0);
             SBAR();
@@ -629,7 +649,7 @@ __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __
             __builtin_amdgcn_s_barrier();
             SBAR();
             issue(stage);
-            load_frags(0, nstage, 0);
+            load_frags(0, nstage, S0{});
             SBAR();
             mma(1);
             SBAR();

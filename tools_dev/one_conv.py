@@ -17,8 +17,11 @@ y = K.conv2d_fwd(x, w, None, None, 1, p, g); dy = torch.randn_like(y); dw = torc
 if mode.startswith('pfwd'):                      # plane convolution: pfwd3 / pfwd1
     npl = int(mode[4:] or 3)
     xp = K.planes_split(x, npl); wf, _ = K.planes_split_weight(w, g, npl)
+if mode == 'pwgrad':
+    xp = K.planes_split(x, 3); dyp = K.planes_split(dy, 3)
 for _ in range(10):
-    if mode.startswith('pfwd'): K.conv2d_fwd_planes(xp, wf, k, k, 1, p, g, bn_stats=True, tile=tile or 0)
+    if mode == 'pwgrad': K.conv2d_wgrad_planes(xp, dyp, dw, p, g)
+    elif mode.startswith('pfwd'): K.conv2d_fwd_planes(xp, wf, k, k, 1, p, g, bn_stats=True, tile=tile or 0)
     elif mode == 'fwd': K.conv2d_fwd(x, w, None, None, 1, p, g, bn_stats=True)
     elif mode == 'dgrad': K.conv2d_dgrad(dy, w, tuple(x.shape), None, 1, p, g)
     else: K.conv2d_wgrad(x, dy, dw, 1, p, g)
