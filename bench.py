@@ -374,6 +374,9 @@ def main():
                                     "off) right after the timed region" % prof_steps,
                         "all_conv_kernels_tflops": round(tot_fl / tot_ms, 2),
                         "all_conv_kernels_frac": round(frac_all, 4),
+                        # the same rate against the pipe the REFERENCE arithmetic would use (round 1's yardstick): the
+                        # bf16x3 plane kernels deliver fp32-grade products faster than the fp32 MFMA can
+                        "all_conv_kernels_frac_of_step_peak": round(tot_fl / tot_ms / step_peak, 4),
                         "whole_step_frac": round(value * 3 * cfg["fwd_gflop"] * 1e9 / world / (step_peak * 1e12), 4)}
         if roofline is not None:
             roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom) if a.config == 2 and not bf16 else (None, None)
