@@ -64,6 +64,22 @@ int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, co
 int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
                              int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
                              void* stream);
+/* Input gradient with the BatchNorm-BACKWARD reductions of its consumer fused into the epilogue.  The tensor being
+ * produced is d(out) of a block output out = relu(bn(x1) [+ bn(x2) | + shortcut]) (resnet.py:404-412, resnest.py:128-143;
+ * the shortcut / downsample gradient arrives through `addend`).  The epilogue applies the ReLU sign (relu_mask: the bit
+ * mask scouter_bn_fwd_f32 wrote, NULL = no ReLU), stores g = d(out) * [out > 0] into dx, and writes per M tile and
+ * input channel the fp64 pairs (sum g, sum g * xhat1) to part1 [rows][Cin][2] -- and (sum g, sum g * xhat2) to part2 for
+ * a second BatchNorm fed by the same gradient (downsample branch; may be NULL).  x1 / x2: the BatchNorm inputs
+ * [B][H][W][Cin]; saved1 / saved2: their [4][Cin] blocks {mean, rstd, scale, shift}.  rows =
+ * scouter_conv2d_dgrad_bn_partial_rows(...) (fp32 / bf16-input kernels: ceil(B*H*W / 64) for tile 2, / 128 otherwise;
+ * plane kernels: / 128, 128, 128, 64, 256 for tile 0..4).  scouter_bn_bwd_f32(ext_partial = part, ext_rows = rows) then
+ * runs without its own reduction pass.  part1 == NULL: exactly scouter_conv2d_dgrad_f32. */
+int scouter_conv2d_dgrad_bn_partial_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                         int groups, int tile_hint);
+int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
+                                   int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
+                                   const void* relu_mask, const float* x1, const float* saved1, double* part1,
+                                   const float* x2, const float* saved2, double* part2, void* stream);
 /* ---- bf16 matrix inputs, fp32 accumulation (mixed-precision mode of BASELINE configs[4]): same tensors (fp32 in HBM),
  * same semantics and fused epilogues as the fp32 entry points; operands are rounded to bf16 (RNE) on their way into
  * LDS and multiplied on v_mfma_f32_32x32x16_bf16.  The forward takes the weights pre-transposed to bf16
@@ -78,6 +94,10 @@ int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, const float* bi
 int scouter_conv2d_dgrad_bf16(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
                               int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
                               void* stream);
+int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
+                                    int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
+                                    const void* relu_mask, const float* x1, const float* saved1, double* part1,
+                                    const float* x2, const float* saved2, double* part2, void* stream);
 int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
                               int kw, int stride, int pad, int groups, int plan_hint, void* ws, size_t ws_bytes,
                               void* stream);
@@ -113,10 +133,14 @@ int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, 
  * from a saved block [4][C] = {mean, rstd, scale, shift} (contiguous rows, as written through the four *_out pointers). */
 int scouter_bn_apply_f32(const float* x, const float* bn_saved, float* y, long M, int C, int relu, void* stream);
 /* g = dy * (y > 0), the sign taken from relu_mask if given, else from ymask (both may be NULL: no ReLU);
- * dgamma/dbeta may be NULL (frozen); gout (may be NULL) receives g. */
+ * dgamma/dbeta may be NULL (frozen); gout (may be NULL) receives g.
+ * ext_partial (may be NULL): [ext_rows][C][2] fp64 (sum g, sum g * xhat) already reduced by the epilogue of the
+ * input-gradient kernel that produced dy (scouter_conv2d_dgrad_bnbwd_*): dy then IS g (ymask / relu_mask / gout must be
+ * NULL) and the reduction pass over (dy, x) is skipped. */
 int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean, const float* rstd,
                        const float* scale, const unsigned long long* relu_mask, long M, int C, int training,
-                       float* dgamma, float* dbeta, float* dx, float* gout, void* ws, size_t ws_bytes, void* stream);
+                       float* dgamma, float* dbeta, float* dx, float* gout, const double* ext_partial, int ext_rows,
+                       void* ws, size_t ws_bytes, void* stream);
 /* out[c] = alpha * sum_m a[m][c] * (b ? b[m][c] : 1)  -- bias gradients, d(initial_slots) */
 int scouter_colsum_f32(const float* a, const float* b, float* out, long M, int C, float alpha, void* ws,
                        size_t ws_bytes, void* stream);
@@ -209,6 +233,11 @@ int scouter_conv2d_fwd_planes(const void* x_planes, const void* w_planes, const 
 int scouter_conv2d_dgrad_planes(const void* dy_planes, const void* w_planes, const float* addend, float* dx, int B, int H,
                                 int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int nplanes,
                                 int tile, void* stream);
+int scouter_conv2d_dgrad_planes_bnbwd(const void* dy_planes, const void* w_planes, const float* addend, float* dx, int B,
+                                      int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups,
+                                      int nplanes, int tile, const void* relu_mask, const float* x1,
+                                      const float* saved1, double* part1, const float* x2, const float* saved2,
+                                      double* part2, void* stream);
 
 /* weight gradient on planes: same-size stride-1 convolutions (2 * pad == k - 1), 64-multiples of channels per group;
  * x_planes [nplanes][B*H*W][Cin], dy_planes [nplanes][B*H*W][Cout]; dw HWIO fp32; split-K slabs in ws, summed in a

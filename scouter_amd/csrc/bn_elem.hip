@@ -27,15 +27,7 @@ static int col_blocks(long M, const ColGeom& g) {
     return (int)nb;
 }
 
-// ReLU sign bitmask (1 bit per element instead of re-reading the 4-byte activation in the backward): float4 index i
-// of the flat tensor owns bit (i & 63) of the four words mask[(i >> 6) * 4 + k], k = component.  Written with one
-// wave ballot per component by the apply pass, whose waves cover 64 consecutive float4s.
-__device__ __forceinline__ void relu_mask_apply(f32x4& g, const unsigned long long* __restrict__ mbits, long i4) {
-    const unsigned long long* w = mbits + (i4 >> 6) * 4;
-    const int bit = (int)(i4 & 63);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) g[k] = ((w[k] >> bit) & 1ull) ? g[k] : 0.f;
-}
+// (ReLU sign bitmask: relu_mask_apply, common.h)
 
 // Per-block partial column sums of up to two quantities produced by `F(row, col4) -> (float4 u, float4 v)`.
 // partial layout: [block][C][2] doubles.
@@ -544,9 +536,11 @@ extern "C" int scouter_bn_apply_f32(const float* x, const float* bn_saved, float
 
 extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean,
                                   const float* rstd, const float* scale, const unsigned long long* relu_mask, long M,
-                                  int C, int training, float* dgamma, float* dbeta, float* dx, float* gout, void* ws,
-                                  size_t ws_bytes, void* stream) {
+                                  int C, int training, float* dgamma, float* dbeta, float* dx, float* gout,
+                                  const double* ext_partial, int ext_rows, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(dy && x && mean && rstd && scale && dx, "bn_bwd: null pointer");
+    SC_REQUIRE(!ext_partial || (ext_rows > 0 && !ymask && !relu_mask && !gout),
+               "bn_bwd: with ext_partial dy is the already masked gradient (no ymask / relu_mask / gout)");
     COL_CHECKS("bn_bwd")
     const size_t coef_off = (size_t)nb * C * 2 * sizeof(double);
     if (ws_bytes < coef_off + 2 * (size_t)C * sizeof(float)) {
@@ -556,11 +550,16 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
     float* c1 = (float*)((char*)ws + coef_off);
     float* c2 = c1 + C;
     hipStream_t st = (hipStream_t)stream;
-    ScProfScope prof("bn_bwd(reduce+finalize+apply)", st, 0,
-                     ((ymask && !relu_mask ? 28.0 : 20.0) + (gout ? 4.0 : 0.0) + (relu_mask ? 0.25 : 0.0)) * M * C);
-    hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, relu_mask,
-                       (double*)ws, g);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+    ScProfScope prof(ext_partial ? "bn_bwd(finalize+apply)" : "bn_bwd(reduce+finalize+apply)", st, 0,
+                     ((ext_partial ? 12.0 : (ymask && !relu_mask ? 28.0 : 20.0)) + (gout ? 4.0 : 0.0) +
+                      (relu_mask ? 0.25 : 0.0)) * M * C);
+    const double* part = (const double*)ws;
+    int nparts = nb;
+    if (ext_partial) { part = ext_partial; nparts = ext_rows; }   // reduced by the epilogue of the kernel that produced dy
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, relu_mask,
+                           (double*)ws, g);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, part, nparts, M, C,
                        training, dgamma, dbeta, c1, c2);
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale, c1,

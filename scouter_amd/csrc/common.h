@@ -108,3 +108,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// ReLU sign bitmask (1 bit per element instead of re-reading the 4-byte activation in the backward): float4 index i
+// of the flat tensor owns bit (i & 63) of the four words mask[(i >> 6) * 4 + k], k = component.  Written with one
+// wave ballot per component by the BatchNorm apply pass, whose waves cover 64 consecutive float4s.
+__device__ __forceinline__ void relu_mask_apply(f32x4& g, const unsigned long long* __restrict__ mbits, long i4) {
+    const unsigned long long* w = mbits + (i4 >> 6) * 4;
+    const int bit = (int)(i4 & 63);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = ((w[k] >> bit) & 1ull) ? g[k] : 0.f;
+}

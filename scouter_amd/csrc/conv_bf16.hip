@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restr
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ addend, float* __restrict__ dst,
                                                             double* __restrict__ bn_part, ConvGeom g, int relu,
-                                                            int mtiles, int ntiles) {
+                                                            int mtiles, int ntiles, BnBwdFuse fz) {
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     constexpr int LDH = KT_ + 8;                          // LDS row stride in bf16
     constexpr int A_H = BM * LDH, B_H = BN * LDH, STAGE_H = A_H + B_H;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restr
         tile(kt, P0{});
         if (kt + 1 < KT) tile(kt + 1, P1{});
     }
-    igemm_epilogue<BM, BN, WM, WN>(acc, (float*)ldsh, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id);
+    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)ldsh, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
 }
 
 // W (HWIO fp32 [taps][Cin/groups][Cout]) -> bf16 W^T [taps][Cout][Cin/groups]
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void weight_bf16t_kernel(const float* __restri
 
 template <int BM, int BN, int WM, int WN, bool DGRAD>
 static void launch_bf16(const float* src, const void* w, const float* bias, const float* addend, float* dst,
-                        double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
+                        double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz) {
     const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
     dim3 grid(mtiles * ntiles * g.groups);
     ConvGeom gg = g;
@@ -226,21 +226,22 @@ static void launch_bf16(const float* src, const void* w, const float* bias, cons
         size_t lds = (size_t)2 * (BM + BN) * (kt + 8) * 2;
         if (lds < epi) lds = epi;
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, src, w, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, src, w, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz);
     };
     if (g.Cg % 64 == 0) go(igemm_bf16_kernel<BM, BN, WM, WN, 64, DGRAD>, 64);
     else go(igemm_bf16_kernel<BM, BN, WM, WN, 32, DGRAD>, 32);
 }
 template <bool DGRAD>
 static int dispatch_bf16(const float* src, const void* w, const float* bias, const float* addend, float* dst,
-                         double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st) {
+                         double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st,
+                         const BnBwdFuse& fz = BnBwdFuse{}) {
     SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 28),
                    "conv2d_bf16: more than 2^31 output pixels or an image above 2^28 elements is not supported");
     switch (tile) {
-        case 0: launch_bf16<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
-        case 1: launch_bf16<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
-        case 2: launch_bf16<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
-        default: launch_bf16<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+        case 0: launch_bf16<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 1: launch_bf16<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 2: launch_bf16<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        default: launch_bf16<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
     }
     return sc_check_launch(DGRAD ? "conv2d_dgrad_bf16" : "conv2d_fwd_bf16");
 }
@@ -283,11 +284,15 @@ extern "C" int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, cons
     return dispatch_bf16<false>(x, wt_bf16, bias, addend, y, bn_partial, g, relu, tile, (hipStream_t)stream);
 }
 
-extern "C" int scouter_conv2d_dgrad_bf16(const float* dy, const float* w, const float* addend, float* dx, int B, int H,
-                                         int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups,
-                                         int tile_hint, void* stream) {
+extern "C" int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, const float* addend, float* dx, int B,
+                                               int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                               int groups, int tile_hint, const void* relu_mask, const float* x1,
+                                               const float* saved1, double* part1, const float* x2,
+                                               const float* saved2, double* part2, void* stream) {
     SC_REQUIRE(dy && w && dx && B > 0, "conv2d_dgrad_bf16: null pointer or empty shape");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad_bf16: channels not divisible by groups");
+    SC_REQUIRE(!part1 || (x1 && saved1), "conv2d_dgrad_bf16: fused BatchNorm backward needs x1 and saved1");
+    SC_REQUIRE(!part2 || (part1 && x2 && saved2), "conv2d_dgrad_bf16: second fused BatchNorm needs the first, x2 and saved2");
     SC_UNSUPPORTED(stride == 1, "conv2d_dgrad_bf16: strided input gradients use the fp32 kernel");
     const int Cig = Cin / groups, Cog = Cout / groups;
     SC_UNSUPPORTED(Cig % 32 == 0 && Cog % 32 == 0, "conv2d_dgrad_bf16: per-group channels must be multiples of 32");
@@ -298,5 +303,13 @@ extern "C" int scouter_conv2d_dgrad_bf16(const float* dy, const float* w, const 
     const int tile = bf16_tile(g, tile_hint);
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw,
                      4.0 * ((double)B * Ho * Wo * Cout + (double)g.M * Cin));
-    return dispatch_bf16<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream);
+    const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, x1, saved1, part1, x2, saved2, part2};
+    return dispatch_bf16<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream, fz);
+}
+
+extern "C" int scouter_conv2d_dgrad_bf16(const float* dy, const float* w, const float* addend, float* dx, int B, int H,
+                                         int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups,
+                                         int tile_hint, void* stream) {
+    return scouter_conv2d_dgrad_bnbwd_bf16(dy, w, addend, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile_hint,
+                                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }

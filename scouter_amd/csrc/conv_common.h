@@ -42,13 +42,25 @@ __device__ __forceinline__ void wgrad_block_coords(int& tile, int& split) {
 // deterministic sum of split-K slabs (conv_igemm.hip)
 void sc_launch_slab_reduce(const float* part, float* dst, long n, int splits, long slab, hipStream_t st);
 
+// BatchNorm BACKWARD reductions fused into the epilogue of the input-gradient kernel that produces the gradient of a
+// block output  out = relu(bn(x1) [+ bn(x2) | + shortcut])  (resnet.py:404-412, resnest.py:128-143): the value about to
+// be stored is d(out); the epilogue applies the ReLU sign (1 bit / element, written by the forward apply pass), stores
+// g = d(out) * [out > 0] instead, and reduces  sum g  and  sum g * xhat1  (and  sum g * xhat2  for the BatchNorm of a
+// downsample branch fed by the same gradient) per channel and M tile in fp64 -- the separate colsum pass over (dy, x)
+// and the masked-gradient copy `gout` of scouter_bn_bwd_f32 disappear (12 of 32 bytes per element of that backward).
+struct BnBwdFuse {
+    const unsigned long long* mask;                        // may be NULL: no ReLU between the BatchNorm and the consumer
+    const float* x1; const float* sv1; double* part1;      // BatchNorm input, saved [4][C] block, partial rows [mt][C][2]
+    const float* x2; const float* sv2; double* part2;      // second BatchNorm (may be NULL)
+};
+
 // Block epilogue.  acc: this wave's (WM x WN) accumulator tiles in MFMA layout; lds: the block's K-loop LDS (free now,
 // at least 4*WM*(WN+4) floats); rows m0.., columns grp*Ng + n0.. of the [M][N] output.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BWD = false>
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], float* lds, const ConvGeom& g,
                                                const float* __restrict__ bias, const float* __restrict__ addend,
                                                float* __restrict__ dst, double* __restrict__ bn_part, int relu,
-                                               long m0, int n0, int grp, int mt_id) {
+                                               long m0, int n0, int grp, int mt_id, const BnBwdFuse* fz = nullptr) {
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -80,7 +92,7 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
     // the first addition on: 16-term fp32 partials were tried and cost accuracy END TO END (a rounding error in a batch
     // mean shifts a whole channel coherently; log-probs moved from 5e-5 to 1.2e-4 off the fp64 reference on the 224x224
     // fixture).  Rows beyond M contribute exact zeros (their A rows read zeros).
-    const bool acc_stats = bn_part && !bias && !addend;
+    const bool acc_stats = bn_part && !bias && !addend && !(BWD && fz && fz->part1);
     double as[NT], aq[NT];
     if (acc_stats) {
 #pragma unroll
@@ -99,6 +111,19 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
         }
     }
     double cs[4] = {0, 0, 0, 0}, cq[4] = {0, 0, 0, 0};        // per-column sum / sum of squares (BatchNorm statistics)
+    double cq2[4] = {0, 0, 0, 0};
+    bool bwd = false, bwd2 = false;
+    f32x4 mu1 = {0, 0, 0, 0}, rs1 = {0, 0, 0, 0}, mu2 = {0, 0, 0, 0}, rs2 = {0, 0, 0, 0};
+    if constexpr (BWD) {
+        bwd = fz != nullptr && fz->part1 != nullptr;
+        if (bwd) {
+            bn_part = fz->part1;
+            bwd2 = fz->part2 != nullptr;
+            mu1 = *(const f32x4*)(fz->sv1 + ncol);
+            rs1 = *(const f32x4*)(fz->sv1 + g.N + ncol);
+            if (bwd2) { mu2 = *(const f32x4*)(fz->sv2 + ncol); rs2 = *(const f32x4*)(fz->sv2 + g.N + ncol); }
+        }
+    }
 #pragma unroll
     for (int rr = 0; rr < WM / RPP; ++rr) {
         const int row = rr * RPP + qrow;
@@ -106,7 +131,21 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
         if (m >= g.M) continue;
         f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
         if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
-        if (bn_part && !acc_stats) {
+        if constexpr (BWD) {
+            if (bwd) {
+                const long off = m * g.N + ncol;
+                if (fz->mask) relu_mask_apply(v, fz->mask, off >> 2);
+                const f32x4 xa = *(const f32x4*)(fz->x1 + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * ((xa[e] - mu1[e]) * rs1[e]); }
+                if (bwd2) {
+                    const f32x4 xb = *(const f32x4*)(fz->x2 + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cq2[e] += (double)v[e] * ((xb[e] - mu2[e]) * rs2[e]);
+                }
+            }
+        }
+        if (bn_part && !acc_stats && !bwd) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * v[e]; }
         }
@@ -150,6 +189,33 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
             double* o = bn_part + ((long)mt_id * g.N + grp * g.Ng + n0 + tid) * 2;
             o[0] = a0;
             o[1] = a1;
+        }
+        if constexpr (BWD) {
+            if (bwd2) {           // the second BatchNorm's (sum g, sum g * xhat2): same reduction once more
+#pragma unroll
+                for (int o = QPR; o < 64; o <<= 1)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cq2[e] += __shfl_xor(cq2[e], o, 64);
+                __syncthreads();
+                if (qrow == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { Ps[(wave * WN + qcol + e) * 2] = cs[e]; Ps[(wave * WN + qcol + e) * 2 + 1] = cq2[e]; }
+                }
+                __syncthreads();
+                if (tid < BN) {
+                    const int wnn = tid / WN, c = tid % WN;
+                    double a0 = 0, a1 = 0;
+#pragma unroll
+                    for (int w = 0; w < BM / WM; ++w) {
+                        const int wv = w * WAVES_N + wnn;
+                        a0 += Ps[(wv * WN + c) * 2];
+                        a1 += Ps[(wv * WN + c) * 2 + 1];
+                    }
+                    double* o = fz->part2 + ((long)mt_id * g.N + grp * g.Ng + n0 + tid) * 2;
+                    o[0] = a0;
+                    o[1] = a1;
+                }
+            }
         }
     }
 }

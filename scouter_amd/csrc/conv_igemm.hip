@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ addend, float* __restrict__ dst,
                                                        double* __restrict__ bn_part, ConvGeom g, int relu, int mtiles,
-                                                       int ntiles) {
+                                                       int ntiles, BnBwdFuse fz) {
     constexpr bool B_KC = DGRAD;
     using T = TileCfg<BM, BN, B_KC>;
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 
     // ---- epilogue (conv_common.h): LDS-staged vector stores, fused bias / addend / ReLU / BatchNorm statistics
     static_assert(4 * WM * (WN + 4) <= 2 * T::STAGE, "epilogue staging fits in the K-loop LDS");
-    igemm_epilogue<BM, BN, WM, WN>(acc, lds, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id);
+    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, lds, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -590,7 +590,7 @@ void sc_launch_slab_reduce(const float* part, float* dst, long n, int splits, lo
 // ----------------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED, bool PW>
 static void launch_igemm_s(const float* src, const float* w, const float* bias, const float* addend, float* dst,
-                           double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
+                           double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz) {
     const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
     dim3 grid(mtiles * ntiles * g.groups);
     ConvGeom gg = g;
@@ -598,17 +598,17 @@ static void launch_igemm_s(const float* src, const float* w, const float* bias, 
     gg.inv_wo = 1.0f / (float)g.Wo;
     gg.inv_ho = 1.0f / (float)g.Ho;
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED, PW>), grid, dim3(256), 0, st, src, w, bias, addend,
-                       dst, bn_part, gg, relu, mtiles, ntiles);
+                       dst, bn_part, gg, relu, mtiles, ntiles, fz);
 }
 template <int BM, int BN, int WM, int WN, bool DGRAD>
 static void launch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
-                         double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
+                         double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz) {
     // pointwise fast path: 1x1 / stride 1 / pad 0 (row m == pixel m on both sides), block rows within 32-bit offsets
     const bool pw = g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.H == g.Ho && g.W == g.Wo &&
                     (long)BM * g.C * 4 < (1L << 31);
-    if (pw) launch_igemm_s<BM, BN, WM, WN, DGRAD, false, true>(src, w, bias, addend, dst, bn_part, g, relu, st);
-    else if (DGRAD && g.stride != 1) launch_igemm_s<BM, BN, WM, WN, DGRAD, true, false>(src, w, bias, addend, dst, bn_part, g, relu, st);
-    else launch_igemm_s<BM, BN, WM, WN, DGRAD, false, false>(src, w, bias, addend, dst, bn_part, g, relu, st);
+    if (pw) launch_igemm_s<BM, BN, WM, WN, DGRAD, false, true>(src, w, bias, addend, dst, bn_part, g, relu, st, fz);
+    else if (DGRAD && g.stride != 1) launch_igemm_s<BM, BN, WM, WN, DGRAD, true, false>(src, w, bias, addend, dst, bn_part, g, relu, st, fz);
+    else launch_igemm_s<BM, BN, WM, WN, DGRAD, false, false>(src, w, bias, addend, dst, bn_part, g, relu, st, fz);
 }
 
 // tile choice: largest tile that still fills the chip (>= ~1.5 rounds of 256 CUs x 2 blocks); Ng is a multiple of 32
@@ -628,14 +628,15 @@ static int igemm_tile(const ConvGeom& g, int hint = -1) {     // 0: 128x128  1: 
 
 template <bool DGRAD>
 static int dispatch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,
-                          double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st) {
+                          double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st,
+                          const BnBwdFuse& fz = BnBwdFuse{}) {
     SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 28),
                    "conv2d: more than 2^31 output pixels or an image above 2^28 elements is not supported");
     switch (tile) {
-        case 0: launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
-        case 1: launch_igemm<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
-        case 2: launch_igemm<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
-        default: launch_igemm<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st); break;
+        case 0: launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 1: launch_igemm<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 2: launch_igemm<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        default: launch_igemm<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
     }
     return sc_check_launch(DGRAD ? "conv2d_dgrad" : "conv2d_fwd");
 }
@@ -680,23 +681,50 @@ extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const floa
     return dispatch_igemm<false>(x, w, bias, addend, y, bn_partial, g, relu, tile, (hipStream_t)stream);
 }
 
-extern "C" int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H,
-                                        int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups,
-                                        int tile_hint, void* stream) {
-    SC_REQUIRE(dy && w && dx && B > 0, "conv2d_dgrad: null pointer or empty shape");
-    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad: channels not divisible by groups");
+static ConvGeom dgrad_geom(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups) {
     const int Cig = Cin / groups, Cog = Cout / groups;
-    SC_UNSUPPORTED(Cig % 32 == 0 && Cog % 32 == 0, "conv2d_dgrad: per-group channels must be multiples of 32");
     const int Ho = conv_out(H, kh, stride, pad), Wo = conv_out(W, kw, stride, pad);
     // A operand = dY [B][Ho][Wo][Cout]; GEMM rows = input pixels (H x W); columns = Cin
     ConvGeom g{B, Ho, Wo, Cout, H, W, Cin, kh, kw, stride, pad, groups, Cog, Cig, 0, Cout, Cig * Cout};
     g.M = (long)B * H * W;
+    return g;
+}
+
+// rows of the [rows][Cin][2] fp64 partials the fused BatchNorm-backward epilogue writes (= M tiles of the chosen kernel)
+extern "C" int scouter_conv2d_dgrad_bn_partial_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                                                    int pad, int groups, int tile_hint) {
+    if (!(groups > 0 && Cin % groups == 0 && Cout % groups == 0)) return 0;
+    const ConvGeom g = dgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
+    return sc_cdiv(g.M, igemm_tile(g, tile_hint) == 2 ? 64 : 128);
+}
+
+extern "C" int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, const float* addend, float* dx, int B,
+                                              int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                              int groups, int tile_hint, const void* relu_mask, const float* x1,
+                                              const float* saved1, double* part1, const float* x2, const float* saved2,
+                                              double* part2, void* stream) {
+    SC_REQUIRE(dy && w && dx && B > 0, "conv2d_dgrad: null pointer or empty shape");
+    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad: channels not divisible by groups");
+    SC_REQUIRE(!part1 || (x1 && saved1), "conv2d_dgrad: fused BatchNorm backward needs x1 and saved1");
+    SC_REQUIRE(!part2 || (part1 && x2 && saved2), "conv2d_dgrad: second fused BatchNorm needs the first, x2 and saved2");
+    const int Cig = Cin / groups, Cog = Cout / groups;
+    SC_UNSUPPORTED(Cig % 32 == 0 && Cog % 32 == 0, "conv2d_dgrad: per-group channels must be multiples of 32");
+    const int Ho = conv_out(H, kh, stride, pad), Wo = conv_out(W, kw, stride, pad);
+    const ConvGeom g = dgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
     static const char* names[4] = {"igemm_dgrad<128x128>", "igemm_dgrad<128x64>", "igemm_dgrad<64x64>",
                                    "igemm_dgrad<128x32>"};
     const int tile = igemm_tile(g, tile_hint);
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw / (stride * stride),
                      4.0 * ((double)B * Ho * Wo * Cout + (double)g.M * Cin));
-    return dispatch_igemm<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream);
+    const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, x1, saved1, part1, x2, saved2, part2};
+    return dispatch_igemm<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream, fz);
+}
+
+extern "C" int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H,
+                                        int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups,
+                                        int tile_hint, void* stream) {
+    return scouter_conv2d_dgrad_bnbwd_f32(dy, w, addend, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile_hint,
+                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 struct WgradPlan { int bm, bn, ci_tiles, co_tiles, splits; long pix_per_split, tiles; };

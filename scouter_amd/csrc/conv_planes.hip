@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NWM * 128, 1) void pconv_kernel(const unsigned shor
                                                        const unsigned short* __restrict__ w_planes, long w_plane_elems,
                                                        const float* __restrict__ bias, const float* __restrict__ addend,
                                                        float* __restrict__ dst, double* __restrict__ bn_part, ConvGeom g,
-                                                       int relu, int mtiles, int ntiles) {
+                                                       int relu, int mtiles, int ntiles, BnBwdFuse fz) {
     constexpr int BK = 32, NW = 2 * NWM, WM = BM / NWM, WN = BN / 2, MT = WM / 32, NT = WN / 32;
     constexpr int A_BYTES = NP * BM * 64, B_BYTES = NP * BN * 64, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int ARG = BM / 16 / NW, BRG = BN / 16 / NW;      // 16-row groups per wave and operand
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NWM * 128, 1) void pconv_kernel(const unsigned shor
             for (int j = 0; j < NT; ++j) acc[i][j] += accl[i][j];
     }
     // epilogue shared with the fp32 kernels (LDS-staged 16-byte stores, bias / addend / ReLU, BatchNorm statistics)
-    igemm_epilogue<BM, BN, WM, WN>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id);
+    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -341,7 +341,7 @@ extern "C" int scouter_planes_split_weight_f32(const float* w_hwio, void* w_fwd,
 
 template <int BM, int BN, int NP, int NSTAGE, bool DGRAD, int NWM = 2>
 static void launch_pconv(const void* a, long a_pe, const void* w, long w_pe, const float* bias, const float* addend,
-                         float* dst, double* bn_part, const ConvGeom& g, int relu, hipStream_t st) {
+                         float* dst, double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz) {
     const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
     ConvGeom gg = g;
     gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
@@ -357,27 +357,27 @@ static void launch_pconv(const void* a, long a_pe, const void* w, long w_pe, con
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(mtiles * ntiles * g.groups), dim3(NWM * 128), lds, st, (const unsigned short*)a, a_pe,
-                       (const unsigned short*)w, w_pe, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles);
+                       (const unsigned short*)w, w_pe, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz);
 }
 
 // tile: 0 = 128x128, 1 = 128x64 (N per group must be a multiple of the tile's N)
 template <bool DGRAD>
 static int dispatch_pconv(const void* a, long a_pe, const void* w, long w_pe, const float* bias, const float* addend,
                           float* dst, double* bn_part, const ConvGeom& g, int relu, int nplanes, int tile,
-                          hipStream_t st) {
+                          hipStream_t st, const BnBwdFuse& fz = BnBwdFuse{}) {
     const bool wide = g.Ng % 128 == 0 && tile != 1;
     if (nplanes == 3 && tile == 2) {        // two workgroups per CU (2 LDS stages of 36 KB)
-        launch_pconv<128, 64, 3, 2, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+        launch_pconv<128, 64, 3, 2, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
     } else if (nplanes == 3 && tile == 3) { // three workgroups per CU
-        launch_pconv<64, 64, 3, 2, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+        launch_pconv<64, 64, 3, 2, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
     } else if (nplanes == 3 && tile == 4 && g.Ng % 128 == 0) {   // 256 x 128, eight waves: 25 % fewer L2 -> LDS bytes
-        launch_pconv<256, 128, 3, 2, DGRAD, 4>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+        launch_pconv<256, 128, 3, 2, DGRAD, 4>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
     } else if (nplanes == 3) {
-        if (wide) launch_pconv<128, 128, 3, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
-        else launch_pconv<128, 64, 3, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+        if (wide) launch_pconv<128, 128, 3, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+        else launch_pconv<128, 64, 3, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
     } else {
-        if (wide) launch_pconv<128, 128, 1, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
-        else launch_pconv<128, 64, 1, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st);
+        if (wide) launch_pconv<128, 128, 1, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+        else launch_pconv<128, 64, 1, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
     }
     return sc_check_launch(DGRAD ? "conv2d_dgrad_planes" : "conv2d_fwd_planes");
 }
@@ -410,11 +410,16 @@ extern "C" int scouter_conv2d_fwd_planes(const void* x_planes, const void* w_pla
 }
 
 // dy_planes: [nplanes][B*Ho*Wo][Cout]; w_planes: the dgrad layout.  Stride-1 convolutions only.
-extern "C" int scouter_conv2d_dgrad_planes(const void* dy_planes, const void* w_planes, const float* addend, float* dx,
-                                           int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
-                                           int groups, int nplanes, int tile, void* stream) {
+extern "C" int scouter_conv2d_dgrad_planes_bnbwd(const void* dy_planes, const void* w_planes, const float* addend,
+                                                 float* dx, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                                                 int stride, int pad, int groups, int nplanes, int tile,
+                                                 const void* relu_mask, const float* x1, const float* saved1,
+                                                 double* part1, const float* x2, const float* saved2, double* part2,
+                                                 void* stream) {
     SC_REQUIRE(dy_planes && w_planes && dx && B > 0 && (nplanes == 1 || nplanes == 3), "conv2d_dgrad_planes: bad arguments");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad_planes: channels not divisible by groups");
+    SC_REQUIRE(!part1 || (x1 && saved1), "conv2d_dgrad_planes: fused BatchNorm backward needs x1 and saved1");
+    SC_REQUIRE(!part2 || (part1 && x2 && saved2), "conv2d_dgrad_planes: second fused BatchNorm needs the first, x2 and saved2");
     SC_UNSUPPORTED(stride == 1, "conv2d_dgrad_planes: stride-1 convolutions only");
     const int Cig = Cin / groups, Cog = Cout / groups;
     SC_UNSUPPORTED(Cog % 32 == 0 && Cig % 64 == 0, "conv2d_dgrad_planes: needs Cout/groups %% 32 == 0 and Cin/groups %% 64 == 0");
@@ -426,8 +431,17 @@ extern "C" int scouter_conv2d_dgrad_planes(const void* dy_planes, const void* w_
                    (long)Ho * Wo * Cout < (1L << 28), "conv2d_dgrad_planes: tensor too large for 32-bit plane offsets");
     ScProfScope prof(nplanes == 3 ? "pconv_dgrad<bf16x3>" : "pconv_dgrad<bf16>", (hipStream_t)stream,
                      2.0 * g.M * Cin * Cog * kh * kw, 2.0 * nplanes * ((double)a_pe) + 4.0 * (double)g.M * Cin);
+    const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, x1, saved1, part1, x2, saved2, part2};
     return dispatch_pconv<true>(dy_planes, a_pe, w_planes, w_pe, nullptr, addend, dx, nullptr, g, 0, nplanes, tile,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, fz);
+}
+
+extern "C" int scouter_conv2d_dgrad_planes(const void* dy_planes, const void* w_planes, const float* addend, float* dx,
+                                           int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                           int groups, int nplanes, int tile, void* stream) {
+    return scouter_conv2d_dgrad_planes_bnbwd(dy_planes, w_planes, addend, dx, B, H, W, Cin, Cout, kh, kw, stride, pad,
+                                             groups, nplanes, tile, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                             nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

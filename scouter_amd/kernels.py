@@ -111,6 +111,60 @@ def _pick_tile(key, launch, candidates=(0, 1, 2, 3)):
     return best
 
 
+class BnBwdFuse:
+    """Hand-over between a BatchNorm's backward and the input-gradient kernel that PRODUCES its dy (csrc/conv_common.h
+    BnBwdFuse): `mask` = ReLU sign bits of the activation whose gradient is being produced (None: no ReLU), `entries` =
+    [(x, saved)] of the one or two BatchNorms fed by that gradient.  A producer that fuses the reductions into its
+    epilogue stores the masked gradient, fills `parts` (one [rows, C, 2] fp64 tensor per entry) and `rows`;
+    `BatchNorm2d.bwd(..., fused=fuse.ext(i))` then skips its reduction pass.  A producer that cannot (unsupported
+    shape / kernel) leaves `parts` None and the BatchNorm backward runs its own passes: `applied` tells which."""
+    __slots__ = ("mask", "entries", "parts", "rows")
+
+    def __init__(self, mask, entries):
+        assert 1 <= len(entries) <= 2
+        self.mask, self.entries = mask, entries
+        self.parts, self.rows = None, 0
+
+    @property
+    def applied(self):
+        return self.parts is not None
+
+    def ext(self, i):
+        return (self.parts[i], self.rows)
+
+    def alloc(self, rows, x_shape):
+        for x, saved in self.entries:
+            assert tuple(x.shape) == tuple(x_shape), (tuple(x.shape), tuple(x_shape))
+            _chk(x, "BatchNorm input"); _chk(saved, "BatchNorm saved block")
+        C = x_shape[-1]
+        self.rows = rows
+        self.parts = [torch.empty((rows, C, 2), dtype=torch.float64, device=self.entries[0][0].device)
+                      for _ in self.entries]
+
+    def args(self):
+        """(relu_mask, x1, saved1, part1, x2, saved2, part2) of the *_bnbwd entry points"""
+        x1, s1 = self.entries[0]
+        x2, s2 = self.entries[1] if len(self.entries) > 1 else (None, None)
+        return (_p(self.mask), _p(x1), _p(s1), _p(self.parts[0]), _p(x2), _p(s2),
+                _p(self.parts[1]) if len(self.entries) > 1 else None)
+
+
+_NO_FUSE = (None,) * 7
+# Which producers fuse -- decided by A/B runs of the real step (interleaved `bench.py --steps 120` runs on one box, three
+# each; DESIGN.md section 5): bit 1 = 1x1 kernels -> one BatchNorm and bit 2 = 1x1 kernels -> two BatchNorms (block
+# output + downsample branch): +1.3 % images/sec together; bit 0 = bf16x3 plane kernels -> the BatchNorm in front of the
+# 3x3 layer: -0.6 % (one 256x128 workgroup per CU: nothing hides the longer epilogue, and the separate reduction pass
+# finds the freshly written gradient in the 256 MB Infinity Cache); bit 3 = fp32 3x3 kernels (stem, resnet18): -0.3 %.
+BN_BWD_FUSE = int(os.environ.get("SCOUTER_BN_FUSE", "6"))
+
+
+def _fuse_wanted(post, kh, plane_kernel=False):
+    if post is None:
+        return False
+    bit = 1 if plane_kernel else (8 if kh > 1 else (2 if len(post.entries) == 1 else 4))
+    return bool(BN_BWD_FUSE & bit)
+
+
 def _tile_legal(ng, t):
     return (t == 0 and ng % 128 == 0) or (t in (1, 2) and ng % 64 == 0) or t == 3
 
@@ -155,7 +209,9 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     return (y, (part, rows)) if bn_stats else y
 
 
-def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, precision="fp32"):
+def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, precision="fp32", post=None):
+    """post (BnBwdFuse): the tensor produced is the gradient of a BatchNorm+ReLU block output -- the epilogue masks it
+    and reduces that BatchNorm's backward sums (see BnBwdFuse)."""
     _chk(dy, "dy"); _chk(w_hwio, "weight"); _chk(addend, "addend")
     B, H, W, Cin = x_shape
     kh, kw, cg, Cout = w_hwio.shape
@@ -166,15 +222,22 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
     # strided input gradients (resnet18) and tiny layers stay on the fp32 kernel
     bf16 = precision == "bf16" and stride == 1 and B * H * W >= BF16_MIN_PIXELS
 
-    def launch(tile, dry=False):
+    def launch(tile, dry=False, fuse=_NO_FUSE):
         if dry:
             return _tile_legal(Cin // groups, tile)
-        fn = L.scouter_conv2d_dgrad_bf16 if bf16 else L.scouter_conv2d_dgrad_f32
+        fn = L.scouter_conv2d_dgrad_bnbwd_bf16 if bf16 else L.scouter_conv2d_dgrad_bnbwd_f32
         _native.check(fn(_p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile,
-                         st), "conv2d_dgrad")
+                         *fuse, st), "conv2d_dgrad")
         return True
 
-    launch(_pick_tile(("dgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch))
+    tile = _pick_tile(("dgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch)
+    if _fuse_wanted(post, kh):
+        if tile < 0:                              # autotuning disabled: name a tile, the partial rows depend on it
+            tile = 2 if (Cin // groups) % 64 == 0 else 3
+        post.alloc(-(-B * H * W // (64 if tile == 2 else 128)), x_shape)
+        launch(tile, fuse=post.args())
+    else:
+        launch(tile)
     return dx
 
 
@@ -264,25 +327,29 @@ def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, adde
     return (y, (part, rows)) if bn_stats else y
 
 
-def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, addend=None, tile=None):
+def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, addend=None, tile=None, post=None):
     nplanes = dyp.shape[0]
     B, H, W, Cin = x_shape
     Cout = dyp.shape[-1]
     dx = torch.empty(x_shape, dtype=F32, device=dyp.device)
     cands = _plane_tiles(Cin // groups)
 
-    def launch(t, dry=False):
+    def launch(t, dry=False, fuse=_NO_FUSE):
         if dry:
             return t in cands
-        _native.check(_native.lib().scouter_conv2d_dgrad_planes(_p(dyp), _p(wd), _p(addend), _p(dx), B, H, W, Cin, Cout,
-                                                                kh, kw, stride, pad, groups, nplanes, t, _stream()),
-                      "conv2d_dgrad_planes")
+        _native.check(_native.lib().scouter_conv2d_dgrad_planes_bnbwd(
+            _p(dyp), _p(wd), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, nplanes, t, *fuse,
+            _stream()), "conv2d_dgrad_planes")
         return True
     if tile is None:
         tile = _pick_tile(("pdgrad", nplanes, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, cands)
         if tile < 0:
             tile = cands[0]
-    launch(tile)
+    if _fuse_wanted(post, kh, True):
+        post.alloc(-(-B * H * W // _PLANE_TILE_ROWS[tile]), x_shape)
+        launch(tile, fuse=post.args())
+    else:
+        launch(tile)
     return dx
 
 
@@ -458,18 +525,25 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=N
     return (y, saved, mask) if want_mask else (y, saved)
 
 
-def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=False, mask=None):
-    """ReLU sign from `mask` (bits written by bn_fwd(want_mask=True)) or from the activation `ymask`; both None: no ReLU."""
+def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=False, mask=None, ext=None):
+    """ReLU sign from `mask` (bits written by bn_fwd(want_mask=True)) or from the activation `ymask`; both None: no ReLU.
+    ext = (partial, rows) from a BnBwdFuse: dy is the already masked gradient, its sums are reduced -- no reduction
+    pass, no mask, and the masked gradient `gout` is dy itself."""
     _chk(dy, "dy"); _chk(ymask, "ymask"); _chk(x, "x")
     C = x.shape[-1]
     M = x.numel() // C
     dx = torch.empty_like(x)
-    gout = torch.empty_like(x) if want_gout else None
     ws = _col_ws(M, C, x.device)
+    if ext is not None:
+        part, rows = ext
+        _native.check(_native.lib().scouter_bn_bwd_f32(
+            _p(dy), None, _p(x), _p(saved[0]), _p(saved[1]), _p(saved[2]), None, M, C, int(training), _p(dgamma),
+            _p(dbeta), _p(dx), None, _p(part), rows, _p(ws), ws.numel(), _stream()), "bn_bwd")
+        return dx, (dy if want_gout else None)
+    gout = torch.empty_like(x) if want_gout else None
     _native.check(_native.lib().scouter_bn_bwd_f32(
         _p(dy), _p(ymask), _p(x), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(mask), M, C, int(training), _p(dgamma),
-        _p(dbeta),
-        _p(dx), _p(gout), _p(ws), ws.numel(), _stream()), "bn_bwd")
+        _p(dbeta), _p(dx), _p(gout), None, 0, _p(ws), ws.numel(), _stream()), "bn_bwd")
     return dx, gout
 
 

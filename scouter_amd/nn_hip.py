@@ -79,7 +79,9 @@ class Conv2d(nn.Module):
             self._capture[0][self._capture[1]] = y
         return y, (x if save else None)
 
-    def bwd(self, dy, ctx, need_dx=True, addend=None):
+    def bwd(self, dy, ctx, need_dx=True, addend=None, post=None):
+        """post (K.BnBwdFuse): the input gradient is the gradient of a BatchNorm(+ReLU) output -- its producer finishes
+        that BatchNorm's backward reductions in the epilogue (only when dx is computed at all)."""
         wd = xp = None
         if isinstance(ctx, tuple):
             x, wd, xp = ctx
@@ -90,7 +92,8 @@ class Conv2d(nn.Module):
             dy, dyp = dy.f32, dy.planes
         if need_dx and dyp is not None and wd is not None:
             k = self.kernel_size
-            dx = K.conv2d_dgrad_planes(dyp, wd, tuple(x.shape), k, k, self.stride, self.padding, self.groups, addend)
+            dx = K.conv2d_dgrad_planes(dyp, wd, tuple(x.shape), k, k, self.stride, self.padding, self.groups, addend,
+                                       post=post)
             need_dx = False
         else:
             dx = None
@@ -107,7 +110,7 @@ class Conv2d(nn.Module):
         if not need_dx:
             return dx
         return K.conv2d_dgrad(dy, K.hwio(self.weight), tuple(x.shape), addend, self.stride, self.padding, self.groups,
-                              precision=self.precision)
+                              precision=self.precision, post=post)
 
 
 class StemConv2d(Conv2d):
@@ -201,8 +204,17 @@ class BatchNorm2d(nn.Module):
             self._capture[0][self._capture[1]] = K.bn_apply(x, saved, True)
         return x, saved
 
-    def bwd(self, dy, ctx, want_gout=False):
+    @staticmethod
+    def fuse(ctx, *more):
+        """K.BnBwdFuse for the kernel that produces this BatchNorm's output gradient (`more`: contexts of further
+        BatchNorms fed by the same gradient -- the downsample branch)."""
+        return K.BnBwdFuse(ctx[1], [(c[0], c[2]) for c in (ctx,) + more])
+
+    def bwd(self, dy, ctx, want_gout=False, fused=None):
+        """fused = BnBwdFuse.ext(i): dy is already masked and its sums are reduced (by the producer's epilogue)."""
         x, mask, saved, training = ctx
+        if fused is not None:
+            return K.bn_bwd(dy, None, x, saved, training, self._dg, self._db, want_gout, ext=fused)
         return K.bn_bwd(dy, None, x, saved, training, self._dg, self._db, want_gout, mask=mask)
 
 

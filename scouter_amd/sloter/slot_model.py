@@ -177,7 +177,8 @@ class SlotModel(nn.Module):
             self.slot.save_vis()
         return logp, stats, ((cctx, xmap, PE, so, logp, stats, target) if save else None)
 
-    def _head_backward(self, hstate, g_logp, g_loss, g_nll, g_term, need_dfeat=True):
+    def _head_backward(self, hstate, g_logp, g_loss, g_nll, g_term, need_dfeat=True, post=None):
+        """post: the last backbone block's K.BnBwdFuse -- conv1x1's input-gradient epilogue finishes its reductions."""
         if not self.use_slot:
             return self._fc_backward(hstate, g_logp, g_loss, g_nll, g_term, need_dfeat)
         cctx, xmap, PE, so, logp, stats, target = hstate
@@ -188,7 +189,7 @@ class SlotModel(nn.Module):
                                           B * S * N, self.lambda_value, self.slot.power)
         dX = self.slot.bwd(xmap.view(B, N, d), PE, so, dlogits, g_area)
         dxr = K.relu_bwd(dX.view(B, h, w, d), xmap)
-        return self.conv1x1.bwd(dxr, cctx, need_dx=need_dfeat)
+        return self.conv1x1.bwd(dxr, cctx, need_dx=need_dfeat, post=post if need_dfeat else None)
 
     def _forward_impl(self, x, target, save):
         if not x.is_cuda:
@@ -208,7 +209,8 @@ class SlotModel(nn.Module):
         bctx, hstate = state
         arena = self.grad_arena()
         need = self.backbone._first_trainable_stage() < 5
-        dfeat = self._head_backward(hstate, g_logp, g_loss, g_nll, g_term, need_dfeat=need)
+        last = self.backbone.last_fuse(bctx) if need and self.use_slot else None
+        dfeat = self._head_backward(hstate, g_logp, g_loss, g_nll, g_term, need_dfeat=need, post=last)
         # gradient ranges become final from the END of the arena (head, layer4) towards its start (stem)
         done_hi = [arena.numel]
 
@@ -220,7 +222,7 @@ class SlotModel(nn.Module):
                     hook(arena, lo, done_hi[0])
                 done_hi[0] = lo
         if need:
-            self.backbone.features_bwd(dfeat, bctx, stage_done if self._grad_ready_hooks else None)
+            self.backbone.features_bwd(dfeat, bctx, stage_done if self._grad_ready_hooks else None, own=last)
         K.join_side_stream(arena.flat.device)               # all weight gradients are in the arena from here on
         if self._grad_ready_hooks and done_hi[0] > 0:
             for hook in self._grad_ready_hooks:

@@ -40,7 +40,8 @@ class SplitAttnConv2d(nn.Module):
         out = K.sa_apply_fwd(x0, a, saved0)                                      # split_attn.py:76-79
         return out, ((c_conv, x0, saved0, self.bn0.training, c_fc1, c_bn1, c_fc2, a) if save else None)
 
-    def bwd(self, dout, ctx):
+    def bwd(self, dout, ctx, post=None):
+        """post: K.BnBwdFuse of the BatchNorm in front of this layer (finished in the input-gradient epilogue)."""
         c_conv, x0, saved0, training0, c_fc1, c_bn1, c_fc2, a = ctx
         B = x0.shape[0]
         da = K.sa_dattn(x0, dout, saved0)
@@ -50,4 +51,4 @@ class SplitAttnConv2d(nn.Module):
         dgap = self.fc1.bwd(dz1, c_fc1, True)
         dc = K.sa_bn_bwd(dout, a, dgap.view(B, -1), x0, saved0, training0, self.bn0._dg, self.bn0._db,
                          planes=self.conv.planes_dy() if isinstance(c_conv, tuple) and c_conv[1] is not None else 0)
-        return self.conv.bwd(dc, c_conv, True)
+        return self.conv.bwd(dc, c_conv, True, post=post)

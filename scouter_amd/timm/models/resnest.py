@@ -39,15 +39,26 @@ class ResNestBottleneck(nn.Module):
         out, b3 = self.bn3.fwd(c3, save, relu=True, residual=res, tracked=tracked)
         return out, ((k1, b1, ksa, tuple(sa.shape), k3, b3, kd) if save else None)
 
-    def bwd(self, dout, ctx, need_dx=True):
+    def out_fuse(self, ctx):
+        """What the kernel producing this block's OUTPUT gradient needs to finish the backward reductions of bn3 (and
+        of the downsample BatchNorm, fed by the same masked gradient) in its epilogue."""
+        b3, kd = ctx[5], ctx[6]
+        return BatchNorm2d.fuse(b3, *([kd[1]] if self.downsample is not None else []))
+
+    def bwd(self, dout, ctx, need_dx=True, own=None, post=None):
+        """own: this block's out_fuse object if the producer of `dout` applied it (dout is then the masked gradient and
+        the bn3 / downsample sums are reduced); post: the previous block's, for conv1's input-gradient epilogue."""
         k1, b1, ksa, sa_shape, k3, b3, kd = ctx
-        dc3, dres = self.bn3.bwd(dout, b3, want_gout=True)
+        own = own if own is not None and own.applied else None
+        dc3, dres = self.bn3.bwd(dout, b3, want_gout=True, fused=own.ext(0) if own else None)
         dp = self.conv3.bwd(dc3, k3, True)
         dsa = self.avd_last.bwd(dp, sa_shape) if self.avd_last is not None else dp
-        dh1 = self.conv2.bwd(dsa, ksa)
-        dc1, _ = self.bn1.bwd(dh1, b1)
-        dxres = dres if self.downsample is None else self.downsample.bwd(dres, kd, need_dx)
-        return self.conv1.bwd(dc1, k1, need_dx, addend=dxres)
+        f1 = BatchNorm2d.fuse(b1)
+        dh1 = self.conv2.bwd(dsa, ksa, post=f1)
+        dc1, _ = self.bn1.bwd(dh1, b1, fused=f1.ext(0) if f1.applied else None)
+        dxres = dres if self.downsample is None else self.downsample.bwd(dres, kd, need_dx,
+                                                                         fused=own.ext(1) if own else None)
+        return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None)
 
 
 def _resnest(name, layers, pretrained, num_classes, in_chans, **kwargs):

@@ -42,10 +42,10 @@ class Downsample(nn.Sequential):
         y, c_bn = mods[1].fwd(c, save, relu=False, tracked=tracked)
         return y, ((c_conv, c_bn, pool, tuple(x.shape)) if save else None)
 
-    def bwd(self, dy, ctx, need_dx):
+    def bwd(self, dy, ctx, need_dx, fused=None):
         c_conv, c_bn, pool, x_shape = ctx
         mods = list(self)[-2:]
-        dc, _ = mods[1].bwd(dy, c_bn)
+        dc, _ = mods[1].bwd(dy, c_bn, fused=fused)
         dx = mods[0].bwd(dc, c_conv, need_dx)
         if dx is not None and pool is not None:
             dx = pool.bwd(dx, x_shape)
@@ -76,13 +76,21 @@ class BasicBlock(nn.Module):
         out, b2 = self.bn2.fwd(c2, save, relu=True, residual=res, tracked=tracked)
         return out, ((k1, b1, k2, b2, kd) if save else None)
 
-    def bwd(self, dout, ctx, need_dx=True):
+    def out_fuse(self, ctx):
+        """see ResNestBottleneck.out_fuse: bn2 (+ the downsample BatchNorm)"""
+        b2, kd = ctx[3], ctx[4]
+        return BatchNorm2d.fuse(b2, *([kd[1]] if self.downsample is not None else []))
+
+    def bwd(self, dout, ctx, need_dx=True, own=None, post=None):
         k1, b1, k2, b2, kd = ctx
-        dc2, dres = self.bn2.bwd(dout, b2, want_gout=True)
-        dh1 = self.conv2.bwd(dc2, k2, True)
-        dc1, _ = self.bn1.bwd(dh1, b1)
-        dxres = dres if self.downsample is None else self.downsample.bwd(dres, kd, need_dx)
-        return self.conv1.bwd(dc1, k1, need_dx, addend=dxres)
+        own = own if own is not None and own.applied else None
+        dc2, dres = self.bn2.bwd(dout, b2, want_gout=True, fused=own.ext(0) if own else None)
+        f1 = BatchNorm2d.fuse(b1)
+        dh1 = self.conv2.bwd(dc2, k2, True, post=f1)
+        dc1, _ = self.bn1.bwd(dh1, b1, fused=f1.ext(0) if f1.applied else None)
+        dxres = dres if self.downsample is None else self.downsample.bwd(dres, kd, need_dx,
+                                                                         fused=own.ext(1) if own else None)
+        return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None)
 
 
 class ResNet(nn.Module):
@@ -164,9 +172,19 @@ class ResNet(nn.Module):
                 return i
         return 5
 
-    def features_bwd(self, dfeat, ctx, on_stage_done=None):
+    def last_fuse(self, ctx):
+        """BnBwdFuse of the LAST block's output BatchNorm(s), for whatever kernel produces d(features) (the head's
+        conv1x1 input gradient); None when the backbone gets no gradient."""
+        if self._first_trainable_stage() > 4:
+            return None
+        return self.layer4[-1].out_fuse(ctx[-1])
+
+    def features_bwd(self, dfeat, ctx, on_stage_done=None, own=None):
         """`on_stage_done(name)` is called when every gradient of layer4 / layer3 / layer2 / layer1 has been
-        written (used to launch that stage's gradient all-reduce while earlier layers are still in backward)."""
+        written (used to launch that stage's gradient all-reduce while earlier layers are still in backward).
+        BatchNorm-backward reductions ride in the epilogue of the input-gradient kernel that produces each gradient
+        (K.BnBwdFuse): block i's conv1 finishes block i-1's bn3 / downsample sums, `own` is the last block's object if
+        the producer of `dfeat` applied it."""
         first = self._first_trainable_stage()
         blocks = [(li, blk) for li in range(1, 5) for blk in getattr(self, "layer%d" % li)]
         d = dfeat
@@ -175,7 +193,9 @@ class ResNet(nn.Module):
             if li < first:
                 return
             is_first_trainable = li == first and (idx == 0 or blocks[idx - 1][0] < first)
-            d = blk.bwd(d, ctx[2 + idx], need_dx=not is_first_trainable)
+            post = blocks[idx - 1][1].out_fuse(ctx[2 + idx - 1]) if idx > 0 and not is_first_trainable else None
+            d = blk.bwd(d, ctx[2 + idx], need_dx=not is_first_trainable, own=own, post=post)
+            own = post
             if on_stage_done is not None and (idx == 0 or blocks[idx - 1][0] != li):
                 on_stage_done("layer%d" % li)
         if first > 0:
@@ -186,10 +206,12 @@ class ResNet(nn.Module):
         if isinstance(self.conv1, nn.Sequential):
             s = self.conv1
             k0, b0, k1, b1, k2 = ctx[0]
-            dh = s[6].bwd(dc, k2, True)
-            dc, _ = s[4].bwd(dh, b1)
-            dh = s[3].bwd(dc, k1, True)
-            dc, _ = s[1].bwd(dh, b0)
+            f = BatchNorm2d.fuse(b1)
+            dh = s[6].bwd(dc, k2, True, post=f)
+            dc, _ = s[4].bwd(dh, b1, fused=f.ext(0) if f.applied else None)
+            f = BatchNorm2d.fuse(b0)
+            dh = s[3].bwd(dc, k1, True, post=f)
+            dc, _ = s[1].bwd(dh, b0, fused=f.ext(0) if f.applied else None)
             s[0].bwd(dc, k0, False)
         else:
             self.conv1.bwd(dc, ctx[0][0], False)

@@ -407,3 +407,83 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
                                    atol=3e-5 * float(dw_ref.abs().max()), rtol=1e-5)
     finally:
         kk.BF16_MIN_PIXELS = old_min
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "planes"])
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, pad, groups, two BatchNorms?, shortcut addend?
+    (3, 14, 14, 256, 64, 1, 0, 1, True, True),       # conv1 of a bottleneck: finishes bn3 + the downsample BatchNorm
+    (2, 9, 9, 128, 128, 3, 1, 2, False, False),      # radix conv: finishes bn1 (ragged last M tile)
+    (5, 7, 7, 64, 32, 1, 0, 1, False, True),
+    (9, 12, 12, 64, 64, 3, 1, 1, True, False)])
+def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision):
+    """conv dgrad with a BnBwdFuse == conv dgrad, then ReLU mask, then the BatchNorm backward's own reduction: the masked
+    gradient bit for bit (every tile), the fp64 partial sums to 1e-10, dx / dgamma / dbeta of the BatchNorm(s) to fp32
+    rounding -- for the fp32-MFMA, the bf16-input and the bf16x3 plane kernels."""
+    B, H, W, Cin, Cout, k, pad, g, two, with_add = case
+    kk = K()
+    rng = np.random.default_rng(sum(case[:8]))
+    if precision == "planes" and ((Cin // g) % 64 or (Cout // g) % 32):
+        pytest.skip("plane input gradient needs 64-multiples of input channels per group")
+    rnd = lambda *s: torch.from_numpy(rng.standard_normal(s)).float().cuda()
+    dy = rnd(B, H, W, Cout)
+    w = (rnd(k, k, Cin // g, Cout) / np.sqrt(Cout * k * k)).contiguous()
+    addend = rnd(B, H, W, Cin) if with_add else None
+    # the BatchNorm(s) whose output gradient the convolution produces: forward first (mask, saved statistics)
+    bns = []
+    res = rnd(B, H, W, Cin)
+    for i in range(2 if two else 1):
+        x = rnd(B, H, W, Cin) * 1.7 + 0.4
+        gamma, beta = torch.rand(Cin, device="cuda") + 0.5, rnd(Cin)
+        rm, rv = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda")
+        bns.append((x, gamma, beta, rm, rv))
+    x1, g1, b1, rm1, rv1 = bns[0]
+    if two:                                            # out = relu(bn1(x1) + bn2(x2))
+        x2, g2, b2, rm2, rv2 = bns[1]
+        y2, saved2 = kk.bn_fwd(x2, g2, b2, rm2, rv2, True, False)
+        _, saved1, mask = kk.bn_fwd(x1, g1, b1, rm1, rv1, True, True, residual=y2, want_mask=True)
+    else:                                              # out = relu(bn1(x1) + shortcut)
+        _, saved1, mask = kk.bn_fwd(x1, g1, b1, rm1, rv1, True, True, residual=res, want_mask=True)
+
+    def dgrad(post, tile=None):
+        if precision == "planes":
+            dyp = kk.planes_split(dy, 3)
+            _, wdg = kk.planes_split_weight(w, g, 3)
+            return kk.conv2d_dgrad_planes(dyp, wdg, (B, H, W, Cin), k, k, 1, pad, g, addend, tile=tile, post=post)
+        if tile is not None:
+            kk._tile_cache[("dgrad", precision == "bf16" and B * H * W >= kk.BF16_MIN_PIXELS, B, H, W, Cin, Cout, k, k, 1,
+                            pad, g)] = tile
+        return kk.conv2d_dgrad(dy, w, (B, H, W, Cin), addend, 1, pad, g, precision=precision, post=post)
+
+    # unfused chain
+    d_plain = dgrad(None)
+    dg = [torch.zeros(Cin, device="cuda") for _ in range(4)]
+    dx1_ref, gout = kk.bn_bwd(d_plain, None, x1, saved1, True, dg[0], dg[1], True, mask=mask)
+    if two:
+        dx2_ref, _ = kk.bn_bwd(gout, None, x2, saved2, True, dg[2], dg[3])
+    tiles = kk._plane_tiles(Cin // g) if precision == "planes" else [t for t in range(4) if kk._tile_legal(Cin // g, t)]
+    for t in tiles:
+        post = kk.BnBwdFuse(mask, [(x1, saved1)] + ([(x2, saved2)] if two else []))
+        gf = dgrad(post, t)
+        assert post.applied
+        assert torch.equal(gf, gout), (t, float((gf - gout).abs().max()))
+        gd = gout.double().view(-1, Cin)
+        for i, (x, saved) in enumerate(post.entries):
+            part, rows = post.ext(i)
+            sums = part.sum(0).cpu().numpy()
+            xhat = ((x.view(-1, Cin) - saved[0]) * saved[1]).double()          # fp32 xhat, as every kernel forms it
+            np.testing.assert_allclose(sums[:, 0], gd.sum(0).cpu().numpy(), rtol=1e-10, atol=1e-9)
+            np.testing.assert_allclose(sums[:, 1], (gd * xhat).sum(0).cpu().numpy(), rtol=1e-10, atol=1e-9)
+        fg = [torch.zeros(Cin, device="cuda") for _ in range(4)]
+        dx1, gg = kk.bn_bwd(gf, None, x1, saved1, True, fg[0], fg[1], True, ext=post.ext(0))
+        assert gg is gf
+        outs, refs = [dx1, fg[0], fg[1]], [dx1_ref, dg[0], dg[1]]
+        if two:
+            dx2, _ = kk.bn_bwd(gf, None, x2, saved2, True, fg[2], fg[3], ext=post.ext(1))
+            outs += [dx2, fg[2], fg[3]]
+            refs += [dx2_ref, dg[2], dg[3]]
+        for a, b in zip(outs, refs):
+            sc = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-6 * sc + 1e-7, (t, float((a - b).abs().max()), sc)
+    if precision != "planes":
+        kk._tile_cache.clear()
