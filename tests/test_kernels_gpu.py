@@ -416,12 +416,13 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
     (2, 9, 9, 128, 128, 3, 1, 2, False, False),      # radix conv: finishes bn1 (ragged last M tile)
     (5, 7, 7, 64, 32, 1, 0, 1, False, True),
     (9, 12, 12, 64, 64, 3, 1, 1, True, False)])
-def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision):
+def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision, monkeypatch):
     """conv dgrad with a BnBwdFuse == conv dgrad, then ReLU mask, then the BatchNorm backward's own reduction: the masked
     gradient bit for bit (every tile), the fp64 partial sums to 1e-10, dx / dgamma / dbeta of the BatchNorm(s) to fp32
     rounding -- for the fp32-MFMA, the bf16-input and the bf16x3 plane kernels."""
     B, H, W, Cin, Cout, k, pad, g, two, with_add = case
     kk = K()
+    monkeypatch.setattr(kk, "BN_BWD_FUSE", 15)         # every producer class (the model default fuses the 1x1 ones only)
     rng = np.random.default_rng(sum(case[:8]))
     if precision == "planes" and ((Cin // g) % 64 or (Cout // g) % 32):
         pytest.skip("plane input gradient needs 64-multiples of input channels per group")
