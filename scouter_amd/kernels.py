@@ -285,9 +285,12 @@ def planes_split_weight(w_hwio, groups, nplanes=3, fwd=True, dgrad=True):
 _PLANE_TILE_ROWS = {0: 128, 1: 128, 2: 128, 3: 64, 4: 256}
 
 
-def _plane_tiles(ng):
-    """Block tiles of the plane kernels (csrc/conv_planes.hip dispatch_pconv): 0 = 128x128, 2 = 128x64 (two workgroups
-    per CU), 3 = 64x64 (three), 4 = 256x128 with eight waves.  Every tile sums each output in the same order."""
+def _plane_tiles(ng, nplanes=3):
+    """Block tiles of the plane kernels (csrc/conv_planes.hip dispatch_pconv): 0 = 128x128, 1 = 128x64 (three LDS
+    stages), and for three planes 2 = 128x64 (two workgroups per CU), 3 = 64x64 (three), 4 = 256x128 with eight waves.
+    Every tile sums each output in the same order."""
+    if nplanes == 1:
+        return (0, 1) if ng % 128 == 0 else (1,)
     return (0, 2, 3, 4) if ng % 128 == 0 else (2, 3)
 
 
@@ -299,7 +302,7 @@ def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, adde
     Cout = wf.shape[2]
     y = torch.empty((B, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout), dtype=F32, device=xp.device)
     L = _native.lib()
-    cands = _plane_tiles(Cout // groups)
+    cands = _plane_tiles(Cout // groups, nplanes)
     M = y.numel() // Cout
     # scratch for the statistics of the largest partial count (64-row tiles) while the tiles are being timed
     scratch = [None]
@@ -332,7 +335,7 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
     B, H, W, Cin = x_shape
     Cout = dyp.shape[-1]
     dx = torch.empty(x_shape, dtype=F32, device=dyp.device)
-    cands = _plane_tiles(Cin // groups)
+    cands = _plane_tiles(Cin // groups, nplanes)
 
     def launch(t, dry=False, fuse=_NO_FUSE):
         if dry:

@@ -44,17 +44,22 @@ class Conv2d(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
 
     # ---- bf16x3 operand planes (csrc/conv_planes.hip): the producer of this layer's input hands over a K.PlaneTensor
+    def _nplanes(self):
+        """3 exact bf16 planes per operand in fp32 mode (fp32-grade products), 1 (the RNE-rounded value: what the
+        bf16-input kernels compute, without their in-flight conversion and with half the operand bytes) in bf16 mode."""
+        return 0 if not self.planes else (self.planes if self.precision == "fp32" else 1)
+
     def planes_in(self):
         """Number of operand planes this layer wants its INPUT in (0: plain fp32 tensor)."""
         cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
-        ok = self.planes and self.precision == "fp32" and self.stride == 1 and cg % 32 == 0 and ng % 64 == 0
-        return self.planes if ok else 0
+        n = self._nplanes()
+        return n if n and self.stride == 1 and cg % 32 == 0 and ng % 64 == 0 else 0
 
     def planes_dy(self):
         """Number of planes this layer wants its OUTPUT GRADIENT in (input-gradient kernel on planes)."""
         cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
-        ok = self.planes and self.precision == "fp32" and self.stride == 1 and ng % 32 == 0 and cg % 64 == 0
-        return self.planes if ok else 0
+        n = self._nplanes()
+        return n if n and self.stride == 1 and ng % 32 == 0 and cg % 64 == 0 else 0
 
     def planes_wgrad(self):
         """Weight gradient on planes too (same-size convolution, 64-multiples of channels per group)."""

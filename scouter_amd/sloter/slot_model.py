@@ -110,8 +110,9 @@ class SlotModel(nn.Module):
         """3 (default): the grouped 3x3 convolutions of the split-attention blocks run on the bf16 matrix cores over
         exact three-way bf16 splits of their fp32 operands (csrc/conv_planes.hip: six products per fp32 product, fp32
         accumulation -- the accuracy of the exact-fp32 MFMA kernel at 1.6x its speed); 0: every convolution on the fp32
-        MFMA kernels.  Only layers whose shapes qualify switch (Conv2d.planes_in / planes_dy); precision="bf16" keeps its
-        own kernels."""
+        MFMA kernels.  Only layers whose shapes qualify switch (Conv2d.planes_in / planes_dy).  With precision="bf16" the
+        same layers take ONE plane -- the RNE-rounded bf16 value the bf16-input kernels would form in flight -- from their
+        producers: half the operand bytes, LDS-DMA instead of a conversion pass through registers."""
         if nplanes not in (0, 3):
             raise ValueError("planes must be 0 or 3")
         from ..timm.models.layers.split_attn import SplitAttnConv2d
