@@ -7,7 +7,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libscouter_hip.so")
+LIB_PATH = os.environ.get("SCOUTER_HIP_LIB") or os.path.join(_HERE, "lib", "libscouter_hip.so")   # (env: dev builds)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "scouter_hip.h")
 
 _lib = None

@@ -305,6 +305,280 @@ __global__ __launch_bounds__(NWM * 128, 1) void pconv_kernel(const unsigned shor
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 on planes with the input rows RESIDENT in LDS for all nine taps ("halo" kernel)
+// ---------------------------------------------------------------------------------------------------------------
+// pconv_kernel fetches the A tile once per filter tap: nine (shifted) copies of the same pixel rows go L2 -> LDS, and
+// that delivery -- not the matrix pipe -- bounds it (48 of the 72 KB per K-tile of the 256x128 tile are A).  In the flat
+// NHWC pixel index the nine taps of a same-size convolution are the row offsets dr*W + dq, so the rows a 256-pixel tile
+// needs for ALL taps are one contiguous range of 256 + 2W + 2 pixels.  This kernel keeps that range resident:
+//   * K order: 16-channel chunk outer, filter tap inner.  Per chunk ONE image [256 + 2W + 2 rows][16 ch] per plane
+//     (32-byte rows, <= 12 KB) is DMA'd and serves 9 taps x 24 MFMAs per wave; only the weights (BN x 16 ch per tap)
+//     stream per tap: 12 + 9 * 12 KB instead of 9 * 36 KB per 16 channels of K (BN = 128, three planes).
+//   * taps that fall outside the image (borders, and the pixels of the neighbouring image that the flat range drags
+//     in) are not masked in the data: the lane reads its fragment from a 32-byte ZERO row instead (one v_cndmask on the
+//     ADDRESS per 32-row block and tap).
+//   * pipeline unit = one filter row (3 taps, 72 MFMAs per wave) per workgroup barrier; weights double-buffered per
+//     unit, the image double-buffered per chunk and fetched in three slices while the previous chunk computes.
+// Same fragment / accumulator scheme as pconv_kernel (two accumulator sets, smallest products first); the summation
+// order over K differs from pconv_kernel's, so results agree with the other tiles to fp32 rounding, not bit for bit.
+#ifndef PHALO_ABLATE
+#define PHALO_ABLATE 0      // dev builds only (tools_dev/phalo_ablate.sh): 1 = no DMA, 2 = no DMA wait / barrier, 4 = no LDS reads
+#endif
+template <int BN, int NP, bool DGRAD>
+__global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __restrict__ a_planes, long a_plane_elems,
+                                                       const unsigned short* __restrict__ w_planes, long w_plane_elems,
+                                                       const float* __restrict__ bias, const float* __restrict__ addend,
+                                                       float* __restrict__ dst, double* __restrict__ bn_part, ConvGeom g,
+                                                       int relu, int mtiles, int ntiles, int agroups, BnBwdFuse fz) {
+    constexpr int BM = 256, NW = 8, WM = 64, WN = BN / 2, MT = 2, NT = WN / 32;
+    constexpr int AG_MAX = 12;                                   // 32-row groups of the image (W <= 63)
+    constexpr int APLANE = (AG_MAX + 1) * 1024;                  // + one zero block behind the image of every plane
+    constexpr int ABUF = NP * APLANE;
+    constexpr int BBLK = BN / 32;                                // 1 KB blocks of one (tap, plane) weight tile
+    constexpr int BTAP = NP * BN * 32, BSTAGE = 3 * BTAP;
+    constexpr int B_OFF = 2 * ABUF;
+    constexpr int ZERO = AG_MAX * 1024;                          // zero block of plane 0 in image buffer 0 (+ pl * APLANE)
+    constexpr int A_SLICE = 2;                                    // image DMAs per wave and unit (see issue_a)
+    constexpr int B_PER_WAVE = (3 * NP * BBLK + NW - 1) / NW;
+    constexpr int NPROD = NP == 3 ? 6 : 1;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nblk = mtiles * ntiles * g.groups;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int grp = bid % g.groups;
+    const int nt_id = (bid / g.groups) % ntiles;
+    const int mt_id = bid / (g.groups * ntiles);
+    const long m0 = (long)mt_id * BM;
+    const int n0 = nt_id * BN;
+    const int W = g.W, cpt16 = g.Cg / 16, KT = 3 * cpt16;
+
+    // ---- zero blocks (one per plane, in image buffer 0)
+    if (tid < NP * 64) *(f32x4*)(lds_raw + (tid >> 6) * APLANE + ZERO + (tid & 63) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          // (published by the barrier at the end of the prologue)
+
+    // ---- tap masks of this lane's two fragment rows (pixels m0 + wm*64 + i*32 + l31) and their image rows
+    const int hw = g.Ho * g.Wo;
+    unsigned amask[MT];
+    int arow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const long m = m0 + wm * WM + i * 32 + l31;
+        const int bimg = (int)(((double)(unsigned)m + 0.5) * g.inv_hw);
+        const int rem = (int)((unsigned)m - (unsigned)bimg * (unsigned)hw);
+        const int y = fast_div(rem, g.inv_wo), x = rem - y * g.Wo;
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int yy = DGRAD ? y + 1 - r : y + r - 1, xx = DGRAD ? x + 1 - q : x + q - 1;
+                mask |= ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)W ? 1u : 0u) << (r * 3 + q);
+            }
+        amask[i] = m < g.M ? mask : 0u;
+        arow[i] = (wm * WM + i * 32 + l31) * 32;
+    }
+    // image row j holds pixel m0 - (W + 1) + j; tap (r, q) of local row t reads image row t + (W + 1) + dr*W + dq
+    int trow[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) trow[r] = ((W + 1) + (DGRAD ? 1 - r : r - 1) * W) * 32;
+
+    // ---- DMA addressing.  Lane = (row in the 32-row group = lane >> 1, 16-byte slot = lane & 1).  LDS rows are 32 bytes;
+    // the two 16-byte halves of row j are stored swapped when bit 3 of j is set, so that 16 consecutive rows read at one
+    // k-half (a quarter of a ds_read_b128) touch all 64 banks once for ANY tap shift (unswizzled: PMC showed half of the
+    // LDS cycles as bank conflicts).  The DMA writes lane-linearly, so the swap is applied on the source address.
+    const int shalf = (lane & 1) ^ ((lane >> 4) & 1);
+    const long p_first = m0 - (W + 1);
+    const long pbase = p_first > 0 ? p_first : 0;                 // folded into the descriptor: offsets stay small
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a_planes + pbase * g.C + grp * g.Cg), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(w_planes + (long)grp * g.Ng * g.Cg), 0, 0x7fffffff, 0x00020000);
+    const long a_plane_bytes = a_plane_elems * 2, w_plane_bytes = w_plane_elems * 2;
+    const long wtap_bytes = (long)g.N * g.Cg * 2;
+    // image: wave w fetches the 32-row groups w and w + 8 of every plane; slice sl of a chunk = plane sl (NP = 3) --
+    // two DMAs per wave and slice, the source offset of a group is the same for every plane and chunk
+    unsigned a_voff[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int gi = wave + NW * v;
+        const long p = p_first + 32 * gi + (lane >> 1);
+        a_voff[v] = (gi < agroups && p >= 0 && p < g.M) ? (unsigned)((p - pbase) * g.C * 2 + shalf * 16) : OOB;
+    }
+    const bool g1 = wave + NW < agroups;                          // (wave-uniform) this wave has a second group
+    auto issue_a = [&](int c16, int sl) {
+        const bool live = c16 < cpt16;
+        static_assert(A_SLICE == 2 || NP == 1, "one plane per slice");
+        if (NP == 3 || sl == 0) {
+            const int pl = NP == 3 ? sl : 0;
+            char* base = lds_raw + (c16 & 1) * ABUF + pl * APLANE;
+            const int soff = (int)(pl * a_plane_bytes) + c16 * 32;
+            dma16(rs_a, base + wave * 1024, live ? a_voff[0] : OOB, soff);
+            dma16(rs_a, g1 ? base + (wave + NW) * 1024 : lds_raw + ZERO, live ? a_voff[1] : OOB, soff);
+        } else {
+            dma16(rs_a, lds_raw + ZERO, OOB, 0);
+            dma16(rs_a, lds_raw + ZERO, OOB, 0);
+        }
+    };
+    // weights of filter row r, chunk c16 into weight stage `stage`: DMA e = wave + 8 u covers (tap column, plane, 1 KB
+    // block) = (e / (NP BBLK), (e / BBLK) % NP, e % BBLK); BBLK divides 8, so a wave always fetches the same block rows
+    static_assert(NW % BBLK == 0, "block index of a wave is fixed");
+    const unsigned b_voff = (unsigned)((n0 + (wave % BBLK) * 32 + (lane >> 1)) * g.Cg * 2 + shalf * 16);
+    auto issue_b = [&](int c16, int r, int stage) {
+        const bool live = c16 < cpt16;
+#pragma unroll
+        for (int u = 0; u < B_PER_WAVE; ++u) {
+            const int e = wave + NW * u;
+            const int q = e / (NP * BBLK), pl = (e / BBLK) % NP, blk = e % BBLK;
+            const bool real = e < 3 * NP * BBLK;
+            char* dstp = lds_raw + (real ? B_OFF + stage * BSTAGE + q * BTAP + pl * (BN * 32) + blk * 1024 : ZERO);
+            dma16(rs_b, dstp, live && real ? b_voff : OOB, (int)((r * 3 + q) * wtap_bytes + c16 * 32 + pl * w_plane_bytes));
+        }
+    };
+
+    constexpr int NACC = NP == 3 ? 2 : 1;
+    f32x16 acc[MT][NT], accl[NACC == 2 ? MT : 1][NACC == 2 ? NT : 1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if (NACC == 2) accl[i][j][e] = 0.f;
+            }
+
+    bf16x8 F[2][MT + NT][NP];
+    const int bfrag = B_OFF + (wn * WN + l31) * 32 + ((h ^ ((l31 >> 3) & 1)) << 4);
+    // fragments of step (filter row r, tap column q) of the chunk in image buffer cp, weights in stage `stage`
+    auto load_frags = [&](int buf, int cp, int r, int q, int stage) {
+        const int tap = r * 3 + q;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            // (the empty asm keeps the 2 x 9 x 2 selected addresses from being hoisted out of the K loop as loop
+            //  invariants: 36 registers this kernel does not have -- they were spilled and reloaded behind vmcnt(0))
+            unsigned am = amask[i];
+            int ar = arow[i];
+            asm volatile("" : "+v"(am), "+v"(ar));
+            const int row32 = ar + cp * ABUF + trow[r] + (DGRAD ? 1 - q : q - 1) * 32;      // image row * 32 (+ buffer)
+            const int live = row32 + ((((row32 >> 8) ^ h) & 1) << 4);                           // swizzled k-half
+            const int addr = ((am >> tap) & 1u) ? live : ZERO + h * 16;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) F[buf][i][pl] = *(const bf16x8*)(lds_raw + addr + pl * APLANE);
+        }
+        const char* bs = lds_raw + bfrag + stage * BSTAGE + q * BTAP;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) F[buf][MT + j][pl] = *(const bf16x8*)(bs + pl * (BN * 32) + j * 1024);
+    };
+    auto mma = [&](int buf) {
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first
+#pragma unroll
+        for (int pr = (NP == 3 ? 0 : 5); pr < 6; ++pr)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (NACC == 2 && pr < 5)
+                        accl[i][j] = mfma_bf16p(F[buf][i][PA[pr]], F[buf][MT + j][PB[pr]], accl[i][j]);
+                    else
+                        acc[i][j] = mfma_bf16p(F[buf][i][NP == 3 ? PA[pr] : 0], F[buf][MT + j][NP == 3 ? PB[pr] : 0], acc[i][j]);
+                }
+    };
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
+#define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+    constexpr int NMMA = MT * NT * NPROD;
+    constexpr int NFR = (MT + NT) * NP;
+    constexpr int DPT = A_SLICE + B_PER_WAVE;
+
+    // ---- prologue: image of chunk 0, weights of units 0 and 1, first slice of chunk 1's image
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) issue_a(0, sl);
+    issue_b(0, 0, 0);
+    issue_a(1, 0);
+    issue_b(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPT) : "memory");          // image 0 and unit 0 have landed
+    __builtin_amdgcn_s_barrier();                                        // (also publishes the zero blocks)
+    load_frags(0, 0, 0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+
+    // One unit = filter row R of the chunk in image buffer CP; FB = fragment buffer holding its first step on entry.
+    // kt = 3 * c16 + R.  Steps q = 0, 1 prefetch the next step's fragments under 24 MFMAs each; step 2 synchronises:
+    // this wave's DMAs for unit kt + 1 have landed, barrier (unit kt + 1 and any image slice issued one unit ago are
+    // complete in LDS; weight stage kt & 1 and -- after R = 2 -- this chunk's image buffer are free), then the DMAs of
+    // unit kt + 2 and one image slice go out and the first fragments of unit kt + 1 are read under the last 24 MFMAs.
+    auto unit = [&](int c16, auto R_, auto CP_, auto FB_) {
+        constexpr int R = decltype(R_)::value, CP = decltype(CP_)::value, FB = decltype(FB_)::value;
+        constexpr int ST = (3 * CP + R) & 1;                             // weight stage = kt & 1 (c16 parity = CP)
+        SBAR();
+        if (!(PHALO_ABLATE & 4)) load_frags(FB ^ 1, CP, R, 1, ST);
+        mma(FB);
+#pragma unroll
+        for (int k = 0; k < NMMA; ++k) { SG(0x008, 1); if (k < NFR) { SG(0x100, 1); SG(0x006, 2); } }
+        SBAR();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        SBAR();
+        if (!(PHALO_ABLATE & 4)) load_frags(FB, CP, R, 2, ST);
+        mma(FB ^ 1);
+#pragma unroll
+        for (int k = 0; k < NMMA; ++k) { SG(0x008, 1); if (k < NFR) { SG(0x100, 1); SG(0x006, 2); } }
+        SBAR();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                              // all LDS reads of this unit are done
+        if (!(PHALO_ABLATE & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's part of unit kt + 1 (+ slice) landed
+            __builtin_amdgcn_s_barrier();
+        }
+        SBAR();
+        // DMAs: weights of unit kt + 2 into this unit's stage; one slice of an upcoming image
+        constexpr int R2 = (R + 2) % 3, DC2 = (R + 2) / 3;
+        if (!(PHALO_ABLATE & 1)) {
+            issue_b(c16 + DC2, R2, ST);
+            if constexpr (R == 2) issue_a(c16 + 2, 0);                   // this chunk's buffer is free now
+            else issue_a(c16 + 1, R + 1);
+        }
+        // first fragments of unit kt + 1
+        constexpr int R1 = (R + 1) % 3, CP1 = R == 2 ? CP ^ 1 : CP;
+        if (!(PHALO_ABLATE & 4)) load_frags(FB ^ 1, CP1, R1, 0, ST ^ 1);
+        mma(FB);
+#pragma unroll
+        for (int k = 0; k < NMMA; ++k) {
+            SG(0x008, 1);
+            if (k < DPT) { SG(0x020, 1); SG(0x006, 4); }
+            else if (k - DPT < NFR) { SG(0x100, 1); SG(0x006, 2); }
+        }
+        SBAR();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    for (int c = 0; c < cpt16; c += 2) {                                 // Cg % 32 == 0: an even number of chunks
+        unit(c, I0{}, I0{}, I0{});
+        unit(c, I1{}, I0{}, I1{});
+        unit(c, I2{}, I0{}, I0{});
+        unit(c + 1, I0{}, I1{}, I1{});
+        unit(c + 1, I1{}, I1{}, I0{});
+        unit(c + 1, I2{}, I1{}, I1{});
+    }
+#undef SBAR
+#undef SG
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (NACC == 2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] += accl[i][j];
+    }
+    (void)KT;
+    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 static int conv_out_p(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
@@ -360,13 +634,43 @@ static void launch_pconv(const void* a, long a_pe, const void* w, long w_pe, con
                        (const unsigned short*)w, w_pe, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz);
 }
 
+template <int BN, int NP, bool DGRAD>
+static void launch_phalo(const void* a, long a_pe, const void* w, long w_pe, const float* bias, const float* addend,
+                         float* dst, double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz) {
+    constexpr int BM = 256;
+    const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
+    ConvGeom gg = g;
+    gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
+    gg.inv_wo = 1.0f / (float)g.Wo;
+    gg.inv_ho = 1.0f / (float)g.Ho;
+    constexpr int IMG = 2 * NP * 13 * 1024, WST = 2 * 3 * NP * BN * 32, EPI = 8 * 64 * (BN / 2 + 4) * 4;
+    constexpr int LDS = IMG + WST > EPI ? IMG + WST : EPI;
+    auto kern = phalo_kernel<BN, NP, DGRAD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int agroups = (BM + 2 * g.W + 2 + 31) / 32;
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles * g.groups), dim3(512), LDS, st, (const unsigned short*)a, a_pe,
+                       (const unsigned short*)w, w_pe, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, agroups, fz);
+}
+// the resident-rows kernel covers same-size 3x3 convolutions on maps up to 63 pixels wide
+static bool phalo_ok(const ConvGeom& g) {
+    return g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.H == g.Ho && g.W == g.Wo && g.W <= 63 &&
+           g.Cg % 32 == 0 && g.Ng % 64 == 0;
+}
+
 // tile: 0 = 128x128, 1 = 128x64 (N per group must be a multiple of the tile's N)
 template <bool DGRAD>
 static int dispatch_pconv(const void* a, long a_pe, const void* w, long w_pe, const float* bias, const float* addend,
                           float* dst, double* bn_part, const ConvGeom& g, int relu, int nplanes, int tile,
                           hipStream_t st, const BnBwdFuse& fz = BnBwdFuse{}) {
     const bool wide = g.Ng % 128 == 0 && tile != 1;
-    if (nplanes == 3 && tile == 2) {        // two workgroups per CU (2 LDS stages of 36 KB)
+    if (nplanes == 3 && tile == 5 && phalo_ok(g)) {   // 256 x (128 | 64), input rows resident in LDS for all nine taps
+        if (g.Ng % 128 == 0) launch_phalo<128, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+        else launch_phalo<64, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+    } else if (nplanes == 3 && tile == 2) {        // two workgroups per CU (2 LDS stages of 36 KB)
         launch_pconv<128, 64, 3, 2, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
     } else if (nplanes == 3 && tile == 3) { // three workgroups per CU
         launch_pconv<64, 64, 3, 2, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);

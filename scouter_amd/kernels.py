@@ -282,16 +282,25 @@ def planes_split_weight(w_hwio, groups, nplanes=3, fwd=True, dgrad=True):
     return wf, wd
 
 
-_PLANE_TILE_ROWS = {0: 128, 1: 128, 2: 128, 3: 64, 4: 256}
+_PLANE_TILE_ROWS = {0: 128, 1: 128, 2: 128, 3: 64, 4: 256, 5: 256}
 
 
-def _plane_tiles(ng, nplanes=3):
+def _plane_tiles(ng, nplanes=3, halo=False):
     """Block tiles of the plane kernels (csrc/conv_planes.hip dispatch_pconv): 0 = 128x128, 1 = 128x64 (three LDS
-    stages), and for three planes 2 = 128x64 (two workgroups per CU), 3 = 64x64 (three), 4 = 256x128 with eight waves.
-    Every tile sums each output in the same order."""
+    stages), and for three planes 2 = 128x64 (two workgroups per CU), 3 = 64x64 (three), 4 = 256x128 with eight waves,
+    5 (halo=True: same-size 3x3 layers on maps up to 63 wide) = 256 x (128 | 64) with the input rows resident in LDS for
+    all nine taps.  Tiles 0-4 sum each output in the same order (bit-identical results); tile 5 sums over K in a
+    different order (16-channel chunk outer, tap inner): equal to fp32 rounding."""
     if nplanes == 1:
         return (0, 1) if ng % 128 == 0 else (1,)
-    return (0, 2, 3, 4) if ng % 128 == 0 else (2, 3)
+    return ((0, 2, 3, 4) if ng % 128 == 0 else (2, 3)) + ((5,) if halo else ())
+
+
+HALO_TILE = int(os.environ.get("SCOUTER_HALO", "3"))      # bit 0: forward, bit 1: input gradient may use tile 5
+
+
+def _halo_ok(kh, kw, stride, pad, H, W, mode=3):
+    return bool(HALO_TILE & mode) and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W <= 63
 
 
 def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, addend=None, relu=False, bn_stats=False,
@@ -302,7 +311,7 @@ def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, adde
     Cout = wf.shape[2]
     y = torch.empty((B, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout), dtype=F32, device=xp.device)
     L = _native.lib()
-    cands = _plane_tiles(Cout // groups, nplanes)
+    cands = _plane_tiles(Cout // groups, nplanes, _halo_ok(kh, kw, stride, pad, H, W, 1))
     M = y.numel() // Cout
     # scratch for the statistics of the largest partial count (64-row tiles) while the tiles are being timed
     scratch = [None]
@@ -335,7 +344,7 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
     B, H, W, Cin = x_shape
     Cout = dyp.shape[-1]
     dx = torch.empty(x_shape, dtype=F32, device=dyp.device)
-    cands = _plane_tiles(Cin // groups, nplanes)
+    cands = _plane_tiles(Cin // groups, nplanes, _halo_ok(kh, kw, stride, pad, H, W, 2))
 
     def launch(t, dry=False, fuse=_NO_FUSE):
         if dry:

@@ -33,7 +33,8 @@ def test_three_plane_split_is_exact():
 
 CASES = [  # B, H, W, Cin, Cout, k, pad, groups
     (2, 14, 14, 64, 128, 3, 1, 1), (3, 9, 7, 128, 256, 3, 1, 2), (2, 12, 12, 32, 64, 3, 1, 1), (1, 8, 8, 256, 256, 1, 0, 1),
-    (5, 7, 7, 64, 128, 1, 0, 1), (2, 20, 20, 128, 128, 3, 1, 2), (1, 30, 30, 64, 64, 3, 1, 1)]
+    (5, 7, 7, 64, 128, 1, 0, 1), (2, 20, 20, 128, 128, 3, 1, 2), (1, 30, 30, 64, 64, 3, 1, 1),
+    (2, 56, 56, 64, 128, 3, 1, 2), (11, 7, 7, 128, 256, 3, 1, 2), (1, 5, 63, 32, 128, 3, 1, 1), (3, 28, 28, 64, 64, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("cfg", CASES)
@@ -61,6 +62,17 @@ def test_plane_convolution_matches_fp64(cfg):
     y_true = F.conv2d(xd.permute(0, 3, 1, 2).cpu().double(), wd.permute(3, 2, 0, 1).cpu().double(), None, 1, pad, 1, groups)
     e3 = float((y.permute(0, 3, 1, 2).cpu().double() - y_true).abs().max())
     sc = float(y_true.abs().max())
+    if kk._halo_ok(k, k, 1, pad, H, W):      # resident-rows kernel: other summation order over K, same accuracy class
+        yh, (ph, rh) = kk.conv2d_fwd_planes(xp, wf, k, k, 1, pad, groups, bn_stats=True, tile=5)
+        eh = float((yh.permute(0, 3, 1, 2).cpu().double() - y_true).abs().max())
+        print("fwd halo %s: |bf16x3 - fp64| %.3g (other tiles %.3g, fp32 MFMA %.3g)" % (cfg, eh, e3, e32))
+        assert eh <= max(2.0 * e32, 4e-7 * sc), (eh, e32, sc)
+        yhf = yh.double().reshape(-1, Cout).cpu().numpy()
+        sth = ph.sum(0).cpu().numpy()
+        assert rh == -(-yhf.shape[0] // 256)
+        np.testing.assert_allclose(sth[:, 0], yhf.sum(0), rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(sth[:, 1], (yhf * yhf).sum(0), rtol=1e-10, atol=1e-8)
+        assert torch.equal(kk.conv2d_fwd_planes(xp, wf, k, k, 1, pad, groups, tile=5), yh)      # run to run
     print("fwd %s: |bf16x3 - fp64| %.3g  |fp32 MFMA - fp64| %.3g  (scale %.3g)" % (cfg, e3, e32, sc))
     assert e3 <= max(2.0 * e32, 4e-7 * sc), (e3, e32, sc)
     yf = y.double().reshape(-1, Cout).cpu().numpy()
@@ -85,6 +97,11 @@ def test_plane_convolution_matches_fp64(cfg):
             assert torch.equal(kk.conv2d_dgrad_planes(kk.planes_split(dyd, 3), wdg, tuple(xd.shape), k, k, 1, pad, groups,
                                                       tile=t), dx3), t
         ed32 = float((dx32.permute(0, 3, 1, 2).cpu().double() - dx_true).abs().max())
+        if kk._halo_ok(k, k, 1, pad, H, W):
+            dxh = kk.conv2d_dgrad_planes(kk.planes_split(dyd, 3), wdg, tuple(xd.shape), k, k, 1, pad, groups, tile=5)
+            edh = float((dxh.permute(0, 3, 1, 2).cpu().double() - dx_true).abs().max())
+            print("dgrad halo %s: |bf16x3 - fp64| %.3g (fp32 MFMA %.3g)" % (cfg, edh, ed32))
+            assert edh <= max(2.0 * ed32, 4e-7 * float(dx_true.abs().max())), (edh, ed32)
         ed3 = float((dx3.permute(0, 3, 1, 2).cpu().double() - dx_true).abs().max())
         print("dgrad %s: |bf16x3 - fp64| %.3g  |fp32 MFMA - fp64| %.3g" % (cfg, ed3, ed32))
         assert ed3 <= max(2.0 * ed32, 4e-7 * float(dx_true.abs().max())), (ed3, ed32)

@@ -9,10 +9,12 @@ python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) gemm >> $OUT
 python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) wgrad >> $OUT
 python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) pconv >> $OUT
 python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) pwgrad >> $OUT
+python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) phalo >> $OUT
 if [ -n "$PMC2" ]; then
   rm -rf $D; mkdir -p $D
   rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS -d $D -- python tools_dev/one_conv.py "$@" > $D/log 2>&1
   python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) pconv >> $OUT
   python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) pwgrad >> $OUT
+  python tools_dev/pmc_dump.py $(find $D -name "*.db" | head -1) phalo >> $OUT
 fi
 rm -rf $D
