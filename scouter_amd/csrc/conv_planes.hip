@@ -322,7 +322,8 @@ __global__ __launch_bounds__(NWM * 128, 1) void pconv_kernel(const unsigned shor
 // Same fragment / accumulator scheme as pconv_kernel (two accumulator sets, smallest products first); the summation
 // order over K differs from pconv_kernel's, so results agree with the other tiles to fp32 rounding, not bit for bit.
 #ifndef PHALO_ABLATE
-#define PHALO_ABLATE 0      // dev builds only (tools_dev/phalo_ablate.sh): 1 = no DMA, 2 = no DMA wait / barrier, 4 = no LDS reads
+#define PHALO_ABLATE 0      // dev builds only (tools_dev/phalo_ablate.sh): 1 = no DMA, 2 = no DMA wait / barrier, 4 = no LDS reads,
+                            // 8 = cycle stamps (start, prologue done, K loop done, stores retired) instead of BatchNorm partials
 #endif
 template <int BN, int NP, bool DGRAD>
 __global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __restrict__ a_planes, long a_plane_elems,
@@ -356,6 +357,10 @@ __global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __r
     const int n0 = nt_id * BN;
     const int W = g.W, cpt16 = g.Cg / 16, KT = 3 * cpt16;
 
+#if PHALO_ABLATE & 8
+    long long stamp[4];
+    stamp[0] = __builtin_readcyclecounter();
+#endif
     // ---- zero blocks (one per plane, in image buffer 0)
     if (tid < NP * 64) *(f32x4*)(lds_raw + (tid >> 6) * APLANE + ZERO + (tid & 63) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_waitcnt(0xc07f);                          // (published by the barrier at the end of the prologue)
@@ -505,6 +510,9 @@ __global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __r
     __builtin_amdgcn_s_barrier();                                        // (also publishes the zero blocks)
     load_frags(0, 0, 0, 0, 0);
     __builtin_amdgcn_s_waitcnt(0xc07f);
+#if PHALO_ABLATE & 8
+    stamp[1] = __builtin_readcyclecounter();
+#endif
 
     // One unit = filter row R of the chunk in image buffer CP; FB = fragment buffer holding its first step on entry.
     // kt = 3 * c16 + R.  Steps q = 0, 1 prefetch the next step's fragments under 24 MFMAs each; step 2 synchronises:
@@ -575,7 +583,18 @@ __global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __r
             for (int j = 0; j < NT; ++j) acc[i][j] += accl[i][j];
     }
     (void)KT;
+#if PHALO_ABLATE & 8
+    stamp[2] = __builtin_readcyclecounter();
+    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, nullptr, relu, m0, n0, grp, mt_id, &fz);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[3] = __builtin_readcyclecounter();
+    if (tid == 0 && bn_part) {           // dev: [block][4] cycle stamps + the CU-local start order
+        long long* o = (long long*)bn_part + (long)blockIdx.x * 4;
+        o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3];
+    }
+#else
     igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
