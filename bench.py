@@ -191,17 +191,17 @@ def pmc_traffic(kernel_class):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
     if not os.path.exists(path):
         return None, None
-    m = re.match(r"(igemm_fwd|igemm_dgrad|wgrad)<(\d+)x(\d+)>", kernel_class)
-    if m:
+    m = re.match(r"(igemm_fwd|igemm_dgrad|wgrad)(?:\+bn_bwd)?<(\d+)x(\d+)>", kernel_class)
+    if m:        # (a fused "+bn_bwd" launch is the same kernel instance: the per-launch mean covers both kinds)
         kind, bm, bn = m.group(1), int(m.group(2)), int(m.group(3))
         want = ("wgrad_kernel<%d, %d," % (bm, bn)) if kind == "wgrad" else "igemm_kernel<%d, %d," % (bm, bn)
         # igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED, PW>
         match = (lambda name: want in name) if kind == "wgrad" else \
             (lambda name: want in name and (", true, " if kind == "igemm_dgrad" else ", false, ") in name.split(want)[1][:24])
     elif kernel_class.startswith("pconv_fwd"):
-        match = lambda name: "pconv_kernel<" in name and ", false" in name
+        match = lambda name: ("pconv_kernel<" in name or "phalo_kernel<" in name) and ", false" in name
     elif kernel_class.startswith("pconv_dgrad"):
-        match = lambda name: "pconv_kernel<" in name and ", true" in name
+        match = lambda name: ("pconv_kernel<" in name or "phalo_kernel<" in name) and ", true" in name
     elif kernel_class.startswith("pwgrad"):
         match = lambda name: "pwgrad_kernel<" in name
     else:

@@ -713,9 +713,16 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, c
     const ConvGeom g = dgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
     static const char* names[4] = {"igemm_dgrad<128x128>", "igemm_dgrad<128x64>", "igemm_dgrad<64x64>",
                                    "igemm_dgrad<128x32>"};
+    // with the BatchNorm-backward reductions in the epilogue the kernel is a different piece of work (it also reads the
+    // BatchNorm input(s), the addend and the ReLU bits -- co-bound by HBM on the short-K layers): its own profile row
+    static const char* names_bn[4] = {"igemm_dgrad+bn_bwd<128x128>", "igemm_dgrad+bn_bwd<128x64>",
+                                      "igemm_dgrad+bn_bwd<64x64>", "igemm_dgrad+bn_bwd<128x32>"};
     const int tile = igemm_tile(g, tile_hint);
-    ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw / (stride * stride),
-                     4.0 * ((double)B * Ho * Wo * Cout + (double)g.M * Cin));
+    const double out_elems = (double)g.M * Cin;
+    ScProfScope prof(part1 ? names_bn[tile] : names[tile], (hipStream_t)stream,
+                     2.0 * g.M * Cin * Cog * kh * kw / (stride * stride),
+                     4.0 * ((double)B * Ho * Wo * Cout + out_elems) + (addend ? 4.0 * out_elems : 0.0) +
+                         (part1 ? (part2 ? 8.0 : 4.0) * out_elems + out_elems / 8 : 0.0));
     const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, x1, saved1, part1, x2, saved2, part2};
     return dispatch_igemm<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream, fz);
 }

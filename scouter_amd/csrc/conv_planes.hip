@@ -689,6 +689,9 @@ static int dispatch_pconv(const void* a, long a_pe, const void* w, long w_pe, co
     if (nplanes == 3 && tile == 5 && phalo_ok(g)) {   // 256 x (128 | 64), input rows resident in LDS for all nine taps
         if (g.Ng % 128 == 0) launch_phalo<128, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
         else launch_phalo<64, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+    } else if (nplanes == 1 && tile == 5 && phalo_ok(g)) {
+        if (g.Ng % 128 == 0) launch_phalo<128, 1, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+        else launch_phalo<64, 1, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
     } else if (nplanes == 3 && tile == 2) {        // two workgroups per CU (2 LDS stages of 36 KB)
         launch_pconv<128, 64, 3, 2, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
     } else if (nplanes == 3 && tile == 3) { // three workgroups per CU

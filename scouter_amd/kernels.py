@@ -292,7 +292,7 @@ def _plane_tiles(ng, nplanes=3, halo=False):
     all nine taps.  Tiles 0-4 sum each output in the same order (bit-identical results); tile 5 sums over K in a
     different order (16-channel chunk outer, tap inner): equal to fp32 rounding."""
     if nplanes == 1:
-        return (0, 1) if ng % 128 == 0 else (1,)
+        return ((0, 1) if ng % 128 == 0 else (1,)) + ((5,) if halo else ())
     return ((0, 2, 3, 4) if ng % 128 == 0 else (2, 3)) + ((5,) if halo else ())
 
 

@@ -84,6 +84,9 @@ def test_plane_convolution_matches_fp64(cfg):
     rb = lambda t: t.float().to(torch.bfloat16).double()
     y1_ref = F.conv2d(rb(xd.permute(0, 3, 1, 2).cpu()), rb(wd.permute(3, 2, 0, 1).cpu()), None, 1, pad, 1, groups)
     np.testing.assert_allclose(y1.permute(0, 3, 1, 2).cpu().numpy(), y1_ref.numpy(), atol=2e-5 * sc, rtol=1e-5)
+    if kk._halo_ok(k, k, 1, pad, H, W):
+        y1h = kk.conv2d_fwd_planes(kk.planes_split(xd, 1), kk.planes_split_weight(wd, groups, 1)[0], k, k, 1, pad, groups, tile=5)
+        np.testing.assert_allclose(y1h.permute(0, 3, 1, 2).cpu().numpy(), y1_ref.numpy(), atol=2e-5 * sc, rtol=1e-5)
     # input gradient
     if (Cin // groups) % 64 == 0:
         dy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
