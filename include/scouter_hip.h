@@ -121,14 +121,18 @@ int scouter_pad_rows_f32(const float* w, float* wpad, long nvalid, long ntotal, 
  * relu_mask_out (optional, needs relu): sign bitmask of y, scouter_relu_mask_words(M*C) 64-bit words (1 bit/element);
  * handing it to scouter_bn_bwd_f32 as relu_mask replaces the 4-byte-per-element read of ymask in both backward passes.
  * planes_out (optional): the output ALSO as nplanes (1 or 3) bf16 operand planes for scouter_conv2d_fwd_planes
- * (likewise dx_planes of scouter_sa_bn_bwd_f32 for scouter_conv2d_dgrad_planes). */
+ * (likewise dx_planes of scouter_sa_bn_bwd_f32 for scouter_conv2d_dgrad_planes).
+ * residual_bn_saved (optional, with residual): `residual` is the RAW output of the downsample convolution and this is
+ * its BatchNorm's saved block [4][C] (statistics finalised by a y == NULL call): y = relu(bn(x) + bn_ds(residual)) in
+ * one pass -- the downsample BatchNorm's output is never stored (resnet.py:404-412 `x += residual` with
+ * residual = downsample(x)). */
 size_t scouter_relu_mask_words(long n);
 size_t scouter_colreduce_workspace_bytes(long M, int C);
 int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                        int training, int relu, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
                        const double* ext_partial, int ext_rows, unsigned long long* relu_mask_out, void* planes_out,
-                       int nplanes, void* ws, size_t ws_bytes, void* stream);
+                       int nplanes, const float* residual_bn_saved, void* ws, size_t ws_bytes, void* stream);
 /* y == NULL in scouter_bn_fwd_f32: statistics / running-stat update only.  scouter_bn_apply_f32: the apply pass alone
  * from a saved block [4][C] = {mean, rstd, scale, shift} (contiguous rows, as written through the four *_out pointers). */
 int scouter_bn_apply_f32(const float* x, const float* bn_saved, float* y, long M, int C, int relu, void* stream);

@@ -176,13 +176,20 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
                                                               const float* __restrict__ res, float* __restrict__ y,
                                                               unsigned long long* __restrict__ mbits, long n4, int C,
                                                               int relu, unsigned short* __restrict__ planes,
-                                                              int nplanes) {
+                                                              int nplanes, const float* __restrict__ res_bn) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
         const f32x4 a = *(const f32x4*)(scale + c), b = *(const f32x4*)(shift + c), mu = *(const f32x4*)(mean + c);
         v = bn_affine(v, mu, a, b);
-        if (res) v += *(const f32x4*)(res + i * 4);
+        if (res) {
+            f32x4 r = *(const f32x4*)(res + i * 4);
+            // the residual is the RAW output of the downsample convolution: its BatchNorm is applied here (saved block
+            // [mean, rstd, scale, shift][C]) -- the same fma the stand-alone apply pass uses, so the sum is bit-identical
+            if (res_bn) r = bn_affine(r, *(const f32x4*)(res_bn + c), *(const f32x4*)(res_bn + 2 * C + c),
+                                      *(const f32x4*)(res_bn + 3 * C + c));
+            v += r;
+        }
         if (relu) {
             if (mbits) {        // i - lane is a multiple of 64 (256-thread blocks, grid stride a multiple of 256)
 #pragma unroll
@@ -499,9 +506,10 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
                                   const float* beta, float* running_mean, float* running_var, float momentum,
                                   float eps, int training, int relu, float* mean_out, float* rstd_out,
                                   float* scale_out, float* shift_out, const double* ext_partial, int ext_rows,
-                                  unsigned long long* relu_mask_out, void* planes_out, int nplanes, void* ws,
-                                  size_t ws_bytes, void* stream) {
+                                  unsigned long long* relu_mask_out, void* planes_out, int nplanes,
+                                  const float* residual_bn_saved, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(x && mean_out && rstd_out && scale_out && shift_out, "bn_fwd: null pointer");   // y == NULL: statistics only
+    SC_REQUIRE(!residual_bn_saved || residual, "bn_fwd: residual_bn_saved without residual");
     SC_REQUIRE(!planes_out || (y && (nplanes == 1 || nplanes == 3)), "bn_fwd: planes_out needs y and 1 or 3 planes");
     SC_REQUIRE(!relu_mask_out || relu, "bn_fwd: relu_mask_out without relu");
     SC_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
@@ -520,7 +528,8 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
     const long n4 = M * C / 4;
     if (y)       // y == NULL: the consumer applies (x - mean) * scale + shift itself (fused split attention)
         hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, scale_out,
-                               shift_out, residual, y, relu_mask_out, n4, C, relu, (unsigned short*)planes_out, nplanes);
+                               shift_out, residual, y, relu_mask_out, n4, C, relu, (unsigned short*)planes_out, nplanes,
+                               residual_bn_saved);
     return sc_check_launch("bn_fwd");
 }
 
@@ -530,7 +539,7 @@ extern "C" int scouter_bn_apply_f32(const float* x, const float* bn_saved, float
     SC_REQUIRE(x && bn_saved && y && M > 0 && C > 0 && C % 4 == 0, "bn_apply: bad arguments");
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, bn_saved,
-                       bn_saved + 2 * C, bn_saved + 3 * C, nullptr, y, nullptr, n4, C, relu, nullptr, 0);
+                       bn_saved + 2 * C, bn_saved + 3 * C, nullptr, y, nullptr, n4, C, relu, nullptr, 0, nullptr);
     return sc_check_launch("bn_apply");
 }
 

@@ -501,8 +501,8 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, momentum=0.1, 
     _native.check(_native.lib().scouter_bn_fwd_f32(
         _p(x), None, None, M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
         int(training), 0, _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]),
-        _p(stats[0]) if stats else None, stats[1] if stats else 0, None, None, 0, _p(ws), ws.numel(), _stream()),
-        "bn_stats")
+        _p(stats[0]) if stats else None, stats[1] if stats else 0, None, None, 0, None, _p(ws), ws.numel(),
+        _stream()), "bn_stats")
     return saved
 
 
@@ -517,7 +517,7 @@ def bn_apply(x, saved, relu):
 
 
 def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=None, momentum=0.1, eps=1e-5,
-           stats=None, want_mask=False, planes=0):
+           stats=None, want_mask=False, planes=0, residual_bn=None):
     """x: [..., C] NHWC.  Returns (y, saved) with saved = (mean, rstd, scale, shift) packed as one [4, C] tensor.
     stats = (partial, rows) from conv2d_fwd(bn_stats=True) replaces the statistics pass over x.
     want_mask (with relu): returns (y, saved, mask) -- the 1-bit/element sign mask bn_bwd takes instead of y."""
@@ -535,8 +535,8 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=N
     _native.check(_native.lib().scouter_bn_fwd_f32(
         _p(x), _p(y), _p(residual), M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
         int(training), int(relu), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]),
-        _p(stats[0]) if stats else None, stats[1] if stats else 0, _p(mask), _p(yp), planes, _p(ws), ws.numel(),
-        _stream()), "bn_fwd")
+        _p(stats[0]) if stats else None, stats[1] if stats else 0, _p(mask), _p(yp), planes, _p(residual_bn), _p(ws),
+        ws.numel(), _stream()), "bn_fwd")
     if planes:
         y = PlaneTensor(y, yp)
     return (y, saved, mask) if want_mask else (y, saved)

@@ -173,9 +173,11 @@ class BatchNorm2d(nn.Module):
         self._dg = self._db = None
         self._capture = None                 # test instrumentation: (dict, key) -> the ReLU'd output is stored there
 
-    def fwd(self, x, save, relu=False, residual=None, tracked=None, planes=0):
+    def fwd(self, x, save, relu=False, residual=None, tracked=None, planes=0, residual_bn=None):
         """x may be the (tensor, stats) pair a conv produced with bn_stats=True.  planes = 1 / 3: the output is a
-        K.PlaneTensor (fp32 + bf16 operand planes for the plane convolution that consumes it)."""
+        K.PlaneTensor (fp32 + bf16 operand planes for the plane convolution that consumes it).  residual_bn: `residual`
+        is the raw output of the downsample convolution and this the saved block of ITS BatchNorm (stats_only): both
+        BatchNorms are applied in this one pass."""
         stats = None
         if isinstance(x, tuple):
             x, stats = x
@@ -184,7 +186,7 @@ class BatchNorm2d(nn.Module):
                              % (tuple(x.shape),))
         out = K.bn_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
                        residual, self.momentum, self.eps, stats if self.training else None,
-                       want_mask=bool(relu and save), planes=planes)
+                       want_mask=bool(relu and save), planes=planes, residual_bn=residual_bn)
         if self.training and tracked is not None:
             tracked.append(self.num_batches_tracked)
         if self._capture is not None and relu:
@@ -192,7 +194,7 @@ class BatchNorm2d(nn.Module):
         # the backward takes the ReLU sign from a 1-bit/element mask, not from the 4-byte activation
         return out[0], ((x, out[2] if relu else None, out[1], self.training) if save else None)
 
-    def stats_only(self, x, tracked=None):
+    def stats_only(self, x, tracked=None, relu_follows=True):
         """Statistics / running-stat update without the apply pass -> (raw x, saved [4, C]); the consumer evaluates
         relu((x - mean) * scale + shift) itself (fused split attention, timm/models/layers/split_attn.py)."""
         stats = None
@@ -205,7 +207,7 @@ class BatchNorm2d(nn.Module):
                            self.momentum, self.eps, stats if self.training else None)
         if self.training and tracked is not None:
             tracked.append(self.num_batches_tracked)
-        if self._capture is not None:                    # test instrumentation: the activation the fused kernels see
+        if self._capture is not None and relu_follows:   # test instrumentation: the activation the fused kernels see
             self._capture[0][self._capture[1]] = K.bn_apply(x, saved, True)
         return x, saved
 

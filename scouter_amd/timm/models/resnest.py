@@ -35,8 +35,8 @@ class ResNestBottleneck(nn.Module):
         sa, ksa = self.conv2.fwd(h1, save, tracked)
         p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
         c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training)
-        res, kd = (x, None) if self.downsample is None else self.downsample.fwd(x, save, tracked)
-        out, b3 = self.bn3.fwd(c3, save, relu=True, residual=res, tracked=tracked)
+        res, rbn, kd = (x, None, None) if self.downsample is None else self.downsample.fwd(x, save, tracked)
+        out, b3 = self.bn3.fwd(c3, save, relu=True, residual=res, tracked=tracked, residual_bn=rbn)
         return out, ((k1, b1, ksa, tuple(sa.shape), k3, b3, kd) if save else None)
 
     def out_fuse(self, ctx):

@@ -32,6 +32,9 @@ class Downsample(nn.Sequential):
     """downsample_conv: [conv1x1(stride), bn]   downsample_avg: [pool | Identity, conv1x1, bn]"""
 
     def fwd(self, x, save, tracked):
+        """-> (raw convolution output, saved block of the BatchNorm, ctx): the BatchNorm itself is applied by the
+        block's last BatchNorm pass together with its own (BatchNorm2d.fwd residual_bn) -- the normalised shortcut is
+        never stored.  ctx[1] has the layout of a BatchNorm2d context (x, mask = None, saved, training)."""
         mods = list(self)
         pool = None
         if len(mods) == 3:
@@ -39,8 +42,9 @@ class Downsample(nn.Sequential):
             mods = mods[1:]
         xin = pool.fwd(x) if pool is not None else x
         c, c_conv = mods[0].fwd(xin, save, bn_stats=mods[1].training)
-        y, c_bn = mods[1].fwd(c, save, relu=False, tracked=tracked)
-        return y, ((c_conv, c_bn, pool, tuple(x.shape)) if save else None)
+        craw, saved = mods[1].stats_only(c, tracked, relu_follows=False)
+        c_bn = (craw, None, saved, mods[1].training)
+        return craw, saved, ((c_conv, c_bn, pool, tuple(x.shape)) if save else None)
 
     def bwd(self, dy, ctx, need_dx, fused=None):
         c_conv, c_bn, pool, x_shape = ctx
@@ -72,8 +76,8 @@ class BasicBlock(nn.Module):
         c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
         h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked)
         c2, k2 = self.conv2.fwd(h1, save, bn_stats=self.bn2.training)
-        res, kd = (x, None) if self.downsample is None else self.downsample.fwd(x, save, tracked)
-        out, b2 = self.bn2.fwd(c2, save, relu=True, residual=res, tracked=tracked)
+        res, rbn, kd = (x, None, None) if self.downsample is None else self.downsample.fwd(x, save, tracked)
+        out, b2 = self.bn2.fwd(c2, save, relu=True, residual=res, tracked=tracked, residual_bn=rbn)
         return out, ((k1, b1, k2, b2, kd) if save else None)
 
     def out_fuse(self, ctx):
