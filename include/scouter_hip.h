@@ -158,6 +158,16 @@ int scouter_maxpool_fwd_f32(const float* x, float* y, unsigned char* argmax, int
                             int stride, int pad, void* stream);
 int scouter_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, float* dx, int B, int H, int W, int C, int k,
                             int stride, int pad, void* stream);
+/* BatchNorm + ReLU + MaxPool2d fused in both directions (the stem: bn1, act1, maxpool -- timm/models/resnet.py:404-412,
+ * 494-496).  bn_saved = the [4][C] block {mean, rstd, scale, shift} finalised by scouter_bn_fwd_f32(y = NULL).
+ * fwd: y = maxpool(relu(bn(x))) and the arg-max taps; the activation and its sign mask are never stored.
+ * bwd: dy = gradient of the pooled tensor -> dx = gradient of the BatchNorm INPUT, dgamma / dbeta (may be NULL);
+ * workspace scouter_colreduce_workspace_bytes(B*Ho*Wo, C) + 2*C*4 bytes; stride 1 / 2. */
+int scouter_bn_maxpool_fwd_f32(const float* x, const float* bn_saved, float* y, unsigned char* argmax, int B, int H, int W,
+                               int C, int k, int stride, int pad, void* stream);
+int scouter_bn_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, const float* x, const float* bn_saved, int B,
+                               int H, int W, int C, int k, int stride, int pad, int training, float* dgamma,
+                               float* dbeta, float* dx, void* ws, size_t ws_bytes, void* stream);
 int scouter_avgpool_fwd_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride, int pad,
                             int ceil_mode, int count_include_pad, void* stream);
 int scouter_avgpool_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, int k, int stride, int pad,

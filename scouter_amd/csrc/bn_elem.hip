@@ -286,8 +286,12 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a,
 struct PoolGeom { int B, H, W, C, Ho, Wo, k, stride, pad, count_pad; };
 
 // max pool: first maximum in (ky,kx) scan order wins (PyTorch CPU semantics); argmax tap stored as uint8
+// bn (optional): saved block [mean, rstd, scale, shift][C] of the BatchNorm in front of the pool -- the windows are taken
+// over relu(bn(x)) evaluated on the fly (the stem's bn1 + act1 + maxpool, resnet.py:404-412: the 4-byte activation and
+// its sign mask are never stored; same fma as the apply pass, so values and the first-maximum choice are identical)
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                          unsigned char* __restrict__ arg, PoolGeom g) {
+                                                          unsigned char* __restrict__ arg, PoolGeom g,
+                                                          const float* __restrict__ bn) {
     const int c4n = g.C / 4;
     const long n = (long)g.B * g.Ho * g.Wo * c4n;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -298,13 +302,20 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         const int b = (int)(p / g.Ho);
         f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bi[4] = {0, 0, 0, 0};
+        f32x4 mu = {0, 0, 0, 0}, sc = mu, sh = mu;
+        if (bn) { mu = *(const f32x4*)(bn + c); sc = *(const f32x4*)(bn + 2 * g.C + c); sh = *(const f32x4*)(bn + 3 * g.C + c); }
         for (int ky = 0; ky < g.k; ++ky) {
             const int iy = oy * g.stride - g.pad + ky;
             if (iy < 0 || iy >= g.H) continue;
             for (int kx = 0; kx < g.k; ++kx) {
                 const int ix = ox * g.stride - g.pad + kx;
                 if (ix < 0 || ix >= g.W) continue;
-                const f32x4 v = *(const f32x4*)(x + (((long)b * g.H + iy) * g.W + ix) * g.C + c);
+                f32x4 v = *(const f32x4*)(x + (((long)b * g.H + iy) * g.W + ix) * g.C + c);
+                if (bn) {
+                    v = bn_affine(v, mu, sc, sh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = ky * g.k + kx; }
@@ -419,10 +430,16 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 // modulo and a division each.  The generic kernels above spent ~900 VALU instructions per 16-byte result on 64-bit
 // index arithmetic, tap tests and 16 divisions (3.0 TB/s); these are memory-bound.  avg: dy * (1 / divisor), the
 // reciprocal taken once per window (within 1 ulp of PyTorch's dy / divisor).
+// bnx / bn / coef (optional, max pool): the pool input was relu(bn(bnx)) evaluated on the fly in the forward -- the gathered
+// gradient is masked by [bn(bnx) > 0] and pushed through the BatchNorm backward in the same pass:
+// dx = scale * (g - c1 - xhat * c2), coef = [c1 | c2][C] from bn_bwd_finalize_kernel.
 template <int S, bool MAXP>
 __global__ __launch_bounds__(256) void pool_bwd_rows_kernel(const float* __restrict__ dy,
                                                             const unsigned char* __restrict__ arg,
-                                                            float* __restrict__ dx, PoolGeom g, float inv_c4n) {
+                                                            float* __restrict__ dx, PoolGeom g, float inv_c4n,
+                                                            const float* __restrict__ bnx,
+                                                            const float* __restrict__ bn,
+                                                            const float* __restrict__ coef) {
     const int c4n = g.C / 4;
     const int xid = blockIdx.x * 256 + threadIdx.x;
     if (xid >= g.W * c4n) return;
@@ -450,17 +467,88 @@ __global__ __launch_bounds__(256) void pool_bwd_rows_kernel(const float* __restr
             }
         }
     }
-    *(f32x4*)(dx + ((long)row * g.W + ix) * g.C + cq * 4) = acc;
+    const long off = ((long)row * g.W + ix) * g.C + cq * 4;
+    if (MAXP && bn) {
+        const int c = cq * 4;
+        const f32x4 xv = *(const f32x4*)(bnx + off);
+        const f32x4 mu = *(const f32x4*)(bn + c), rs = *(const f32x4*)(bn + g.C + c), sc = *(const f32x4*)(bn + 2 * g.C + c),
+                    sh = *(const f32x4*)(bn + 3 * g.C + c);
+        const f32x4 k1 = *(const f32x4*)(coef + c), k2 = *(const f32x4*)(coef + g.C + c);
+        const f32x4 hv = bn_affine(xv, mu, sc, sh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = hv[e] > 0.f ? acc[e] : 0.f;
+        const f32x4 xh = (xv - mu) * rs;
+        acc = sc * (acc - k1 - xh * k2);
+    }
+    *(f32x4*)(dx + off) = acc;
 }
 
-template <bool MAXP>
-static bool pool_bwd_rows(const float* dy, const unsigned char* arg, float* dx, const PoolGeom& g, hipStream_t st) {
+// Reduction pass of the fused BatchNorm + ReLU + max-pool backward: g is non-zero only at the arg-max positions, so
+// sum g and sum g * xhat run over the POOLED grid (a quarter of the elements), gathering x at each window's arg-max.
+__global__ __launch_bounds__(256) void bn_maxpool_bwd_partial_kernel(const float* __restrict__ dy,
+                                                                     const unsigned char* __restrict__ arg,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ bn,
+                                                                     double* __restrict__ part, PoolGeom g, ColGeom cg) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x;
+    const int cq = tid % cg.tpr, rl = tid / cg.tpr;
+    const int c = blockIdx.y * cg.cslab + cq * 4;
+    double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+    if (rl < cg.rpb && c < g.C) {
+        const f32x4 mu = *(const f32x4*)(bn + c), rs = *(const f32x4*)(bn + g.C + c), sc = *(const f32x4*)(bn + 2 * g.C + c),
+                    sh = *(const f32x4*)(bn + 3 * g.C + c);
+        const long rstep = (long)gridDim.x * cg.rpb;
+        const int hwo = g.Ho * g.Wo;
+        for (long r = (long)blockIdx.x * cg.rpb + rl; r < cg.M; r += rstep) {
+            const int b = (int)(r / hwo), rem = (int)(r - (long)b * hwo), oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            const f32x4 d = *(const f32x4*)(dy + r * g.C + c);
+            const uchar4 a = *(const uchar4*)(arg + r * g.C + c);
+            const int taps[4] = {a.x, a.y, a.z, a.w};
+            f32x4 xv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ky = taps[e] / g.k, kx = taps[e] - ky * g.k;
+                const int iy = oy * g.stride - g.pad + ky, ix = ox * g.stride - g.pad + kx;
+                xv[e] = x[(((long)b * g.H + iy) * g.W + ix) * g.C + c + e];
+            }
+            const f32x4 hv = bn_affine(xv, mu, sc, sh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = hv[e] > 0.f ? d[e] : 0.f;
+                s[e] += gg;
+                t[e] += (double)gg * ((xv[e] - mu[e]) * rs[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = s[k]; red[tid * 8 + 4 + k] = t[k]; }
+    __syncthreads();
+    if (rl == 0 && c < g.C) {
+        for (int j = 1; j < cg.rpb; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += red[(j * cg.tpr + cq) * 8 + k]; t[k] += red[(j * cg.tpr + cq) * 8 + 4 + k]; }
+        double* o = part + ((long)blockIdx.x * g.C + c) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k * 2] = s[k]; o[k * 2 + 1] = t[k]; }
+    }
+}
+
+static bool pool_bwd_rows_ok(const PoolGeom& g) {
     const long xw = (long)g.W * (g.C / 4), rows = (long)g.B * g.H;
-    if ((g.stride != 1 && g.stride != 2) || xw >= (1 << 20) || rows > 65535) return false;
+    return (g.stride == 1 || g.stride == 2) && xw < (1 << 20) && rows <= 65535;
+}
+template <bool MAXP>
+static bool pool_bwd_rows(const float* dy, const unsigned char* arg, float* dx, const PoolGeom& g, hipStream_t st,
+                          const float* bnx = nullptr, const float* bn = nullptr, const float* coef = nullptr) {
+    const long xw = (long)g.W * (g.C / 4), rows = (long)g.B * g.H;
+    if (!pool_bwd_rows_ok(g)) return false;
     dim3 grid((unsigned)((xw + 255) / 256), (unsigned)rows);
     const float inv = 1.0f / (float)(g.C / 4);
-    if (g.stride == 1) hipLaunchKernelGGL((pool_bwd_rows_kernel<1, MAXP>), grid, dim3(256), 0, st, dy, arg, dx, g, inv);
-    else hipLaunchKernelGGL((pool_bwd_rows_kernel<2, MAXP>), grid, dim3(256), 0, st, dy, arg, dx, g, inv);
+    if (g.stride == 1)
+        hipLaunchKernelGGL((pool_bwd_rows_kernel<1, MAXP>), grid, dim3(256), 0, st, dy, arg, dx, g, inv, bnx, bn, coef);
+    else
+        hipLaunchKernelGGL((pool_bwd_rows_kernel<2, MAXP>), grid, dim3(256), 0, st, dy, arg, dx, g, inv, bnx, bn, coef);
     return true;
 }
 
@@ -727,8 +815,51 @@ extern "C" int scouter_maxpool_fwd_f32(const float* x, float* y, unsigned char* 
                                        int k, int stride, int pad, void* stream) {
     const int ceil_mode = 0, count_include_pad = 0;
     POOL_SETUP("maxpool_fwd")
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 4)), dim3(256), 0, st, x, y, argmax, g);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 4)), dim3(256), 0, st, x, y, argmax, g,
+                       (const float*)nullptr);
     return sc_check_launch("maxpool_fwd");
+}
+
+// ---- BatchNorm + ReLU + MaxPool2d in one pass each way (the stem: bn1, act1, maxpool -- resnet.py:404-412, 494-496).
+// bn_saved = [4][C] block (mean, rstd, scale, shift) finalised by scouter_bn_fwd_f32(y = NULL).  Forward: pooled
+// relu(bn(x)) and the arg-max taps; the activation and its sign mask are never stored.  Backward: dy (pooled gradient)
+// -> dx of the BatchNorm input, dgamma / dbeta; the ReLU sign is re-evaluated with the same fma.
+extern "C" int scouter_bn_maxpool_fwd_f32(const float* x, const float* bn_saved, float* y, unsigned char* argmax, int B,
+                                          int H, int W, int C, int k, int stride, int pad, void* stream) {
+    const int ceil_mode = 0, count_include_pad = 0;
+    SC_REQUIRE(x && bn_saved && y, "bn_maxpool_fwd: null pointer");
+    POOL_SETUP("bn_maxpool_fwd")
+    ScProfScope prof("bn_maxpool_fwd", st, 0, 4.0 * ((double)B * H * W * C + (double)B * g.Ho * g.Wo * C * 1.25));
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 4)), dim3(256), 0, st, x, y, argmax, g,
+                       bn_saved);
+    return sc_check_launch("bn_maxpool_fwd");
+}
+extern "C" int scouter_bn_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, const float* x,
+                                          const float* bn_saved, int B, int H, int W, int C, int k, int stride, int pad,
+                                          int training, float* dgamma, float* dbeta, float* dx, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    const int ceil_mode = 0, count_include_pad = 0;
+    SC_REQUIRE(dy && argmax && x && bn_saved && dx, "bn_maxpool_bwd: null pointer");
+    POOL_SETUP("bn_maxpool_bwd")
+    SC_UNSUPPORTED(pool_bwd_rows_ok(g), "bn_maxpool_bwd: stride 1 / 2, B*H <= 65535 only");
+    const long Mp = (long)B * g.Ho * g.Wo;
+    ColGeom cg = col_geom(Mp, C);
+    SC_REQUIRE(cg.cslab % 4 == 0 && 256 % cg.tpr == 0, "bn_maxpool_bwd: unsupported channel count %d", C);
+    const int nb = col_blocks(Mp, cg);
+    const size_t coef_off = (size_t)nb * C * 2 * sizeof(double);
+    if (!ws || ws_bytes < coef_off + 2 * (size_t)C * sizeof(float)) {
+        sc_set_error("bn_maxpool_bwd: workspace too small");
+        return SC_ERR_WORKSPACE;
+    }
+    float* coef = (float*)((char*)ws + coef_off);
+    ScProfScope prof("bn_maxpool_bwd(reduce+finalize+apply)", st, 0,
+                     8.0 * (double)B * H * W * C + 9.0 * (double)Mp * C);
+    dim3 pgrid(nb, (C + cg.cslab - 1) / cg.cslab);
+    hipLaunchKernelGGL(bn_maxpool_bwd_partial_kernel, pgrid, dim3(256), 0, st, dy, argmax, x, bn_saved, (double*)ws, g, cg);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb,
+                       (long)B * H * W, C, training, dgamma, dbeta, coef, coef + C);
+    pool_bwd_rows<true>(dy, argmax, dx, g, st, x, bn_saved, coef);
+    return sc_check_launch("bn_maxpool_bwd");
 }
 extern "C" int scouter_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, float* dx, int B, int H, int W,
                                        int C, int k, int stride, int pad, void* stream) {

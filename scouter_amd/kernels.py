@@ -610,6 +610,30 @@ def maxpool_bwd(dy, arg, x_shape, k=3, stride=2, pad=1):
     return dx
 
 
+def bn_maxpool_fwd(x, saved, k=3, stride=2, pad=1, want_argmax=True):
+    """maxpool(relu(bn(x))) with the BatchNorm applied on the fly from its saved block (bn_stats): the activation is
+    never stored.  Returns (pooled, argmax taps)."""
+    _chk(x, "x"); _chk(saved, "saved")
+    B, H, W, C = x.shape
+    y = torch.empty((B, pool_out(H, k, stride, pad), pool_out(W, k, stride, pad), C), dtype=F32, device=x.device)
+    arg = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if want_argmax else None
+    _native.check(_native.lib().scouter_bn_maxpool_fwd_f32(_p(x), _p(saved), _p(y), _p(arg), B, H, W, C, k, stride, pad,
+                                                           _stream()), "bn_maxpool_fwd")
+    return y, arg
+
+
+def bn_maxpool_bwd(dy, arg, x, saved, training, dgamma=None, dbeta=None, k=3, stride=2, pad=1):
+    """Backward of bn_maxpool_fwd: pooled gradient -> gradient of the BatchNorm input (+ dgamma, dbeta in place)."""
+    _chk(dy, "dy"); _chk(x, "x")
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    ws = _col_ws(dy.numel() // C, C, x.device)
+    _native.check(_native.lib().scouter_bn_maxpool_bwd_f32(
+        _p(dy), _p(arg), _p(x), _p(saved), B, H, W, C, k, stride, pad, int(training), _p(dgamma), _p(dbeta), _p(dx),
+        _p(ws), ws.numel(), _stream()), "bn_maxpool_bwd")
+    return dx
+
+
 def avgpool_fwd(x, k, stride, pad, ceil_mode, count_include_pad):
     _chk(x, "x")
     B, H, W, C = x.shape

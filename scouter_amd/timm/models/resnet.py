@@ -2,6 +2,8 @@
 (downsample_conv / downsample_avg), :380-509 (ResNet) of the reference for the configurations the xSlot path
 uses: stem '' (7x7, or the MNIST 3x3 1-channel stem swapped in by sloter/slot_model.py:23-24) and 'deep'
 (32-32-64), output stride 32, no drop-path / drop-block / anti-aliasing.  Activations are NHWC internally."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -116,6 +118,7 @@ class ResNet(nn.Module):
         self.act1 = Act()
         self.maxpool = Identity()      # MaxPool2d(3, 2, 1) runs in scouter_maxpool_*_f32
         self._capture = None           # test instrumentation: (dict, key) -> the max-pool window indices go there
+        self.fuse_stem_pool = os.environ.get("SCOUTER_FUSE_STEM_POOL", "1") == "1"   # bn1 + act1 + maxpool in one pass
         chans, strides = [64, 128, 256, 512], [1, 2, 2, 2]
         for i in range(4):
             setattr(self, "layer%d" % (i + 1), self._make_layer(block, chans[i], layers[i], strides[i], avg_down,
@@ -156,11 +159,18 @@ class ResNet(nn.Module):
         else:
             c, k0 = self.conv1.fwd(x_nchw, save, bn_stats=self.bn1.training)
             ctx.append((k0,))
-        h, bb = self.bn1.fwd(c, save, relu=True, tracked=tracked)
-        p, arg = K.maxpool_fwd(h, 3, 2, 1, want_argmax=save)
+        # bn1 + act1 + maxpool in one pass: only bn1's statistics are finalised, relu(bn1(c)) is evaluated inside the
+        # pooling windows (and again, with the same fma, in the backward) -- the 112x112 activation is never stored
+        if self.fuse_stem_pool:
+            craw, saved = self.bn1.stats_only(c, tracked)
+            p, arg = K.bn_maxpool_fwd(craw, saved, 3, 2, 1, want_argmax=save)
+            ctx.append((craw, saved, self.bn1.training, arg))
+        else:
+            h, bb = self.bn1.fwd(c, save, relu=True, tracked=tracked)
+            p, arg = K.maxpool_fwd(h, 3, 2, 1, want_argmax=save)
+            ctx.append((bb, arg, tuple(h.shape)))
         if self._capture is not None and arg is not None:
             self._capture[0][self._capture[1]] = arg
-        ctx.append((bb, arg, tuple(h.shape)))
         x = p
         for li in range(1, 5):
             for blk in getattr(self, "layer%d" % li):
@@ -204,9 +214,13 @@ class ResNet(nn.Module):
                 on_stage_done("layer%d" % li)
         if first > 0:
             return
-        bb, arg, hshape = ctx[1]
-        dh = K.maxpool_bwd(d, arg, hshape, 3, 2, 1)
-        dc, _ = self.bn1.bwd(dh, bb)
+        if len(ctx[1]) == 4:
+            craw, saved, training1, arg = ctx[1]
+            dc = K.bn_maxpool_bwd(d, arg, craw, saved, training1, self.bn1._dg, self.bn1._db, 3, 2, 1)
+        else:
+            bb, arg, hshape = ctx[1]
+            dh = K.maxpool_bwd(d, arg, hshape, 3, 2, 1)
+            dc, _ = self.bn1.bwd(dh, bb)
         if isinstance(self.conv1, nn.Sequential):
             s = self.conv1
             k0, b0, k1, b1, k2 = ctx[0]

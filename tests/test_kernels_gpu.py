@@ -488,3 +488,36 @@ def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision, mo
             assert float((a - b).abs().max()) <= 2e-6 * sc + 1e-7, (t, float((a - b).abs().max()), sc)
     if precision != "planes":
         kk._tile_cache.clear()
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("shape", [(3, 17, 13, 64), (2, 28, 28, 32), (5, 8, 8, 128)])
+def test_batchnorm_relu_maxpool_fused(shape, training):
+    """bn_maxpool_fwd / _bwd == BatchNorm apply (+ReLU, sign mask) -> MaxPool2d(3, 2, 1) and their backward chain, the
+    stem's bn1 + act1 + maxpool (resnet.py:404-412): pooled values and arg-max taps bit for bit (same fma, same
+    first-maximum rule incl. the many exact-zero ties ReLU creates), gradients to fp32 rounding of the fp64 sums."""
+    B, H, W, C = shape
+    kk = K()
+    rng = np.random.default_rng(B * H + C)
+    x = torch.from_numpy(rng.standard_normal(shape) * 1.3 - 0.2).float().cuda()
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, C)).float().cuda()
+    beta = torch.from_numpy(rng.standard_normal(C) * 0.3).float().cuda()
+    rm = torch.from_numpy(rng.standard_normal(C) * 0.1).float().cuda()
+    rv = torch.from_numpy(rng.uniform(0.5, 1.5, C)).float().cuda()
+    # unfused chain
+    h, saved, mask = kk.bn_fwd(x, gamma, beta, rm.clone(), rv.clone(), training, True, want_mask=True)
+    p_ref, arg_ref = kk.maxpool_fwd(h, 3, 2, 1)
+    dp = torch.from_numpy(rng.standard_normal(tuple(p_ref.shape))).float().cuda()
+    dh = kk.maxpool_bwd(dp, arg_ref, tuple(h.shape), 3, 2, 1)
+    dg_ref, db_ref = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx_ref, _ = kk.bn_bwd(dh, None, x, saved, training, dg_ref, db_ref, mask=mask)
+    # fused
+    saved2 = kk.bn_stats(x, gamma, beta, rm.clone(), rv.clone(), training)
+    assert torch.equal(saved2, saved)
+    p, arg = kk.bn_maxpool_fwd(x, saved2, 3, 2, 1)
+    assert torch.equal(p, p_ref) and torch.equal(arg, arg_ref)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = kk.bn_maxpool_bwd(dp, arg, x, saved2, training, dg, db, 3, 2, 1)
+    for a, b in ((dx, dx_ref), (dg, dg_ref), (db, db_ref)):
+        sc = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * sc + 1e-7, (float((a - b).abs().max()), sc)
