@@ -133,7 +133,8 @@ int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, 
                        int training, int relu, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
                        const double* ext_partial, int ext_rows, unsigned long long* relu_mask_out, void* planes_out,
                        int nplanes, const float* residual_bn_saved, void* ws, size_t ws_bytes, void* stream);
-/* y == NULL in scouter_bn_fwd_f32: statistics / running-stat update only.  scouter_bn_apply_f32: the apply pass alone
+/* y == NULL in scouter_bn_fwd_f32: with planes_out the apply pass writes the planes only (every consumer reads planes: 6
+ * instead of 10 bytes per element); without, statistics / running-stat update only.  scouter_bn_apply_f32: the apply pass alone
  * from a saved block [4][C] = {mean, rstd, scale, shift} (contiguous rows, as written through the four *_out pointers). */
 int scouter_bn_apply_f32(const float* x, const float* bn_saved, float* y, long M, int C, int relu, void* stream);
 /* g = dy * (y > 0), the sign taken from relu_mask if given, else from ymask (both may be NULL: no ReLU);

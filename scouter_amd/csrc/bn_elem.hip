@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         }
-        *(f32x4*)(y + i * 4) = v;
+        if (y) *(f32x4*)(y + i * 4) = v;                               // (NULL: the consumers read the planes only)
         if (planes) store_planes4(planes, n4 * 4, nplanes, i, v);     // operand planes of the consuming plane convolution
     }
 }
@@ -598,7 +598,7 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
                                   const float* residual_bn_saved, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(x && mean_out && rstd_out && scale_out && shift_out, "bn_fwd: null pointer");   // y == NULL: statistics only
     SC_REQUIRE(!residual_bn_saved || residual, "bn_fwd: residual_bn_saved without residual");
-    SC_REQUIRE(!planes_out || (y && (nplanes == 1 || nplanes == 3)), "bn_fwd: planes_out needs y and 1 or 3 planes");
+    SC_REQUIRE(!planes_out || nplanes == 1 || nplanes == 3, "bn_fwd: planes_out needs 1 or 3 planes");
     SC_REQUIRE(!relu_mask_out || relu, "bn_fwd: relu_mask_out without relu");
     SC_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
     COL_CHECKS("bn_fwd")
@@ -614,7 +614,7 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
                        gamma, beta, running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out,
                        shift_out);
     const long n4 = M * C / 4;
-    if (y)       // y == NULL: the consumer applies (x - mean) * scale + shift itself (fused split attention)
+    if (y || planes_out)       // neither: the consumer applies (x - mean) * scale + shift itself (fused split attention)
         hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, scale_out,
                                shift_out, residual, y, relu_mask_out, n4, C, relu, (unsigned short*)planes_out, nplanes,
                                residual_bn_saved);
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __res
         const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, C, Cp, inv_hw, x, mu, sc, sh);
         const f32x4 xh = (x - mu) * rs;
         const f32x4 o = sc * (gg - *(const f32x4*)(c1 + c) - xh * *(const f32x4*)(c2 + c));
-        *(f32x4*)(dx + i * 4) = o;
+        if (dx) *(f32x4*)(dx + i * 4) = o;                              // (NULL: dgrad and wgrad both run on the planes)
         if (planes) store_planes4(planes, n4 * 4, nplanes, i, o);      // A operand of the plane input-gradient kernel
     }
 }
@@ -747,7 +747,8 @@ extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const fl
                                      const float* bn_saved, int B, int HW, int Cp, int training, float* dgamma,
                                      float* dbeta, float* dx, void* dx_planes, int nplanes, void* ws, size_t ws_bytes,
                                      void* stream) {
-    SC_REQUIRE(dout && a && dgap && x0 && bn_saved && dx && B > 0 && HW > 0 && Cp % 4 == 0, "sa_bn_bwd: bad arguments");
+    SC_REQUIRE(dout && a && dgap && x0 && bn_saved && (dx || dx_planes) && B > 0 && HW > 0 && Cp % 4 == 0,
+               "sa_bn_bwd: bad arguments");
     const long M = (long)B * HW;
     const int C = 2 * Cp;
     SC_UNSUPPORTED(M < (1L << 31), "sa_bn_bwd: more than 2^31 pixels per batch");

@@ -246,8 +246,8 @@ BF16 = torch.bfloat16
 
 
 class PlaneTensor:
-    """An activation held twice: `f32` (NHWC fp32, what the weight-gradient kernel and the elementwise passes read) and
-    `planes` ([np, B, H, W, C] bf16, the A operand of the plane convolutions).  Produced by bn_fwd(planes=np) and
+    """An activation as `planes` ([np, B, H, W, C] bf16, the operand of the plane convolutions) and, unless every
+    consumer runs on planes, also as `f32` (NHWC fp32; None otherwise).  Produced by bn_fwd(planes=np) and
     sa_bn_bwd(planes=np)."""
     __slots__ = ("f32", "planes")
 
@@ -256,11 +256,11 @@ class PlaneTensor:
 
     @property
     def shape(self):
-        return self.f32.shape
+        return self.planes.shape[1:]
 
     @property
     def device(self):
-        return self.f32.device
+        return self.planes.device
 
 
 def planes_split(x, nplanes=3):
@@ -517,14 +517,14 @@ def bn_apply(x, saved, relu):
 
 
 def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=None, momentum=0.1, eps=1e-5,
-           stats=None, want_mask=False, planes=0, residual_bn=None):
+           stats=None, want_mask=False, planes=0, residual_bn=None, keep_f32=True):
     """x: [..., C] NHWC.  Returns (y, saved) with saved = (mean, rstd, scale, shift) packed as one [4, C] tensor.
     stats = (partial, rows) from conv2d_fwd(bn_stats=True) replaces the statistics pass over x.
     want_mask (with relu): returns (y, saved, mask) -- the 1-bit/element sign mask bn_bwd takes instead of y."""
     _chk(x, "x"); _chk(residual, "residual")
     C = x.shape[-1]
     M = x.numel() // C
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if keep_f32 or not planes else None      # keep_f32=False: planes only
     saved = torch.empty((4, C), dtype=F32, device=x.device)
     ws = _col_ws(M, C, x.device)
     mask = None
@@ -696,11 +696,12 @@ def sa_dattn(x, dout, bn=None):
     return out
 
 
-def sa_bn_bwd(dout, a, dgap, x0, bn, training, dgamma=None, dbeta=None, planes=0):
+def sa_bn_bwd(dout, a, dgap, x0, bn, training, dgamma=None, dbeta=None, planes=0, keep_f32=True):
     """Backward of [bn0 -> ReLU -> split-attention weighting / GAP] in one fused chain: returns the gradient w.r.t. the
-    radix convolution's raw output x0 [B, H, W, 2C'] (a PlaneTensor when `planes`) and fills dgamma / dbeta."""
+    radix convolution's raw output x0 [B, H, W, 2C'] (a PlaneTensor when `planes`; keep_f32=False: planes only) and fills
+    dgamma / dbeta."""
     B, H, W, Cp = dout.shape
-    dx = torch.empty_like(x0)
+    dx = torch.empty_like(x0) if keep_f32 or not planes else None
     dxp = torch.empty((planes,) + tuple(x0.shape), dtype=BF16, device=x0.device) if planes else None
     ws = _col_ws(B * H * W, 2 * Cp, x0.device)
     _native.check(_native.lib().scouter_sa_bn_bwd_f32(_p(dout), _p(a), _p(dgap), _p(x0), _p(bn), B, H * W, Cp,

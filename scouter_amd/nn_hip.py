@@ -61,6 +61,12 @@ class Conv2d(nn.Module):
         n = self._nplanes()
         return n if n and self.stride == 1 and ng % 32 == 0 and cg % 64 == 0 else 0
 
+    def planes_only(self, H, W):
+        """True if forward, input gradient AND weight gradient of this layer all run on planes for an H x W map: its
+        producers then need not write the fp32 copy of the tensor at all."""
+        return bool(self.bias is None and self.planes_in() and self.planes_dy() and self.planes_wgrad() and
+                    32 // W + 1 < H)
+
     def planes_wgrad(self):
         """Weight gradient on planes too (same-size convolution, 64-multiples of channels per group)."""
         cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
@@ -77,7 +83,8 @@ class Conv2d(nn.Module):
                                     bn_stats)
             if self._capture is not None and relu:
                 self._capture[0][self._capture[1]] = y
-            return y, ((x.f32, wd, x.planes if self.planes_wgrad() else None) if save else None)
+            return y, ((x.f32 if x.f32 is not None else tuple(x.shape), wd,
+                        x.planes if self.planes_wgrad() else None) if save else None)
         y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
                          bn_stats, precision=self.precision)
         if self._capture is not None and relu:
@@ -95,26 +102,31 @@ class Conv2d(nn.Module):
         dyp = None
         if isinstance(dy, K.PlaneTensor):
             dy, dyp = dy.f32, dy.planes
+        xshape = x if isinstance(x, tuple) else tuple(x.shape)       # (a shape only: the producer wrote planes only)
+        xt = None if isinstance(x, tuple) else x
+        dev = dy.device if dy is not None else dyp.device
         if need_dx and dyp is not None and wd is not None:
             k = self.kernel_size
-            dx = K.conv2d_dgrad_planes(dyp, wd, tuple(x.shape), k, k, self.stride, self.padding, self.groups, addend,
-                                       post=post)
+            dx = K.conv2d_dgrad_planes(dyp, wd, xshape, k, k, self.stride, self.padding, self.groups, addend, post=post)
             need_dx = False
         else:
             dx = None
         if self._dw is not None or self._db is not None:
             # weight / bias gradients: off the critical path
-            with K.side_stream(dy.device, x, dy, xp, dyp, enabled=self.use_side_stream):
+            with K.side_stream(dev, xt, dy, xp, dyp, enabled=self.use_side_stream):
                 # (the plane kernel's branch-free pixel walk needs maps that are not tiny: 32 // W + 1 < H)
-                if self._dw is not None and xp is not None and dyp is not None and 32 // x.shape[2] + 1 < x.shape[1]:
+                if self._dw is not None and xp is not None and dyp is not None and 32 // xshape[2] + 1 < xshape[1]:
                     K.conv2d_wgrad_planes(xp, dyp, self._dw, self.padding, self.groups)
                 elif self._dw is not None:
-                    K.conv2d_wgrad(x, dy, self._dw, self.stride, self.padding, self.groups, precision=self.precision)
+                    if xt is None or dy is None:
+                        raise RuntimeError("Conv2d.bwd: the fp32 operands were dropped (planes_only) but the weight "
+                                           "gradient cannot run on planes for this shape")
+                    K.conv2d_wgrad(xt, dy, self._dw, self.stride, self.padding, self.groups, precision=self.precision)
                 if self._db is not None:
                     K.colsum(dy, self._db)
         if not need_dx:
             return dx
-        return K.conv2d_dgrad(dy, K.hwio(self.weight), tuple(x.shape), addend, self.stride, self.padding, self.groups,
+        return K.conv2d_dgrad(dy, K.hwio(self.weight), xshape, addend, self.stride, self.padding, self.groups,
                               precision=self.precision, post=post)
 
 
@@ -173,7 +185,7 @@ class BatchNorm2d(nn.Module):
         self._dg = self._db = None
         self._capture = None                 # test instrumentation: (dict, key) -> the ReLU'd output is stored there
 
-    def fwd(self, x, save, relu=False, residual=None, tracked=None, planes=0, residual_bn=None):
+    def fwd(self, x, save, relu=False, residual=None, tracked=None, planes=0, residual_bn=None, keep_f32=True):
         """x may be the (tensor, stats) pair a conv produced with bn_stats=True.  planes = 1 / 3: the output is a
         K.PlaneTensor (fp32 + bf16 operand planes for the plane convolution that consumes it).  residual_bn: `residual`
         is the raw output of the downsample convolution and this the saved block of ITS BatchNorm (stats_only): both
@@ -186,11 +198,12 @@ class BatchNorm2d(nn.Module):
                              % (tuple(x.shape),))
         out = K.bn_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
                        residual, self.momentum, self.eps, stats if self.training else None,
-                       want_mask=bool(relu and save), planes=planes, residual_bn=residual_bn)
+                       want_mask=bool(relu and save), planes=planes, residual_bn=residual_bn, keep_f32=keep_f32)
         if self.training and tracked is not None:
             tracked.append(self.num_batches_tracked)
         if self._capture is not None and relu:
-            self._capture[0][self._capture[1]] = out[0].f32 if isinstance(out[0], K.PlaneTensor) else out[0]
+            o = out[0].f32 if isinstance(out[0], K.PlaneTensor) else out[0]
+            self._capture[0][self._capture[1]] = o if o is not None else K.bn_apply(x, out[1], True)
         # the backward takes the ReLU sign from a 1-bit/element mask, not from the 4-byte activation
         return out[0], ((x, out[2] if relu else None, out[1], self.training) if save else None)
 

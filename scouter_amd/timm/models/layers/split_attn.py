@@ -49,6 +49,8 @@ class SplitAttnConv2d(nn.Module):
         dg1 = self.fc2.bwd(dz2.view(B, 1, 1, -1), c_fc2, True)
         dz1, _ = self.bn1.bwd(dg1, c_bn1)
         dgap = self.fc1.bwd(dz1, c_fc1, True)
+        on_planes = isinstance(c_conv, tuple) and c_conv[1] is not None
+        only = on_planes and c_conv[2] is not None and self.conv.planes_only(x0.shape[1], x0.shape[2])
         dc = K.sa_bn_bwd(dout, a, dgap.view(B, -1), x0, saved0, training0, self.bn0._dg, self.bn0._db,
-                         planes=self.conv.planes_dy() if isinstance(c_conv, tuple) and c_conv[1] is not None else 0)
+                         planes=self.conv.planes_dy() if on_planes else 0, keep_f32=not only)
         return self.conv.bwd(dc, c_conv, True, post=post)

@@ -31,7 +31,10 @@ class ResNestBottleneck(nn.Module):
 
     def fwd(self, x, save, tracked):
         c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
-        h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked, planes=self.conv2.conv.planes_in())
+        t1 = c1[0] if isinstance(c1, tuple) else c1
+        conv = self.conv2.conv                   # (all three of its kernels on planes: no fp32 copy of h1 is written)
+        h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked, planes=conv.planes_in(),
+                              keep_f32=not conv.planes_only(t1.shape[1], t1.shape[2]))
         sa, ksa = self.conv2.fwd(h1, save, tracked)
         p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
         c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training)
