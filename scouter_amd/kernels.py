@@ -230,14 +230,23 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
                          *fuse, st), "conv2d_dgrad")
         return True
 
-    tile = _pick_tile(("dgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch)
     if _fuse_wanted(post, kh):
+        # the fused launch is tuned as what it is (its epilogue reads one or two more tensors: on the short-K layers a
+        # different tile wins than for the plain input gradient); partials sized for the most rows while timing
+        def launch_fused(tile, dry=False):
+            if dry:
+                return launch(tile, dry=True)
+            if not post.applied:
+                post.alloc(-(-B * H * W // 64), x_shape)
+            return launch(tile, fuse=post.args())
+        tile = _pick_tile(("dgrad+bn", len(post.entries), addend is not None, bf16, B, H, W, Cin, Cout, kh, kw, stride,
+                           pad, groups), launch_fused)
         if tile < 0:                              # autotuning disabled: name a tile, the partial rows depend on it
             tile = 2 if (Cin // groups) % 64 == 0 else 3
         post.alloc(-(-B * H * W // (64 if tile == 2 else 128)), x_shape)
         launch(tile, fuse=post.args())
     else:
-        launch(tile)
+        launch(_pick_tile(("dgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch))
     return dx
 
 

@@ -452,8 +452,9 @@ def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision, mo
             _, wdg = kk.planes_split_weight(w, g, 3)
             return kk.conv2d_dgrad_planes(dyp, wdg, (B, H, W, Cin), k, k, 1, pad, g, addend, tile=tile, post=post)
         if tile is not None:
-            kk._tile_cache[("dgrad", precision == "bf16" and B * H * W >= kk.BF16_MIN_PIXELS, B, H, W, Cin, Cout, k, k, 1,
-                            pad, g)] = tile
+            b16 = precision == "bf16" and B * H * W >= kk.BF16_MIN_PIXELS
+            kk._tile_cache[("dgrad", b16, B, H, W, Cin, Cout, k, k, 1, pad, g)] = tile
+            kk._tile_cache[("dgrad+bn", 2 if two else 1, addend is not None, b16, B, H, W, Cin, Cout, k, k, 1, pad, g)] = tile
         return kk.conv2d_dgrad(dy, w, (B, H, W, Cin), addend, 1, pad, g, precision=precision, post=post)
 
     # unfused chain
