@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd,
                                                              const unsigned long long* __restrict__ mbits,
-                                                             double* __restrict__ part, ColGeom g) {
+                                                             double* __restrict__ part, ColGeom g,
+                                                             float* __restrict__ direct_out = nullptr,
+                                                             float direct_alpha = 1.f) {
     __shared__ double red[256 * 8];
     const int tid = threadIdx.x;
     const int cq = tid % g.tpr, rl = tid / g.tpr;
@@ -96,6 +98,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         for (int j = 1; j < g.rpb; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) { s[k] += red[(j * g.tpr + cq) * 8 + k]; t[k] += red[(j * g.tpr + cq) * 8 + 4 + k]; }
+        if (direct_out) {            // single row-block launch (small M): this IS the final sum, no finalize launch
+#pragma unroll
+            for (int k = 0; k < 4; ++k) direct_out[c + k] = (float)(s[k] * (double)direct_alpha);
+            return;
+        }
         double* o = part + ((long)blockIdx.x * g.C + c) * 2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o[k * 2] = s[k]; o[k * 2 + 1] = t[k]; }
@@ -778,6 +785,12 @@ extern "C" int scouter_colsum_f32(const float* a, const float* b, float* out, lo
     SC_REQUIRE(a && out, "colsum: null pointer");
     COL_CHECKS("colsum")
     hipStream_t st = (hipStream_t)stream;
+    if (M <= 4096) {             // bias gradients of the pooled-vector layers, d(initial slots): ONE launch, one row block
+        dim3 sgrid(1, pgrid.y);
+        if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, sgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, nullptr, (double*)ws, g, out, alpha);
+        else hipLaunchKernelGGL(colsum_partial_kernel<2>, sgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)ws, g, out, alpha);
+        return sc_check_launch("colsum");
+    }
     if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, pgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
     else hipLaunchKernelGGL(colsum_partial_kernel<2>, pgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, C, out, alpha);
