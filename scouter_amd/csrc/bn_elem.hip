@@ -785,7 +785,7 @@ extern "C" int scouter_colsum_f32(const float* a, const float* b, float* out, lo
     SC_REQUIRE(a && out, "colsum: null pointer");
     COL_CHECKS("colsum")
     hipStream_t st = (hipStream_t)stream;
-    if (M <= 4096) {             // bias gradients of the pooled-vector layers, d(initial slots): ONE launch, one row block
+    if (M <= (long)g.rpb * 12) {   // few row passes (narrow bias gradients of the pooled-vector layers): ONE launch, one row block
         dim3 sgrid(1, pgrid.y);
         if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, sgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, nullptr, (double*)ws, g, out, alpha);
         else hipLaunchKernelGGL(colsum_partial_kernel<2>, sgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)ws, g, out, alpha);
