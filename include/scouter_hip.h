@@ -261,10 +261,14 @@ int scouter_conv2d_dgrad_planes_bnbwd(const void* dy_planes, const void* w_plane
 
 /* weight gradient on planes: same-size stride-1 convolutions (2 * pad == k - 1), 64-multiples of channels per group;
  * x_planes [nplanes][B*H*W][Cin], dy_planes [nplanes][B*H*W][Cout]; dw HWIO fp32; split-K slabs in ws, summed in a
- * fixed order. */
-size_t scouter_conv2d_wgrad_planes_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int groups);
+ * fixed order.  plan_hint: -1 = static plan; else bits 0-1 = workgroup budget {512, 1024, 2048, 4096}, bit 4 / bit 5 = 64
+ * instead of 128 input / output channels per tile (callers autotune it; every plan is deterministic, different plans
+ * sum the pixels in a different order). */
+size_t scouter_conv2d_wgrad_planes_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int groups,
+                                                   int plan_hint);
 int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_planes, float* dw, int B, int H, int W, int Cin,
-                                int Cout, int kh, int kw, int pad, int groups, int nplanes, void* ws, size_t ws_bytes,
+                                int Cout, int kh, int kw, int pad, int groups, int nplanes, int plan_hint,
+                                void* ws, size_t ws_bytes,
                                 void* stream);
 
 /* ---- optimizer: torch.optim.AdamW defaults (train.py:146).  chunk table = array of {float* param; long offset

@@ -1013,26 +1013,43 @@ __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __
         }
 }
 
-extern "C" size_t scouter_conv2d_wgrad_planes_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw,
-                                                              int groups) {
-    if (groups <= 0 || Cin % groups || Cout % groups) return 0;
-    const long M = (long)B * H * W;
-    const int Cg = Cin / groups, Ng = Cout / groups;
-    const int bm = Cg % 128 == 0 ? 128 : 64, bn = Ng % 128 == 0 ? 128 : 64;
-    const long tiles = (long)(Cg / bm) * (Ng / bn) * groups * kh * kw;
-    long want = 1024 / tiles;
+// (tile, split-K) plan of the plane weight gradient.  plan_hint < 0: static (largest tile, ~1024 workgroups); otherwise
+// (autotuned by the caller) bits 0-1 = workgroup budget {512, 1024, 2048, 4096}, bit 4 / bit 5 = 64 instead of 128 input /
+// output channels per tile.  Every plan is deterministic; different plans sum the pixels in a different order.
+struct PwgPlan { int bm, bn; long tiles, pps; int splits; };
+static PwgPlan pwg_plan(long M, int Cg, int Ng, int groups, int taps, int plan_hint) {
+    PwgPlan p;
+    p.bm = Cg % 128 == 0 ? 128 : 64;
+    p.bn = Ng % 128 == 0 ? 128 : 64;
+    long budget = 1024;
+    if (plan_hint >= 0) {
+        budget = 512L << (plan_hint & 3);
+        if (plan_hint & 16) p.bm = 64;
+        if (plan_hint & 32) p.bn = 64;
+    }
+    p.tiles = (long)(Cg / p.bm) * (Ng / p.bn) * groups * taps;
+    long want = budget / p.tiles;
     if (want < 1) want = 1;
     const long chunks = (M + 31) / 32;
     long cps = (chunks + want - 1) / want;
     if (cps < 8) cps = 8;
-    const long splits = (M + cps * 32 - 1) / (cps * 32);
-    return splits > 1 ? (size_t)splits * kh * kw * Cg * Cout * sizeof(float) : 0;
+    p.pps = cps * 32;
+    p.splits = (int)((M + p.pps - 1) / p.pps);
+    return p;
+}
+
+extern "C" size_t scouter_conv2d_wgrad_planes_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                                                              int groups, int plan_hint) {
+    if (groups <= 0 || Cin % groups || Cout % groups) return 0;
+    const int Cg = Cin / groups, Ng = Cout / groups;
+    const PwgPlan p = pwg_plan((long)B * H * W, Cg, Ng, groups, kh * kw, plan_hint);
+    return p.splits > 1 ? (size_t)p.splits * kh * kw * Cg * Cout * sizeof(float) : 0;
 }
 
 // x_planes [np][B*H*W][Cin], dy_planes [np][B*H*W][Cout] (stride 1, output size == input size); dw: HWIO fp32.
 extern "C" int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_planes, float* dw, int B, int H, int W,
-                                           int Cin, int Cout, int kh, int kw, int pad, int groups, int nplanes, void* ws,
-                                           size_t ws_bytes, void* stream) {
+                                           int Cin, int Cout, int kh, int kw, int pad, int groups, int nplanes,
+                                           int plan_hint, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(x_planes && dy_planes && dw && B > 0 && (nplanes == 1 || nplanes == 3), "conv2d_wgrad_planes: bad arguments");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_wgrad_planes: channels not divisible by groups");
     const int Cg = Cin / groups, Ng = Cout / groups;
@@ -1046,16 +1063,12 @@ extern "C" int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_
     const long x_pe = g.M * Cin, dy_pe = g.M * Cout;
     SC_UNSUPPORTED(g.M < (1L << 31) && (long)nplanes * x_pe * 2 < (1L << 32) && (long)nplanes * dy_pe * 2 < (1L << 32),
                    "conv2d_wgrad_planes: tensor too large for 32-bit plane offsets");
-    const int bm = Cg % 128 == 0 ? 128 : 64, bn = Ng % 128 == 0 ? 128 : 64;
+    const PwgPlan plan = pwg_plan(g.M, Cg, Ng, groups, kh * kw, plan_hint);
+    const int bm = plan.bm, bn = plan.bn;
     const int ci_tiles = Cg / bm, co_tiles = Ng / bn;
-    const long tiles = (long)ci_tiles * co_tiles * groups * kh * kw;
-    long want = 1024 / tiles;
-    if (want < 1) want = 1;
-    const long chunks = (g.M + 31) / 32;
-    long cps = (chunks + want - 1) / want;
-    if (cps < 8) cps = 8;
-    const long pps = cps * 32;
-    const int splits = (int)((g.M + pps - 1) / pps);
+    const long tiles = plan.tiles;
+    const long pps = plan.pps;
+    const int splits = plan.splits;
     const long slab = (long)kh * kw * Cg * Cout;
     const size_t need = splits > 1 ? (size_t)splits * slab * sizeof(float) : 0;
     if (need > ws_bytes || (need && !ws)) {

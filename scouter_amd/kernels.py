@@ -379,13 +379,21 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
 
 
 def conv2d_wgrad_planes(xp, dyp, dw_hwio, pad, groups=1):
-    """xp [np, B, H, W, Cin], dyp [np, B, H, W, Cout] -> dw (HWIO fp32, written in place)."""
+    """xp [np, B, H, W, Cin], dyp [np, B, H, W, Cout] -> dw (HWIO fp32, written in place).  The (tile, split-K) plan is
+    autotuned once per layer shape like the fp32 kernel's (_WGRAD_PLANS)."""
     nplanes, B, H, W, Cin = xp.shape
     kh, kw, cg, Cout = dw_hwio.shape
     L = _native.lib()
-    ws = workspace(L.scouter_conv2d_wgrad_planes_workspace_bytes(B, H, W, Cin, Cout, kh, kw, groups), xp.device)
-    _native.check(L.scouter_conv2d_wgrad_planes(_p(xp), _p(dyp), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, pad, groups,
-                                                nplanes, _p(ws), ws.numel(), _stream()), "conv2d_wgrad_planes")
+
+    def launch(plan, dry=False):
+        if dry:
+            return True
+        ws = workspace(L.scouter_conv2d_wgrad_planes_workspace_bytes(B, H, W, Cin, Cout, kh, kw, groups, plan), xp.device)
+        _native.check(L.scouter_conv2d_wgrad_planes(_p(xp), _p(dyp), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, pad, groups,
+                                                    nplanes, plan, _p(ws), ws.numel(), _stream()), "conv2d_wgrad_planes")
+        return True
+
+    launch(_pick_tile(("pwgrad", nplanes, B, H, W, Cin, Cout, kh, kw, pad, groups), launch, _WGRAD_PLANS))
     return dw_hwio
 
 
