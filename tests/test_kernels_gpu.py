@@ -522,3 +522,39 @@ def test_batchnorm_relu_maxpool_fused(shape, training):
     for a, b in ((dx, dx_ref), (dg, dg_ref), (db, db_ref)):
         sc = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-6 * sc + 1e-7, (float((a - b).abs().max()), sc)
+
+
+def test_downsample_batchnorm_applied_in_the_last_apply_pass_and_planes_only_outputs():
+    """(1) bn_fwd(residual = raw shortcut, residual_bn = its BatchNorm's saved block) == the two apply passes run
+    separately, bit for bit (same fma); (2) keep_f32=False writes the same planes and sign mask without the fp32 copy;
+    (3) sa_bn_bwd(keep_f32=False) likewise."""
+    kk = K()
+    rng = np.random.default_rng(5)
+    shp = (3, 9, 11, 64)
+    rnd = lambda *s_: torch.from_numpy(rng.standard_normal(s_)).float().cuda()
+    x, xd = rnd(*shp) * 1.5 + 0.3, rnd(*shp) * 0.7 - 0.1
+    C = shp[-1]
+    g1, b1, g2, b2 = torch.rand(C, device="cuda") + 0.5, rnd(C), torch.rand(C, device="cuda") + 0.5, rnd(C)
+    new = lambda: (torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"))
+    y2, saved2 = kk.bn_fwd(xd, g2, b2, *new(), True, False)
+    y_ref, saved1, mask_ref = kk.bn_fwd(x, g1, b1, *new(), True, True, residual=y2, want_mask=True)
+    saved2b = kk.bn_stats(xd, g2, b2, *new(), True)
+    assert torch.equal(saved2b, saved2)
+    y, saved1b, mask = kk.bn_fwd(x, g1, b1, *new(), True, True, residual=xd, want_mask=True, residual_bn=saved2b)
+    assert torch.equal(y, y_ref) and torch.equal(mask, mask_ref) and torch.equal(saved1b, saved1)
+    # planes only
+    full, _, m_full = kk.bn_fwd(x, g1, b1, *new(), True, True, want_mask=True, planes=3)
+    only, _, m_only = kk.bn_fwd(x, g1, b1, *new(), True, True, want_mask=True, planes=3, keep_f32=False)
+    assert only.f32 is None and tuple(only.shape) == shp
+    assert torch.equal(only.planes, full.planes) and torch.equal(m_only, m_full)
+    rec = only.planes.float().double().sum(0)
+    assert torch.equal(rec.float(), full.f32)                      # hi + mid + lo reproduces the fp32 value exactly
+    # split-attention backward, planes only
+    B, H, W, Cp = 2, 6, 5, 32
+    x0 = rnd(B, H, W, 2 * Cp)
+    ga, be = torch.rand(2 * Cp, device="cuda") + 0.5, rnd(2 * Cp)
+    sv = kk.bn_stats(x0, ga, be, torch.zeros(2 * Cp, device="cuda"), torch.ones(2 * Cp, device="cuda"), True)
+    dout, a, dgap = rnd(B, H, W, Cp), torch.rand(B, 2 * Cp, device="cuda"), rnd(B, Cp)
+    d_full = kk.sa_bn_bwd(dout, a, dgap, x0, sv, True, planes=3)
+    d_only = kk.sa_bn_bwd(dout, a, dgap, x0, sv, True, planes=3, keep_f32=False)
+    assert d_only.f32 is None and torch.equal(d_only.planes, d_full.planes)

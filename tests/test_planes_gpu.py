@@ -136,3 +136,14 @@ def test_plane_weight_gradient_matches_fp64(cfg):
     dw3b = torch.zeros_like(dw3)
     kk.conv2d_wgrad_planes(kk.planes_split(xd, 3), kk.planes_split(dyd, 3), dw3b, pad, groups)
     assert torch.equal(dw3, dw3b)                                   # deterministic
+    # every (tile, split-K) plan the autotuner may choose: same accuracy, each deterministic
+    key = ("pwgrad", 3, B, H, W, Cin, Cout, k, k, pad, groups)
+    try:
+        for plan in kk._WGRAD_PLANS:
+            kk._tile_cache[key] = plan
+            dwp = torch.full_like(dw3, float("nan"))
+            kk.conv2d_wgrad_planes(kk.planes_split(xd, 3), kk.planes_split(dyd, 3), dwp, pad, groups)
+            ep = float((dwp.permute(3, 2, 0, 1).cpu().double() - dw_true).abs().max())
+            assert ep <= max(2.0 * e32, 4e-7 * sc), (plan, ep, e32, sc)
+    finally:
+        kk._tile_cache.pop(key, None)
