@@ -180,13 +180,15 @@ int scouter_transpose_f32(const float* in, float* out, int batch, int rows, int 
  * RAW output of the radix convolution and relu(bn0(x)) is evaluated on the fly -- the activation is never stored
  * (scouter_bn_fwd_f32 with y == NULL only finalises the statistics).  scouter_sa_bn_bwd_f32 is the matching backward:
  * gradient w.r.t. the split-attention input h0 (from dout, the attention weights a and d(gap)), ReLU mask recomputed from
- * x0, BatchNorm backward of bn0 (dgamma / dbeta may be NULL) -> dx = gradient w.r.t. the convolution output. */
+ * x0, BatchNorm backward of bn0 (dgamma / dbeta may be NULL) -> dx = gradient w.r.t. the convolution output.  * bn_sums (optional): the per-image statistics [B][2C'][4] (fp64) that scouter_sa_reduce_f32(mode 1, bn_sums_out) produced
+ * in the d(attention) pass -- g = (dout * a + dgap / HW) * [bn0(x0) > 0] is affine in (a, dgap), constants of an image,
+ * so its BatchNorm-backward sums follow from them and the reduction pass over (dout, x0) is skipped. */
 size_t scouter_sa_workspace_bytes(int B, int HW, int C2);
-int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out, int B, int HW, int Cp,
-                          int mode, void* ws, size_t ws_bytes, void* stream);
+int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out, double* bn_sums_out,
+                          int B, int HW, int Cp, int mode, void* ws, size_t ws_bytes, void* stream);
 int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0, const float* bn_saved,
-                          int B, int HW, int Cp, int training, float* dgamma, float* dbeta, float* dx, void* dx_planes,
-                          int nplanes, void* ws, size_t ws_bytes, void* stream);
+                          const double* bn_sums, int B, int HW, int Cp, int training, float* dgamma, float* dbeta,
+                          float* dx, void* dx_planes, int nplanes, void* ws, size_t ws_bytes, void* stream);
 int scouter_radix_softmax_fwd_f32(const float* z, float* a, int B, int Cp, void* stream);
 int scouter_radix_softmax_bwd_f32(const float* a, const float* da, float* dz, int B, int Cp, void* stream);
 int scouter_sa_apply_fwd_f32(const float* x, const float* a, const float* bn_saved, float* out, int B, int HW, int Cp,

@@ -750,10 +750,33 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __res
     }
 }
 
+// Finalize of the split-attention / bn0 backward from the per-image statistics the d(attention) pass produced
+// (misc_ops.hip sa_colsum_partial_kernel<true, true>): one thread per channel sums over the images.
+__global__ __launch_bounds__(256) void sa_bn_bwd_sums_kernel(const double* __restrict__ sums, const float* __restrict__ a,
+                                                             const float* __restrict__ dgap, int B, int C, int Cp,
+                                                             float inv_hw, long M, int training,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ c1, float* __restrict__ c2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int cp = c >= Cp ? c - Cp : c;
+    double s = 0.0, t = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const double* q = sums + ((long)b * C + c) * 4;
+        const double av = (double)a[(long)b * C + c], gp = (double)(dgap[(long)b * Cp + cp] * inv_hw);
+        s += av * q[0] + gp * q[2];
+        t += av * q[1] + gp * q[3];
+    }
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)t;
+    c1[c] = training ? (float)(s / (double)M) : 0.f;
+    c2[c] = training ? (float)(t / (double)M) : 0.f;
+}
+
 extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0,
-                                     const float* bn_saved, int B, int HW, int Cp, int training, float* dgamma,
-                                     float* dbeta, float* dx, void* dx_planes, int nplanes, void* ws, size_t ws_bytes,
-                                     void* stream) {
+                                     const float* bn_saved, const double* bn_sums, int B, int HW, int Cp, int training,
+                                     float* dgamma, float* dbeta, float* dx, void* dx_planes, int nplanes, void* ws,
+                                     size_t ws_bytes, void* stream) {
     SC_REQUIRE(dout && a && dgap && x0 && bn_saved && (dx || dx_planes) && B > 0 && HW > 0 && Cp % 4 == 0,
                "sa_bn_bwd: bad arguments");
     const long M = (long)B * HW;
@@ -768,11 +791,17 @@ extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const fl
     float* c1 = (float*)((char*)ws + coef_off);
     float* c2 = c1 + C;
     hipStream_t st = (hipStream_t)stream;
-    ScProfScope prof("sa_bn_bwd(reduce+finalize+apply)", st, 0, (12.0 * C + 8.0 * Cp) * M);
-    hipLaunchKernelGGL(sa_bn_bwd_partial_kernel, pgrid, dim3(256), 0, st, dout, a, dgap, x0, bn_saved, (double*)ws, g,
-                       HW, Cp, 1.f / HW);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
-                       training, dgamma, dbeta, c1, c2);
+    ScProfScope prof(bn_sums ? "sa_bn_bwd(finalize+apply)" : "sa_bn_bwd(reduce+finalize+apply)", st, 0,
+                     ((bn_sums ? 8.0 : 12.0) * C + (bn_sums ? 4.0 : 8.0) * Cp) * M);
+    if (bn_sums) {
+        hipLaunchKernelGGL(sa_bn_bwd_sums_kernel, dim3(sc_cdiv(C, 256)), dim3(256), 0, st, bn_sums, a, dgap, B, C, Cp,
+                           1.f / HW, M, training, dgamma, dbeta, c1, c2);
+    } else {
+        hipLaunchKernelGGL(sa_bn_bwd_partial_kernel, pgrid, dim3(256), 0, st, dout, a, dgap, x0, bn_saved, (double*)ws, g,
+                           HW, Cp, 1.f / HW);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+                           training, dgamma, dbeta, c1, c2);
+    }
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(sa_bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved, c1, c2,
                        dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);

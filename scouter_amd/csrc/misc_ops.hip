@@ -13,42 +13,93 @@ static inline int ew_blocks(long n) { long b = (n + 255) / 256; return (int)(b >
 // over the radix halves).  partial: [B][nsplit][C2] doubles.
 // bn != NULL ([4][C2]: mean, rstd, scale, shift): x is the RAW convolution output and the summed quantity is
 // relu(bn(x)) -- the BatchNorm apply pass of bn0 is folded into the reductions that read the tensor anyway.
-template <bool WITH_W>
+// STATS (with WITH_W and bn): the pass that forms d(attention) also reduces, per image and channel, what the backward of
+// bn0 needs -- g = (dout * a + dgap / HW) * [bn0(x0) > 0] is affine in (a, dgap), which are constant over an image, so
+//   sum g       = sum_b  a[b,c] * S1 + dgap[b,c'] / HW * S3,     S1 = sum_hw dout * m,         S3 = sum_hw m
+//   sum g xhat  = sum_b  a[b,c] * S2 + dgap[b,c'] / HW * S4,     S2 = sum_hw dout * m * xhat,  S4 = sum_hw m * xhat
+// with m = [bn0(x0) > 0]: the separate reduction pass of scouter_sa_bn_bwd_f32 over (dout, x0) disappears.
+// partial planes: [1 + 4][B][nsplit][C2] doubles (plane 0 = the column sums as before).
+template <bool WITH_W, bool STATS>
 __global__ __launch_bounds__(256) void sa_colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bn,
                                                                 double* __restrict__ part, int HW, int C2, int Cp,
-                                                                int tpr, int rpb, int rows_per_split) {
-    __shared__ double red[256 * 4];
+                                                                int tpr, int rpb, int rows_per_split, long plane) {
+    constexpr int NQ = STATS ? 5 : 1;
+    __shared__ double red[256 * 4 * NQ];
     const int tid = threadIdx.x, cq = tid % tpr, rl = tid / tpr, b = blockIdx.y, sp = blockIdx.x;
     const int c = cq * 4;
     const int r0 = sp * rows_per_split, r1 = min(HW, r0 + rows_per_split);
-    double s[4] = {0, 0, 0, 0};
+    double s[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[q][k] = 0.0;
     const float* xb = x + (long)b * HW * C2;
     const float* wb = WITH_W ? w + (long)b * HW * Cp : nullptr;
-    f32x4 mu = {0, 0, 0, 0}, sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
-    if (bn) { mu = *(const f32x4*)(bn + c); sc = *(const f32x4*)(bn + 2 * C2 + c); sh = *(const f32x4*)(bn + 3 * C2 + c); }
+    f32x4 mu = {0, 0, 0, 0}, rs = {1, 1, 1, 1}, sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (bn) {
+        mu = *(const f32x4*)(bn + c); rs = *(const f32x4*)(bn + C2 + c);
+        sc = *(const f32x4*)(bn + 2 * C2 + c); sh = *(const f32x4*)(bn + 3 * C2 + c);
+    }
     for (int r = r0 + rl; r < r1; r += rpb) {
-        f32x4 v = *(const f32x4*)(xb + (long)r * C2 + c);
+        const f32x4 xr = *(const f32x4*)(xb + (long)r * C2 + c);
+        f32x4 v = xr, hv = xr;
         if (bn) {
-            v = bn_affine(v, mu, sc, sh);
+            hv = bn_affine(xr, mu, sc, sh);                      // (the sign of THIS value is the ReLU mask everywhere)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(hv[k], 0.f);
         }
-        if (WITH_W) v *= *(const f32x4*)(wb + (long)r * Cp + (c % Cp));
+        f32x4 d = {1, 1, 1, 1};
+        if (WITH_W) { d = *(const f32x4*)(wb + (long)r * Cp + (c % Cp)); v *= d; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += v[k];
+        for (int k = 0; k < 4; ++k) s[0][k] += v[k];
+        if (STATS) {
+            const f32x4 xh = (xr - mu) * rs;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool m = hv[k] > 0.f;
+                const float dm = m ? d[k] : 0.f;
+                s[1][k] += dm;
+                s[2][k] += (double)dm * xh[k];
+                s[3][k] += m ? 1.0 : 0.0;
+                s[4][k] += m ? (double)xh[k] : 0.0;
+            }
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) red[tid * 4 + k] = s[k];
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[(q * 256 + tid) * 4 + k] = s[q][k];
     __syncthreads();
     if (rl == 0) {
-        for (int j = 1; j < rpb; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s[k] += red[(j * tpr + cq) * 4 + k];
-        double* o = part + ((long)b * gridDim.x + sp) * C2 + c;
+        for (int q = 0; q < NQ; ++q) {
+            for (int j = 1; j < rpb; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = s[k];
+                for (int k = 0; k < 4; ++k) s[q][k] += red[(q * 256 + j * tpr + cq) * 4 + k];
+            double* o = part + q * plane + ((long)b * gridDim.x + sp) * C2 + c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = s[q][k];
+        }
     }
+}
+
+// d(attention) and the four per-image statistics out of the five partial planes of the STATS pass: one thread per
+// (image, channel); stats [B][C2][4] doubles = (S1, S2, S3, S4).
+__global__ void sa_dattn_stats_finalize_kernel(const double* __restrict__ part, float* __restrict__ da,
+                                               double* __restrict__ stats, int B, int nsplit, int C2, long plane) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * C2) return;
+    const int b = (int)(i / C2), c = (int)(i % C2);
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < nsplit; ++k) {
+        const double* p = part + ((long)b * nsplit + k) * C2 + c;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[q] += p[q * plane];
+    }
+    da[i] = (float)acc[0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stats[i * 4 + q] = acc[1 + q];
 }
 
 // gap[b][c] = alpha * sum_splits (part[b][s][c] + part[b][s][Cp+c])     (fold_radix = 1)
@@ -140,25 +191,33 @@ static int sa_plan(int HW, int C2, int* tpr, int* rpb, int* nsplit, int* rps) {
     *rps = (HW + ns - 1) / ns;
     return 0;
 }
-extern "C" size_t scouter_sa_workspace_bytes(int B, int HW, int C2) { (void)HW; return (size_t)B * 32 * C2 * sizeof(double); }
+extern "C" size_t scouter_sa_workspace_bytes(int B, int HW, int C2) { (void)HW; return (size_t)5 * B * 32 * C2 * sizeof(double); }
 
 // mode 0: gap[b][c]  = mean_hw (x[.,c] + x[.,Cp+c])          (out: [B][Cp])
-// mode 1: da[b][c2]  = sum_hw dout[b,hw,c2 % Cp] * x[b,hw,c2] (out: [B][2Cp])
-extern "C" int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out, int B, int HW,
-                                     int Cp, int mode, void* ws, size_t ws_bytes, void* stream) {
+// mode 1: da[b][c2]  = sum_hw dout[b,hw,c2 % Cp] * x[b,hw,c2] (out: [B][2Cp]); with bn_sums_out (needs bn_saved) also
+//         the per-image statistics [B][2Cp][4] (fp64) that let scouter_sa_bn_bwd_f32 skip its reduction pass
+extern "C" int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out,
+                                     double* bn_sums_out, int B, int HW, int Cp, int mode, void* ws, size_t ws_bytes,
+                                     void* stream) {
     const int C2 = 2 * Cp;
     int tpr, rpb, ns, rps;
     SC_REQUIRE(x && out && B > 0 && HW > 0, "sa_reduce: bad arguments");
+    SC_REQUIRE(!bn_sums_out || (mode == 1 && bn_saved), "sa_reduce: bn_sums_out needs mode 1 and bn_saved");
     SC_UNSUPPORTED(sa_plan(HW, C2, &tpr, &rpb, &ns, &rps) == 0, "sa_reduce: unsupported channel count %d", C2);
-    if (!ws || ws_bytes < (size_t)B * ns * C2 * sizeof(double)) { sc_set_error("sa_reduce: workspace too small"); return SC_ERR_WORKSPACE; }
+    const long plane = (long)B * ns * C2;
+    if (!ws || ws_bytes < (size_t)(bn_sums_out ? 5 : 1) * plane * sizeof(double)) { sc_set_error("sa_reduce: workspace too small"); return SC_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(ns, B);
     if (mode == 0) {
-        hipLaunchKernelGGL(sa_colsum_partial_kernel<false>, grid, dim3(256), 0, st, x, nullptr, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps);
+        hipLaunchKernelGGL((sa_colsum_partial_kernel<false, false>), grid, dim3(256), 0, st, x, nullptr, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane);
         hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * Cp, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 1, 1.f / HW);
+    } else if (bn_sums_out) {
+        SC_REQUIRE(dout, "sa_reduce: dout missing");
+        hipLaunchKernelGGL((sa_colsum_partial_kernel<true, true>), grid, dim3(256), 0, st, x, dout, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane);
+        hipLaunchKernelGGL(sa_dattn_stats_finalize_kernel, dim3(sc_cdiv((long)B * C2, 256)), dim3(256), 0, st, (const double*)ws, out, bn_sums_out, B, ns, C2, plane);
     } else {
         SC_REQUIRE(dout, "sa_reduce: dout missing");
-        hipLaunchKernelGGL(sa_colsum_partial_kernel<true>, grid, dim3(256), 0, st, x, dout, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps);
+        hipLaunchKernelGGL((sa_colsum_partial_kernel<true, false>), grid, dim3(256), 0, st, x, dout, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane);
         hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * C2, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 0, 1.f);
     }
     return sc_check_launch("sa_reduce");

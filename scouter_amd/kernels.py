@@ -702,22 +702,24 @@ def sa_gap(x, bn=None):
     B, H, W, C2 = x.shape
     out = torch.empty((B, C2 // 2), dtype=F32, device=x.device)
     ws = _sa_ws(B, H * W, C2, x.device)
-    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), None, _p(bn), _p(out), B, H * W, C2 // 2, 0, _p(ws),
+    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), None, _p(bn), _p(out), None, B, H * W, C2 // 2, 0, _p(ws),
                                                       ws.numel(), _stream()), "sa_gap")
     return out
 
 
-def sa_dattn(x, dout, bn=None):
-    """da[b, r*C'+c] = sum_hw dout[b,hw,c] * h[b,hw,r*C'+c]   (h as in sa_gap)"""
+def sa_dattn(x, dout, bn=None, want_stats=False):
+    """da[b, r*C'+c] = sum_hw dout[b,hw,c] * h[b,hw,r*C'+c]   (h as in sa_gap).  want_stats (needs bn): returns
+    (da, sums) with the per-image statistics [B, 2C', 4] (fp64) that let sa_bn_bwd skip its reduction pass."""
     B, H, W, C2 = x.shape
     out = torch.empty((B, C2), dtype=F32, device=x.device)
+    sums = torch.empty((B, C2, 4), dtype=torch.float64, device=x.device) if want_stats else None
     ws = _sa_ws(B, H * W, C2, x.device)
-    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), _p(dout), _p(bn), _p(out), B, H * W, C2 // 2, 1, _p(ws),
-                                                      ws.numel(), _stream()), "sa_dattn")
-    return out
+    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), _p(dout), _p(bn), _p(out), _p(sums), B, H * W, C2 // 2, 1,
+                                                      _p(ws), ws.numel(), _stream()), "sa_dattn")
+    return (out, sums) if want_stats else out
 
 
-def sa_bn_bwd(dout, a, dgap, x0, bn, training, dgamma=None, dbeta=None, planes=0, keep_f32=True):
+def sa_bn_bwd(dout, a, dgap, x0, bn, training, dgamma=None, dbeta=None, planes=0, keep_f32=True, sums=None):
     """Backward of [bn0 -> ReLU -> split-attention weighting / GAP] in one fused chain: returns the gradient w.r.t. the
     radix convolution's raw output x0 [B, H, W, 2C'] (a PlaneTensor when `planes`; keep_f32=False: planes only) and fills
     dgamma / dbeta."""
@@ -725,7 +727,7 @@ def sa_bn_bwd(dout, a, dgap, x0, bn, training, dgamma=None, dbeta=None, planes=0
     dx = torch.empty_like(x0) if keep_f32 or not planes else None
     dxp = torch.empty((planes,) + tuple(x0.shape), dtype=BF16, device=x0.device) if planes else None
     ws = _col_ws(B * H * W, 2 * Cp, x0.device)
-    _native.check(_native.lib().scouter_sa_bn_bwd_f32(_p(dout), _p(a), _p(dgap), _p(x0), _p(bn), B, H * W, Cp,
+    _native.check(_native.lib().scouter_sa_bn_bwd_f32(_p(dout), _p(a), _p(dgap), _p(x0), _p(bn), _p(sums), B, H * W, Cp,
                                                       int(training), _p(dgamma), _p(dbeta), _p(dx), _p(dxp), planes,
                                                       _p(ws), ws.numel(), _stream()), "sa_bn_bwd")
     return PlaneTensor(dx, dxp) if planes else dx

@@ -1,10 +1,15 @@
 """Split-attention convolution (ResNeSt), radix 2 / cardinality 1 -- HIP forward + hand-written backward.
 Mirrors timm/models/layers/split_attn.py:31-80 of the reference (module / parameter names: conv, bn0, fc1, bn1, fc2).
 Channel layout of the radix conv output: [radix 0: C' channels | radix 1: C' channels] (split_attn.py:64-66)."""
+import os
+
 import torch.nn as nn
 
 from ....nn_hip import Act, BatchNorm2d, Conv2d
 from .... import kernels as K
+
+# the d(attention) pass also reduces the per-image statistics of bn0's backward (kernels.sa_dattn want_stats)
+SA_SUMS = os.environ.get("SCOUTER_SA_SUMS", "1") == "1"
 
 
 class SplitAttnConv2d(nn.Module):
@@ -44,7 +49,7 @@ class SplitAttnConv2d(nn.Module):
         """post: K.BnBwdFuse of the BatchNorm in front of this layer (finished in the input-gradient epilogue)."""
         c_conv, x0, saved0, training0, c_fc1, c_bn1, c_fc2, a = ctx
         B = x0.shape[0]
-        da = K.sa_dattn(x0, dout, saved0)
+        da, sums = K.sa_dattn(x0, dout, saved0, want_stats=True) if SA_SUMS else (K.sa_dattn(x0, dout, saved0), None)
         dz2 = K.radix_softmax_bwd(a, da)
         dg1 = self.fc2.bwd(dz2.view(B, 1, 1, -1), c_fc2, True)
         dz1, _ = self.bn1.bwd(dg1, c_bn1)
@@ -52,5 +57,5 @@ class SplitAttnConv2d(nn.Module):
         on_planes = isinstance(c_conv, tuple) and c_conv[1] is not None
         only = on_planes and c_conv[2] is not None and self.conv.planes_only(x0.shape[1], x0.shape[2])
         dc = K.sa_bn_bwd(dout, a, dgap.view(B, -1), x0, saved0, training0, self.bn0._dg, self.bn0._db,
-                         planes=self.conv.planes_dy() if on_planes else 0, keep_f32=not only)
+                         planes=self.conv.planes_dy() if on_planes else 0, keep_f32=not only, sums=sums)
         return self.conv.bwd(dc, c_conv, True, post=post)

@@ -254,6 +254,15 @@ def test_split_attention_fused_with_its_batchnorm(shape, training):
     np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=2e-6 * max(sc, 1.0), rtol=2e-5)
     np.testing.assert_allclose(dg.cpu().numpy(), gr.grad.numpy(), atol=2e-5 * float(gr.grad.abs().max()), rtol=1e-5)
     np.testing.assert_allclose(db.cpu().numpy(), br.grad.numpy(), atol=2e-5 * float(br.grad.abs().max()), rtol=1e-5)
+    # the same backward from the per-image statistics of the d(attention) pass (no reduction pass over dout / x0):
+    # g is affine in (a, dgap), so the BatchNorm sums follow from S1..S4 -- equal to the reduced ones to fp32 rounding
+    da2, sums = kk.sa_dattn(xd, f(dout), saved, want_stats=True)
+    assert torch.equal(da2, kk.sa_dattn(xd, f(dout), saved))
+    dg2, db2 = torch.zeros(C2, device="cuda"), torch.zeros(C2, device="cuda")
+    dx2 = kk.sa_bn_bwd(f(dout), f(a), f(dgap), xd, saved, training, dg2, db2, sums=sums)
+    for got, ref in ((dx2, dx), (dg2, dg), (db2, db)):
+        scl = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 3e-6 * scl + 1e-7, (float((got - ref).abs().max()), scl)
 
 
 def test_colsum_relu_axpby_matmul_tn():
