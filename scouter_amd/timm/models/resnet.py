@@ -46,6 +46,7 @@ class Downsample(nn.Sequential):
         c, c_conv = mods[0].fwd(xin, save, bn_stats=mods[1].training)
         craw, saved = mods[1].stats_only(c, tracked, relu_follows=False)
         c_bn = (craw, None, saved, mods[1].training)
+        self._made = [t for t in (xin, craw, saved) if t is not x]       # (for record_stream when run on the side stream)
         return craw, saved, ((c_conv, c_bn, pool, tuple(x.shape)) if save else None)
 
     def bwd(self, dy, ctx, need_dx, fused=None):

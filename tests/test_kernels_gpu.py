@@ -466,14 +466,15 @@ def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision, mo
             kk._tile_cache[("dgrad+bn", 2 if two else 1, addend is not None, b16, B, H, W, Cin, Cout, k, k, 1, pad, g)] = tile
         return kk.conv2d_dgrad(dy, w, (B, H, W, Cin), addend, 1, pad, g, precision=precision, post=post)
 
-    # unfused chain
-    d_plain = dgrad(None)
-    dg = [torch.zeros(Cin, device="cuda") for _ in range(4)]
-    dx1_ref, gout = kk.bn_bwd(d_plain, None, x1, saved1, True, dg[0], dg[1], True, mask=mask)
-    if two:
-        dx2_ref, _ = kk.bn_bwd(gout, None, x2, saved2, True, dg[2], dg[3])
-    tiles = kk._plane_tiles(Cin // g) if precision == "planes" else [t for t in range(4) if kk._tile_legal(Cin // g, t)]
+    tiles = (kk._plane_tiles(Cin // g, 3, kk._halo_ok(k, k, 1, pad, H, W, 2)) if precision == "planes"
+             else [t for t in range(4) if kk._tile_legal(Cin // g, t)])
     for t in tiles:
+        # unfused chain on the SAME tile (plane tile 5 sums K in another order than tiles 0-4)
+        d_plain = dgrad(None, t)
+        dg = [torch.zeros(Cin, device="cuda") for _ in range(4)]
+        dx1_ref, gout = kk.bn_bwd(d_plain, None, x1, saved1, True, dg[0], dg[1], True, mask=mask)
+        if two:
+            dx2_ref, _ = kk.bn_bwd(gout, None, x2, saved2, True, dg[2], dg[3])
         post = kk.BnBwdFuse(mask, [(x1, saved1)] + ([(x2, saved2)] if two else []))
         gf = dgrad(post, t)
         assert post.applied
