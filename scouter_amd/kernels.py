@@ -408,14 +408,16 @@ class side_stream:
     (MFMA-bound) is off the critical path and overlaps the HBM-bound BatchNorm-backward passes of earlier layers.
     `join_side_stream()` makes the current stream wait for it again."""
 
-    def __init__(self, device, *tensors, enabled=True):
-        self.device, self.tensors, self.enabled = device, tensors, enabled
+    def __init__(self, device, *tensors, enabled=True, which="wgrad"):
+        """which: "wgrad" (weight gradients) or "branch" (the shortcut branch of a downsampling block, forward and
+        backward) -- separate streams, so joining the branch never waits for a backlog of weight gradients."""
+        self.device, self.tensors, self.enabled, self.which = device, tensors, enabled, which
 
     def __enter__(self):
         self.ctx = None
         if not self.enabled:
             return None
-        key = (self.device.type, self.device.index)
+        key = (self.device.type, self.device.index, self.which)
         st = _side.get(key)
         if st is None:
             st = _side[key] = torch.cuda.Stream(device=self.device)
@@ -431,15 +433,12 @@ class side_stream:
         return self.ctx.__exit__(*exc) if self.ctx is not None else False
 
 
-def join_side_stream(device):
-    st = _side.get((device.type, device.index))
+def join_side_stream(device, which="wgrad"):
+    st = _side.get((device.type, device.index, which))
     if st is not None:
         torch.cuda.current_stream(device).wait_stream(st)
 
 
-# wgrad plans (library default, or tile-halving bits | block budget, include/scouter_hip.h).  Autotuning them gains 5 %
-# on the kernels timed alone but nothing inside the step, where they share the GPU with the main stream's dgrad /
-# BatchNorm kernels -- and plans differ in summation order -- so the static plan is the default: bit-reproducible runs.
 # (tile, split-K) plans of the fp32 / bf16-input weight-gradient kernels: -1 = the library's static plan; the others
 # (include/scouter_hip.h plan_hint) are timed once per layer shape like the block tiles.  Every plan is deterministic,
 # but different plans sum the pixels in a different order, so -- like plane tile 5 -- the choice is reproducible per

@@ -13,6 +13,10 @@ from ... import kernels as K
 # forward: the shortcut branch of a downsampling block on the weight-gradient side stream (+0.5 % images/sec, A/B on one
 # box, 3 x 120 steps: 3 970 -> 3 991); follows the model's side-stream switch (SlotModel.set_side_stream)
 SIDE_FWD = os.environ.get("SCOUTER_SIDE_FWD", "1") == "1"
+# backward: the same branch (BatchNorm backward, 1x1 input gradient, pool backward) next to the main branch, joined in
+# front of conv1's input-gradient epilogue that adds it: +1.6 % (3 947 -> 4 011).  Its own stream ("branch"), so the join
+# never waits for the backlog of weight gradients on the other side stream.
+SIDE_BWD = os.environ.get("SCOUTER_SIDE_BWD", "1") == "1"
 
 
 class ResNestBottleneck(nn.Module):
@@ -40,7 +44,7 @@ class ResNestBottleneck(nn.Module):
     def fwd(self, x, save, tracked):
         side = SIDE_FWD and self.downsample is not None and self.conv1.use_side_stream
         if side:          # the shortcut branch (pool, 1x1 convolution, statistics) under the main branch's small kernels
-            with K.side_stream(x.device, x, enabled=True):
+            with K.side_stream(x.device, x, enabled=True, which="branch"):
                 res, rbn, kd = self.downsample.fwd(x, save, tracked)
         c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
         t1 = c1[0] if isinstance(c1, tuple) else c1
@@ -51,7 +55,7 @@ class ResNestBottleneck(nn.Module):
         p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
         c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training)
         if side:
-            K.join_side_stream(x.device)
+            K.join_side_stream(x.device, "branch")
             cur = torch.cuda.current_stream(x.device)
             for t in self.downsample._made:
                 t.record_stream(cur)
@@ -72,14 +76,28 @@ class ResNestBottleneck(nn.Module):
         k1, b1, ksa, sa_shape, k3, b3, kd = ctx
         own = own if own is not None and own.applied else None
         dc3, dres = self.bn3.bwd(dout, b3, want_gout=True, fused=own.ext(0) if own else None)
+        branch = self._bwd_branch()
+        if branch:        # the shortcut branch's backward next to the main branch's (joined in front of conv1's epilogue)
+            f2 = own.ext(1) if own else None
+            with K.side_stream(dres.device, dres, f2[0] if f2 else None, enabled=True, which="branch"):
+                dxres_b = self.downsample.bwd(dres, kd, need_dx, fused=f2)
         dp = self.conv3.bwd(dc3, k3, True)
         dsa = self.avd_last.bwd(dp, sa_shape) if self.avd_last is not None else dp
         f1 = BatchNorm2d.fuse(b1)
         dh1 = self.conv2.bwd(dsa, ksa, post=f1)
         dc1, _ = self.bn1.bwd(dh1, b1, fused=f1.ext(0) if f1.applied else None)
-        dxres = dres if self.downsample is None else self.downsample.bwd(dres, kd, need_dx,
-                                                                         fused=own.ext(1) if own else None)
+        if branch:
+            K.join_side_stream(dres.device, "branch")
+            dxres = dxres_b
+            if dxres is not None:
+                dxres.record_stream(torch.cuda.current_stream(dres.device))
+        else:
+            dxres = dres if self.downsample is None else self.downsample.bwd(dres, kd, need_dx,
+                                                                             fused=own.ext(1) if own else None)
         return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None)
+
+    def _bwd_branch(self):
+        return SIDE_BWD and self.downsample is not None and self.conv1.use_side_stream
 
 
 def _resnest(name, layers, pretrained, num_classes, in_chans, **kwargs):
