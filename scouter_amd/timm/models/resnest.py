@@ -1,22 +1,10 @@
 """ResNeSt bottleneck (radix 2, cardinality 1, avd after the split-attention conv, avg-pool downsample).
 Mirrors timm/models/resnest.py:58-143 and :161-189 of the reference."""
-import os
-
-import torch
 import torch.nn as nn
 
 from ...nn_hip import Act, BatchNorm2d, Conv2d
 from .layers.split_attn import SplitAttnConv2d
-from .resnet import AvgPool2dSpec, ResNet
-from ... import kernels as K
-
-# forward: the shortcut branch of a downsampling block on the weight-gradient side stream (+0.5 % images/sec, A/B on one
-# box, 3 x 120 steps: 3 970 -> 3 991); follows the model's side-stream switch (SlotModel.set_side_stream)
-SIDE_FWD = os.environ.get("SCOUTER_SIDE_FWD", "1") == "1"
-# backward: the same branch (BatchNorm backward, 1x1 input gradient, pool backward) next to the main branch, joined in
-# front of conv1's input-gradient epilogue that adds it: +1.6 % (3 947 -> 4 011).  Its own stream ("branch"), so the join
-# never waits for the backlog of weight gradients on the other side stream.
-SIDE_BWD = os.environ.get("SCOUTER_SIDE_BWD", "1") == "1"
+from .resnet import AvgPool2dSpec, ResNet, BRANCH_FWD, BRANCH_BWD
 
 
 class ResNestBottleneck(nn.Module):
@@ -42,10 +30,9 @@ class ResNestBottleneck(nn.Module):
         nn.init.zeros_(self.bn3.weight)
 
     def fwd(self, x, save, tracked):
-        side = SIDE_FWD and self.downsample is not None and self.conv1.use_side_stream
-        if side:          # the shortcut branch (pool, 1x1 convolution, statistics) under the main branch's small kernels
-            with K.side_stream(x.device, x, enabled=True, which="branch"):
-                res, rbn, kd = self.downsample.fwd(x, save, tracked)
+        res, rbn, kd = (x, None, None)
+        if self.downsample is not None:       # (on its own stream next to the main branch, Downsample.fwd_async)
+            res, rbn, kd = self.downsample.fwd_async(x, save, tracked, BRANCH_FWD and self.conv1.use_side_stream)
         c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
         t1 = c1[0] if isinstance(c1, tuple) else c1
         conv = self.conv2.conv                   # (all three of its kernels on planes: no fp32 copy of h1 is written)
@@ -54,13 +41,8 @@ class ResNestBottleneck(nn.Module):
         sa, ksa = self.conv2.fwd(h1, save, tracked)
         p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
         c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training)
-        if side:
-            K.join_side_stream(x.device, "branch")
-            cur = torch.cuda.current_stream(x.device)
-            for t in self.downsample._made:
-                t.record_stream(cur)
-        else:
-            res, rbn, kd = (x, None, None) if self.downsample is None else self.downsample.fwd(x, save, tracked)
+        if self.downsample is not None:
+            self.downsample.fwd_join(x.device)
         out, b3 = self.bn3.fwd(c3, save, relu=True, residual=res, tracked=tracked, residual_bn=rbn)
         return out, ((k1, b1, ksa, tuple(sa.shape), k3, b3, kd) if save else None)
 
@@ -76,28 +58,18 @@ class ResNestBottleneck(nn.Module):
         k1, b1, ksa, sa_shape, k3, b3, kd = ctx
         own = own if own is not None and own.applied else None
         dc3, dres = self.bn3.bwd(dout, b3, want_gout=True, fused=own.ext(0) if own else None)
-        branch = self._bwd_branch()
-        if branch:        # the shortcut branch's backward next to the main branch's (joined in front of conv1's epilogue)
-            f2 = own.ext(1) if own else None
-            with K.side_stream(dres.device, dres, f2[0] if f2 else None, enabled=True, which="branch"):
-                dxres_b = self.downsample.bwd(dres, kd, need_dx, fused=f2)
+        dxres = dres
+        if self.downsample is not None:       # the branch's backward next to the main branch's (Downsample.bwd_async)
+            dxres = self.downsample.bwd_async(dres, kd, need_dx, own.ext(1) if own else None,
+                                              BRANCH_BWD and self.conv1.use_side_stream)
         dp = self.conv3.bwd(dc3, k3, True)
         dsa = self.avd_last.bwd(dp, sa_shape) if self.avd_last is not None else dp
         f1 = BatchNorm2d.fuse(b1)
         dh1 = self.conv2.bwd(dsa, ksa, post=f1)
         dc1, _ = self.bn1.bwd(dh1, b1, fused=f1.ext(0) if f1.applied else None)
-        if branch:
-            K.join_side_stream(dres.device, "branch")
-            dxres = dxres_b
-            if dxres is not None:
-                dxres.record_stream(torch.cuda.current_stream(dres.device))
-        else:
-            dxres = dres if self.downsample is None else self.downsample.bwd(dres, kd, need_dx,
-                                                                             fused=own.ext(1) if own else None)
+        if self.downsample is not None:
+            dxres = self.downsample.bwd_join(dxres, dres.device)
         return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None)
-
-    def _bwd_branch(self):
-        return SIDE_BWD and self.downsample is not None and self.conv1.use_side_stream
 
 
 def _resnest(name, layers, pretrained, num_classes, in_chans, **kwargs):
