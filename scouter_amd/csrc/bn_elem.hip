@@ -256,6 +256,74 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// BatchNorm backward of a SMALL tensor (few rows: the BatchNorm between the two 1x1 layers of the split attention acts
+// on one pooled vector per image) in ONE launch: a workgroup per channel slab reduces sum g, sum g * xhat over all rows
+// (fp64), then applies -- instead of three launches whose latency, not their work, is the cost.
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                           const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ scale,
+                                                           const unsigned long long* __restrict__ mbits, int training,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dx, float* __restrict__ gout, ColGeom g) {
+    __shared__ double red[256 * 8];
+    __shared__ float coef[256 * 8];
+    const int tid = threadIdx.x;
+    const int cq = tid % g.tpr, rl = tid / g.tpr;
+    const int c = blockIdx.y * g.cslab + cq * 4;
+    const bool live = rl < g.rpb && c < g.C;
+    double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+    f32x4 mu = {0, 0, 0, 0}, rs = {1, 1, 1, 1}, sc = {1, 1, 1, 1};
+    auto masked = [&](long off) {
+        f32x4 a = *(const f32x4*)(dy + off);
+        if (mbits) {
+            relu_mask_apply(a, mbits, off >> 2);
+        } else if (ymask) {
+            const f32x4 y = *(const f32x4*)(ymask + off);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = y[k] > 0.f ? a[k] : 0.f;
+        }
+        return a;
+    };
+    if (live) {
+        mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); sc = *(const f32x4*)(scale + c);
+        for (long r = rl; r < g.M; r += g.rpb) {
+            const long off = r * g.C + c;
+            const f32x4 a = masked(off), xv = *(const f32x4*)(x + off);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += a[k]; t[k] += (double)a[k] * ((xv[k] - mu[k]) * rs[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = s[k]; red[tid * 8 + 4 + k] = t[k]; }
+    __syncthreads();
+    if (rl == 0 && c < g.C) {
+        for (int j = 1; j < g.rpb; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += red[(j * g.tpr + cq) * 8 + k]; t[k] += red[(j * g.tpr + cq) * 8 + 4 + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dbeta) dbeta[c + k] = (float)s[k];
+            if (dgamma) dgamma[c + k] = (float)t[k];
+            coef[cq * 8 + k] = training ? (float)(s[k] / (double)g.M) : 0.f;
+            coef[cq * 8 + 4 + k] = training ? (float)(t[k] / (double)g.M) : 0.f;
+        }
+    }
+    __syncthreads();
+    if (live) {
+        f32x4 k1, k2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { k1[k] = coef[cq * 8 + k]; k2[k] = coef[cq * 8 + 4 + k]; }
+        for (long r = rl; r < g.M; r += g.rpb) {
+            const long off = r * g.C + c;
+            const f32x4 a = masked(off), xv = *(const f32x4*)(x + off);
+            const f32x4 xh = (xv - mu) * rs;
+            *(f32x4*)(dx + off) = sc * (a - k1 - xh * k2);
+            if (gout) *(f32x4*)(gout + off) = a;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int nb, int C,
                                                               float* __restrict__ out, float alpha) {
     __shared__ double red[FIN_LANES][FIN_CH][2];
@@ -657,6 +725,11 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
     ScProfScope prof(ext_partial ? "bn_bwd(finalize+apply)" : "bn_bwd(reduce+finalize+apply)", st, 0,
                      ((ext_partial ? 12.0 : (ymask && !relu_mask ? 28.0 : 20.0)) + (gout ? 4.0 : 0.0) +
                       (relu_mask ? 0.25 : 0.0)) * M * C);
+    if (!ext_partial && M <= (long)g.rpb * 24) {                 // few row passes: everything in one launch
+        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, pgrid.y), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale,
+                           relu_mask, training, dgamma, dbeta, dx, gout, g);
+        return sc_check_launch("bn_bwd");
+    }
     const double* part = (const double*)ws;
     int nparts = nb;
     if (ext_partial) { part = ext_partial; nparts = ext_rows; }   // reduced by the epilogue of the kernel that produced dy

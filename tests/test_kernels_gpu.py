@@ -106,7 +106,8 @@ def test_stem_im2col_path():
 
 
 @pytest.mark.parametrize("shape,relu,res", [((4, 14, 14, 64), True, False), ((3, 7, 7, 2048), False, True),
-                                            ((6, 1, 1, 32), True, False), ((2, 28, 28, 32), True, True)])
+                                            ((6, 1, 1, 32), True, False), ((2, 28, 28, 32), True, True),
+                                            ((70, 1, 1, 256), True, False), ((9, 1, 1, 64), False, True)])   # one-launch backward
 def test_bn_fwd_bwd(shape, relu, res):
     rng = np.random.default_rng(4)
     B, H, W, C = shape
