@@ -56,7 +56,7 @@ struct BnBwdFuse {
 
 // Block epilogue.  acc: this wave's (WM x WN) accumulator tiles in MFMA layout; lds: the block's K-loop LDS (free now,
 // at least 4*WM*(WN+4) floats); rows m0.., columns grp*Ng + n0.. of the [M][N] output.
-template <int BM, int BN, int WM, int WN, bool BWD = false>
+template <int BM, int BN, int WM, int WN, bool BWD = false, bool BWD_PREFETCH = false>
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], float* lds, const ConvGeom& g,
                                                const float* __restrict__ bias, const float* __restrict__ addend,
                                                float* __restrict__ dst, double* __restrict__ bn_part, int relu,
@@ -67,6 +67,30 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
     // ---- epilogue: stage each wave's WMxWN accumulator tile through LDS (the K-loop buffers are free now) and write
     // whole 16-byte row segments: 16 dwordx4 stores (+16 vector addend loads) per lane instead of 64 scalar ones --
     // for the short-K 1x1 layers the scalar epilogue was a quarter of the block's lifetime.
+    constexpr int QPR = WN / 4;                               // float4 per tile row
+    constexpr int RPP = 64 / QPR;                             // rows covered per pass by the 64 lanes
+    constexpr int NR = WM / RPP;                              // rows per lane
+    const int qcol = (lane % QPR) * 4, qrow = lane / QPR;
+    const int ncol = grp * g.Ng + n0 + wn * WN + qcol;
+    // Fused BatchNorm-backward epilogue: its global operands (shortcut gradient, BatchNorm inputs) do not depend on the
+    // GEMM -- request them BEFORE the accumulators are staged through LDS, so the two latencies overlap (these launches
+    // are HBM-latency bound: tools_dev/fused_dgrad_tiles.py).  Up to 8 rows per lane (64x64, 128x64, 128x32 tiles).
+    constexpr bool PREF = BWD && BWD_PREFETCH && NR <= 8;      // (the fp32 kernels; the plane kernels have no registers to spare)
+    f32x4 p_add[PREF ? NR : 1], p_x1[PREF ? NR : 1], p_x2[PREF ? NR : 1];
+    bool pref = false;
+    if constexpr (PREF) {
+        pref = fz != nullptr && fz->part1 != nullptr;
+        if (pref) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const long m = m0 + wm * WM + rr * RPP + qrow;
+                const long off = (m < g.M ? m : 0) * g.N + ncol;      // (rows beyond M: any valid address, never used)
+                p_add[rr] = addend ? *(const f32x4*)(addend + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+                p_x1[rr] = *(const f32x4*)(fz->x1 + off);
+                p_x2[rr] = fz->part2 ? *(const f32x4*)(fz->x2 + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
     __syncthreads();
     constexpr int LDE = WN + 4;                               // padded row (16B aligned, breaks the 32-bank stride)
     float* Es = lds + wave * (WM * LDE);
@@ -78,10 +102,6 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
             for (int e = 0; e < 16; ++e) Es[(i * 32 + mfma32_row(e, lane)) * LDE + j * 32 + l31] = acc[i][j][e];
     // each wave reads back its own tile only: no block barrier needed, just this wave's LDS writes
     __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
-    constexpr int QPR = WN / 4;                               // float4 per tile row
-    constexpr int RPP = 64 / QPR;                             // rows covered per pass by the 64 lanes
-    const int qcol = (lane % QPR) * 4, qrow = lane / QPR;
-    const int ncol = grp * g.Ng + n0 + wn * WN + qcol;
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv4 = *(const f32x4*)(bias + ncol);
     // BatchNorm statistics straight from the accumulators when the stored value IS the accumulator (no bias / addend --
@@ -130,16 +150,23 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
         const long m = m0 + wm * WM + row;
         if (m >= g.M) continue;
         f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
-        if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
+        if constexpr (PREF) {
+            if (pref) v += p_add[rr];
+            else if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
+        } else {
+            if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
+        }
         if constexpr (BWD) {
             if (bwd) {
                 const long off = m * g.N + ncol;
                 if (fz->mask) relu_mask_apply(v, fz->mask, off >> 2);
-                const f32x4 xa = *(const f32x4*)(fz->x1 + off);
+                f32x4 xa;
+                if constexpr (PREF) xa = p_x1[rr]; else xa = *(const f32x4*)(fz->x1 + off);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * ((xa[e] - mu1[e]) * rs1[e]); }
                 if (bwd2) {
-                    const f32x4 xb = *(const f32x4*)(fz->x2 + off);
+                    f32x4 xb;
+                    if constexpr (PREF) xb = p_x2[rr]; else xb = *(const f32x4*)(fz->x2 + off);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) cq2[e] += (double)v[e] * ((xb[e] - mu2[e]) * rs2[e]);
                 }

@@ -35,7 +35,9 @@ struct TileCfg {
 // (rows beyond M read zeros through num_records).  36 of resnest26d's 48 convolutions are pointwise and they have the
 // SHORTEST K loops (Cin/32 = 2..64 tiles), where the general prologue's ~300 VALU instructions per thread -- fp32 MFMA
 // shares the vector lanes -- were a tenth to a third of the block's matrix time (tools_dev/isa_phases.py).
-template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED, bool PW>
+// FUSE: the epilogue carries a BatchNorm-backward reduction (conv_common.h BnBwdFuse) -- its own instantiation, so the
+// plain input gradient keeps its leaner epilogue (the fused one prefetches up to three more operands: +30 registers)
+template <int BM, int BN, int WM, int WN, bool DGRAD, bool STRIDED, bool PW, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ addend, float* __restrict__ dst,
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 
     // ---- epilogue (conv_common.h): LDS-staged vector stores, fused bias / addend / ReLU / BatchNorm statistics
     static_assert(4 * WM * (WN + 4) <= 2 * T::STAGE, "epilogue staging fits in the K-loop LDS");
-    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, lds, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
+    igemm_epilogue<BM, BN, WM, WN, DGRAD && FUSE, true>(acc, lds, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -597,8 +599,12 @@ static void launch_igemm_s(const float* src, const float* w, const float* bias, 
     gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
     gg.inv_wo = 1.0f / (float)g.Wo;
     gg.inv_ho = 1.0f / (float)g.Ho;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED, PW>), grid, dim3(256), 0, st, src, w, bias, addend,
-                       dst, bn_part, gg, relu, mtiles, ntiles, fz);
+    if (DGRAD && fz.part1)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED, PW, DGRAD>), grid, dim3(256), 0, st, src, w, bias,
+                           addend, dst, bn_part, gg, relu, mtiles, ntiles, fz);
+    else
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED, PW, false>), grid, dim3(256), 0, st, src, w, bias,
+                           addend, dst, bn_part, gg, relu, mtiles, ntiles, fz);
 }
 template <int BM, int BN, int WM, int WN, bool DGRAD>
 static void launch_igemm(const float* src, const float* w, const float* bias, const float* addend, float* dst,

@@ -367,8 +367,8 @@ __global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __r
 
     // ---- tap masks of this lane's two fragment rows (pixels m0 + wm*64 + i*32 + l31) and their image rows
     const int hw = g.Ho * g.Wo;
-    unsigned amask[MT];
-    int arow[MT];
+    unsigned amask2 = 0;                                         // both rows' 9-bit masks in one register
+    const int arow0 = (wm * WM + l31) * 32;                      // row i: + i * 1024
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const long m = m0 + wm * WM + i * 32 + l31;
@@ -383,8 +383,7 @@ __global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __r
                 const int yy = DGRAD ? y + 1 - r : y + r - 1, xx = DGRAD ? x + 1 - q : x + q - 1;
                 mask |= ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)W ? 1u : 0u) << (r * 3 + q);
             }
-        amask[i] = m < g.M ? mask : 0u;
-        arow[i] = (wm * WM + i * 32 + l31) * 32;
+        amask2 |= (m < g.M ? mask : 0u) << (16 * i);
     }
     // image row j holds pixel m0 - (W + 1) + j; tap (r, q) of local row t reads image row t + (W + 1) + dr*W + dq
     int trow[3];
@@ -465,12 +464,12 @@ __global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __r
         for (int i = 0; i < MT; ++i) {
             // (the empty asm keeps the 2 x 9 x 2 selected addresses from being hoisted out of the K loop as loop
             //  invariants: 36 registers this kernel does not have -- they were spilled and reloaded behind vmcnt(0))
-            unsigned am = amask[i];
-            int ar = arow[i];
+            unsigned am = amask2;
+            int ar = arow0;
             asm volatile("" : "+v"(am), "+v"(ar));
-            const int row32 = ar + cp * ABUF + trow[r] + (DGRAD ? 1 - q : q - 1) * 32;      // image row * 32 (+ buffer)
+            const int row32 = ar + i * 1024 + cp * ABUF + trow[r] + (DGRAD ? 1 - q : q - 1) * 32;   // image row * 32 (+ buffer)
             const int live = row32 + ((((row32 >> 8) ^ h) & 1) << 4);                           // swizzled k-half
-            const int addr = ((am >> tap) & 1u) ? live : ZERO + h * 16;
+            const int addr = ((am >> (tap + 16 * i)) & 1u) ? live : ZERO + h * 16;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) F[buf][i][pl] = *(const bf16x8*)(lds_raw + addr + pl * APLANE);
         }
