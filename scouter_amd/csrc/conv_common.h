@@ -54,13 +54,46 @@ struct BnBwdFuse {
     const float* x2; const float* sv2; double* part2;      // second BatchNorm (may be NULL)
 };
 
+// Operands of the fused BatchNorm-backward epilogue that do not depend on the GEMM (shortcut gradient, BatchNorm inputs):
+// requested at the START of the workgroup (igemm_epilogue_prefetch), so their latency overlaps the K loop -- these launches
+// are HBM-latency bound (tools_dev/fused_dgrad_tiles.py).  NR = rows per lane of the epilogue's row-major pass (<= 8: the
+// 64x64, 128x64, 128x32 tiles; the instantiation's register count is set by the epilogue anyway, occupancy by LDS).
+template <int NR>
+struct EpiPre { f32x4 add[NR], x1[NR], x2[NR]; bool on; };
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_prefetch(EpiPre<(WM / (64 / (WN / 4)) <= 8 ? WM / (64 / (WN / 4)) : 1)>& pre,
+                                                        const ConvGeom& g, const float* __restrict__ addend, long m0,
+                                                        int n0, int grp, const BnBwdFuse& fz) {
+    constexpr int QPR = WN / 4, RPP = 64 / QPR, NR = WM / RPP, WAVES_N = BN / WN;
+    pre.on = false;
+    if constexpr (NR <= 8) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+        const int qcol = (lane % QPR) * 4, qrow = lane / QPR;
+        const int ncol = grp * g.Ng + n0 + wn * WN + qcol;
+        pre.on = fz.part1 != nullptr;
+        if (pre.on) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const long m = m0 + wm * WM + rr * RPP + qrow;
+                const long off = (m < g.M ? m : 0) * g.N + ncol;      // (rows beyond M: any valid address, never used)
+                pre.add[rr] = addend ? *(const f32x4*)(addend + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+                pre.x1[rr] = *(const f32x4*)(fz.x1 + off);
+                pre.x2[rr] = fz.part2 ? *(const f32x4*)(fz.x2 + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
 // Block epilogue.  acc: this wave's (WM x WN) accumulator tiles in MFMA layout; lds: the block's K-loop LDS (free now,
 // at least 4*WM*(WN+4) floats); rows m0.., columns grp*Ng + n0.. of the [M][N] output.
 template <int BM, int BN, int WM, int WN, bool BWD = false, bool BWD_PREFETCH = false>
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], float* lds, const ConvGeom& g,
                                                const float* __restrict__ bias, const float* __restrict__ addend,
                                                float* __restrict__ dst, double* __restrict__ bn_part, int relu,
-                                               long m0, int n0, int grp, int mt_id, const BnBwdFuse* fz = nullptr) {
+                                               long m0, int n0, int grp, int mt_id, const BnBwdFuse* fz = nullptr,
+                                               const EpiPre<(WM / (64 / (WN / 4)) <= 8 ? WM / (64 / (WN / 4)) : 1)>* pre = nullptr) {
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -72,25 +105,8 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
     constexpr int NR = WM / RPP;                              // rows per lane
     const int qcol = (lane % QPR) * 4, qrow = lane / QPR;
     const int ncol = grp * g.Ng + n0 + wn * WN + qcol;
-    // Fused BatchNorm-backward epilogue: its global operands (shortcut gradient, BatchNorm inputs) do not depend on the
-    // GEMM -- request them BEFORE the accumulators are staged through LDS, so the two latencies overlap (these launches
-    // are HBM-latency bound: tools_dev/fused_dgrad_tiles.py).  Up to 8 rows per lane (64x64, 128x64, 128x32 tiles).
     constexpr bool PREF = BWD && BWD_PREFETCH && NR <= 8;      // (the fp32 kernels; the plane kernels have no registers to spare)
-    f32x4 p_add[PREF ? NR : 1], p_x1[PREF ? NR : 1], p_x2[PREF ? NR : 1];
-    bool pref = false;
-    if constexpr (PREF) {
-        pref = fz != nullptr && fz->part1 != nullptr;
-        if (pref) {
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-                const long m = m0 + wm * WM + rr * RPP + qrow;
-                const long off = (m < g.M ? m : 0) * g.N + ncol;      // (rows beyond M: any valid address, never used)
-                p_add[rr] = addend ? *(const f32x4*)(addend + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-                p_x1[rr] = *(const f32x4*)(fz->x1 + off);
-                p_x2[rr] = fz->part2 ? *(const f32x4*)(fz->x2 + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    }
+    const bool pref = PREF && pre != nullptr && pre->on;
     __syncthreads();
     constexpr int LDE = WN + 4;                               // padded row (16B aligned, breaks the 32-bank stride)
     float* Es = lds + wave * (WM * LDE);
@@ -151,7 +167,7 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
         if (m >= g.M) continue;
         f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
         if constexpr (PREF) {
-            if (pref) v += p_add[rr];
+            if (pref) v += pre->add[rr];
             else if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
         } else {
             if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
@@ -161,12 +177,12 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
                 const long off = m * g.N + ncol;
                 if (fz->mask) relu_mask_apply(v, fz->mask, off >> 2);
                 f32x4 xa;
-                if constexpr (PREF) xa = p_x1[rr]; else xa = *(const f32x4*)(fz->x1 + off);
+                if constexpr (PREF) xa = pre->x1[rr]; else xa = *(const f32x4*)(fz->x1 + off);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * ((xa[e] - mu1[e]) * rs1[e]); }
                 if (bwd2) {
                     f32x4 xb;
-                    if constexpr (PREF) xb = p_x2[rr]; else xb = *(const f32x4*)(fz->x2 + off);
+                    if constexpr (PREF) xb = pre->x2[rr]; else xb = *(const f32x4*)(fz->x2 + off);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) cq2[e] += (double)v[e] * ((xb[e] - mu2[e]) * rs2[e]);
                 }

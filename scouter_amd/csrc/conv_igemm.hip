@@ -61,6 +61,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     const int n0 = nt_id * BN;
     const int cpt = g.Cg / BK;                 // K chunks per filter tap
     const int KT = g.R * g.S * cpt;
+    EpiPre<(WM / (64 / (WN / 4)) <= 8 ? WM / (64 / (WN / 4)) : 1)> epre;
+    epre.on = false;
+    if constexpr (DGRAD && FUSE) igemm_epilogue_prefetch<BM, BN, WM, WN>(epre, g, addend, m0, n0, grp, fz);
 
     unsigned a_mask[AI];
     int a_y[AI], a_x[AI];
@@ -310,7 +313,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 
     // ---- epilogue (conv_common.h): LDS-staged vector stores, fused bias / addend / ReLU / BatchNorm statistics
     static_assert(4 * WM * (WN + 4) <= 2 * T::STAGE, "epilogue staging fits in the K-loop LDS");
-    igemm_epilogue<BM, BN, WM, WN, DGRAD && FUSE, true>(acc, lds, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
+    igemm_epilogue<BM, BN, WM, WN, DGRAD && FUSE, true>(acc, lds, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz,
+                                                        &epre);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
