@@ -151,11 +151,12 @@ class BnBwdFuse:
 
 _NO_FUSE = (None,) * 7
 # Which producers fuse -- decided by A/B runs of the real step (interleaved `bench.py --steps 120` runs on one box, three
-# each): bit 1 = 1x1 kernels -> one BatchNorm and bit 2 = 1x1 kernels -> two BatchNorms (block
-# output + downsample branch): +1.3 % images/sec together; bit 0 = bf16x3 plane kernels -> the BatchNorm in front of the
-# 3x3 layer: -0.6 % (one 256x128 workgroup per CU: nothing hides the longer epilogue, and the separate reduction pass
-# finds the freshly written gradient in the 256 MB Infinity Cache); bit 3 = fp32 3x3 kernels (stem, resnet18): -0.3 %.
-BN_BWD_FUSE = int(os.environ.get("SCOUTER_BN_FUSE", "6"))
+# each): bit 1 = 1x1 kernels -> one BatchNorm, bit 2 = 1x1 kernels -> two BatchNorms (block output +
+# downsample branch), bit 3 = fp32 3x3 kernels (stem, resnet18), bit 0 = bf16x3 plane kernels -> the BatchNorm in front
+# of the 3x3 layer.  First measurement (plain epilogue): bits 1+2 +1.3 %, bit 3 -0.3 %, bit 0 -0.6 %.  With the epilogue
+# that requests its operands at workgroup start (fp32 kernels): 6 -> 4 012, 14 -> 4 043, 7 -> 4 018, 15 -> 4 048 img/s:
+# everything fuses.
+BN_BWD_FUSE = int(os.environ.get("SCOUTER_BN_FUSE", "15"))
 
 
 def _fuse_wanted(post, kh, plane_kernel=False):

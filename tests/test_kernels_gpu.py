@@ -432,7 +432,7 @@ def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision, mo
     rounding -- for the fp32-MFMA, the bf16-input and the bf16x3 plane kernels."""
     B, H, W, Cin, Cout, k, pad, g, two, with_add = case
     kk = K()
-    monkeypatch.setattr(kk, "BN_BWD_FUSE", 15)         # every producer class (the model default fuses the 1x1 ones only)
+    monkeypatch.setattr(kk, "BN_BWD_FUSE", 15)         # every producer class (also the model default)
     rng = np.random.default_rng(sum(case[:8]))
     if precision == "planes" and ((Cin // g) % 64 or (Cout // g) % 32):
         pytest.skip("plane input gradient needs 64-multiples of input channels per group")
