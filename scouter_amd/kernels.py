@@ -381,7 +381,7 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
         tile = _pick_tile(("pdgrad", nplanes, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, cands)
         if tile < 0:
             tile = cands[0]
-    if _fuse_wanted(post, kh, True):
+    if _fuse_wanted(post, kh, True) and nplanes == 3:     # (one-plane kernels, bf16 mode: measured -0.6 % on config 5)
         post.alloc(-(-B * H * W // _PLANE_TILE_ROWS[tile]), x_shape)
         launch(tile, fuse=post.args())
     else:
