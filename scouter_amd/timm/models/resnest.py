@@ -32,7 +32,7 @@ class ResNestBottleneck(nn.Module):
     def fwd(self, x, save, tracked):
         res, rbn, kd = (x, None, None)
         if self.downsample is not None:       # (on its own stream next to the main branch, Downsample.fwd_async)
-            res, rbn, kd = self.downsample.fwd_async(x, save, tracked, BRANCH_FWD and self.conv1.use_side_stream)
+            res, rbn, kd, hnd = self.downsample.fwd_async(x, save, tracked, BRANCH_FWD and self.conv1.use_side_stream)
         c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
         t1 = c1[0] if isinstance(c1, tuple) else c1
         conv = self.conv2.conv                   # (all three of its kernels on planes: no fp32 copy of h1 is written)
@@ -42,7 +42,7 @@ class ResNestBottleneck(nn.Module):
         p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
         c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training)
         if self.downsample is not None:
-            self.downsample.fwd_join(x.device)
+            self.downsample.fwd_join(x.device, hnd)
         out, b3 = self.bn3.fwd(c3, save, relu=True, residual=res, tracked=tracked, residual_bn=rbn)
         return out, ((k1, b1, ksa, tuple(sa.shape), k3, b3, kd) if save else None)
 
@@ -60,15 +60,15 @@ class ResNestBottleneck(nn.Module):
         dc3, dres = self.bn3.bwd(dout, b3, want_gout=True, fused=own.ext(0) if own else None)
         dxres = dres
         if self.downsample is not None:       # the branch's backward next to the main branch's (Downsample.bwd_async)
-            dxres = self.downsample.bwd_async(dres, kd, need_dx, own.ext(1) if own else None,
-                                              BRANCH_BWD and self.conv1.use_side_stream)
+            dxres, hnd = self.downsample.bwd_async(dres, kd, need_dx, own.ext(1) if own else None,
+                                                   BRANCH_BWD and self.conv1.use_side_stream)
         dp = self.conv3.bwd(dc3, k3, True)
         dsa = self.avd_last.bwd(dp, sa_shape) if self.avd_last is not None else dp
         f1 = BatchNorm2d.fuse(b1)
         dh1 = self.conv2.bwd(dsa, ksa, post=f1)
         dc1, _ = self.bn1.bwd(dh1, b1, fused=f1.ext(0) if f1.applied else None)
         if self.downsample is not None:
-            dxres = self.downsample.bwd_join(dxres, dres.device)
+            dxres = self.downsample.bwd_join(dxres, dres.device, hnd)
         return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None)
 
 

@@ -36,8 +36,6 @@ class AvgPool2dSpec(nn.Module):
 class Downsample(nn.Sequential):
     """downsample_conv: [conv1x1(stride), bn]   downsample_avg: [pool | Identity, conv1x1, bn]"""
 
-    _async = False
-
     def fwd(self, x, save, tracked):
         """-> (raw convolution output, saved block of the BatchNorm, ctx): the BatchNorm itself is applied by the
         block's last BatchNorm pass together with its own (BatchNorm2d.fwd residual_bn) -- the normalised shortcut is
@@ -51,35 +49,38 @@ class Downsample(nn.Sequential):
         c, c_conv = mods[0].fwd(xin, save, bn_stats=mods[1].training)
         craw, saved = mods[1].stats_only(c, tracked, relu_follows=False)
         c_bn = (craw, None, saved, mods[1].training)
-        self._made = [t for t in (xin, craw, saved) if t is not x]       # (for record_stream when run on the side stream)
         return craw, saved, ((c_conv, c_bn, pool, tuple(x.shape)) if save else None)
 
     # ---- the branch on its own stream ("branch": never behind the backlog of weight gradients), next to the block's
     # main branch whose many small launches leave the GPU idle in between.  Measured on the benchmark step (3 x 120 steps,
     # interleaved, one box): forward +0.5 % (3 970 -> 3 991), backward +1.6 % (3 947 -> 4 011).
     def fwd_async(self, x, save, tracked, on):
-        self._async = bool(on)
+        """-> (raw output, saved block, ctx, handle); handle goes to fwd_join (no per-call state on the module)."""
         if not on:
-            return self.fwd(x, save, tracked)
+            return self.fwd(x, save, tracked) + (None,)
         with K.side_stream(x.device, x, enabled=True, which="branch"):
-            return self.fwd(x, save, tracked)
+            craw, saved, ctx = self.fwd(x, save, tracked)
+        made = [craw, saved] + ([ctx[0][0] if isinstance(ctx[0], tuple) else ctx[0]] if ctx is not None else [])
+        return craw, saved, ctx, [t for t in made if torch.is_tensor(t) and t is not x]
 
-    def fwd_join(self, device):
-        if self._async:
+    @staticmethod
+    def fwd_join(device, handle):
+        if handle is not None:
             K.join_side_stream(device, "branch")
             cur = torch.cuda.current_stream(device)
-            for t in self._made:
+            for t in handle:
                 t.record_stream(cur)
 
     def bwd_async(self, dy, ctx, need_dx, fused, on):
-        self._async = bool(on)
+        """-> (dx, handle) for bwd_join."""
         if not on:
-            return self.bwd(dy, ctx, need_dx, fused=fused)
+            return self.bwd(dy, ctx, need_dx, fused=fused), False
         with K.side_stream(dy.device, dy, fused[0] if fused else None, enabled=True, which="branch"):
-            return self.bwd(dy, ctx, need_dx, fused=fused)
+            return self.bwd(dy, ctx, need_dx, fused=fused), True
 
-    def bwd_join(self, dx, device):
-        if self._async:
+    @staticmethod
+    def bwd_join(dx, device, handle):
+        if handle:
             K.join_side_stream(device, "branch")
             if dx is not None:
                 dx.record_stream(torch.cuda.current_stream(device))
@@ -115,12 +116,12 @@ class BasicBlock(nn.Module):
         res, rbn, kd = (x, None, None)
         if self.downsample is not None:
             # (not on the branch stream: resnet18's step is launch-bound -- measured 7 460 -> 7 280 img/s with it)
-            res, rbn, kd = self.downsample.fwd_async(x, save, tracked, False)
+            res, rbn, kd, hnd = self.downsample.fwd_async(x, save, tracked, False)
         c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
         h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked)
         c2, k2 = self.conv2.fwd(h1, save, bn_stats=self.bn2.training)
         if self.downsample is not None:
-            self.downsample.fwd_join(x.device)
+            self.downsample.fwd_join(x.device, hnd)
         out, b2 = self.bn2.fwd(c2, save, relu=True, residual=res, tracked=tracked, residual_bn=rbn)
         return out, ((k1, b1, k2, b2, kd) if save else None)
 
@@ -135,12 +136,12 @@ class BasicBlock(nn.Module):
         dc2, dres = self.bn2.bwd(dout, b2, want_gout=True, fused=own.ext(0) if own else None)
         dxres = dres
         if self.downsample is not None:
-            dxres = self.downsample.bwd_async(dres, kd, need_dx, own.ext(1) if own else None, False)
+            dxres, hnd = self.downsample.bwd_async(dres, kd, need_dx, own.ext(1) if own else None, False)
         f1 = BatchNorm2d.fuse(b1)
         dh1 = self.conv2.bwd(dc2, k2, True, post=f1)
         dc1, _ = self.bn1.bwd(dh1, b1, fused=f1.ext(0) if f1.applied else None)
         if self.downsample is not None:
-            dxres = self.downsample.bwd_join(dxres, dres.device)
+            dxres = self.downsample.bwd_join(dxres, dres.device, hnd)
         return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None)
 
 
