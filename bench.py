@@ -56,6 +56,21 @@ PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md chip table (v_
 PEAK_BF16_MFMA_TFLOPS = 2500.0              # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), same table
 
 
+# forward convolution GFLOP per image of the backbones (probed on the reference's timm
+# models), by (model, image size)
+BACKBONE_GFLOP = {("resnest26d", 224): 7.243, ("resnest26d", 260): 10.302, ("resnest50d", 224): 10.738,
+                  ("resnest50d", 260): 15.403, ("resnet18", 224): 3.406, ("resnet18", 260): 4.978}
+
+
+def fwd_gflop(cfg):
+    """Algorithmic forward GFLOP per image: backbone convolutions + the head (conv1x1 channel -> d, to_k MLP, T x (QK^T +
+    AV), (T-1) GRUs)."""
+    n = (-(-cfg["img_size"] // 32)) ** 2
+    d, S, T = cfg["hidden_dim"], cfg["num_classes"] * cfg["slots_per_class"], 3
+    head = 2.0 * n * cfg["channel"] * d + 2.0 * cfg["to_k_layer"] * n * d * d + T * 4.0 * S * n * d + (T - 1) * 12.0 * S * d * d
+    return BACKBONE_GFLOP[(cfg["model"], cfg["img_size"])] + head * 1e-9
+
+
 def make_args(cfg):
     return argparse.Namespace(model=cfg["model"], pre_trained=False, num_classes=cfg["num_classes"],
                               dataset=cfg.get("dataset", "ImageNet"),
@@ -179,41 +194,83 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
             "measured": "hipEvents around each launch, median of 8 batches x 20 launches after 60 warm-up launches"}
 
 
-PMC_TRAFFIC_FILE = "r02_pmc_hbm_traffic.json"
+PMC_TRAFFIC_FILE = "r03_pmc_hbm_traffic.json"
+PMC_MFMA_FILE = "r03_pmc_mfma_util.json"
+# Kernel classes of the roofline object: bench label prefixes (the library's hipEvent scopes) and the rocprofv3 kernel-name
+# prefixes of the SAME kernels.  Names are matched by exact prefix ("void wgrad_kernel<" does not match
+# "void pwgrad_kernel<": round 2's substring match mixed the two).
+CLASSES = {
+    "fp32_mfma_conv": {
+        "labels": ("igemm_fwd<", "igemm_dgrad<", "igemm_dgrad+bn_bwd<", "wgrad<", "wgrad_taps"),
+        "rocprof": ("void igemm_kernel<", "void wgrad_kernel<", "void wgrad_taps_kernel<"),
+        "peak": 157.3, "what": "fp32 implicit-GEMM convolutions (forward, input gradient incl. the fused BatchNorm-backward "
+                               "epilogue, weight gradient), v_mfma_f32_32x32x2_f32"},
+    "bf16x3_plane_conv": {
+        "labels": ("pconv_fwd<bf16x3>", "pconv_dgrad<bf16x3>", "pwgrad<bf16x3>"),
+        "rocprof": ("void pconv_kernel<", "void phalo_kernel<", "void pwgrad_kernel<", "void ppersist_kernel<"),
+        "peak": 2500.0 / 6.0, "what": "grouped 3x3 convolutions on exact three-way bf16 operand splits: 6 x "
+                                      "v_mfma_f32_32x32x16_bf16 per fp32-grade product, fp32 accumulate; peak = 2500 / 6 "
+                                      "TFLOP/s of algorithmic work"},
+    "bf16_mfma_conv": {
+        "labels": ("igemm_fwd_bf16<", "igemm_dgrad_bf16<", "igemm_dgrad_bf16+bn_bwd<", "wgrad_bf16", "pconv_fwd<bf16>",
+                   "pconv_dgrad<bf16>", "pwgrad<bf16>"),
+        "rocprof": ("void igemm_bf16_kernel<", "void wgrad_bf16_kernel<", "void pconv_kernel<", "void phalo_kernel<",
+                    "void pwgrad_kernel<"),
+        "peak": 2500.0, "what": "bf16-input convolutions (--precision bf16), v_mfma_f32_32x32x16_bf16, fp32 accumulate"},
+}
 
 
-def pmc_traffic(kernel_class):
-    """HBM-side bytes per launch of a kernel class (e.g. 'igemm_dgrad<64x64>', 'pconv_fwd<bf16x3>') from the committed
-    rocprofv3 PMC passes (profiles/r02_pmc_hbm_traffic.json, made by tools_dev/pmc_traffic.py: 2 x FETCH_SIZE +
-    WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md) -- PMC counters cannot be collected from inside the timed
-    process.  None if the file or the kernel is missing."""
-    import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
+def _profile_json(fname):
+    path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path):
-        return None, None
-    m = re.match(r"(igemm_fwd|igemm_dgrad|wgrad)(?:\+bn_bwd)?<(\d+)x(\d+)>", kernel_class)
-    if m:        # (a fused "+bn_bwd" launch is the same kernel instance: the per-launch mean covers both kinds)
-        kind, bm, bn = m.group(1), int(m.group(2)), int(m.group(3))
-        want = ("wgrad_kernel<%d, %d," % (bm, bn)) if kind == "wgrad" else "igemm_kernel<%d, %d," % (bm, bn)
-        # igemm_kernel<BM, BN, WM, WN, DGRAD, STRIDED, PW>
-        match = (lambda name: want in name) if kind == "wgrad" else \
-            (lambda name: want in name and (", true, " if kind == "igemm_dgrad" else ", false, ") in name.split(want)[1][:24])
-    elif kernel_class.startswith("pconv_fwd"):
-        match = lambda name: ("pconv_kernel<" in name or "phalo_kernel<" in name) and ", false" in name
-    elif kernel_class.startswith("pconv_dgrad"):
-        match = lambda name: ("pconv_kernel<" in name or "phalo_kernel<" in name) and ", true" in name
-    elif kernel_class.startswith("pwgrad"):
-        match = lambda name: "pwgrad_kernel<" in name
-    else:
-        return None, None
-    tot = n = 0.0
-    for name, rec in json.load(open(path)).items():
-        if match(name):
-            tot += (rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]) * rec["launches"]
-            n += rec["launches"]
-    if not n:
-        return None, None
-    return round(tot / n), "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % PMC_TRAFFIC_FILE
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def pmc_class(prefixes):
+    """(HBM-side bytes per launch, MFMA-busy fraction, sources) of the kernels whose rocprofv3 names start with one of
+    `prefixes`, from the committed PMC passes over THIS command (profiles/r03_pmc_*.json, made by tools_dev/pmc_traffic.py
+    -- 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md -- and tools_dev/pmc_mfma.py); PMC
+    counters cannot be collected from inside the timed process.  The static tile table makes the instances of those
+    runs the instances of this one.  None where a file is missing."""
+    traffic = busy = None
+    src = []
+    t = _profile_json(PMC_TRAFFIC_FILE)
+    if t:
+        rows = [r for n, r in t["kernels"].items() if n.startswith(prefixes)]
+        nl = sum(r["launches"] for r in rows)
+        if nl:
+            traffic = round(sum((r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] for r in rows) / nl)
+            src.append("profiles/" + PMC_TRAFFIC_FILE)
+    m = _profile_json(PMC_MFMA_FILE)
+    if m:
+        rows = [r for n, r in m["kernels"].items() if n.startswith(prefixes)]
+        tot = sum(r["avg_us"] * r["launches"] for r in rows)
+        if tot:
+            busy = round(sum(r["mfma_busy"] * r["avg_us"] * r["launches"] for r in rows) / tot, 4)
+            src.append("profiles/" + PMC_MFMA_FILE)
+    return traffic, busy, src
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) the way the reference's README
+    does with torch.distributed.launch (reference README.md:20-22, tools/prepare_things.py:9-31) and pass their single
+    JSON line through.  Refuses when the node has fewer than N devices."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: this node exposes %d HIP device(s); refusing to run fewer ranks than "
+                         "asked for (the reported n_gpus would be wrong)" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -226,6 +283,8 @@ def main():
     ap.add_argument("--precision", choices=("fp32", "bf16"), default=None,
                     help="backbone matrix-input precision (default: fp32; bf16 for --config 5, the config that names it)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's; weak scaling)")
+    ap.add_argument("--img-size", type=int, default=None, choices=(224, 260),
+                    help="input resolution (default 224, the metric's; 260 = the reference's --img_size default, 9x9 tokens)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (scouter_amd/graph.py) instead of issuing it kernel by "
                          "kernel; measured SLOWER on ROCm 7.0 / MI355X for this GPU-bound step, hence opt-in")
@@ -234,8 +293,12 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=5, help="steps of the serial per-kernel timing pass")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a.gpus, sys.argv[1:])
     import __graft_entry__ as G
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and not os.environ.get("SCOUTER_FORCE_DP"):
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -263,6 +326,9 @@ def main():
         cfg["batch"] = a.batch
     if a.precision:
         cfg["precision"] = a.precision
+    if a.img_size:
+        cfg["img_size"] = a.img_size
+    cfg["fwd_gflop"] = fwd_gflop(cfg)
     bf16 = cfg["precision"] == "bf16"
     mnist = cfg["dataset"] == "MNIST"
     torch.manual_seed(0)
@@ -344,49 +410,58 @@ def main():
             kern[name] = {"launches_per_step": n / prof_steps, "ms_per_step": round(ms / prof_steps, 4),
                           "avg_us": round(1e3 * ms / n, 2), "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None,
                           "gbps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1) if by else None}
-        conv = [k for k in kern if k.startswith(("igemm_", "wgrad<", "wgrad_taps", "wgrad_bf16", "pconv_", "pwgrad"))]
-        is_bf16_kernel = lambda k: "bf16" in k
-        # peaks per kernel family: exact-fp32 MFMA 157.3; plain bf16 MFMA 2500; "bf16x3" = fp32-accurate products rebuilt
-        # from SIX bf16 MFMA products each, so its algorithmic-FLOP ceiling is 2500 / 6 = 416.7 TFLOP/s
-        kpeak = lambda k: (PEAK_BF16_MFMA_TFLOPS / 6.0 if "bf16x3" in k else PEAK_BF16_MFMA_TFLOPS) if is_bf16_kernel(k) \
-            else PEAK_FP32_MFMA_TFLOPS
-        kdesc = lambda k: (" (convolution on exact three-way bf16 operand splits: 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, "
-                           "fp32 accumulate; peak = 2500 / 6 TFLOP/s of algorithmic work)" if "bf16x3" in k else
-                           " (bf16-input implicit-GEMM convolution, v_mfma_f32_32x32x16_bf16, fp32 accumulate)"
-                           if is_bf16_kernel(k) else " (fp32 implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)")
+        # ---- roofline: stable kernel CLASSES (not an argmax over near-tied instances): each with its algorithmic FLOPs,
+        # time, fraction of ITS matrix peak and -- from the committed PMC passes of this command -- MFMA-busy and HBM-side
+        # traffic per launch against the algorithmic bytes.  `roofline` itself = the class with the most time per step.
+        classes = {}
+        for cname, c in CLASSES.items():
+            rows = [k for k in kern if k.startswith(c["labels"]) and kern[k]["tflops"]]
+            if not rows:
+                continue
+            ms = sum(kern[k]["ms_per_step"] for k in rows)
+            fl = sum(kern[k]["tflops"] * kern[k]["ms_per_step"] for k in rows)            # GFLOP per step
+            nl = sum(kern[k]["launches_per_step"] for k in rows)
+            by = sum((kern[k]["gbps_algorithmic"] or 0.0) * kern[k]["ms_per_step"] * 1e6 for k in rows)   # bytes per step
+            traffic, busy, src = pmc_class(c["rocprof"]) if a.config == 2 and cfg["img_size"] == 224 and \
+                cfg["batch"] == CONFIGS[2]["batch"] and not bf16 else (None, None, [])
+            classes[cname] = {"kernels": c["what"], "instances": sorted(rows), "gflop_per_step": round(fl, 1),
+                              "ms_per_step": round(ms, 4), "launches_per_step": nl, "avg_launch_us": round(1e3 * ms / nl, 2),
+                              "achieved": round(fl / ms, 2), "peak": round(c["peak"], 1), "unit": "TFLOP/s",
+                              "frac": round(fl / ms / c["peak"], 4), "pmc_mfma_busy": busy,
+                              "algorithmic_bytes_per_launch": round(by / nl), "traffic": traffic,
+                              "traffic_over_algorithmic": round(traffic / (by / nl), 2) if traffic and by else None,
+                              "pmc_source": src or None}
         roofline = None
-        if conv:
-            # the dominant kernel INSTANCE (most time per step); its rocprofv3 row is igemm_kernel<BM,BN,..> / wgrad_kernel<..>
-            dom = max(conv, key=lambda k: kern[k]["ms_per_step"])
-            ach = kern[dom]["tflops"]
-            tot_ms = sum(kern[k]["ms_per_step"] for k in conv)
-            tot_fl = sum(kern[k]["tflops"] * kern[k]["ms_per_step"] for k in conv)
-            # time-weighted fraction of each kernel's OWN matrix peak (fp32-MFMA kernels vs 157.3, bf16-MFMA kernels vs
-            # 2500 TFLOP/s): in bf16 mode the small / strided layers stay on the fp32 kernels
-            frac_all = sum(kern[k]["tflops"] * kern[k]["ms_per_step"] / kpeak(k) for k in conv) / tot_ms
+        if classes:
+            dom = max(classes, key=lambda c: classes[c]["ms_per_step"])
+            d = classes[dom]
+            tot_ms = sum(c["ms_per_step"] for c in classes.values())
+            tot_fl = sum(c["gflop_per_step"] for c in classes.values())
             step_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-            roofline = {"bound": "mfma",
-                        "kernel": dom + kdesc(dom),
-                        "achieved": ach, "peak": round(kpeak(dom), 1), "unit": "TFLOP/s",
-                        "frac": round(ach / kpeak(dom), 4), "traffic": None,
-                        "avg_launch_us": kern[dom]["avg_us"], "launches_per_step": kern[dom]["launches_per_step"],
+            roofline = {"bound": "mfma", "kernel": "%s: %s" % (dom, d["kernels"]),
+                        "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],
+                        "traffic": d["traffic"], "traffic_source": d["pmc_source"],
+                        "avg_launch_us": d["avg_launch_us"], "launches_per_step": d["launches_per_step"],
                         "measured": "hipEvents on the launch stream over %d serial steps (weight-gradient side stream "
-                                    "off) right after the timed region" % prof_steps,
+                                    "off) right after the timed region; class = all launches of the listed kernel "
+                                    "instances (same instances in every process: static tile table "
+                                    "scouter_amd/tuning/gfx950.json)" % prof_steps,
+                        "classes": classes,
                         "all_conv_kernels_tflops": round(tot_fl / tot_ms, 2),
-                        "all_conv_kernels_frac": round(frac_all, 4),
-                        # the same rate against the pipe the REFERENCE arithmetic would use (round 1's yardstick): the
-                        # bf16x3 plane kernels deliver fp32-grade products faster than the fp32 MFMA can
+                        # time-weighted fraction of each class's OWN matrix peak
+                        "all_conv_kernels_frac": round(sum(c["frac"] * c["ms_per_step"] for c in classes.values()) / tot_ms, 4),
+                        # the same FLOPs against the pipe the REFERENCE arithmetic would use (fp32 MFMA; round 1's
+                        # yardstick): the bf16x3 plane kernels deliver fp32-grade products faster than the fp32 MFMA can
                         "all_conv_kernels_frac_of_step_peak": round(tot_fl / tot_ms / step_peak, 4),
                         "whole_step_frac": round(value * 3 * cfg["fwd_gflop"] * 1e9 / world / (step_peak * 1e12), 4)}
-        if roofline is not None:
-            roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom) if a.config == 2 and not bf16 else (None, None)
-        line = {"metric": cfg["metric"] if cfg["batch"] == CONFIGS[a.config]["batch"] else
-                cfg["metric"].rsplit(", bs", 1)[0] + ", bs%d)" % cfg["batch"], "value": round(value, 2),
+        metric = cfg["metric"].replace("224^2", "%d^2" % cfg["img_size"])
+        line = {"metric": metric if cfg["batch"] == CONFIGS[a.config]["batch"] else
+                metric.rsplit(", bs", 1)[0] + ", bs%d)" % cfg["batch"], "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-                "config": {"workload": "%s, 224x224, per-GPU batch %d, random init, AdamW lr 1e-4%s"
-                                       % (cfg["name"], cfg["batch"],
+                "config": {"workload": "%s, %dx%d, per-GPU batch %d, random init, AdamW lr 1e-4%s"
+                                       % (cfg["name"], cfg["img_size"], cfg["img_size"], cfg["batch"],
                                           "; backbone convolution matrix inputs in bf16 (fp32 accumulate, fp32 storage, "
                                           "fp32 head)" if bf16 else ""),
                            "baseline_config": a.config, "precision": cfg["precision"],
@@ -397,6 +472,8 @@ def main():
                 "roofline": roofline, "kernels": kern}
         if world == 1 and not a.no_prof:
             line["xslot_roofline"] = xslot_roofline(device)
+            # the reference's default geometry (--img_size 260 -> 9 x 9 = 81 tokens, reference train.py:39)
+            line["xslot_roofline_n81"] = xslot_roofline(device, tokens=81)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

@@ -79,19 +79,104 @@ def conv_out(n, k, s, p):
 # by the layer object (nn_hip.Conv2d.precision, set per model by SlotModel) -- there is no module-global switch, so
 # models of different precision, or a backward on the autograd thread next to another model's forward, cannot race.
 BF16_MIN_PIXELS = 1024      # layers with fewer GEMM rows (the split-attention FCs on the pooled vector) stay in fp32
-AUTOTUNE = os.environ.get("SCOUTER_AUTOTUNE", "1") != "0"
+# Block tiles / weight-gradient plans per layer shape.  DEFAULT: a STATIC table (scouter_amd/tuning/gfx950.json, made
+# offline on an MI355X by tools_dev/tune_table.py with the timing autotuner below and committed), so every process, every
+# data-parallel rank and every profiler run launches the SAME kernel instance for a layer shape -- gradients are
+# bit-reproducible across processes and the rocprofv3 rows under profiles/ are the instances bench.py times.  Shapes the
+# table does not hold take the entry of the nearest batch size with otherwise equal geometry, else the library's static
+# heuristic (-1).  SCOUTER_AUTOTUNE=1 brings back timing on first use (per process; SCOUTER_TUNE_RECORD=<file> writes
+# what it chose, which is how the table is made); SCOUTER_AUTOTUNE=0 ignores the table too (library heuristics only).
+AUTOTUNE = os.environ.get("SCOUTER_AUTOTUNE", "table")
 _tile_cache = {}
+_tune_table = None
+_tune_index = None
+TUNE_TABLE_PATH = os.environ.get("SCOUTER_TUNE_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                       "tuning", "gfx950.json")
+
+
+def _key_str(key):
+    return "|".join(str(int(k)) if isinstance(k, bool) else str(k) for k in key)
+
+
+def _batch_pos(key):
+    """Index of the batch entry in a tuning key: ("fwd", bf16, B, ...), ("dgrad+bn", n, addend, bf16, B, ...),
+    ("pfwd" | "pdgrad" | "pwgrad", nplanes, B, ...), ("wgrad" | "dgrad", bf16, B, ...)."""
+    return 4 if key[0] == "dgrad+bn" else 2
+
+
+def _load_tune_table():
+    global _tune_table, _tune_index
+    import json
+    _tune_table, _tune_index = {}, {}
+    if os.path.exists(TUNE_TABLE_PATH):
+        with open(TUNE_TABLE_PATH) as f:
+            _tune_table = {k: int(v) for k, v in json.load(f)["choices"].items()}
+    for ks, v in _tune_table.items():
+        parts = ks.split("|")
+        bp = _batch_pos(parts)
+        _tune_index.setdefault("|".join(parts[:bp] + ["*"] + parts[bp + 1:]), []).append((int(parts[bp]), v))
+    for lst in _tune_index.values():
+        lst.sort()
+
+
+def _table_choice(key, launch):
+    """The committed choice for this layer shape (exact key, else the same geometry at the nearest batch size -- ties
+    to the smaller batch), if it is a legal candidate here; else -1."""
+    import math
+    if _tune_table is None:
+        _load_tune_table()
+    ks = _key_str(key)
+    v = _tune_table.get(ks)
+    if v is None:
+        bp = _batch_pos(key)
+        near = _tune_index.get("|".join([_key_str(key[:bp]), "*", _key_str(key[bp + 1:])]))
+        if near:
+            v = min(near, key=lambda e: (abs(math.log(e[0] / float(key[bp]))), e[0]))[1]
+    if v is None or v < 0 or not launch(v, dry=True):
+        return -1
+    return v
+
+
+def _record_choice(key, choice):
+    path = os.environ.get("SCOUTER_TUNE_RECORD")
+    if not path:
+        return
+    import atexit
+    import json
+    if not hasattr(_record_choice, "pending"):
+        _record_choice.pending = {}
+
+        def flush():
+            old = {}
+            if os.path.exists(path):
+                with open(path) as f:
+                    old = json.load(f).get("choices", {})
+            old.update(_record_choice.pending)
+            with open(path, "w") as f:
+                json.dump({"arch": "gfx950", "choices": dict(sorted(old.items()))}, f, indent=0)
+        atexit.register(flush)
+    _record_choice.pending[_key_str(key)] = int(choice)
+
+
+TUNE_REPS = int(os.environ.get("SCOUTER_TUNE_REPS", "3"))
 
 
 def _pick_tile(key, launch, candidates=(0, 1, 2, 3)):
-    """Block-tile choice per (mode, layer shape): time the four tile shapes once (hipEvents on the current stream, first
-    call only) and cache the winner.  Every tile gives bit-identical results, so tuning never changes numerics."""
+    """Block-tile / plan choice per (mode, layer shape).  Default: the committed static table (see AUTOTUNE above).
+    SCOUTER_AUTOTUNE=1: time the candidates once (hipEvents on the current stream, first call only) and cache the winner.
+    Forward tiles give bit-identical results; weight-gradient plans and plane tile 5 change the summation order."""
     t = _tile_cache.get(key)
     if t is not None:
         return t
-    if not AUTOTUNE:
+    if AUTOTUNE == "0":
         _tile_cache[key] = -1
         return -1
+    if AUTOTUNE != "1":
+        t = _table_choice(key, launch)
+        if t >= 0 and t not in candidates:
+            t = -1
+        _tile_cache[key] = t
+        return t
     best, best_ms = -1, None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()          # nothing else on the device while the candidates are timed (side-stream callers!)
@@ -99,15 +184,19 @@ def _pick_tile(key, launch, candidates=(0, 1, 2, 3)):
         if not launch(cand, dry=True):
             continue
         launch(cand)
-        ev0.record()
-        for _ in range(3):
-            launch(cand)
-        ev1.record()
-        ev1.synchronize()
-        ms = ev0.elapsed_time(ev1)
+        ms = None
+        for _ in range(2 if TUNE_REPS > 3 else 1):          # (offline table runs: best of two batches)
+            ev0.record()
+            for _ in range(TUNE_REPS):
+                launch(cand)
+            ev1.record()
+            ev1.synchronize()
+            m = ev0.elapsed_time(ev1)
+            ms = m if ms is None else min(ms, m)
         if best_ms is None or ms < best_ms:
             best, best_ms = cand, ms
     _tile_cache[key] = best
+    _record_choice(key, best)
     return best
 
 

@@ -97,7 +97,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def _plan_valid(self):
         if self._plan is None:
             return False
-        for group, plan in zip(self.param_groups, self._plan):
+        for gi, (group, plan) in enumerate(zip(self.param_groups, self._plan)):
             ps = [p for p in group["params"] if p.grad is not None]
             if plan is None:
                 if ps:
@@ -106,7 +106,7 @@ class FusedAdamW(torch.optim.Optimizer):
             if [id(p) for p in ps] != plan["ids"] or [p.grad.data_ptr() for p in ps] != plan["gptrs"] \
                     or [p.data_ptr() for p in ps] != plan["pptrs"]:
                 return False
-            if plan["state"] is not self.state.get("_flat_%d" % self._plan.index(plan)):
+            if plan["state"] is not self.state.get("_flat_%d" % gi):
                 return False
         return True
 
@@ -119,7 +119,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if not self._plan_valid():
             self._build_plan()
         L = _native.lib()
-        for group, plan in zip(self.param_groups, self._plan):
+        for gi, (group, plan) in enumerate(zip(self.param_groups, self._plan)):
             if plan is None:
                 continue
             st = plan["state"]
@@ -127,7 +127,6 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             grads = ctypes.c_void_p(plan["base"])
             if self.capturable:
-                gi = self._plan.index(plan)
                 dyn = self._dyn_buffer(gi, group, st, advance=True)
                 _native.check(L.scouter_adamw_step_dev_f32(plan["table"].data_ptr(), plan["n"], grads,
                                                            st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),

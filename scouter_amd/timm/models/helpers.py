@@ -63,6 +63,10 @@ def load_pretrained(model, model_name, num_classes=1000, in_chans=3, strict=True
         state.pop("fc.bias", None)
         strict = False
     missing, unexpected = model.load_state_dict(state, strict=False)
+    # checkpoints saved before torch 0.4.1 (the genuine resnet18-5c106cde.pth has 102 keys) carry no
+    # `num_batches_tracked`; torch's own BatchNorm fills the absent counter in silently (_NormBase._load_from_state_dict,
+    # version < 2) and so does this loader: the buffer keeps its initial 0
+    missing = [k for k in missing if not k.endswith(".num_batches_tracked")]
     missing = [k for k in missing if not (k.startswith("fc.") and not strict)]
     if missing or unexpected:
         raise RuntimeError("pretrained checkpoint %s does not fit %s: missing %s, unexpected %s"

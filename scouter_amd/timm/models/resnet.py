@@ -207,7 +207,10 @@ class ResNet(nn.Module):
             ctx.append((k0,))
         # bn1 + act1 + maxpool in one pass: only bn1's statistics are finalised, relu(bn1(c)) is evaluated inside the
         # pooling windows (and again, with the same fma, in the backward) -- the 112x112 activation is never stored
-        if self.fuse_stem_pool:
+        ct = c[0] if isinstance(c, tuple) else c
+        # (the fused backward walks one workgroup row per input pixel row: grid.y = B * H <= 65535, i.e. 585 images of
+        # 224 x 224 per GPU; larger batches take the unfused chain, whose pool backward has a generic fallback)
+        if self.fuse_stem_pool and ct.shape[0] * ct.shape[1] <= 65535:
             craw, saved = self.bn1.stats_only(c, tracked)
             p, arg = K.bn_maxpool_fwd(craw, saved, 3, 2, 1, want_argmax=save)
             ctx.append((craw, saved, self.bn1.training, arg))

@@ -33,7 +33,9 @@ def pretrained_dir(tmp_path, monkeypatch):
     monkeypatch.setenv("SCOUTER_PRETRAINED_DIR", str(d))
     monkeypatch.setenv("TORCH_HOME", str(tmp_path / "no_torch_home"))
 
-    def make(arch, seed=11):
+    def make(arch, seed=11, legacy=False):
+        """legacy=True: no `num_batches_tracked` entries -- the genuine torchvision resnet18-5c106cde.pth (102 keys)
+        was saved before torch 0.4.1 introduced that buffer."""
         from scouter_amd.timm.models import create_model
         from scouter_amd.timm.models.helpers import PRETRAINED
         g = torch.Generator().manual_seed(seed)
@@ -43,6 +45,8 @@ def pretrained_dir(tmp_path, monkeypatch):
             sd[k] = (torch.randn(v.shape, generator=g) * 0.05 if v.dtype.is_floating_point else v.clone()).contiguous()
             if k.endswith("running_var"):
                 sd[k] = sd[k].abs() + 0.5
+        if legacy:
+            sd = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
         torch.save(sd, d / PRETRAINED[arch][0])
         return sd
     return make

@@ -106,6 +106,41 @@ def test_pretrained_first_conv_channel_sum_for_one_channel_models(pretrained_dir
     assert torch.equal(m.state_dict()["fc.weight"], sd["fc.weight"])
 
 
+def test_pretrained_legacy_checkpoint_without_num_batches_tracked_loads(pretrained_dir):
+    """resnet18-5c106cde.pth predates `num_batches_tracked` (102 keys); torch's BatchNorm fills the counter in
+    (_NormBase._load_from_state_dict), the reference therefore loads it, and so must this loader."""
+    from scouter_amd.sloter.slot_model import SlotModel
+    from scouter_amd.timm.models import create_model
+    sd = pretrained_dir("resnet18", legacy=True)
+    assert len(sd) == 102 and not any(k.endswith("num_batches_tracked") for k in sd)
+    m = SlotModel(_args("resnet18", mnist=True, L=1, pre_trained=True, freeze_layers=1))
+    got = m.state_dict()
+    assert torch.equal(got["backbone.layer2.0.bn1.running_var"], sd["layer2.0.bn1.running_var"])
+    assert int(got["backbone.layer2.0.bn1.num_batches_tracked"]) == 0
+    # a genuinely missing tensor is still an error
+    sd.pop("layer1.0.bn1.weight")
+    from scouter_amd.timm.models.helpers import find_pretrained
+    torch.save(sd, find_pretrained("resnet18"))
+    with pytest.raises(RuntimeError, match="layer1.0.bn1.weight"):
+        create_model("resnet18", pretrained=True, num_classes=1000)
+
+
+def test_fused_adamw_plan_lookup_with_two_param_groups():
+    """the plan of the second group was looked up with list.index (dict == dict compares tensors)."""
+    from scouter_amd.optim import FusedAdamW
+    a, b = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(4, 4))
+    opt = FusedAdamW([{"params": [a]}, {"params": [b], "lr": 1e-2}], lr=1e-3)
+    st = [{"step": 0}, {"step": 0}]
+    opt.state["_flat_0"], opt.state["_flat_1"] = st
+    a.grad, b.grad = torch.zeros(8), torch.zeros(4, 4)
+    mk = lambda p, s: dict(table=torch.zeros(3), n=1, base=0, span=0, ids=[id(p)], gptrs=[p.grad.data_ptr()],
+                           pptrs=[p.data_ptr()], state=s)
+    opt._plan = [mk(a, st[0]), mk(b, st[1])]
+    assert opt._plan_valid()                       # (raised "Boolean value of Tensor ... ambiguous" before)
+    opt._plan[1]["state"] = {"step": 0}
+    assert not opt._plan_valid()
+
+
 def test_grad_arena_views_alias_flat_buffer():
     from scouter_amd.nn_hip import GradArena
     from scouter_amd.sloter.slot_model import SlotModel

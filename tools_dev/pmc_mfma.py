@@ -29,7 +29,15 @@ for name, a in agg.items():
     rows.append((a["dur"], name, a["n"], a["SQ_VALU_MFMA_BUSY_CYCLES"], a["GRBM_GUI_ACTIVE"], a.get("SQ_BUSY_CYCLES", 0)))
 rows.sort(reverse=True)
 print("%-62s %6s %10s %12s %10s %9s" % ("kernel", "calls", "avg us", "MFMA busy", "GUI active", "MFMA util"))
-for dur, name, n, mf, gui, sqb in rows[:30]:
+out = {}
+for dur, name, n, mf, gui, sqb in rows[:60]:
     # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs
     util = mf / (1024.0 * gui / 8.0)
     print("%-62s %6d %10.1f %12.3e %10.3e %8.1f%%" % (name[:62], n, dur / n / 1e3, mf / n, gui / n / 8.0, 100 * util))
+    out[name] = {"launches": n, "avg_us": dur / n / 1e3, "mfma_busy": util}
+if len(sys.argv) > 3:
+    import json
+    json.dump({"command": "SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE "
+                          "SQ_BUSY_CYCLES -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-prof",
+               "mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD)", "kernels": out},
+              open(sys.argv[3], "w"), indent=1)

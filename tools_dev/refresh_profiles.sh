@@ -19,7 +19,7 @@ SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/write" --
 python tools_dev/pmc_traffic.py "$(db $O/fetch)" "$(db $O/write)" adamw_kernel:3 > "$O/pmc_traffic.txt" 2> "$O/pmc_traffic.err"
 cp pmc_traffic.json "$O/" 2>/dev/null; cp gpurun_out/pmc_traffic.json "$O/" 2>/dev/null
 SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d "$O/mfma" -- $B3 > "$O/mfma.log" 2>&1
-python tools_dev/pmc_mfma.py "$(db $O/mfma)" adamw_kernel:3 > "$O/mfma_bench.txt"
+python tools_dev/pmc_mfma.py "$(db $O/mfma)" adamw_kernel:3 "$O/pmc_mfma_util.json" > "$O/mfma_bench.txt"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d "$O/mfma_xs" -- python tools_dev/xslot_bench.py > "$O/mfma_xs.log" 2>&1
 python tools_dev/pmc_mfma.py "$(db $O/mfma_xs)" > "$O/mfma_xs.txt"
 grep -h '"metric"' "$O/off.log" "$O/on.log" | tail -2 > "$O/bench_lines.json"
