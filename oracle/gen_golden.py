@@ -91,8 +91,34 @@ def run_reference_head(case, dtype):
                d_conv_w_digest=torch.from_numpy(grad_digest(conv.weight.grad)), d_conv_b=conv.bias.grad)
     for k, p in slot.named_parameters():
         res["d_slot." + k] = p.grad if p.grad is not None else torch.zeros(0)
-    res["vis"] = torch.from_numpy(O.vis_maps(store[-1], C, spc, 0))
+    res["vis"] = torch.from_numpy(reference_vis_pngs(slot, x_pe.detach(), x.detach(), C))
     return {k: v.detach().numpy() for k, v in res.items()}
+
+
+def reference_vis_pngs(slot, x_pe, x, C):
+    """The reference's OWN --vis output (sloter/utils/slot_attention.py:68-85): a second forward of the same module with
+    vis=True / vis_id=0 in a scratch working directory holding `sloter/vis/`; the `slot_{id}.png` files it writes are read
+    back -> uint8 [C, side, side].  (Round 2 applied the oracle's vis_maps to the captured attention instead, which pinned
+    the oracle to itself.)"""
+    import contextlib
+    import io
+    import tempfile
+    from PIL import Image
+    side = int(x.shape[1] ** 0.5)
+    cwd = os.getcwd()
+    slot.vis, slot.vis_id = True, 0
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            os.makedirs(os.path.join(tmp, "sloter", "vis"))
+            os.chdir(tmp)
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+                slot(x_pe, x)
+            maps = np.stack([np.array(Image.open(os.path.join(tmp, "sloter", "vis", "slot_%d.png" % i))) for i in range(C)])
+    finally:
+        os.chdir(cwd)
+        slot.vis = False
+    assert maps.dtype == np.uint8 and maps.shape == (C, side, side), (maps.dtype, maps.shape)
+    return maps
 
 
 def model_inputs(case, seed=200):
@@ -193,7 +219,7 @@ def run_reference_engine():
         param_keys=np.array(keys), param_digest=np.stack([grad_digest(sd[k]) for k in keys]))
 
 
-def main():
+def main(heads_only=False):
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -205,6 +231,8 @@ def main():
                                                                      "attn")})
         np.savez_compressed(os.path.join(OUT, f"head_{case}.npz"), **blob)
         print("head", case, "logit fp32-vs-fp64 gap", np.abs(f32["logits"] - f64["logits"]).max())
+    if heads_only:
+        return
     for case in MODEL_CASES:
         f32 = run_reference_model(case, torch.float32)
         f64 = run_reference_model(case, torch.float64)
@@ -222,4 +250,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(heads_only="--heads-only" in sys.argv)

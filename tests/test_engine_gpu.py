@@ -186,6 +186,71 @@ def test_data_parallel_wrapper_on_rccl_single_rank_group():
         dist.destroy_process_group()
 
 
+def test_rccl_step_with_side_streams_equals_the_plain_step_bit_for_bit():
+    """the REAL resnest26d step (weight-gradient side stream + shortcut-branch stream on, five stage
+    buckets all-reduced asynchronously on RCCL's stream while the backward continues) on a 1-rank 'nccl' group must
+    leave exactly the parameters of the un-wrapped step: a missing join between the side streams, the collective's
+    stream and the compute stream would show up as stale / torn gradient buckets."""
+    import socket
+    import torch.distributed as dist
+    from scouter_amd.optim import FusedAdamW
+    from scouter_amd.parallel import DistributedDataParallel
+    from scouter_amd.sloter.slot_model import SlotModel
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        a = _mnist_args()
+        a.model, a.dataset, a.channel, a.to_k_layer, a.power = "resnest26d", "ImageNet", 2048, 3, 2
+        spec = O.state_dict_spec("resnest26d", 10, 1, 3)
+        P = O.synth_state(spec, 300)
+        img, lab = O.synth_batch(6, 3, 96, 10, 311)
+        results = []
+        for wrap in (False, True, True):
+            m = SlotModel(a)
+            m.load_state_dict(P)
+            m = m.cuda().train()
+            assert m.backbone.layer2[0].conv1.use_side_stream            # the configuration the benchmark times
+            net = DistributedDataParallel(m, device_ids=[0]) if wrap else m
+            opt = FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+            buckets = []
+            if wrap:
+                m._grad_ready_hooks.append(lambda arena, lo, hi: buckets.append((lo, hi)))
+            for _ in range(3):
+                opt.zero_grad()
+                out, losses = net(img.cuda(), lab.cuda())
+                losses[0].backward()
+                opt.step()
+            torch.cuda.synchronize()
+            if wrap:
+                assert len(buckets) == 3 * 5 and net._pending == []      # head+layer4, layer3, layer2, layer1, stem
+            results.append(([p.detach().clone() for p in m.parameters()], m.grad_arena().flat.clone(),
+                            [b.detach().clone() for b in m.buffers()]))
+        for other in results[1:]:
+            assert torch.equal(results[0][1], other[1])
+            assert all(torch.equal(x, y) for x, y in zip(results[0][0], other[0]))
+            assert all(torch.equal(x, y) for x, y in zip(results[0][2], other[2]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_self_launches_ranks_and_reports_the_group_size():
+    """`python bench.py --gpus N` needs no wrapper: N > devices is refused loudly; under a launcher the line's n_gpus is
+    the RCCL group size (1-rank group through torch.distributed.run, SCOUTER_FORCE_DP)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "64"], cwd=root, capture_output=True, text=True)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    env = dict(os.environ, SCOUTER_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    s = __import__("socket").socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "1", "--steps", "2",
+                        "--warmup", "1", "--config", "1", "--batch", "8", "--no-prof", "--no-cpu-baseline"],
+                       cwd=root, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["parallelism"] == "dp1" and line["value"] > 0
+
+
 def test_vis_inference_path_writes_reference_style_maps(tmp_path):
     """scouter_amd.test.run: eval forward of one image, per-class uint8 maps == the oracle's vis_maps (<= 1 level)."""
     from scouter_amd import test as vis_cli
@@ -250,9 +315,10 @@ def test_train_main_end_to_end_with_checkpoint_resume(tmp_path, monkeypatch):
 def test_training_learns_a_separable_task(precision):
     """160 AdamW steps on a linearly separable synthetic task (class = which quadrant is bright): the loss must fall
     and the accuracy leave chance level -- an end-to-end check that gradients, optimizer and BatchNorm statistics move
-    the model the right way, in both precisions.  (The trajectory of the first hundred steps is chaotic: gradients
-    that differ in their last bits -- autotuned summation orders differ from box to box -- give final losses between
-    0.5 and 1.0 from a start at ln 4 = 1.39; the thresholds leave room for that, a wrong gradient stays at 1.39.)"""
+    the model the right way, in both precisions.  Since round 3 block tiles and weight-gradient plans come from the
+    committed static table (kernels._pick_tile), so the trajectory is the same in every process: measured NLL 1.40 ->
+    0.17 with accuracy 0.92 (fp32), 1.38 -> 0.01 / 1.00 (bf16); round 2's timing-autotuned summation orders made the
+    first hundred steps chaotic and the thresholds had been loosened to 0.85 / 0.45 -- back to 0.7 / 0.6."""
     from scouter_amd.optim import FusedAdamW
     from scouter_amd.sloter.slot_model import SlotModel
     from scouter_amd.train import get_args_parser
@@ -283,8 +349,9 @@ def test_training_learns_a_separable_task(precision):
         (first if it < 5 else last).append(float(losses[1].detach()))   # NLL part
         if it >= 140:
             acc.append(float((out.argmax(1) == y).float().mean()))
-    assert np.mean(last[-10:]) < 0.85 * np.mean(first), (np.mean(first), np.mean(last[-10:]))
-    assert np.mean(acc) > 0.45, np.mean(acc)                      # chance level is 0.25
+    print("separable task [%s]: NLL %.3f -> %.3f, accuracy %.3f" % (precision, np.mean(first), np.mean(last[-10:]), np.mean(acc)))
+    assert np.mean(last[-10:]) < 0.7 * np.mean(first), (np.mean(first), np.mean(last[-10:]))
+    assert np.mean(acc) > 0.6, np.mean(acc)                      # chance level is 0.25
 
 
 def test_two_stage_recipe_fc_baseline_then_use_pre_xslot(tmp_path, monkeypatch):
