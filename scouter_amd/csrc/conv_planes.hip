@@ -304,6 +304,8 @@ __global__ __launch_bounds__(NWM * 128, 1) void pconv_kernel(const unsigned shor
     igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
 }
 
+#include "conv_planes_persist.h"
+
 // ---------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 on planes with the input rows RESIDENT in LDS for all nine taps ("halo" kernel)
 // ---------------------------------------------------------------------------------------------------------------
@@ -652,6 +654,38 @@ static void launch_pconv(const void* a, long a_pe, const void* w, long w_pe, con
                        (const unsigned short*)w, w_pe, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz);
 }
 
+// persistent 256 x BN kernel (conv_planes_persist.h): one workgroup per CU walks the tile list
+static int sc_persistent_grid() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+            n = 256;
+        cus = n / 8 * 8;
+    }
+    return cus;
+}
+template <int BN, int NP, bool DGRAD>
+static void launch_ppersist(const void* a, long a_pe, const void* w, long w_pe, const float* bias, const float* addend,
+                            float* dst, double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz) {
+    constexpr int BM = 256;
+    const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
+    ConvGeom gg = g;
+    gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
+    gg.inv_wo = 1.0f / (float)g.Wo;
+    gg.inv_ho = 1.0f / (float)g.Ho;
+    constexpr int LDS = 2 * NP * (BM + BN) * 64 + 1024;
+    auto kern = ppersist_kernel<BN, NP, DGRAD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int ntot = mtiles * ntiles * g.groups, cus = sc_persistent_grid();
+    hipLaunchKernelGGL(kern, dim3(ntot <= cus ? ntot : cus), dim3(512), LDS, st, (const unsigned short*)a, a_pe,
+                       (const unsigned short*)w, w_pe, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz);
+}
+
 template <int BN, int NP, bool DGRAD>
 static void launch_phalo(const void* a, long a_pe, const void* w, long w_pe, const float* bias, const float* addend,
                          float* dst, double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz) {
@@ -685,7 +719,18 @@ static int dispatch_pconv(const void* a, long a_pe, const void* w, long w_pe, co
                           float* dst, double* bn_part, const ConvGeom& g, int relu, int nplanes, int tile,
                           hipStream_t st, const BnBwdFuse& fz = BnBwdFuse{}) {
     const bool wide = g.Ng % 128 == 0 && tile != 1;
-    if (nplanes == 3 && tile == 5 && phalo_ok(g)) {   // 256 x (128 | 64), input rows resident in LDS for all nine taps
+    // tile 6: persistent 256 x (128 | 64); its register epilogue takes BatchNorm statistics from the accumulators, so a
+    // launch that wants statistics of bias / addend-shifted values keeps the LDS-staged epilogue of tile 4 / 2
+    if (tile == 6 && ((bn_part && (bias || addend)) || g.R * g.S * (g.Cg / 32) < 2)) tile = g.Ng % 128 == 0 ? 4 : 2;
+    if (tile == 6) {
+        if (nplanes == 3) {
+            if (g.Ng % 128 == 0) launch_ppersist<128, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+            else launch_ppersist<64, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+        } else {
+            if (g.Ng % 128 == 0) launch_ppersist<128, 1, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+            else launch_ppersist<64, 1, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
+        }
+    } else if (nplanes == 3 && tile == 5 && phalo_ok(g)) {   // 256 x (128 | 64), input rows resident in LDS for all nine taps
         if (g.Ng % 128 == 0) launch_phalo<128, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
         else launch_phalo<64, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
     } else if (nplanes == 1 && tile == 5 && phalo_ok(g)) {

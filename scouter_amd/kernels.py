@@ -381,18 +381,28 @@ def planes_split_weight(w_hwio, groups, nplanes=3, fwd=True, dgrad=True):
     return wf, wd
 
 
-_PLANE_TILE_ROWS = {0: 128, 1: 128, 2: 128, 3: 64, 4: 256, 5: 256}
+_PLANE_TILE_ROWS = {0: 128, 1: 128, 2: 128, 3: 64, 4: 256, 5: 256, 6: 64}
+
+
+def _plane_part_rows(tile, M):
+    """Partial rows the plane kernels write for fused BatchNorm sums: one per M tile -- tile 6 (persistent 256-row tiles)
+    one per 64-row WAVE row of every tile, 4 per tile, incl. the all-zero ones beyond M."""
+    if tile == 6:
+        return (M + 255) // 256 * 4
+    return (M + _PLANE_TILE_ROWS[tile] - 1) // _PLANE_TILE_ROWS[tile]
 
 
 def _plane_tiles(ng, nplanes=3, halo=False):
     """Block tiles of the plane kernels (csrc/conv_planes.hip dispatch_pconv): 0 = 128x128, 1 = 128x64 (three LDS
     stages), and for three planes 2 = 128x64 (two workgroups per CU), 3 = 64x64 (three), 4 = 256x128 with eight waves,
     5 (halo=True: same-size 3x3 layers on maps up to 63 wide) = 256 x (128 | 64) with the input rows resident in LDS for
-    all nine taps.  Tiles 0-4 sum each output in the same order (bit-identical results); tile 5 sums over K in a
-    different order (16-channel chunk outer, tap inner): equal to fp32 rounding."""
+    all nine taps, 6 = PERSISTENT 256 x (128 | 64): one workgroup per CU walks the tile list, the DMA stream prefetches
+    the next tile under the current one, register epilogue (csrc/conv_planes_persist.h).  Tiles 0-4 and 6 sum each output
+    in the same order (bit-identical results); tile 5 sums over K in a different order (16-channel chunk outer, tap
+    inner): equal to fp32 rounding."""
     if nplanes == 1:
-        return ((0, 1) if ng % 128 == 0 else (1,)) + ((5,) if halo else ())
-    return ((0, 2, 3, 4) if ng % 128 == 0 else (2, 3)) + ((5,) if halo else ())
+        return ((0, 1) if ng % 128 == 0 else (1,)) + ((5,) if halo else ()) + (6,)
+    return ((0, 2, 3, 4) if ng % 128 == 0 else (2, 3)) + ((5,) if halo else ()) + (6,)
 
 
 # Plane tile 5 (input rows resident in LDS) sums K in another order than tiles 0-4.  bit 1: the input gradient may use it
@@ -426,6 +436,8 @@ def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, adde
     if tile == 5:
         cands = cands + (5,)
     M = y.numel() // Cout
+    if bn_stats and (bias is not None or addend is not None):
+        cands = tuple(t for t in cands if t != 6)      # (tile 6 takes the statistics from the raw accumulators)
     # scratch for the statistics of the largest partial count (64-row tiles) while the tiles are being timed
     scratch = [None]
 
@@ -434,7 +446,7 @@ def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, adde
             return t in cands
         if bn_stats and part is None:
             if scratch[0] is None:
-                scratch[0] = torch.empty(((M + 63) // 64, Cout, 2), dtype=torch.float64, device=xp.device)
+                scratch[0] = torch.empty(((M + 255) // 256 * 4, Cout, 2), dtype=torch.float64, device=xp.device)
             part = scratch[0]
         _native.check(L.scouter_conv2d_fwd_planes(_p(xp), _p(wf), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
                                                   Cout, kh, kw, stride, pad, groups, int(relu), nplanes, t, _stream()),
@@ -446,7 +458,7 @@ def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, adde
             tile = cands[0]
     part, rows = None, 0
     if bn_stats:
-        rows = (M + _PLANE_TILE_ROWS[tile] - 1) // _PLANE_TILE_ROWS[tile]      # one partial per M tile of the kernel
+        rows = _plane_part_rows(tile, M)                                       # one partial per M tile of the kernel
         part = torch.empty((rows, Cout, 2), dtype=torch.float64, device=xp.device)
     launch(tile, part=part)
     return (y, (part, rows)) if bn_stats else y
@@ -471,7 +483,7 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
         if tile < 0:
             tile = cands[0]
     if _fuse_wanted(post, kh, True) and nplanes == 3:     # (one-plane kernels, bf16 mode: measured -0.6 % on config 5)
-        post.alloc(-(-B * H * W // _PLANE_TILE_ROWS[tile]), x_shape)
+        post.alloc(_plane_part_rows(tile, B * H * W), x_shape)
         launch(tile, fuse=post.args())
     else:
         launch(tile)

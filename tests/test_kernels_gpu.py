@@ -425,7 +425,8 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
     (3, 14, 14, 256, 64, 1, 0, 1, True, True),       # conv1 of a bottleneck: finishes bn3 + the downsample BatchNorm
     (2, 9, 9, 128, 128, 3, 1, 2, False, False),      # radix conv: finishes bn1 (ragged last M tile)
     (5, 7, 7, 64, 32, 1, 0, 1, False, True),
-    (9, 12, 12, 64, 64, 3, 1, 1, True, False)])
+    (9, 12, 12, 64, 64, 3, 1, 1, True, False),
+    (45, 28, 27, 128, 128, 3, 1, 2, True, True)])     # > 256 plane tiles: the persistent kernel's second round
 def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision, monkeypatch):
     """conv dgrad with a BnBwdFuse == conv dgrad, then ReLU mask, then the BatchNorm backward's own reduction: the masked
     gradient bit for bit (every tile), the fp64 partial sums to 1e-10, dx / dgamma / dbeta of the BatchNorm(s) to fp32

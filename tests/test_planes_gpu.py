@@ -34,7 +34,9 @@ def test_three_plane_split_is_exact():
 CASES = [  # B, H, W, Cin, Cout, k, pad, groups
     (2, 14, 14, 64, 128, 3, 1, 1), (3, 9, 7, 128, 256, 3, 1, 2), (2, 12, 12, 32, 64, 3, 1, 1), (1, 8, 8, 256, 256, 1, 0, 1),
     (5, 7, 7, 64, 128, 1, 0, 1), (2, 20, 20, 128, 128, 3, 1, 2), (1, 30, 30, 64, 64, 3, 1, 1),
-    (2, 56, 56, 64, 128, 3, 1, 2), (11, 7, 7, 128, 256, 3, 1, 2), (1, 5, 63, 32, 128, 3, 1, 1), (3, 28, 28, 64, 64, 3, 1, 1)]
+    (2, 56, 56, 64, 128, 3, 1, 2), (11, 7, 7, 128, 256, 3, 1, 2), (1, 5, 63, 32, 128, 3, 1, 1), (3, 28, 28, 64, 64, 3, 1, 1),
+    # more tiles than CUs: the persistent kernel (tile 6) walks 2 tiles per workgroup, last round partial, ragged last tile
+    (17, 55, 56, 128, 256, 3, 1, 2), (33, 28, 27, 256, 512, 1, 0, 1)]
 
 
 @pytest.mark.parametrize("cfg", CASES)

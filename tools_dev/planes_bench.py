@@ -20,12 +20,12 @@ for cin, cout, k, g, H in shapes:
     t32 = timeit(lambda: K.conv2d_fwd(x, w, None, None, 1, p, g, bn_stats=True))
     xp3, xp1 = K.planes_split(x, 3), K.planes_split(x, 1)
     wf3, wd3 = K.planes_split_weight(w, g, 3); wf1, _ = K.planes_split_weight(w, g, 1)
-    t3 = [timeit(lambda: K.conv2d_fwd_planes(xp3, wf3, k, k, 1, p, g, bn_stats=False, tile=t)) for t in ((0, 1, 2, 3, 4) if (cout // g) % 128 == 0 else (1, 2, 3)) + ((5,) if k == 3 and H <= 63 else ())]; best3 = min(t3)
+    t3 = [timeit(lambda: K.conv2d_fwd_planes(xp3, wf3, k, k, 1, p, g, bn_stats=False, tile=t)) for t in ((0, 1, 2, 3, 4) if (cout // g) % 128 == 0 else (1, 2, 3)) + ((5,) if k == 3 and H <= 63 else ()) + (6,)]; best3 = min(t3)
     best1 = min(timeit(lambda: K.conv2d_fwd_planes(xp1, wf1, k, k, 1, p, g, bn_stats=True, tile=t)) for t in (1,))
     td = float('nan')
     if (cin // g) % 64 == 0:
         y = K.conv2d_fwd(x, w, None, None, 1, p, g); dyp = K.planes_split(torch.randn_like(y), 3)
-        tds = [timeit(lambda: K.conv2d_dgrad_planes(dyp, wd3, tuple(x.shape), k, k, 1, p, g, tile=t)) for t in ((0, 2, 4) if (cin // g) % 128 == 0 else (2, 3)) + ((5,) if k == 3 and H <= 63 else ())]
+        tds = [timeit(lambda: K.conv2d_dgrad_planes(dyp, wd3, tuple(x.shape), k, k, 1, p, g, tile=t)) for t in ((0, 2, 4) if (cin // g) % 128 == 0 else (2, 3)) + ((5,) if k == 3 and H <= 63 else ()) + (6,)]
         td = min(tds); print('   dgrad x3 by tile', ['%.0f' % v for v in tds])
     tw32 = tw3 = float('nan')
     if (cin // g) % 64 == 0 and (cout // g) % 64 == 0:
