@@ -72,7 +72,7 @@ int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* adden
  * a second BatchNorm fed by the same gradient (downsample branch; may be NULL).  x1 / x2: the BatchNorm inputs
  * [B][H][W][Cin]; saved1 / saved2: their [4][Cin] blocks {mean, rstd, scale, shift}.  rows =
  * scouter_conv2d_dgrad_bn_partial_rows(...) (fp32 / bf16-input kernels: ceil(B*H*W / 64) for tile 2, / 128 otherwise;
- * plane kernels: / 128, 128, 128, 64, 256, 256 for tile 0..5).  scouter_bn_bwd_f32(ext_partial = part, ext_rows = rows) then
+ * plane kernels: / 128, 128, 128, 64, 256, 256 for tile 0..5, 4 * ceil(B*H*W / 256) for tile 6).  scouter_bn_bwd_f32(ext_partial = part, ext_rows = rows) then
  * runs without its own reduction pass.  part1 == NULL: exactly scouter_conv2d_dgrad_f32. */
 int scouter_conv2d_dgrad_bn_partial_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
                                          int groups, int tile_hint);
@@ -242,12 +242,21 @@ int scouter_linear_small_bwd_f32(const float* dy, const float* x, const float* w
  * w_fwd [nplanes][tap][Cout][Cin/groups], w_dgrad [nplanes][tap][Cin][Cout/groups]; either may be NULL.
  * tile (block tile, callers autotune it): nplanes = 3: 0 = 128x128, 2 = 128x64 (two workgroups per CU), 3 = 64x64,
  * 4 = 256x128 (eight waves), 5 = 256 x (128 | 64) with the input rows resident in LDS for all nine taps (same-size 3x3
- * layers on maps up to 63 pixels wide; falls back to tile 0 / 1 otherwise); nplanes = 1: 0 = 128x128, 1 = 128x64.
- * Fused BatchNorm-statistics rows = ceil(M / BM) with BM = 128, 128, 128, 64, 256, 256 for tile 0..5.  Tiles 0-4 sum
- * every output in the same K order (bit-identical results); tile 5 sums 16-channel chunks outer / taps inner. */
+ * layers on maps up to 63 pixels wide; falls back to tile 0 / 1 otherwise); nplanes = 1: 0 = 128x128, 1 = 128x64;
+ * 6 (1 or 3 planes) = PERSISTENT 256 x (128 | 64): one workgroup per CU walks the tile list, the LDS-DMA stream runs on into
+ * the next tile, register epilogue (csrc/conv_planes_persist.h; needs >= 2 K-tiles of 32 channels x taps).
+ * Fused BatchNorm-statistics rows = ceil(M / BM) with BM = 128, 128, 128, 64, 256, 256 for tile 0..5; tile 6 writes one row
+ * per 64-row wave row of its 256-row tiles: 4 * ceil(M / 256).  Tiles 0-4 and 6 sum every output in the same K order
+ * (bit-identical results); tile 5 sums 16-channel chunks outer / taps inner. */
 int scouter_planes_split_f32(const float* x, void* planes, long n, int nplanes, void* stream);
 int scouter_planes_split_weight_f32(const float* w_hwio, void* w_fwd, void* w_dgrad, int kh, int kw, int Cin, int Cout,
                                     int groups, int nplanes, void* stream);
+/* The weight split of EVERY plane convolution of a model in one launch (the weights change with every optimizer step):
+ * `table` = nrows device-resident rows of scouter_planes_split_weights_row_bytes() bytes each, laid out as
+ * { const float* w_hwio; void* w_fwd; void* w_dgrad; int taps, cin_per_group, cout, groups; long first; } with `first` the
+ * running element count and total = sum of taps * cin_per_group * cout. */
+size_t scouter_planes_split_weights_row_bytes(void);
+int scouter_planes_split_weights_multi(const void* table, int nrows, long total, int nplanes, void* stream);
 int scouter_conv2d_fwd_planes_bn_partial_rows(int B, int H, int W, int kh, int kw, int stride, int pad);
 int scouter_conv2d_fwd_planes(const void* x_planes, const void* w_planes, const float* bias, const float* addend,
                               float* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw,

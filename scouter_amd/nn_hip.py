@@ -37,6 +37,7 @@ class Conv2d(nn.Module):
         self.precision = "fp32"                                     # per layer; SlotModel.set_precision (no global)
         self.use_side_stream = K.SIDE_STREAM_DEFAULT                # weight gradient on the side stream
         self.planes = 0                                             # 3: bf16x3 plane kernels (SlotModel.set_planes)
+        self._wsplit = None                                         # (wf, wd) of this step, from the model's one-launch split
         self._capture = None                                        # test instrumentation, see BatchNorm2d
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # timm resnet.py:447-448
         if bias:
@@ -78,7 +79,11 @@ class Conv2d(nn.Module):
         if isinstance(x, K.PlaneTensor):
             k = self.kernel_size
             want_wd = save and self.planes_dy() > 0
-            wf, wd = K.planes_split_weight(K.hwio(self.weight), self.groups, x.planes.shape[0], fwd=True, dgrad=want_wd)
+            ws, self._wsplit = self._wsplit, None
+            if ws is not None and ws[0] is not None and ws[0].shape[0] == x.planes.shape[0] and (ws[1] is not None or not want_wd):
+                wf, wd = ws[0], (ws[1] if want_wd else None)        # split by SlotModel for the whole model in one launch
+            else:
+                wf, wd = K.planes_split_weight(K.hwio(self.weight), self.groups, x.planes.shape[0], fwd=True, dgrad=want_wd)
             y = K.conv2d_fwd_planes(x.planes, wf, k, k, self.stride, self.padding, self.groups, self.bias, addend, relu,
                                     bn_stats)
             if self._capture is not None and relu:

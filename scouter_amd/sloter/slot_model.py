@@ -119,6 +119,8 @@ class SlotModel(nn.Module):
         for mod in self.backbone.modules():
             if isinstance(mod, SplitAttnConv2d):
                 mod.conv.planes = nplanes
+        self._plane_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and m.planes]
+        self._wsplitter = K.PlaneWeightSplitter()
 
     def set_side_stream(self, enabled):
         """Weight gradients on the side stream (default) or serially on the compute stream (per-kernel timing)."""
@@ -200,6 +202,12 @@ class SlotModel(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         tracked = []
+        convs = [c for c in getattr(self, "_plane_convs", ()) if c._nplanes()]
+        if convs:      # this step's weight planes of every plane convolution: one launch into persistent buffers
+            outs = self._wsplitter.run([(K.hwio(c.weight), c.groups, True, bool(save and c.planes_dy())) for c in convs],
+                                       convs[0]._nplanes())
+            for c, o in zip(convs, outs):
+                c._wsplit = o
         feat, bctx = self.backbone.features_fwd(x, save, tracked)             # NHWC [B, h, w, channel]
         logp, stats, hstate = self._head_forward(feat, target, save)
         if tracked:
