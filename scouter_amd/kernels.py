@@ -469,8 +469,9 @@ def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, adde
     if tile == 5:
         cands = cands + (5,)
     M = y.numel() // Cout
-    if bn_stats and (bias is not None or addend is not None):
-        cands = tuple(t for t in cands if t != 6)      # (tile 6 takes the statistics from the raw accumulators)
+    if (bn_stats and (bias is not None or addend is not None)) or kh * kw * (Cin // groups // 32) < 2:
+        cands = tuple(t for t in cands if t != 6)      # (tile 6 takes the statistics from the raw accumulators and needs
+        #                                                  two K-tiles of 32 channels x taps for its DMA pipeline)
     # scratch for the statistics of the largest partial count (64-row tiles) while the tiles are being timed
     scratch = [None]
 
@@ -503,6 +504,8 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
     Cout = dyp.shape[-1]
     dx = torch.empty(x_shape, dtype=F32, device=dyp.device)
     cands = _plane_tiles(Cin // groups, nplanes, _halo_ok(kh, kw, stride, pad, H, W, 2))
+    if kh * kw * (Cout // groups // 32) < 2:
+        cands = tuple(t for t in cands if t != 6)      # (tile 6 needs two K-tiles of 32 channels x taps)
 
     def launch(t, dry=False, fuse=_NO_FUSE):
         if dry:
