@@ -100,8 +100,9 @@ def _key_str(key):
 
 def _batch_pos(key):
     """Index of the batch entry in a tuning key: ("fwd", bf16, B, ...), ("dgrad+bn", n, addend, bf16, B, ...),
-    ("pfwd" | "pdgrad" | "pwgrad", nplanes, B, ...), ("wgrad" | "dgrad", bf16, B, ...)."""
-    return 4 if key[0] == "dgrad+bn" else 2
+    ("pdgrad+bn", n, addend, nplanes, B, ...), ("pfwd" | "pdgrad" | "pwgrad", nplanes, B, ...),
+    ("wgrad" | "dgrad", bf16, B, ...)."""
+    return 4 if key[0] in ("dgrad+bn", "pdgrad+bn") else 2
 
 
 def _load_tune_table():
@@ -514,11 +515,25 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
             _p(dyp), _p(wd), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, nplanes, t, *fuse,
             _stream()), "conv2d_dgrad_planes")
         return True
+    fused = _fuse_wanted(post, kh, True) and nplanes == 3  # (one-plane kernels, bf16 mode: measured -0.6 % on config 5)
+    if tile is None and fused:
+        # the fused launch is tuned as what it is (its epilogue masks the gradient, reads the BatchNorm input(s) and
+        # reduces their sums: the persistent tile's register epilogue and the LDS-staged one cost differently)
+        def launch_fused(t, dry=False):
+            if dry:
+                return t in cands
+            if not post.applied:
+                post.alloc((B * H * W + 255) // 256 * 4, x_shape)         # (the most rows any tile writes)
+            return launch(t, fuse=post.args())
+        tile = _pick_tile(("pdgrad+bn", len(post.entries), addend is not None, nplanes, B, H, W, Cin, Cout, kh, kw, stride,
+                           pad, groups), launch_fused, cands)
+        if tile < 0:
+            tile = None
     if tile is None:
         tile = _pick_tile(("pdgrad", nplanes, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, cands)
         if tile < 0:
             tile = cands[0]
-    if _fuse_wanted(post, kh, True) and nplanes == 3:     # (one-plane kernels, bf16 mode: measured -0.6 % on config 5)
+    if fused:
         post.alloc(_plane_part_rows(tile, B * H * W), x_shape)
         launch(tile, fuse=post.args())
     else:

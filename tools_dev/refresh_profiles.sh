@@ -12,15 +12,17 @@ SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d "$O/off" -- $B > "$O/o
 python tools_dev/rocpd_summary.py "$(db $O/off)" adamw_kernel:3 > "$O/sum_off.txt"
 rocprofv3 --kernel-trace --stats -d "$O/on" -- $B > "$O/on.log" 2>&1
 python tools_dev/rocpd_summary.py "$(db $O/on)" adamw_kernel:3 > "$O/sum_on.txt"
-rocprofv3 --kernel-trace --stats -d "$O/xs" -- python tools_dev/xslot_bench.py > "$O/xs.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$O/xs" -- python tools_dev/xslot_bench.py 256 300 3 49 3 3 > "$O/xs.log" 2>&1
 python tools_dev/rocpd_summary.py "$(db $O/xs)" > "$O/sum_xs.txt"
+rocprofv3 --kernel-trace --stats -d "$O/xs81" -- python tools_dev/xslot_bench.py 256 300 3 81 3 3 > "$O/xs81.log" 2>&1
+python tools_dev/rocpd_summary.py "$(db $O/xs81)" > "$O/sum_xs81.txt"
 SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/fetch" -- $B3 > "$O/fetch.log" 2>&1
 SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/write" -- $B3 > "$O/write.log" 2>&1
 python tools_dev/pmc_traffic.py "$(db $O/fetch)" "$(db $O/write)" adamw_kernel:3 > "$O/pmc_traffic.txt" 2> "$O/pmc_traffic.err"
 cp pmc_traffic.json "$O/" 2>/dev/null; cp gpurun_out/pmc_traffic.json "$O/" 2>/dev/null
 SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d "$O/mfma" -- $B3 > "$O/mfma.log" 2>&1
 python tools_dev/pmc_mfma.py "$(db $O/mfma)" adamw_kernel:3 "$O/pmc_mfma_util.json" > "$O/mfma_bench.txt"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d "$O/mfma_xs" -- python tools_dev/xslot_bench.py > "$O/mfma_xs.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d "$O/mfma_xs" -- python tools_dev/xslot_bench.py 256 300 3 49 3 3 > "$O/mfma_xs.log" 2>&1
 python tools_dev/pmc_mfma.py "$(db $O/mfma_xs)" > "$O/mfma_xs.txt"
 grep -h '"metric"' "$O/off.log" "$O/on.log" | tail -2 > "$O/bench_lines.json"
 find "$O" -name "*.db" -delete; find "$O" -name "*.csv" -size +1M -delete
