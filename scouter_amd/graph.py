@@ -78,6 +78,11 @@ class GraphedTrainStep:
         ws_before = set(K._ws)
         with torch.cuda.graph(self.graph):
             self.logp, self.stats = self._eager(self.x, self.y)
+        # Every scratch buffer the captured kernels may address stays alive as long as the graph does: the
+        # persistent side streams ("wgrad", "branch") re-use workspaces that existed BEFORE the capture, so the graph has
+        # their addresses baked in -- if a later eager call on those streams needed a bigger workspace, kernels.workspace()
+        # would replace the buffer and the caching allocator could hand the old one to someone else under the replays.
+        self._pinned_ws = list(K._ws.values())
         for key in set(K._ws) - ws_before:        # scratch allocated from the graph's private pool: never hand it to
             del K._ws[key]                        # eager code that happens to run on a stream with the same handle
         self._shape = (tuple(images.shape), tuple(labels.shape))
