@@ -887,7 +887,10 @@ extern "C" int scouter_colsum_f32(const float* a, const float* b, float* out, lo
     SC_REQUIRE(a && out, "colsum: null pointer");
     COL_CHECKS("colsum")
     hipStream_t st = (hipStream_t)stream;
-    if (M <= (long)g.rpb * 12) {   // few row passes (narrow bias gradients of the pooled-vector layers): ONE launch, one row block
+    // few rows (bias gradients of the pooled-vector layers: M = batch): ONE launch, one row block per channel slab -- also
+    // for the wide layers (C >= 256: 1-4 rows per pass), where a second 5-us launch costs more than the 70 sequential,
+    // independent row loads of a thread
+    if (M <= (long)g.rpb * 12 || M <= 256) {
         dim3 sgrid(1, pgrid.y);
         if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, sgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, nullptr, (double*)ws, g, out, alpha);
         else hipLaunchKernelGGL(colsum_partial_kernel<2>, sgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)ws, g, out, alpha);
