@@ -107,7 +107,10 @@ def test_stem_im2col_path():
 
 @pytest.mark.parametrize("shape,relu,res", [((4, 14, 14, 64), True, False), ((3, 7, 7, 2048), False, True),
                                             ((6, 1, 1, 32), True, False), ((2, 28, 28, 32), True, True),
-                                            ((70, 1, 1, 256), True, False), ((9, 1, 1, 64), False, True)])   # one-launch backward
+                                            ((70, 1, 1, 256), True, False), ((9, 1, 1, 64), False, True),   # one-launch backward
+                                            # more small shapes: whole rows per pass / 1024-channel slabs / ragged
+                                            ((70, 1, 1, 128), True, False), ((70, 1, 1, 2048), True, False),
+                                            ((5, 2, 2, 128), True, False), ((3, 1, 1, 96), True, False)])
 def test_bn_fwd_bwd(shape, relu, res):
     rng = np.random.default_rng(4)
     B, H, W, C = shape
