@@ -86,20 +86,32 @@ __global__ __launch_bounds__(256) void sa_colsum_partial_kernel(const float* __r
 
 // d(attention) and the four per-image statistics out of the five partial planes of the STATS pass: one thread per
 // (image, channel); stats [B][C2][4] doubles = (S1, S2, S3, S4).
+// SA_FL lanes share one output: lane j sums the splits j, j + SA_FL, ... and a fixed-order shuffle tree adds the lanes
+// (deterministic).  One thread per output walked up to 32 dependent partial loads -- these finalizes sit on the critical
+// path of every block, where the length of the dependent-load chain, not the work, is the cost.
+constexpr int SA_FL = 8;
 __global__ void sa_dattn_stats_finalize_kernel(const double* __restrict__ part, float* __restrict__ da,
                                                double* __restrict__ stats, int B, int nsplit, int C2, long plane) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * C2) return;
-    const int b = (int)(i / C2), c = (int)(i % C2);
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = t / SA_FL;
+    const int j = (int)(t % SA_FL);
+    const bool ok = i < (long)B * C2;
+    const int b = ok ? (int)(i / C2) : 0, c = ok ? (int)(i % C2) : 0;
     double acc[5] = {0, 0, 0, 0, 0};
-    for (int k = 0; k < nsplit; ++k) {
+    for (int k = j; k < nsplit; k += SA_FL) {
         const double* p = part + ((long)b * nsplit + k) * C2 + c;
 #pragma unroll
         for (int q = 0; q < 5; ++q) acc[q] += p[q * plane];
     }
-    da[i] = (float)acc[0];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) stats[i * 4 + q] = acc[1 + q];
+    for (int o = 1; o < SA_FL; o <<= 1)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[q] += __shfl_xor(acc[q], o, SA_FL);
+    if (ok && j == 0) {
+        da[i] = (float)acc[0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stats[i * 4 + q] = acc[1 + q];
+    }
 }
 
 // gap[b][c] = alpha * sum_splits (part[b][s][c] + part[b][s][Cp+c])     (fold_radix = 1)
@@ -107,17 +119,21 @@ __global__ void sa_dattn_stats_finalize_kernel(const double* __restrict__ part, 
 __global__ void sa_colsum_finalize_kernel(const double* __restrict__ part, float* __restrict__ out, int B, int nsplit,
                                           int C2, int Cp, int fold_radix, float alpha) {
     const int Co = fold_radix ? Cp : C2;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * Co) return;
-    const int b = (int)(i / Co), c = (int)(i % Co);
-    double acc[4] = {0, 0, 0, 0};                       // four chains: the loads of consecutive splits overlap
-    for (int k = 0; k < nsplit; ++k) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = t / SA_FL;
+    const int j = (int)(t % SA_FL);
+    const bool ok = i < (long)B * Co;
+    const int b = ok ? (int)(i / Co) : 0, c = ok ? (int)(i % Co) : 0;
+    double acc = 0;
+    for (int k = j; k < nsplit; k += SA_FL) {
         const double* p = part + ((long)b * nsplit + k) * C2;
         double v = p[c];
         if (fold_radix) for (int r = 1; r * Cp < C2; ++r) v += p[r * Cp + c];
-        acc[k & 3] += v;
+        acc += v;
     }
-    out[i] = (float)(((acc[0] + acc[1]) + (acc[2] + acc[3])) * alpha);
+#pragma unroll
+    for (int o = 1; o < SA_FL; o <<= 1) acc += __shfl_xor(acc, o, SA_FL);
+    if (ok && j == 0) out[i] = (float)(acc * alpha);
 }
 
 // radix-2 softmax over (z[b][c], z[b][Cp+c])  (RadixSoftmax with cardinality 1, split_attn.py:20-28)
@@ -210,15 +226,15 @@ extern "C" int scouter_sa_reduce_f32(const float* x, const float* dout, const fl
     dim3 grid(ns, B);
     if (mode == 0) {
         hipLaunchKernelGGL((sa_colsum_partial_kernel<false, false>), grid, dim3(256), 0, st, x, nullptr, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane);
-        hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * Cp, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 1, 1.f / HW);
+        hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * Cp * SA_FL, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 1, 1.f / HW);
     } else if (bn_sums_out) {
         SC_REQUIRE(dout, "sa_reduce: dout missing");
         hipLaunchKernelGGL((sa_colsum_partial_kernel<true, true>), grid, dim3(256), 0, st, x, dout, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane);
-        hipLaunchKernelGGL(sa_dattn_stats_finalize_kernel, dim3(sc_cdiv((long)B * C2, 256)), dim3(256), 0, st, (const double*)ws, out, bn_sums_out, B, ns, C2, plane);
+        hipLaunchKernelGGL(sa_dattn_stats_finalize_kernel, dim3(sc_cdiv((long)B * C2 * SA_FL, 256)), dim3(256), 0, st, (const double*)ws, out, bn_sums_out, B, ns, C2, plane);
     } else {
         SC_REQUIRE(dout, "sa_reduce: dout missing");
         hipLaunchKernelGGL((sa_colsum_partial_kernel<true, false>), grid, dim3(256), 0, st, x, dout, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane);
-        hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * C2, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 0, 1.f);
+        hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * C2 * SA_FL, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 0, 1.f);
     }
     return sc_check_launch("sa_reduce");
 }
