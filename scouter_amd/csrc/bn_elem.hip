@@ -111,10 +111,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 // Sums the per-block partials of FIN_CH channels per workgroup: FIN_LANES lanes split the nb partials (4 loads in flight
 // each), fixed-order combine through LDS.
-#define FIN_CH 4
-#define FIN_LANES 64
+// FIN_CH = 1 (256 lanes per channel) for the narrow layers with MANY partial rows (stem / layer1: 32-64 channels, up to
+// 3 430 rows): with four channels per workgroup those finalizes ran on 8-16 workgroups whose lanes each walked 54 rows
+// (13 us); on this step's critical path the length of that dependent chain is the cost.
+template <int FIN_CH>
 __device__ __forceinline__ void partial_reduce(const double* __restrict__ part, int nb, int C, int c, int bl,
                                                double& s, double& t, double (*red)[FIN_CH][2]) {
+    constexpr int FIN_LANES = 256 / FIN_CH;
     double s4[4] = {0, 0, 0, 0}, t4[4] = {0, 0, 0, 0};
     if (c < C) {
         int b = bl;
@@ -147,16 +150,18 @@ __device__ __forceinline__ void partial_reduce(const double* __restrict__ part, 
     t = red[0][threadIdx.x % FIN_CH][1];
 }
 
+template <int FIN_CH>
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                          float eps, int training, float* __restrict__ mean_o,
                                          float* __restrict__ rstd_o, float* __restrict__ scale_o,
                                          float* __restrict__ shift_o) {
+    constexpr int FIN_LANES = 256 / FIN_CH;
     __shared__ double red[FIN_LANES][FIN_CH][2];
     const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), bl = threadIdx.x / FIN_CH;
     double mean, var, s = 0, t = 0;
-    if (training) partial_reduce(part, nb, C, c, bl, s, t, red);
+    if (training) partial_reduce<FIN_CH>(part, nb, C, c, bl, s, t, red);
     if (bl != 0 || c >= C) return;
     if (training) {
         mean = s / (double)M;
@@ -213,14 +218,16 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
     }
 }
 
+template <int FIN_CH>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
                                                               int training, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ c1,
                                                               float* __restrict__ c2) {
+    constexpr int FIN_LANES = 256 / FIN_CH;
     __shared__ double red[FIN_LANES][FIN_CH][2];
     const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), bl = threadIdx.x / FIN_CH;
     double s, t;
-    partial_reduce(part, nb, C, c, bl, s, t, red);
+    partial_reduce<FIN_CH>(part, nb, C, c, bl, s, t, red);
     if (bl != 0 || c >= C) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)t;
@@ -324,12 +331,14 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* __restri
     }
 }
 
+template <int FIN_CH>
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ part, int nb, int C,
                                                               float* __restrict__ out, float alpha) {
+    constexpr int FIN_LANES = 256 / FIN_CH;
     __shared__ double red[FIN_LANES][FIN_CH][2];
     const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH), bl = threadIdx.x / FIN_CH;
     double s, t;
-    partial_reduce(part, nb, C, c, bl, s, t, red);
+    partial_reduce<FIN_CH>(part, nb, C, c, bl, s, t, red);
     if (bl != 0 || c >= C) return;
     out[c] = (float)(s * alpha);
 }
@@ -648,6 +657,7 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 // ---------------------------------------------------------------------------------------------------------------
 // host entry points
 // ---------------------------------------------------------------------------------------------------------------
+static inline bool fin_narrow(int C, int nparts) { return C <= 64 && nparts > 512; }   // see partial_reduce
 static inline int ew_blocks(long n) { long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
 extern "C" size_t scouter_colreduce_workspace_bytes(long M, int C) { (void)M; return (size_t)MAXB * C * 2 * sizeof(double); }
@@ -685,9 +695,12 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
     else if (training)
         hipLaunchKernelGGL(colsum_partial_kernel<0>, pgrid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                            nullptr, (double*)ws, g);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, part, nparts, M, C,
-                       gamma, beta, running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out,
-                       shift_out);
+    if (fin_narrow(C, nparts))
+        hipLaunchKernelGGL(bn_stats_finalize_kernel<1>, dim3(C), dim3(256), 0, st, part, nparts, M, C, gamma, beta,
+                           running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out, shift_out);
+    else
+        hipLaunchKernelGGL(bn_stats_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, part, nparts, M, C, gamma, beta,
+                           running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out, shift_out);
     const long n4 = M * C / 4;
     if (y || planes_out)       // neither: the consumer applies (x - mean) * scale + shift itself (fused split attention)
         hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, scale_out,
@@ -726,8 +739,13 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
                      ((ext_partial ? 12.0 : (ymask && !relu_mask ? 28.0 : 20.0)) + (gout ? 4.0 : 0.0) +
                       (relu_mask ? 0.25 : 0.0)) * M * C);
     if (!ext_partial && M <= (long)g.rpb * 24) {                 // few row passes: everything in one launch
-        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, pgrid.y), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale,
-                           relu_mask, training, dgamma, dbeta, dx, gout, g);
+        // 16-channel slabs (4 threads per row, 64 rows per pass) when the channel count allows: C / 16 workgroups with one or
+        // two passes each instead of ONE workgroup walking up to 24 dependent passes (14 us on every block's critical path)
+        ColGeom gs = g;
+        int slabs = pgrid.y;
+        if (C % 16 == 0 && C >= 32) { gs.cslab = 16; gs.tpr = 4; gs.rpb = 64; slabs = C / 16; }
+        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, slabs), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale,
+                           relu_mask, training, dgamma, dbeta, dx, gout, gs);
         return sc_check_launch("bn_bwd");
     }
     const double* part = (const double*)ws;
@@ -736,8 +754,11 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
     else
         hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, relu_mask,
                            (double*)ws, g);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, part, nparts, M, C,
-                       training, dgamma, dbeta, c1, c2);
+    if (fin_narrow(C, nparts))
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<1>, dim3(C), dim3(256), 0, st, part, nparts, M, C, training, dgamma, dbeta, c1, c2);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, part, nparts, M, C, training, dgamma,
+                           dbeta, c1, c2);
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale, c1,
                        c2, relu_mask, dx, gout, n4, C);
@@ -825,21 +846,29 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __res
 
 // Finalize of the split-attention / bn0 backward from the per-image statistics the d(attention) pass produced
 // (misc_ops.hip sa_colsum_partial_kernel<true, true>): one thread per channel sums over the images.
+// (SBS_L lanes per channel share the loop over the images and are added by a fixed-order shuffle tree: one thread per
+//  channel walked B dependent rounds of five loads in ONE to FOUR workgroups -- 23 us on the critical path of every block)
+constexpr int SBS_L = 16;
 __global__ __launch_bounds__(256) void sa_bn_bwd_sums_kernel(const double* __restrict__ sums, const float* __restrict__ a,
                                                              const float* __restrict__ dgap, int B, int C, int Cp,
                                                              float inv_hw, long M, int training,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              float* __restrict__ c1, float* __restrict__ c2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const int cp = c >= Cp ? c - Cp : c;
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = t0 / SBS_L, j = t0 % SBS_L;
+    const bool ok = c < C;
+    const int cc = ok ? c : 0;
+    const int cp = cc >= Cp ? cc - Cp : cc;
     double s = 0.0, t = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const double* q = sums + ((long)b * C + c) * 4;
-        const double av = (double)a[(long)b * C + c], gp = (double)(dgap[(long)b * Cp + cp] * inv_hw);
+    for (int b = j; b < B; b += SBS_L) {
+        const double* q = sums + ((long)b * C + cc) * 4;
+        const double av = (double)a[(long)b * C + cc], gp = (double)(dgap[(long)b * Cp + cp] * inv_hw);
         s += av * q[0] + gp * q[2];
         t += av * q[1] + gp * q[3];
     }
+#pragma unroll
+    for (int o = 1; o < SBS_L; o <<= 1) { s += __shfl_xor(s, o, SBS_L); t += __shfl_xor(t, o, SBS_L); }
+    if (!ok || j != 0) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)t;
     c1[c] = training ? (float)(s / (double)M) : 0.f;
@@ -867,12 +896,12 @@ extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const fl
     ScProfScope prof(bn_sums ? "sa_bn_bwd(finalize+apply)" : "sa_bn_bwd(reduce+finalize+apply)", st, 0,
                      ((bn_sums ? 8.0 : 12.0) * C + (bn_sums ? 4.0 : 8.0) * Cp) * M);
     if (bn_sums) {
-        hipLaunchKernelGGL(sa_bn_bwd_sums_kernel, dim3(sc_cdiv(C, 256)), dim3(256), 0, st, bn_sums, a, dgap, B, C, Cp,
+        hipLaunchKernelGGL(sa_bn_bwd_sums_kernel, dim3(sc_cdiv((long)C * SBS_L, 256)), dim3(256), 0, st, bn_sums, a, dgap, B, C, Cp,
                            1.f / HW, M, training, dgamma, dbeta, c1, c2);
     } else {
         hipLaunchKernelGGL(sa_bn_bwd_partial_kernel, pgrid, dim3(256), 0, st, dout, a, dgap, x0, bn_saved, (double*)ws, g,
                            HW, Cp, 1.f / HW);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, M, C,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nb, M, C,
                            training, dgamma, dbeta, c1, c2);
     }
     const long n4 = M * C / 4;
@@ -898,7 +927,7 @@ extern "C" int scouter_colsum_f32(const float* a, const float* b, float* out, lo
     }
     if (b) hipLaunchKernelGGL(colsum_partial_kernel<3>, pgrid, dim3(256), 0, st, a, b, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
     else hipLaunchKernelGGL(colsum_partial_kernel<2>, pgrid, dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)ws, g);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb, C, out, alpha);
+    hipLaunchKernelGGL(colsum_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, out, alpha);
     return sc_check_launch("colsum");
 }
 
@@ -975,7 +1004,7 @@ extern "C" int scouter_bn_maxpool_bwd_f32(const float* dy, const unsigned char* 
                      8.0 * (double)B * H * W * C + 9.0 * (double)Mp * C);
     dim3 pgrid(nb, (C + cg.cslab - 1) / cg.cslab);
     hipLaunchKernelGGL(bn_maxpool_bwd_partial_kernel, pgrid, dim3(256), 0, st, dy, argmax, x, bn_saved, (double*)ws, g, cg);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sc_cdiv(C, FIN_CH)), dim3(256), 0, st, (const double*)ws, nb,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nb,
                        (long)B * H * W, C, training, dgamma, dbeta, coef, coef + C);
     pool_bwd_rows<true>(dy, argmax, dx, g, st, x, bn_saved, coef);
     return sc_check_launch("bn_maxpool_bwd");
