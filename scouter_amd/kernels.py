@@ -88,6 +88,7 @@ BF16_MIN_PIXELS = 1024      # layers with fewer GEMM rows (the split-attention F
 # what it chose, which is how the table is made); SCOUTER_AUTOTUNE=0 ignores the table too (library heuristics only).
 AUTOTUNE = os.environ.get("SCOUTER_AUTOTUNE", "table")
 _tile_cache = {}
+_tile_cands = {}            # key -> legal candidates, recorded for tools_dev/tune_in_step.py
 _tune_table = None
 _tune_index = None
 TUNE_TABLE_PATH = os.environ.get("SCOUTER_TUNE_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -169,6 +170,7 @@ def _pick_tile(key, launch, candidates=(0, 1, 2, 3)):
     t = _tile_cache.get(key)
     if t is not None:
         return t
+    _tile_cands[key] = tuple(c for c in candidates if c < 0 or launch(c, dry=True))
     if AUTOTUNE == "0":
         _tile_cache[key] = -1
         return -1
