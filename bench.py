@@ -144,7 +144,8 @@ def cpu_baseline(cfg, budget_s=20.0, steps=3):
 def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, layers=3):
     """north_star target: the fused xSlot forward at batch 256 (BASELINE configs[4]'s head: 100 classes x 3 slots, 7x7
     grid, to_k_layer 3) against the fp32 MFMA roofline.  Kernel time = the library's hipEvents around each launch, median of 8
-    batches of 20 launches after 60 warm-up launches (the clock settles); FLOPs are algorithmic (no padding counted)."""
+    batches of 20 launches after 200 warm-up launches (the clock needs ~150 launches of THIS kernel to settle after the
+    training steps: 135 -> 122 us); FLOPs are algorithmic (no padding counted)."""
     from scouter_amd import _native, kernels as K
     g = torch.Generator(device=device).manual_seed(0)
     r = lambda *sh: torch.randn(*sh, device=device, generator=g)
@@ -158,7 +159,7 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
     buf = ctypes.create_string_buffer(1 << 14)
 
     def median_launch(fn, kernel):
-        for _ in range(60):
+        for _ in range(200):
             fn()
         torch.cuda.synchronize()
         L.scouter_prof_collect(buf, len(buf))
@@ -191,7 +192,7 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
             "batch": batch, "slots": slots, "tokens": tokens, "to_k_layers": layers, "avg_launch_us": round(t * 1e6, 1),
             "achieved": round(fl / t / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "bound": "mfma",
-            "measured": "hipEvents around each launch, median of 8 batches x 20 launches after 60 warm-up launches"}
+            "measured": "hipEvents around each launch, median of 8 batches x 20 launches after 200 warm-up launches"}
 
 
 PMC_TRAFFIC_FILE = "r03_pmc_hbm_traffic.json"
