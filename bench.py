@@ -195,8 +195,8 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
             "measured": "hipEvents around each launch, median of 8 batches x 20 launches after 200 warm-up launches"}
 
 
-PMC_TRAFFIC_FILE = "r03_pmc_hbm_traffic.json"
-PMC_MFMA_FILE = "r03_pmc_mfma_util.json"
+PMC_TRAFFIC_FILE = "r04_pmc_hbm_traffic.json"
+PMC_MFMA_FILE = "r04_pmc_mfma_util.json"
 # Kernel classes of the roofline object: bench label prefixes (the library's hipEvent scopes) and the rocprofv3 kernel-name
 # prefixes of the SAME kernels.  Names are matched by exact prefix ("void wgrad_kernel<" does not match
 # "void pwgrad_kernel<": round 2's substring match mixed the two).
@@ -226,12 +226,20 @@ def _profile_json(fname):
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f)
+        doc = json.load(f)
+    # the PMC passes describe the kernel instances of the tile table they ran with: a profile taken under another table is
+    # stale -- dropped, the line then carries traffic / pmc_mfma_busy = null rather than wrong numbers
+    import hashlib
+    tp = os.path.join(ROOT, "scouter_amd", "tuning", "gfx950.json")
+    sha = hashlib.sha256(open(tp, "rb").read()).hexdigest()[:16] if os.path.exists(tp) else None
+    if doc.get("tuning_sha16") != sha:
+        return None
+    return doc
 
 
 def pmc_class(prefixes):
     """(HBM-side bytes per launch, MFMA-busy fraction, sources) of the kernels whose rocprofv3 names start with one of
-    `prefixes`, from the committed PMC passes over THIS command (profiles/r03_pmc_*.json, made by tools_dev/pmc_traffic.py
+    `prefixes`, from the committed PMC passes over THIS command (profiles/r04_pmc_*.json, made by tools_dev/pmc_traffic.py
     -- 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md -- and tools_dev/pmc_mfma.py); PMC
     counters cannot be collected from inside the timed process.  The static tile table makes the instances of those
     runs the instances of this one.  None where a file is missing."""
@@ -258,19 +266,16 @@ def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) the way the reference's README
     does with torch.distributed.launch (reference README.md:20-22, tools/prepare_things.py:9-31) and pass their single
     JSON line through.  Refuses when the node has fewer than N devices."""
-    import socket
     import subprocess
     have = torch.cuda.device_count()
     if have < n:
         raise SystemExit("bench.py --gpus %d: this node exposes %d HIP device(s); refusing to run fewer ranks than "
                          "asked for (the reported n_gpus would be wrong)" % (n, have))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # --standalone: torchrun's own c10d rendezvous binds a free port and KEEPS it (no bind-close-reuse race, ADVICE r3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + argv
     raise SystemExit(subprocess.call(cmd, env=env))
 
 

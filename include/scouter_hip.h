@@ -246,8 +246,12 @@ int scouter_linear_small_bwd_f32(const float* dy, const float* x, const float* w
  * 6 (1 or 3 planes) = PERSISTENT 256 x (128 | 64): one workgroup per CU walks the tile list, the LDS-DMA stream runs on into
  * the next tile, register epilogue (csrc/conv_planes_persist.h; needs >= 2 K-tiles of 32 channels x taps).
  * Fused BatchNorm-statistics rows = ceil(M / BM) with BM = 128, 128, 128, 64, 256, 256 for tile 0..5; tile 6 writes one row
- * per 64-row wave row of its 256-row tiles: 4 * ceil(M / 256).  Tiles 0-4 and 6 sum every output in the same K order
- * (bit-identical results); tile 5 sums 16-channel chunks outer / taps inner. */
+ * per 64-row wave row of its 256-row tiles: 4 * ceil(M / 256).  scouter_conv2d_fwd_planes_bn_partial_rows returns the
+ * largest count any tile writes (4 * ceil(M / 256)).  Tile 6 with bn_partial AND bias / addend, or with fewer than two
+ * K-tiles, is refused with SC_ERR_UNSUPPORTED (no silent re-routing: the row layout depends on the tile).  Tiles 0-4 and 6
+ * sum every output ELEMENT in the same K order (bit-identical convolution outputs); the fused BatchNorm statistics are
+ * per-tile partial sums, grouped differently per tile, so batch statistics -- and everything downstream -- agree between
+ * tiles to fp64 rounding of the partial sums, not bit for bit; tile 5 sums 16-channel chunks outer / taps inner. */
 int scouter_planes_split_f32(const float* x, void* planes, long n, int nplanes, void* stream);
 int scouter_planes_split_weight_f32(const float* w_hwio, void* w_fwd, void* w_dgrad, int kh, int kw, int Cin, int Cout,
                                     int groups, int nplanes, void* stream);

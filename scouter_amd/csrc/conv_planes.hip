@@ -767,7 +767,13 @@ static int dispatch_pconv(const void* a, long a_pe, const void* w, long w_pe, co
     const bool wide = g.Ng % 128 == 0 && tile != 1;
     // tile 6: persistent 256 x (128 | 64); its register epilogue takes BatchNorm statistics from the accumulators, so a
     // launch that wants statistics of bias / addend-shifted values keeps the LDS-staged epilogue of tile 4 / 2
-    if (tile == 6 && ((bn_part && (bias || addend)) || g.R * g.S * (g.Cg / 32) < 2)) tile = g.Ng % 128 == 0 ? 4 : 2;
+    // -- that request is REFUSED, not silently re-routed: the caller sized bn_part / the fused partial rows for the tile
+    // it named (tile 6: four rows per 256-row tile), another tile writes another row layout
+    if (tile == 6 && ((bn_part && (bias || addend)) || g.R * g.S * (g.Cg / 32) < 2)) {
+        sc_set_error("conv planes: tile 6 (persistent) cannot take BatchNorm statistics of bias / addend-shifted outputs "
+                     "and needs at least two K-tiles of 32 channels x taps; name another tile");
+        return SC_ERR_UNSUPPORTED;
+    }
     if (tile == 6) {
         if (nplanes == 3) {
             if (g.Ng % 128 == 0) launch_ppersist<128, 3, DGRAD>(a, a_pe, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz);
@@ -799,7 +805,9 @@ static int dispatch_pconv(const void* a, long a_pe, const void* w, long w_pe, co
 }
 
 extern "C" int scouter_conv2d_fwd_planes_bn_partial_rows(int B, int H, int W, int kh, int kw, int stride, int pad) {
-    return sc_cdiv((long)B * conv_out_p(H, kh, stride, pad) * conv_out_p(W, kw, stride, pad), 64);     // upper bound
+    // upper bound over every tile: tile 6 writes one row per 64-row WAVE row of each 256-row tile, incl. the all-zero
+    // ones beyond M (4 * ceil(M / 256) >= ceil(M / 64), the count of the 64-row tile 3)
+    return 4 * sc_cdiv((long)B * conv_out_p(H, kh, stride, pad) * conv_out_p(W, kw, stride, pad), 256);
 }
 
 // x_planes: [nplanes][B*H*W][Cin] bf16; w_planes: scouter_planes_split_weight_f32's forward layout.

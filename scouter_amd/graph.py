@@ -83,6 +83,8 @@ class GraphedTrainStep:
         # their addresses baked in -- if a later eager call on those streams needed a bigger workspace, kernels.workspace()
         # would replace the buffer and the caching allocator could hand the old one to someone else under the replays.
         self._pinned_ws = list(K._ws.values())
+        sp = getattr(self.model, "_wsplitter", None)          # plane-weight tables / plane buffers of the captured key
+        self._pinned_ws += sp.buffers() if sp is not None else []
         for key in set(K._ws) - ws_before:        # scratch allocated from the graph's private pool: never hand it to
             del K._ws[key]                        # eager code that happens to run on a stream with the same handle
         self._shape = (tuple(images.shape), tuple(labels.shape))

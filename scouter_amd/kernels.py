@@ -112,7 +112,13 @@ def _load_tune_table():
     _tune_table, _tune_index = {}, {}
     if os.path.exists(TUNE_TABLE_PATH):
         with open(TUNE_TABLE_PATH) as f:
-            _tune_table = {k: int(v) for k, v in json.load(f)["choices"].items()}
+            doc = json.load(f)
+        # the table is only meaningful on the architecture it was timed on: elsewhere the library heuristics
+        arch = ""
+        if torch.cuda.is_available():
+            arch = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "").split(":")[0]
+        if not arch or arch == doc.get("arch", arch):
+            _tune_table = {k: int(v) for k, v in doc["choices"].items()}
     for ks, v in _tune_table.items():
         parts = ks.split("|")
         bp = _batch_pos(parts)
@@ -390,7 +396,11 @@ class PlaneWeightSplitter:
     `split_weight_kernel` launch per layer was 0.13 ms per step."""
 
     def __init__(self):
-        self._key, self._table, self._outs, self._total = None, None, None, 0
+        # one entry per (planes, device, weights, wanted outputs) key, kept for the life of the model: a training forward
+        # (forward + input-gradient planes) and an eval forward (forward planes only) have different keys, and a captured
+        # hipGraph has the table / plane-buffer addresses of ITS key baked in -- replacing the single cached entry freed
+        # buffers under the graph's replays (ADVICE r3).  Alternating train / eval also no longer rebuilds the table.
+        self._entries = {}
 
     def run(self, items, nplanes):
         """items: [(w_hwio, groups, want_fwd, want_dgrad)] -> [(wf, wd)]"""
@@ -398,7 +408,8 @@ class PlaneWeightSplitter:
         L = _native.lib()
         dev = items[0][0].device
         key = (nplanes, dev, tuple((w.data_ptr(), g, f, d) for w, g, f, d in items))
-        if key != self._key:
+        ent = self._entries.get(key)
+        if ent is None:
             rows, outs, first = [], [], 0
             for w, groups, fwd, dgrad in items:
                 _chk(w, "weight")
@@ -410,11 +421,15 @@ class PlaneWeightSplitter:
                 first += kh * kw * cg * Cout
             blob = b"".join(rows)
             assert len(blob) == len(rows) * L.scouter_planes_split_weights_row_bytes()
-            self._table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-            self._key, self._outs, self._total = key, outs, first
-        _native.check(L.scouter_planes_split_weights_multi(_p(self._table), len(self._outs), self._total, nplanes, _stream()),
+            ent = self._entries[key] = (torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev), outs, first)
+        table, outs, total = ent
+        _native.check(L.scouter_planes_split_weights_multi(_p(table), len(outs), total, nplanes, _stream()),
                       "planes_split_weights_multi")
-        return self._outs
+        return outs
+
+    def buffers(self):
+        """Every device buffer of every entry (GraphedTrainStep keeps them alive next to the workspaces)."""
+        return [t for table, outs, _ in self._entries.values() for t in [table] + [b for o in outs for b in o if b is not None]]
 
 
 _PLANE_TILE_ROWS = {0: 128, 1: 128, 2: 128, 3: 64, 4: 256, 5: 256, 6: 64}
@@ -434,8 +449,9 @@ def _plane_tiles(ng, nplanes=3, halo=False):
     5 (halo=True: same-size 3x3 layers on maps up to 63 wide) = 256 x (128 | 64) with the input rows resident in LDS for
     all nine taps, 6 = PERSISTENT 256 x (128 | 64): one workgroup per CU walks the tile list, the DMA stream prefetches
     the next tile under the current one, register epilogue (csrc/conv_planes_persist.h).  Tiles 0-4 and 6 sum each output
-    in the same order (bit-identical results); tile 5 sums over K in a different order (16-channel chunk outer, tap
-    inner): equal to fp32 rounding."""
+    ELEMENT in the same order (bit-identical convolution outputs; the fused BatchNorm partial sums are grouped per tile,
+    so statistics agree between tiles to fp64 rounding, not bit for bit); tile 5 sums over K in a different order
+    (16-channel chunk outer, tap inner): equal to fp32 rounding."""
     if nplanes == 1:
         return ((0, 1) if ng % 128 == 0 else (1,)) + ((5,) if halo else ()) + (6,)
     return ((0, 2, 3, 4) if ng % 128 == 0 else (2, 3)) + ((5,) if halo else ()) + (6,)

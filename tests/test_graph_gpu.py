@@ -110,3 +110,40 @@ def test_capturable_adamw_matches_host_stepped_adamw_eagerly():
     assert outs[0][1] == outs[1][1] == 5
     # the bias corrections are formed in fp64 on the host vs in the kernel from the same fp64 formula
     assert torch.allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-7)
+
+
+def test_eval_forward_and_empty_cache_between_replays_leave_the_graph_intact():
+    """ADVICE r3: the captured graph has the plane-weight pointer table and plane buffers of the TRAINING key baked in;
+    an eval forward in between (forward planes only: another key) must not free or replace them, even when the caching
+    allocator is emptied and refilled with other tensors before the next replay."""
+    from scouter_amd.graph import GraphedTrainStep
+    from scouter_amd.optim import FusedAdamW
+    m_e, batches = _model(seed=9)
+    opt_e = FusedAdamW([p for p in m_e.parameters() if p.requires_grad], lr=1e-3)
+    warm = 2
+    for x, y in [batches[0]] * warm + batches:
+        opt_e.zero_grad()
+        out, losses = m_e(x, y)
+        losses[0].backward()
+        opt_e.step()
+    torch.cuda.synchronize()
+
+    m_g, _ = _model(seed=9)
+    opt_g = FusedAdamW([p for p in m_g.parameters() if p.requires_grad], lr=1e-3, capturable=True)
+    step = GraphedTrainStep(m_g, opt_g, warmup=warm, preserve_state=False).prepare(*batches[0])
+    n_keys = len(m_g._wsplitter._entries)
+    for i, (x, y) in enumerate(batches):
+        step(x, y)
+        if i < len(batches) - 1:
+            m_g.eval()
+            with torch.no_grad():
+                m_g(x, y)                                   # forward planes only: a second splitter key
+            m_g.train()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(16)]   # whoever gets freed blocks
+            del junk
+    torch.cuda.synchronize()
+    assert len(m_g._wsplitter._entries) == n_keys + 1      # the eval key was ADDED, the training key kept
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k

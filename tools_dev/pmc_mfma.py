@@ -28,16 +28,22 @@ for name, a in agg.items():
         continue
     rows.append((a["dur"], name, a["n"], a["SQ_VALU_MFMA_BUSY_CYCLES"], a["GRBM_GUI_ACTIVE"], a.get("SQ_BUSY_CYCLES", 0)))
 rows.sort(reverse=True)
-print("%-62s %6s %10s %12s %10s %9s" % ("kernel", "calls", "avg us", "MFMA busy", "GUI active", "MFMA util"))
+print("%-62s %6s %10s %12s %10s %9s %9s" % ("kernel", "calls", "avg us", "MFMA busy", "GUI active", "MFMA util", "sclk GHz"))
 out = {}
 for dur, name, n, mf, gui, sqb in rows[:60]:
     # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs
     util = mf / (1024.0 * gui / 8.0)
-    print("%-62s %6d %10.1f %12.3e %10.3e %8.1f%%" % (name[:62], n, dur / n / 1e3, mf / n, gui / n / 8.0, 100 * util))
-    out[name] = {"launches": n, "avg_us": dur / n / 1e3, "mfma_busy": util}
+    # shader clock during the dispatch: GRBM_GUI_ACTIVE cycles (per XCD) / the dispatch's duration from the same row
+    ghz = (gui / 8.0) / dur
+    print("%-62s %6d %10.1f %12.3e %10.3e %8.1f%% %9.3f" % (name[:62], n, dur / n / 1e3, mf / n, gui / n / 8.0, 100 * util, ghz))
+    out[name] = {"launches": n, "avg_us": dur / n / 1e3, "mfma_busy": util, "sclk_ghz": round(ghz, 3)}
 if len(sys.argv) > 3:
     import json
+    import hashlib, os
+    tp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scouter_amd", "tuning", "gfx950.json")
+    sha = hashlib.sha256(open(tp, "rb").read()).hexdigest()[:16]
     json.dump({"command": "SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE "
                           "SQ_BUSY_CYCLES -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-prof",
-               "mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD)", "kernels": out},
+               "mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD)",
+               "sclk_ghz": "GRBM_GUI_ACTIVE per XCD / dispatch duration (same rocprofv3 row)", "tuning_sha16": sha, "kernels": out},
               open(sys.argv[3], "w"), indent=1)

@@ -42,7 +42,12 @@ out = {}
 for tot, name, n, rd, wr in rows[:60]:
     print("%-70s %7d %14.2f %14.2f %14.2f" % (name[:70], n, rd / 1e6, wr / 1e6, tot / 1e6))
     out[name] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr}
+import hashlib, os
+def _table_sha16():
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scouter_amd", "tuning", "gfx950.json")
+    return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16]
 json.dump({"command": "SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE} -- python bench.py "
                       "--steps 3 --warmup 2 --no-cpu-baseline --no-prof (dispatches after the warm-up only)",
-           "correction": "read = 2 x FETCH_SIZE KB (gfx950), write = WRITE_SIZE KB", "kernels": out},
+           "correction": "read = 2 x FETCH_SIZE KB (gfx950), write = WRITE_SIZE KB", "tuning_sha16": _table_sha16(),
+           "kernels": out},
           open("gpurun_out/pmc_traffic.json", "w"), indent=1)
