@@ -138,7 +138,10 @@ def vis_maps(attn, num_classes, slots_per_class, vis_id=0):
         a = a.reshape(a.shape[0], num_classes, slots_per_class, a.shape[-1]).sum(2)
     a = a[vis_id]
     side = int(a.size(1) ** 0.5)
-    a = ((a - a.min()) / (a.max() - a.min()) * 255.0).reshape(a.shape[0], side, side)
+    span = a.max() - a.min()
+    if float(span) == 0.0:      # constant map: the reference's 0 / 0 -> NaN -> uint8 cast is platform-defined; pinned to 0
+        return np.zeros((a.shape[0], side, side), dtype=np.uint8)       # (what the reference's own PNGs hold on x86)
+    a = ((a - a.min()) / span * 255.0).reshape(a.shape[0], side, side)
     return a.detach().cpu().numpy().astype(np.uint8)
 
 

@@ -26,6 +26,10 @@ class DistributedDataParallel(nn.Module):
             self._sync_module_states()
         self._pending = []
         self._buf_flat = None
+        self._buf_version = -1
+        self._buf_work = None            # the asynchronous buffer broadcast issued at the end of the previous backward
+        self.measure_exposed = False     # bench.py: hipEvent pairs around the wait for the gradient collectives
+        self.exposed_events = []
         if self._active and broadcast_buffers:
             self._flatten_float_buffers()
         module._grad_ready_hooks.append(self._launch_bucket)
@@ -77,8 +81,24 @@ class DistributedDataParallel(nn.Module):
             off += k
         self._buf_flat, self._buf_first = flat, named[0][0]._buffers[named[0][1]]
 
+    def _buffers_are_flat(self):
+        return self._buf_flat is not None and self._buf_first.data_ptr() == self._buf_flat.data_ptr()
+
     def _broadcast_buffers(self):
-        if self._buf_flat is not None and self._buf_first.data_ptr() == self._buf_flat.data_ptr():
+        """DDP's per-forward buffer broadcast from rank 0 (BatchNorm running statistics).  The running statistics only
+        change inside a training forward, so the broadcast for step n + 1 is issued ASYNCHRONOUSLY at the end of step n's
+        backward (`_finish_gradients`: on RCCL's stream, ordered after the forward's finalize kernels, overlapping the
+        optimizer step) and the next forward merely waits for it -- no blocking collective in front of every forward.
+        The first forward, and any forward whose buffers were re-allocated in between, broadcast synchronously."""
+        work, self._buf_work = self._buf_work, None
+        if work is not None:
+            work.wait()                         # compute stream waits for the collective (no host sync on NCCL)
+            # DDP's contract is "rank 0's buffers as they are AT this forward": if anything wrote the buffers through
+            # torch since the prefetch was issued (load_state_dict, a manual edit -- the tensor version counter tells;
+            # the HIP kernels only write them inside a training forward), broadcast again now
+            if self._buffers_are_flat() and self._buf_flat._version == self._buf_version:
+                return
+        if self._buffers_are_flat():
             dist.broadcast(self._buf_flat, src=0, group=self.process_group)
         else:                                   # buffers were re-allocated (e.g. module.to(...)): gather / scatter
             self._coalesced_broadcast(self._float_buffers())
@@ -94,13 +114,31 @@ class DistributedDataParallel(nn.Module):
     def _finish_gradients(self, arena):
         if not self._active:
             return
+        ev = None
+        if self.measure_exposed and arena.flat.is_cuda:
+            # what the compute stream loses to the gradient exchange: from "every backward kernel is queued" to "the last
+            # bucket has arrived" on the compute stream (0 when the buckets finished under the backward)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for work in self._pending:
             work.wait()                  # makes the compute stream wait for the collective (no host sync on NCCL)
         self._pending = []
+        if ev is not None:
+            ev[1].record()
+            self.exposed_events.append(ev)
+        if self.broadcast_buffers and self.module.training and self._buffers_are_flat():
+            self._buf_work = dist.broadcast(self._buf_flat, src=0, group=self.process_group, async_op=True)
+            self._buf_version = self._buf_flat._version
         if arena.flat.is_cuda:
             K.axpby(arena.flat, None, 1.0 / self.world_size, 0.0, out=arena.flat)
         else:                                                 # gloo/CPU plumbing tests only
             arena.flat.mul_(1.0 / self.world_size)
+
+    def exposed_allreduce_ms(self):
+        """Mean per-step time the compute stream waited for the gradient collectives (measure_exposed; call after a
+        device synchronisation) and clears the log."""
+        evs, self.exposed_events = self.exposed_events, []
+        return sum(a.elapsed_time(b) for a, b in evs) / len(evs) if evs else None
 
     def forward(self, *args, **kwargs):
         if self._active and self.broadcast_buffers and self.module.training and torch.is_grad_enabled():

@@ -125,7 +125,12 @@ class SlotAttention(nn.Module):
             a = a.reshape(a.shape[0], self.num_classes, self.slots_per_class, a.shape[-1]).sum(2)
         a = a[self.vis_id]
         side = int(a.size(1) ** 0.5)
-        a = ((a - a.min()) / (a.max() - a.min()) * 255.).reshape(a.shape[0], side, side)
+        span = a.max() - a.min()
+        if float(span) == 0.0:
+            # a constant map (one token, or every attention equal): the reference divides 0 / 0 and casts the NaNs to uint8,
+            # which is platform-defined in NumPy (x86 gives 0, and warns); defined here -- and in the oracle -- as 0
+            return np.zeros((a.shape[0], side, side), dtype=np.uint8)
+        a = ((a - a.min()) / span * 255.).reshape(a.shape[0], side, side)
         return a.numpy().astype(np.uint8)
 
     def save_vis(self, folder="sloter/vis"):

@@ -72,6 +72,18 @@ def _worker(rank, world, port, q):
             m.conv.weight.grad.stride() == m.conv.weight.stride()
         # 3. buffers were re-broadcast from rank 0 before the training forward
         buf_ok = float(m.bn.running_mean[0]) == 10.0
+        # 4. the NEXT step's buffer broadcast was issued asynchronously at the end of this backward and
+        #    the next forward consumes it without another collective ...
+        prefetched = ddp._buf_work is not None
+        if rank == 0:
+            import time
+            time.sleep(0.2)                                   # (rank 0 late: a blocking collective would show here)
+        ddp(float(rank + 1))
+        buf_ok = buf_ok and prefetched and float(m.bn.running_mean[0]) == 10.0
+        #    ... unless the buffers were written in between: DDP's "rank 0's buffers as of THIS forward" still holds
+        m.bn.running_mean.fill_(float(100 * (rank + 1)))
+        ddp(float(rank + 1))
+        buf_ok = buf_ok and float(m.bn.running_mean[0]) == 100.0
         q.put((rank, same_params, mean_ok, grad_view_ok, buf_ok, bool(torch.equal(w_before, m.conv.weight)) == (rank == 0)))
     finally:
         dist.destroy_process_group()
