@@ -38,22 +38,106 @@ def normalize_table(mean, std):
     return torch.from_numpy(((v - m) / s).astype(np.float32))
 
 
+class PackedImages(object):
+    """A batch of decoded frames of different sizes as ONE contiguous uint8 buffer (frames back to back, each at a
+    16-byte aligned offset) + their shapes: one pinned allocation and one host-to-device copy per batch instead of one
+    pageable copy per frame (70 per step: 2.1 ms, 12 % of a training step, round 3).  Indexing / iteration give the frames
+    back as [h, w, c] views, so code written for a list of frames keeps working.  DataLoader(pin_memory=True) pins it
+    through `pin_memory()` in its background thread."""
+
+    def __init__(self, flat, shapes):
+        self.flat, self.shapes = flat, [tuple(int(v) for v in s) for s in shapes]
+        self.offsets, off = [], 0
+        for h, w, c in self.shapes:
+            self.offsets.append(off)
+            off += (h * w * c + 15) // 16 * 16
+        assert off <= flat.numel()
+
+    @staticmethod
+    def nbytes(shapes):
+        return sum((int(h) * int(w) * int(c) + 15) // 16 * 16 for h, w, c in shapes)
+
+    @classmethod
+    def pack(cls, images, out=None):
+        """images: uint8 [h, w, c] host tensors -> PackedImages (in `out`, a flat uint8 buffer, when given and big enough)"""
+        shapes = [tuple(t.shape) for t in images]
+        n = cls.nbytes(shapes)
+        flat = out[:n] if out is not None and out.numel() >= n else torch.empty(n, dtype=torch.uint8)
+        p = cls(flat, shapes)
+        for t, o, (h, w, c) in zip(images, p.offsets, shapes):
+            if t.dtype != torch.uint8 or t.dim() != 3:
+                raise RuntimeError("PackedImages: dense uint8 [h, w, c] frames expected, got %s %s" % (t.dtype, tuple(t.shape)))
+            flat[o:o + h * w * c].copy_(t.reshape(-1))
+        return p
+
+    def pin_memory(self):
+        return PackedImages(self.flat.pin_memory(), self.shapes)
+
+    def frames(self, flat=None):
+        flat = self.flat if flat is None else flat
+        return [flat[o:o + h * w * c].view(h, w, c) for o, (h, w, c) in zip(self.offsets, self.shapes)]
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def __getitem__(self, i):
+        h, w, c = self.shapes[i]
+        return self.flat[self.offsets[i]:self.offsets[i] + h * w * c].view(h, w, c)
+
+    def __iter__(self):
+        return iter(self.frames())
+
+
 class GpuTransform(object):
-    """Batch-level Resize + ToTensor + Normalize on the device (the `val` / aug-free `train` transform)."""
+    """Batch-level Resize + ToTensor + Normalize on the device (the `val` / aug-free `train` transform).  The decoded
+    frames travel as ONE pinned buffer in ONE asynchronous copy (PackedImages); the engine issues that copy and the two
+    resize launches for batch n + 1 on a feed stream while step n computes (engine.device_batches)."""
 
     def __init__(self, dataset, img_size):
         mean, std = NORMALIZE_VALUE[dataset]
         self.size = int(img_size)
         self.table = normalize_table(mean, std)
         self._dev_table = {}
+        self._staging = [None, None]          # pinned staging buffers for callers that hand over unpinned frames
+        self._turn = 0
+        self._in_flight = [None, None]        # event: the copy out of staging buffer i has finished
+
+    def _stage(self, images):
+        """list of frames / unpinned PackedImages -> PackedImages in one of two alternating pinned staging buffers"""
+        shapes = images.shapes if isinstance(images, PackedImages) else [tuple(t.shape) for t in images]
+        n = PackedImages.nbytes(shapes)
+        i = self._turn
+        self._turn ^= 1
+        if self._in_flight[i] is not None:
+            self._in_flight[i].synchronize()  # the copy issued two batches ago still reads this buffer (normally long done)
+        buf = self._staging[i]
+        if buf is None or buf.numel() < n:
+            buf = self._staging[i] = torch.empty(max(n, 1 << 20) * 5 // 4, dtype=torch.uint8).pin_memory()
+        if isinstance(images, PackedImages):
+            buf[:n].copy_(images.flat[:n])
+            return PackedImages(buf[:n], shapes), i
+        return PackedImages.pack(list(images), out=buf), i
 
     def __call__(self, images_u8, device):
         from .. import kernels
+        device = torch.device(device)
         key = str(device)
         if key not in self._dev_table:
             self._dev_table[key] = self.table.to(device)
-        dev_imgs = [t.to(device, non_blocking=True) for t in images_u8]
-        return kernels.resize_normalize(dev_imgs, self.size, self._dev_table[key])
+        slot = None
+        if isinstance(images_u8, PackedImages) and images_u8.flat.is_cuda:
+            packed, dev_flat = images_u8, images_u8.flat
+        else:
+            packed = images_u8
+            if not (isinstance(packed, PackedImages) and packed.flat.is_pinned()):
+                packed, slot = self._stage(packed)
+            dev_flat = torch.empty(packed.flat.numel(), dtype=torch.uint8, device=device)
+            dev_flat.copy_(packed.flat, non_blocking=True)            # the ONE host-to-device copy of the batch
+            if slot is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+                self._in_flight[slot] = ev
+        return kernels.resize_normalize(packed.frames(dev_flat), self.size, self._dev_table[key])
 
     def __repr__(self):
         return "GpuTransform(size=%d)" % self.size
@@ -74,7 +158,8 @@ def make_gpu_transform(args):
 
 
 def collate_raw(samples):
-    """Keeps the decoded images as a list (they differ in size); labels become one int64 tensor."""
-    return {"image": [s["image"] for s in samples],
+    """Keeps the decoded images at their native sizes, packed into one buffer (PackedImages; indexable like a list);
+    labels become one int64 tensor."""
+    return {"image": PackedImages.pack([s["image"] for s in samples]),
             "label": torch.as_tensor([int(s["label"]) for s in samples], dtype=torch.int64),
             "names": [s.get("names", "") for s in samples]}

@@ -45,18 +45,70 @@ def _unwrap(model):
     return model.module if hasattr(model, "module") else model
 
 
+_feed_streams = {}
+
+
+def device_batches(data_loader, device):
+    """Yields (images float32 on `device`, labels int64 on `device`) for every batch of `data_loader`, one batch AHEAD:
+    after batch n has been handed out -- i.e. after the caller has queued step n's kernels -- batch n + 1 is taken from
+    the loader and its host-to-device copy (ONE pinned buffer, dataset.transform_func.PackedImages) and GPU transform are
+    issued on a separate feed stream, where they run under step n; the compute stream then only waits for an event.  The
+    counterpart of the reference's DataLoaderX / prefetch_generator thread (reference train.py:158-160,
+    tools/prepare_things.py), which prefetches on the host only.  CPU devices (plumbing tests): plain iteration."""
+    from .dataset.transform_func import PackedImages
+    device = torch.device(device)
+    on_gpu = device.type == "cuda"
+    feed = None
+    if on_gpu:
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        feed = _feed_streams.get(key)
+        if feed is None:
+            feed = _feed_streams[key] = torch.cuda.Stream(device=device)
+
+    def stage(batch):
+        images = batch["image"]
+        raw = isinstance(images, (list, tuple, PackedImages))
+        if not on_gpu:
+            images = data_loader.gpu_transform(images, device) if raw else images.to(device, dtype=torch.float32)
+            return images, batch["label"].to(device, dtype=torch.int64), None
+        # (no feed.wait_stream(compute): that would order the copy BEHIND step n -- the feed stream has its own allocator
+        # pool and workspace, and everything it hands over is fenced by the event + record_stream below)
+        with torch.cuda.stream(feed):
+            if raw:                                   # decoded uint8 frames: Resize + ToTensor + Normalize on the GPU
+                images = data_loader.gpu_transform(images, device)
+            else:
+                images = images.to(device, dtype=torch.float32, non_blocking=True)
+            labels = batch["label"].to(device, dtype=torch.int64, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(feed)
+        return images, labels, ev
+
+    it = iter(data_loader)
+    try:
+        cur = stage(next(it))
+    except StopIteration:
+        return
+    while cur is not None:
+        images, labels, ev = cur
+        if ev is not None:
+            st = torch.cuda.current_stream(device)
+            st.wait_event(ev)
+            images.record_stream(st)
+            labels.record_stream(st)
+        yield images, labels
+        # (the caller's loop body has run: step n is queued; now fetch and stage batch n + 1 under it)
+        try:
+            cur = stage(next(it))
+        except StopIteration:
+            cur = None
+
+
 def calculation(model, mode, data_loader, device, record, epoch, optimizer=None):
     training = mode == "train"
     meter = _DeviceMeter()
     print("start " + mode + " :" + str(epoch))
     steps = 0
-    for batch in _progress(data_loader):
-        images = batch["image"]
-        if isinstance(images, (list, tuple)):         # decoded uint8 images: Resize + ToTensor + Normalize on the GPU
-            images = data_loader.gpu_transform(images, device)
-        else:
-            images = images.to(device, dtype=torch.float32)
-        labels = batch["label"].to(device, dtype=torch.int64)
+    for images, labels in _progress(device_batches(data_loader, device)):
         if training:
             optimizer.zero_grad()
         logits, losses = model(images, labels)

@@ -97,7 +97,8 @@ def _build_loaders(args):
     else:
         train_sampler, val_sampler = RandomSampler(train_set), SequentialSampler(val_set)
     raw = not getattr(args, "synthetic_data", True)     # real data: samples are decoded uint8 images of any size
-    extra = {"collate_fn": collate_raw} if raw else {}
+    # raw frames travel packed in one buffer per batch, pinned by the DataLoader's pin thread (one async H2D per batch)
+    extra = {"collate_fn": collate_raw, "pin_memory": torch.cuda.is_available()} if raw else {}
     train_loader = prt.DataLoaderX(train_set, batch_sampler=BatchSampler(train_sampler, args.batch_size, drop_last=True),
                                    num_workers=args.num_workers, **extra)
     val_loader = prt.DataLoaderX(val_set, args.batch_size, sampler=val_sampler, num_workers=args.num_workers, **extra)

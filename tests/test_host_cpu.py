@@ -192,3 +192,43 @@ def test_use_pre_stage2_handoff_loads_fc_baseline_checkpoint(tmp_path, monkeypat
     prt.save_on_master({"model": bad.state_dict()}, tmp_path / "saved_model" / "MNIST_no_slot_checkpoint.pth")
     with pytest.raises(RuntimeError, match="size mismatch"):
         SlotModel(_args("resnet18", mnist=True, L=1, use_slot=True, use_pre=True))
+
+
+def test_packed_images_roundtrip_and_collate():
+    """dataset.transform_func.PackedImages: frames of ragged sizes in one buffer at 16-byte aligned offsets, indexable
+    like the list it replaces; collate_raw packs in the DataLoader worker (the H2D copy is then ONE per batch)."""
+    import numpy as np
+    from scouter_amd.dataset.transform_func import PackedImages, collate_raw
+    rng = np.random.default_rng(3)
+    frames = [torch.from_numpy(rng.integers(0, 256, (h, w, c), dtype=np.uint8))
+              for h, w, c in ((5, 7, 3), (1, 1, 3), (33, 17, 3), (16, 16, 3))]
+    p = PackedImages.pack(frames)
+    assert len(p) == 4 and all(o % 16 == 0 for o in p.offsets) and p.flat.numel() == PackedImages.nbytes(p.shapes)
+    for a, b in zip(frames, p):
+        assert torch.equal(a, b)
+    assert torch.equal(p[2], frames[2])
+    big = torch.zeros(1 << 16, dtype=torch.uint8)
+    q = PackedImages.pack(frames, out=big)                       # into a caller-owned (pinned staging) buffer
+    assert q.flat.data_ptr() == big.data_ptr() and torch.equal(q[3], frames[3])
+    with pytest.raises(RuntimeError):
+        PackedImages.pack([frames[0].float()])
+    batch = collate_raw([{"image": f, "label": i, "names": "n%d" % i} for i, f in enumerate(frames)])
+    assert isinstance(batch["image"], PackedImages) and batch["label"].tolist() == [0, 1, 2, 3]
+    assert torch.equal(batch["image"][1], frames[1])
+    # travels through a worker process like any batch
+    loader = torch.utils.data.DataLoader([{"image": f, "label": i} for i, f in enumerate(frames)], batch_size=2,
+                                         collate_fn=collate_raw, num_workers=1)
+    got = [b["image"] for b in loader]
+    assert torch.equal(got[1][0], frames[2]) and got[0].shapes == [(5, 7, 3), (1, 1, 3)]
+
+
+def test_device_batches_plain_iteration_on_cpu():
+    """engine.device_batches on a CPU device (plumbing): every batch once, in order, already-transformed tensors pass
+    through, labels become int64"""
+    from scouter_amd import engine
+    data = [{"image": torch.full((2, 1, 4, 4), float(i)), "label": torch.tensor([i, i + 1], dtype=torch.int32)} for i in range(3)]
+    out = list(engine.device_batches(data, torch.device("cpu")))
+    assert len(out) == 3
+    for i, (x, y) in enumerate(out):
+        assert x.dtype == torch.float32 and float(x[0, 0, 0, 0]) == i and y.dtype == torch.int64 and y.tolist() == [i, i + 1]
+    assert list(engine.device_batches([], torch.device("cpu"))) == []

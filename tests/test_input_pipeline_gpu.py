@@ -104,3 +104,47 @@ def test_train_main_on_image_folders(tmp_path):
         "--synthetic_data", "false", "--dataset_dir", str(tmp_path / "data") + "/", "--output_dir", ""])
     accs = train.param_translation(args)
     assert len(accs) == 2 and all(0.0 <= a <= 1.0 for a in accs)
+
+
+def test_prefetching_feed_delivers_the_same_batches_as_the_direct_transform():
+    """engine.device_batches: batch n + 1 is copied (one pinned buffer, one async H2D on the feed stream) and transformed
+    while step n runs; what arrives on the compute stream is bit-identical to transforming each batch directly -- with
+    DataLoader workers + pin_memory, and for unpinned batches through the transform's own pinned staging buffers (every
+    buffer is poisoned / recycled in between: a missing event or record_stream would show)."""
+    from scouter_amd import engine
+    from scouter_amd.dataset.transform_func import GpuTransform, PackedImages, collate_raw
+    from scouter_amd.tools.prepare_things import DataLoaderX
+
+    class Raw(torch.utils.data.Dataset):
+        def __len__(self):
+            return 24
+
+        def __getitem__(self, i):
+            r = np.random.default_rng(500 + i)
+            return {"image": torch.from_numpy(r.integers(0, 256, (40 + 3 * i, 64 - i, 3), dtype=np.uint8)),
+                    "label": int(r.integers(0, 10))}
+    dev = torch.device("cuda")
+    tf = GpuTransform("ImageNet", 64)
+    ds = Raw()
+    want = []
+    for b0 in range(0, 24, 4):
+        frames = [ds[i]["image"] for i in range(b0, b0 + 4)]
+        want.append((tf(frames, dev).clone(), [ds[i]["label"] for i in range(b0, b0 + 4)]))
+    torch.cuda.synchronize()
+    for kwargs in (dict(num_workers=2, pin_memory=True), dict(num_workers=0, pin_memory=False)):
+        loader = DataLoaderX(ds, batch_size=4, collate_fn=collate_raw, **kwargs)
+        loader.gpu_transform = GpuTransform("ImageNet", 64)
+        n = 0
+        for (x, y), (xw, yw) in zip(engine.device_batches(loader, dev), want):
+            # the "training step": work on the compute stream that recycles memory while the next batch is being staged
+            junk = [torch.full((1 << 18,), float("nan"), device=dev) for _ in range(8)]
+            got = x.clone()
+            del junk
+            assert torch.equal(got, xw), (kwargs, n)
+            assert y.tolist() == yw and y.dtype == torch.int64 and y.is_cuda
+            n += 1
+        assert n == 6
+    # an already packed batch on the device goes straight to the kernels
+    p = PackedImages.pack([ds[i]["image"] for i in range(4)])
+    on_dev = PackedImages(p.flat.cuda(), p.shapes)
+    assert torch.equal(tf(on_dev, dev), want[0][0])
