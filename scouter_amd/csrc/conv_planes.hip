@@ -1111,19 +1111,29 @@ __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __
         }
 }
 
+#include "conv_planes_wgrad_taps.h"
+
 // (tile, split-K) plan of the plane weight gradient.  plan_hint < 0: static (largest tile, ~1024 workgroups); otherwise
 // (autotuned by the caller) bits 0-1 = workgroup budget {512, 1024, 2048, 4096}, bit 4 / bit 5 = 64 instead of 128 input /
 // output channels per tile.  Every plan is deterministic; different plans sum the pixels in a different order.
-struct PwgPlan { int bm, bn; long tiles, pps; int splits; };
+// bit 6 (3x3 only): TAP-FUSED kernel (conv_planes_wgrad_taps.h) -- 64 x 64 tiles that carry all nine taps, one workgroup per
+// CU, budget {256, 512, 1024, 2048} workgroups.
+struct PwgPlan { int bm, bn; long tiles, pps; int splits; bool fused; };
 static PwgPlan pwg_plan(long M, int Cg, int Ng, int groups, int taps, int plan_hint) {
     PwgPlan p;
     p.bm = Cg % 128 == 0 ? 128 : 64;
     p.bn = Ng % 128 == 0 ? 128 : 64;
+    p.fused = plan_hint >= 0 && (plan_hint & 64) && taps == 9;
     long budget = 1024;
     if (plan_hint >= 0) {
         budget = 512L << (plan_hint & 3);
         if (plan_hint & 16) p.bm = 64;
         if (plan_hint & 32) p.bn = 64;
+    }
+    if (p.fused) {
+        p.bm = p.bn = 64;
+        budget = 256L << (plan_hint & 3);
+        taps = 1;                                    // (a tile carries all nine taps)
     }
     p.tiles = (long)(Cg / p.bm) * (Ng / p.bn) * groups * taps;
     long want = budget / p.tiles;
@@ -1141,7 +1151,11 @@ extern "C" size_t scouter_conv2d_wgrad_planes_workspace_bytes(int B, int H, int 
     if (groups <= 0 || Cin % groups || Cout % groups) return 0;
     const int Cg = Cin / groups, Ng = Cout / groups;
     const PwgPlan p = pwg_plan((long)B * H * W, Cg, Ng, groups, kh * kw, plan_hint);
-    return p.splits > 1 ? (size_t)p.splits * kh * kw * Cg * Cout * sizeof(float) : 0;
+    size_t need = p.splits > 1 ? (size_t)p.splits * kh * kw * Cg * Cout * sizeof(float) : 0;
+#ifdef PWT_STAMPS
+    need += (size_t)p.tiles * p.splits * 48;
+#endif
+    return need;
 }
 
 // x_planes [np][B*H*W][Cin], dy_planes [np][B*H*W][Cout] (stride 1, output size == input size); dw: HWIO fp32.
@@ -1176,7 +1190,26 @@ extern "C" int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_
     hipStream_t st = (hipStream_t)stream;
     float* out = splits > 1 ? (float*)ws : dw;
     dim3 grid((unsigned)tiles, (unsigned)splits);
-    {
+    if (plan.fused) {
+        SC_UNSUPPORTED(kh == 3 && kw == 3 && pad == 1 && W <= 63 && x_pe * 2 < (1L << 31) && dy_pe * 2 < (1L << 31),
+                       "conv2d_wgrad_planes: the tap-fused plan covers 3x3 / pad 1 layers on maps up to 63 pixels wide");
+        ScProfScope prof(nplanes == 3 ? "pwgrad<bf16x3>" : "pwgrad<bf16>", st, 2.0 * g.M * Cout * Cg * kh * kw,
+                         2.0 * nplanes * ((double)x_pe + (double)dy_pe));
+        const size_t lds = (size_t)nplanes * (256 * 128 + 128) + (size_t)3 * nplanes * 32 * 64 * 2;
+        if (nplanes == 3) {
+            auto kern = pwgrad_taps_kernel<3, 1>;
+            static bool attr_set = false;
+            if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned short*)x_planes, x_pe,
+                               (const unsigned short*)dy_planes, dy_pe, out, g, ci_tiles, co_tiles, pps, slab);
+        } else {
+            auto kern = pwgrad_taps_kernel<1, 1>;
+            static bool attr_set = false;
+            if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned short*)x_planes, x_pe,
+                               (const unsigned short*)dy_planes, dy_pe, out, g, ci_tiles, co_tiles, pps, slab);
+        }
+    } else {
         ScProfScope prof(nplanes == 3 ? "pwgrad<bf16x3>" : "pwgrad<bf16>", st, 2.0 * g.M * Cout * Cg * kh * kw,
                          2.0 * nplanes * ((double)x_pe + (double)dy_pe));
 #define PWG(BM_, BN_, NP_)                                                                                          \

@@ -567,14 +567,15 @@ def conv2d_wgrad_planes(xp, dyp, dw_hwio, pad, groups=1):
     L = _native.lib()
 
     def launch(plan, dry=False):
-        if dry:
-            return True
+        if dry:         # tap-fused plans (bit 6): 3x3 / pad 1 on maps up to 63 wide, 31-bit byte offsets inside a plane
+            return plan < 64 or (kh == 3 and kw == 3 and pad == 1 and W <= 63 and
+                                 2 * B * H * W * max(Cin, Cout) < (1 << 31))
         ws = workspace(L.scouter_conv2d_wgrad_planes_workspace_bytes(B, H, W, Cin, Cout, kh, kw, groups, plan), xp.device)
         _native.check(L.scouter_conv2d_wgrad_planes(_p(xp), _p(dyp), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, pad, groups,
                                                     nplanes, plan, _p(ws), ws.numel(), _stream()), "conv2d_wgrad_planes")
         return True
 
-    launch(_pick_tile(("pwgrad", nplanes, B, H, W, Cin, Cout, kh, kw, pad, groups), launch, _WGRAD_PLANS))
+    launch(_pick_tile(("pwgrad", nplanes, B, H, W, Cin, Cout, kh, kw, pad, groups), launch, _PWGRAD_PLANS))
     return dw_hwio
 
 
@@ -628,6 +629,11 @@ def join_side_stream(device, which="wgrad"):
 _WGRAD_PLANS = (-1,)
 if os.environ.get("SCOUTER_WGRAD_TUNE", "1") == "1":
     _WGRAD_PLANS += tuple(t | b for t in (0, 16, 32, 48) for b in (0, 1, 2, 3))
+
+
+# plane weight gradient: the same plans + the TAP-FUSED kernel (csrc/conv_planes_wgrad_taps.h: one workgroup carries all
+# nine taps of a 64 x 64 tile from an LDS-resident ring of X rows), bit 6, with a budget of 256 / 512 / 1024 / 2048 workgroups
+_PWGRAD_PLANS = _WGRAD_PLANS + ((64, 65, 66, 67) if len(_WGRAD_PLANS) > 1 else ())
 
 
 def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):

@@ -22,6 +22,23 @@ __global__ __launch_bounds__(256) void burn_kernel(unsigned long long budget, un
     int s = 0;
     const bool rec = blockIdx.x == 0 && threadIdx.x == 0;
     const unsigned long long max_n = budget / 100000ull * 50ull * 2048ull;   // safety: ends even if the realtime counter stalls
+    // KIND 2 / 3: the same with RANDOM operand bits that change from MFMA to MFMA (eight operand registers per side,
+    // xorshift-filled per lane): constant operands toggle almost nothing in the multiplier arrays, real data does --
+    // the power (and with it the sustained clock) of a real kernel is that of random operands
+    float ra[8], rb[8];
+    bf16x8 qa[8], qb[8];
+    {
+        unsigned x = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x * 0x85EBCA6Bu;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+        for (int k = 0; k < 8; ++k) {
+            ra[k] = __builtin_bit_cast(float, (rnd() & 0x807fffffu) | 0x3f000000u);       // random sign / mantissa, |v| in [0.5, 1)
+            rb[k] = __builtin_bit_cast(float, (rnd() & 0x807fffffu) | 0x3f000000u);
+            for (int e = 0; e < 8; ++e) {
+                qa[k][e] = __builtin_bit_cast(__bf16, (unsigned short)((rnd() & 0x807fu) | 0x3f00u));
+                qb[k][e] = __builtin_bit_cast(__bf16, (unsigned short)((rnd() & 0x807fu) | 0x3f00u));
+            }
+        }
+    }
     for (;;) {
         for (int it = 0; it < 64; ++it) {
 #pragma unroll
@@ -29,10 +46,19 @@ __global__ __launch_bounds__(256) void burn_kernel(unsigned long long budget, un
                 if (KIND == 0) {
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
-                } else {
+                } else if (KIND == 1) {
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, pb, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pb, pa, acc1, 0, 0, 0);
+                } else if (KIND == 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[u & 7], rb[(u + 3) & 7], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[u & 7], ra[(u + 5) & 7], acc1, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[u & 7], qb[(u + 3) & 7], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qb[u & 7], qa[(u + 5) & 7], acc1, 0, 0, 0);
                 }
+            }
+            if (KIND >= 2 && (it & 7) == 7) {            // keep the accumulators finite (random signs: a random walk, but cheap insurance)
+                for (int e = 0; e < 16; ++e) { acc0[e] *= 0.5f; acc1[e] *= 0.5f; }
             }
         }
         n += 64 * 32;
@@ -52,15 +78,17 @@ __global__ __launch_bounds__(256) void burn_kernel(unsigned long long budget, un
     if (rec) samples[3 * maxs] = (unsigned long long)s;
 }
 
-// kind 0: fp32 MFMA, 1: bf16 MFMA.  samples: device buffer of 3 * maxs + 1 u64; per_wave: blocks * 4 u64; sink: blocks * 256 f32.
+// kind 0: fp32 MFMA, 1: bf16 MFMA (constant operands); 2 / 3: the same with random, changing operands.  samples: device buffer of 3 * maxs + 1 u64; per_wave: blocks * 4 u64; sink: blocks * 256 f32.
 extern "C" int clock_probe_launch(int kind, int ms, int blocks, void* samples, int maxs, void* per_wave, void* sink,
                                   void* stream) {
     const unsigned long long budget = (unsigned long long)ms * 100000ull;      // 100 MHz ticks
-    if (kind == 0)
-        hipLaunchKernelGGL(burn_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, budget,
-                           (unsigned long long*)samples, maxs, (unsigned long long*)per_wave, (float*)sink);
-    else
-        hipLaunchKernelGGL(burn_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, budget,
-                           (unsigned long long*)samples, maxs, (unsigned long long*)per_wave, (float*)sink);
+#define BURN(K_)                                                                                       \
+    hipLaunchKernelGGL(burn_kernel<K_>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, budget,         \
+                       (unsigned long long*)samples, maxs, (unsigned long long*)per_wave, (float*)sink)
+    if (kind == 0) BURN(0);
+    else if (kind == 1) BURN(1);
+    else if (kind == 2) BURN(2);
+    else BURN(3);
+#undef BURN
     return (int)hipGetLastError();
 }

@@ -63,7 +63,7 @@ def burn(kind, ms):
     rt, cyc = s[0:3 * n:3].astype(float), s[1:3 * n:3].astype(float)
     ticks_per_s = rt[-1] / host_s              # s_memrealtime rate, calibrated against the host clock (nominal 100 MHz)
     total = float(per_wave.sum())
-    flop_per = 4096.0 if kind == 0 else 32768.0
+    flop_per = 4096.0 if kind in (0, 2) else 32768.0
     rate = ticks_per_s if abs(ticks_per_s / 1e8 - 1.0) > 0.02 else 1e8     # (trust the nominal 100 MHz if the host agrees)
     tf = total * flop_per / (rt[-1] / rate) / 1e12
     out = []
@@ -79,7 +79,10 @@ steps(3)
 torch.cuda.synchronize()
 print("# tools_dev/clocks.py: sustained shader clock under pure MFMA load, right after training steps in the same process")
 print("# device:", torch.cuda.get_device_name(0), "| burn", MS, "ms per kernel,", BLOCKS, "workgroups x 4 waves (2 per SIMD)")
-for kind, name, peak in ((0, "fp32 v_mfma_f32_32x32x2_f32", 157.3), (1, "bf16 v_mfma_f32_32x32x16_bf16", 2500.0)):
+for kind, name, peak in ((0, "fp32 v_mfma_f32_32x32x2_f32, CONSTANT operands", 157.3),
+                         (2, "fp32 v_mfma_f32_32x32x2_f32, RANDOM operands changing per MFMA", 157.3),
+                         (1, "bf16 v_mfma_f32_32x32x16_bf16, CONSTANT operands", 2500.0),
+                         (3, "bf16 v_mfma_f32_32x32x16_bf16, RANDOM operands changing per MFMA", 2500.0)):
     for rep in range(2):
         steps(10)                           # the training step itself as the warm-up / thermal state
         r = burn(kind, MS)
