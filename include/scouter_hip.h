@@ -100,15 +100,20 @@ int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, const float
                                     const float* x2, const float* saved2, double* part2, void* stream);
 int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
                               int kw, int stride, int pad, int groups, int plan_hint, void* ws, size_t ws_bytes,
-                              void* stream);
+                              void* arrival, int arrival_slots, void* stream);
 /* plan_hint: -1 = built-in plan; otherwise bits 0-1 = block budget {512,1024,2048,4096} (sets the split-K count),
  * bit 4 / bit 5 = halve the ci / co tile edge.  Every plan is deterministic; different plans sum the pixels in a
- * different order (results differ in the last bits), so a caller that autotunes keeps its choice for the whole run. */
+ * different order (results differ in the last bits), so a caller that autotunes keeps its choice for the whole run.
+ * arrival (may be NULL), arrival_slots: caller-owned device buffer of arrival_slots 32-bit counters, ZERO on entry and left
+ * zero on exit, private to the stream (two launches that overlap in time must not share it).  With it the split-K slabs
+ * are summed INSIDE the kernel -- the last workgroup of an output tile to arrive adds the tile's partials in slab order
+ * (deterministic) and writes dw; without it (or when the plan has more output tiles than slots) a separate slab-sum
+ * kernel is launched.  The two paths add the slabs in different association orders: results agree to fp32 rounding. */
 size_t scouter_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
                                             int groups, int plan_hint);
 int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
                              int kw, int stride, int pad, int groups, int plan_hint, void* ws, size_t ws_bytes,
-                             void* stream);
+                             void* arrival, int arrival_slots, void* stream);
 /* stem (Cin < 32): im2col of the NCHW image into [M][Kpad] rows so the stem runs as a 1x1 conv on the same path */
 int scouter_im2col_nchw_f32(const float* x, float* col, int B, int Cin, int H, int W, int k, int stride, int pad,
                             int Kpad, void* stream);
@@ -277,14 +282,15 @@ int scouter_conv2d_dgrad_planes_bnbwd(const void* dy_planes, const void* w_plane
 /* weight gradient on planes: same-size stride-1 convolutions (2 * pad == k - 1), 64-multiples of channels per group;
  * x_planes [nplanes][B*H*W][Cin], dy_planes [nplanes][B*H*W][Cout]; dw HWIO fp32; split-K slabs in ws, summed in a
  * fixed order.  plan_hint: -1 = static plan; else bits 0-1 = workgroup budget {512, 1024, 2048, 4096}, bit 4 / bit 5 = 64
- * instead of 128 input / output channels per tile (callers autotune it; every plan is deterministic, different plans
- * sum the pixels in a different order). */
+ * instead of 128 input / output channels per tile; bit 6 (3x3, pad 1, maps up to 63 wide) = the TAP-FUSED kernel
+ * (csrc/conv_planes_wgrad_taps.h: one workgroup accumulates all nine taps of a 64 x 64 tile from an LDS-resident ring of X
+ * rows), bits 0-1 then = budget {256, 512, 1024, 2048} workgroups (callers autotune it; every plan is deterministic,
+ * different plans sum the pixels in a different order).  arrival / arrival_slots: as for scouter_conv2d_wgrad_f32. */
 size_t scouter_conv2d_wgrad_planes_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int groups,
                                                    int plan_hint);
 int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_planes, float* dw, int B, int H, int W, int Cin,
                                 int Cout, int kh, int kw, int pad, int groups, int nplanes, int plan_hint,
-                                void* ws, size_t ws_bytes,
-                                void* stream);
+                                void* ws, size_t ws_bytes, void* arrival, int arrival_slots, void* stream);
 
 /* ---- optimizer: torch.optim.AdamW defaults (train.py:146).  chunk table = array of {float* param; long offset
  * into the flat grad/moment arenas; int n; int pad} built by the host (scouter_adamw_chunk_bytes() each). */

@@ -42,6 +42,62 @@ __device__ __forceinline__ void wgrad_block_coords(int& tile, int& split) {
 // deterministic sum of split-K slabs (conv_igemm.hip)
 void sc_launch_slab_reduce(const float* part, float* dst, long n, int splits, long slab, hipStream_t st);
 
+// ---- the split-K slab sum INSIDE the weight-gradient kernel: the LAST workgroup of an output tile to
+// arrive sums that tile's `splits` partial tiles in slab order 0, 1, 2, ... (a fixed order: deterministic, whichever
+// workgroup happens to be last) and writes dW -- no slab_reduce launch (35 per step, 0.36 ms).  Cross-XCD protocol (each
+// XCD has its own, non-coherent L2):
+//   * partial tiles are stored with agent-scope relaxed atomic stores (write-through: sc1) -- slab_store();
+//   * s_waitcnt vmcnt(0) + workgroup barrier: every partial of this workgroup has reached the device coherence point;
+//   * thread 0 increments the tile's arrival counter (agent-scope atomic RMW); the workgroup that reads splits - 1 is last,
+//     resets the counter to 0 (the caller's buffer is zero on entry and left zero) and
+//   * reads all partials back with agent-scope atomic loads (sc1: past the local L2), 8 bytes each, eight in flight.
+// `arrival` == NULL: the caller launches slab_reduce_kernel as before (plain stores).
+__device__ __forceinline__ void slab_store(float* p, float v, bool coherent) {
+    if (coherent) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// ws: split 0's slab; the tile = ntaps x [nrows][ncols] elements at ws + tap * tap_stride + row0 + r * row_stride + col0 + c
+__device__ __forceinline__ void slab_tile_finish(const float* ws, float* dw, long slab, int splits, unsigned* counter,
+                                                 int ntaps, long tap_stride, long row0, int nrows, long row_stride, int col0,
+                                                 int ncols) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == (unsigned)(splits - 1);
+        if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    typedef unsigned long long u64;
+    const int pairs = ncols >> 1, per_tap = nrows * pairs;
+    for (int e = threadIdx.x; e < ntaps * per_tap; e += blockDim.x) {
+        const int t = e / per_tap, r = (e - t * per_tap) / pairs, c2 = e % pairs;
+        const long a = (long)t * tap_stride + row0 + (long)r * row_stride + col0 + 2 * c2;
+        float s0 = 0.f, s1 = 0.f;
+        int k = 0;
+        for (; k + 8 <= splits; k += 8) {
+            u64 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = __hip_atomic_load((const u64*)(ws + (long)(k + u) * slab + a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s0 += __builtin_bit_cast(float, (unsigned)v[u]);
+                s1 += __builtin_bit_cast(float, (unsigned)(v[u] >> 32));
+            }
+        }
+        for (; k < splits; ++k) {
+            const u64 v = __hip_atomic_load((const u64*)(ws + (long)k * slab + a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s0 += __builtin_bit_cast(float, (unsigned)v);
+            s1 += __builtin_bit_cast(float, (unsigned)(v >> 32));
+        }
+        *(float2*)(dw + a) = float2{s0, s1};
+    }
+}
+
 // BatchNorm BACKWARD reductions fused into the epilogue of the input-gradient kernel that produces the gradient of a
 // block output  out = relu(bn(x1) [+ bn(x2) | + shortcut])  (resnet.py:404-412, resnest.py:128-143): the value about to
 // be stored is d(out); the epilogue applies the ReLU sign (1 bit / element, written by the forward apply pass), stores

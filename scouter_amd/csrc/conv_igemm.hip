@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__ act, const float* __restrict__ dy,
                                                        float* __restrict__ out, ConvGeom g, int ci_tiles,
-                                                       int co_tiles, long pix_per_split, long slab) {
+                                                       int co_tiles, long pix_per_split, long slab,
+                                                       float* __restrict__ dw, unsigned* __restrict__ arrival) {
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN, WAVES_MN = (BM / WM) * (BN / WN);
     constexpr int WK = 4 / WAVES_MN;           // small tiles: the spare waves split the 16 k-steps of a chunk
     constexpr int SPW = 16 / WK;
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
     int bid, split_id;
     wgrad_block_coords(bid, split_id);
+    const int tile_id = bid;
     const int co_t = bid % co_tiles; bid /= co_tiles;
     const int ci_t = bid % ci_tiles; bid /= ci_tiles;
     const int grp = bid % g.groups;
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     }
 #undef SB
     float* o = out + (long)split_id * slab + (long)tap * g.Cg * g.N;
+    const bool coh = arrival != nullptr;               // partial tiles leave write-through: another workgroup sums them
     if (WK == 1) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int co = grp * g.Ng + co0 + wn * WN + j * 32 + l31;
-                    o[(long)ci * g.N + co] = acc[i][j][e];
+                    slab_store(o + (long)ci * g.N + co, acc[i][j][e], coh);
                 }
             }
     } else {   // cross-wave (k-split) reduction through LDS, fixed order
@@ -553,9 +556,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
             float v = lds[e];
 #pragma unroll
             for (int k = 1; k < WK; ++k) v += lds[k * BM * BN + e];
-            o[(long)(ci0 + e / BN) * g.N + grp * g.Ng + co0 + e % BN] = v;
+            slab_store(o + (long)(ci0 + e / BN) * g.N + grp * g.Ng + co0 + e % BN, v, coh);
         }
     }
+    if (coh)
+        slab_tile_finish(out + (long)tap * g.Cg * g.N, dw + (long)tap * g.Cg * g.N, slab, gridDim.y, arrival + tile_id, 1, 0,
+                         (long)ci0 * g.N, BM, g.N, grp * g.Ng + co0, BN);
 }
 
 // Sums the split slabs in a fixed order (deterministic).  Block = 8 float4 columns x 32 split-lanes: each lane adds
@@ -807,7 +813,7 @@ extern "C" size_t scouter_conv2d_wgrad_workspace_bytes(int B, int H, int W, int 
 
 extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin,
                                         int Cout, int kh, int kw, int stride, int pad, int groups, int plan_hint,
-                                        void* ws, size_t ws_bytes, void* stream) {
+                                        void* ws, size_t ws_bytes, void* arrival, int arrival_slots, void* stream) {
     SC_REQUIRE(x && dy && dw && B > 0, "conv2d_wgrad: null pointer or empty shape");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_wgrad: channels not divisible by groups");
     ConvGeom g = wgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
@@ -829,6 +835,7 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
         if (need_t <= ws_bytes && (!need_t || ws)) {
             hipStream_t st = (hipStream_t)stream;
             float* out = splits > 1 ? (float*)ws : dw;
+            unsigned* arr = splits > 1 && arrival && tiles <= arrival_slots ? (unsigned*)arrival : nullptr;
             const size_t lds = (size_t)(9 * 32 * 32 + 32 * bn) * sizeof(float);
             {
                 ScProfScope prof("wgrad_taps", st, 2.0 * g.M * Cout * g.Cg * 9,
@@ -837,17 +844,17 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
                     auto kern = wgrad_taps_kernel<64>;
                     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, x, dy, out, g,
-                                       co_tiles, pps, slab_t);
+                                       co_tiles, pps, slab_t, dw, arr);
                 } else {
                     auto kern = wgrad_taps_kernel<32>;
                     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, x, dy, out, g,
-                                       co_tiles, pps, slab_t);
+                                       co_tiles, pps, slab_t, dw, arr);
                 }
             }
             int rc = sc_check_launch("conv2d_wgrad_taps");
             if (rc) return rc;
-            if (splits > 1) {
+            if (splits > 1 && !arr) {
                 ScProfScope prof2("slab_reduce", st, 0, 4.0 * (double)slab_t * (splits + 1));
                 hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(slab_t / 4, 8)), dim3(256), 0, st, (const float*)ws,
                                    dw, slab_t, splits, slab_t);
@@ -865,6 +872,7 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
     }
     hipStream_t st = (hipStream_t)stream;
     float* out = p.splits > 1 ? (float*)ws : dw;
+    unsigned* arr = p.splits > 1 && arrival && p.tiles <= arrival_slots ? (unsigned*)arrival : nullptr;
     dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
     static char wname[9][24];
     static const int wb[9][2] = {{128, 128}, {128, 64}, {128, 32}, {64, 128}, {64, 64}, {64, 32}, {32, 128}, {32, 64}, {32, 32}};
@@ -883,13 +891,13 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
     do {                                                                                                            \
         if (mode == 2)                                                                                              \
             hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_, 2>), grid, dim3(256), 0, st, x, dy, out, g,       \
-                               p.ci_tiles, p.co_tiles, p.pix_per_split, slab);                                     \
+                               p.ci_tiles, p.co_tiles, p.pix_per_split, slab, dw, arr);                            \
         else if (mode == 1)                                                                                         \
             hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(256), 0, st, x, dy, out, g,       \
-                               p.ci_tiles, p.co_tiles, p.pix_per_split, slab);                                     \
+                               p.ci_tiles, p.co_tiles, p.pix_per_split, slab, dw, arr);                            \
         else                                                                                                        \
             hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_, 0>), grid, dim3(256), 0, st, x, dy, out, g,       \
-                               p.ci_tiles, p.co_tiles, p.pix_per_split, slab);                                     \
+                               p.ci_tiles, p.co_tiles, p.pix_per_split, slab, dw, arr);                            \
     } while (0)
     if (p.bm == 128 && p.bn == 128) WG(128, 128, 64, 64);
     else if (p.bm == 128 && p.bn == 64) WG(128, 64, 64, 32);
@@ -904,7 +912,7 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
     }
     rc = sc_check_launch("conv2d_wgrad");
     if (rc) return rc;
-    if (p.splits > 1) {
+    if (p.splits > 1 && !arr) {
         const long n = slab;
         ScProfScope prof2("slab_reduce", st, 0, 4.0 * (double)slab * (p.splits + 1));
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(n / 4, 8)), dim3(256), 0, st, (const float*)ws, dw, n,
@@ -919,7 +927,7 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
 // caller to use the fp32 kernel for that layer.  Same workspace as scouter_conv2d_wgrad_f32.
 extern "C" int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin,
                                          int Cout, int kh, int kw, int stride, int pad, int groups, int plan_hint,
-                                         void* ws, size_t ws_bytes, void* stream) {
+                                         void* ws, size_t ws_bytes, void* arrival, int arrival_slots, void* stream) {
     SC_REQUIRE(x && dy && dw && B > 0, "conv2d_wgrad_bf16: null pointer or empty shape");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_wgrad_bf16: channels not divisible by groups");
     ConvGeom g = wgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
@@ -937,6 +945,7 @@ extern "C" int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float*
     }
     hipStream_t st = (hipStream_t)stream;
     float* out = p.splits > 1 ? (float*)ws : dw;
+    unsigned* arr = p.splits > 1 && arrival && p.tiles <= arrival_slots ? (unsigned*)arrival : nullptr;
     dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
     int rc;
     {
@@ -948,12 +957,12 @@ extern "C" int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float*
             auto kern = wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 2>;                                                   \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, dy, out, g, p.ci_tiles, p.co_tiles,              \
-                               p.pix_per_split, slab);                                                             \
+                               p.pix_per_split, slab, dw, arr);                                                    \
         } else {                                                                                                    \
             auto kern = wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 1>;                                                   \
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, dy, out, g, p.ci_tiles, p.co_tiles,              \
-                               p.pix_per_split, slab);                                                             \
+                               p.pix_per_split, slab, dw, arr);                                                    \
         }                                                                                                           \
     } while (0)
     if (p.bm == 128 && p.bn == 128) WGH(128, 128, 64, 64);
@@ -964,7 +973,7 @@ extern "C" int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float*
     }
     rc = sc_check_launch("conv2d_wgrad_bf16");
     if (rc) return rc;
-    if (p.splits > 1) {
+    if (p.splits > 1 && !arr) {
         ScProfScope prof2("slab_reduce", st, 0, 4.0 * (double)slab * (p.splits + 1));
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(slab / 4, 8)), dim3(256), 0, st, (const float*)ws, dw, slab,
                            p.splits, slab);

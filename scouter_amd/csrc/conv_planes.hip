@@ -894,7 +894,8 @@ template <int BM, int BN, int NP, int NSTAGE>
 __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __restrict__ x_planes, long x_pe,
                                                         const unsigned short* __restrict__ dy_planes, long dy_pe,
                                                         float* __restrict__ out, ConvGeom g, int ci_tiles, int co_tiles,
-                                                        long pix_per_split, long slab) {
+                                                        long pix_per_split, long slab, float* __restrict__ dw,
+                                                        unsigned* __restrict__ arrival) {
     constexpr int BK = 32, WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
     constexpr int A_BYTES = NP * BK * BM * 2, B_BYTES = NP * BK * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int APX = 512 / BM, BPX = 512 / BN;               // pixel rows one DMA instruction covers (1 KB)
@@ -910,6 +911,7 @@ __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __
     const int wm = wave >> 1, wn = wave & 1;
     int bid, split_id;
     wgrad_block_coords(bid, split_id);
+    const int tile_id = bid;
     const int co_t = bid % co_tiles; bid /= co_tiles;
     const int ci_t = bid % ci_tiles; bid /= ci_tiles;
     const int grp = bid % g.groups;
@@ -1106,9 +1108,12 @@ __global__ __launch_bounds__(256, 1) void pwgrad_kernel(const unsigned short* __
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int co = grp * g.Ng + co0 + wn * WN + j * 32 + l31;
-                o[(long)ci * g.N + co] = NACC == 2 ? acc[i][j][e] + accl[i][j][e] : acc[i][j][e];
+                slab_store(o + (long)ci * g.N + co, NACC == 2 ? acc[i][j][e] + accl[i][j][e] : acc[i][j][e], arrival != nullptr);
             }
         }
+    if (arrival)        // the last workgroup of this tile sums the slabs itself (conv_common.h slab_tile_finish)
+        slab_tile_finish(out + (long)tap * g.Cg * g.N, dw + (long)tap * g.Cg * g.N, slab, gridDim.y, arrival + tile_id, 1, 0,
+                         (long)ci0 * g.N, BM, g.N, grp * g.Ng + co0, BN);
 }
 
 #include "conv_planes_wgrad_taps.h"
@@ -1161,7 +1166,8 @@ extern "C" size_t scouter_conv2d_wgrad_planes_workspace_bytes(int B, int H, int 
 // x_planes [np][B*H*W][Cin], dy_planes [np][B*H*W][Cout] (stride 1, output size == input size); dw: HWIO fp32.
 extern "C" int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_planes, float* dw, int B, int H, int W,
                                            int Cin, int Cout, int kh, int kw, int pad, int groups, int nplanes,
-                                           int plan_hint, void* ws, size_t ws_bytes, void* stream) {
+                                           int plan_hint, void* ws, size_t ws_bytes, void* arrival, int arrival_slots,
+                                           void* stream) {
     SC_REQUIRE(x_planes && dy_planes && dw && B > 0 && (nplanes == 1 || nplanes == 3), "conv2d_wgrad_planes: bad arguments");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_wgrad_planes: channels not divisible by groups");
     const int Cg = Cin / groups, Ng = Cout / groups;
@@ -1189,6 +1195,7 @@ extern "C" int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_
     }
     hipStream_t st = (hipStream_t)stream;
     float* out = splits > 1 ? (float*)ws : dw;
+    unsigned* arr = splits > 1 && arrival && tiles <= arrival_slots ? (unsigned*)arrival : nullptr;
     dim3 grid((unsigned)tiles, (unsigned)splits);
     if (plan.fused) {
         SC_UNSUPPORTED(kh == 3 && kw == 3 && pad == 1 && W <= 63 && x_pe * 2 < (1L << 31) && dy_pe * 2 < (1L << 31),
@@ -1201,13 +1208,13 @@ extern "C" int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_
             static bool attr_set = false;
             if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned short*)x_planes, x_pe,
-                               (const unsigned short*)dy_planes, dy_pe, out, g, ci_tiles, co_tiles, pps, slab);
+                               (const unsigned short*)dy_planes, dy_pe, out, g, ci_tiles, co_tiles, pps, slab, dw, arr);
         } else {
             auto kern = pwgrad_taps_kernel<1, 1>;
             static bool attr_set = false;
             if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned short*)x_planes, x_pe,
-                               (const unsigned short*)dy_planes, dy_pe, out, g, ci_tiles, co_tiles, pps, slab);
+                               (const unsigned short*)dy_planes, dy_pe, out, g, ci_tiles, co_tiles, pps, slab, dw, arr);
         }
     } else {
         ScProfScope prof(nplanes == 3 ? "pwgrad<bf16x3>" : "pwgrad<bf16>", st, 2.0 * g.M * Cout * Cg * kh * kw,
@@ -1220,7 +1227,7 @@ extern "C" int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_
         static bool attr_set = false;                                                                               \
         if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const unsigned short*)x_planes, x_pe,                   \
-                           (const unsigned short*)dy_planes, dy_pe, out, g, ci_tiles, co_tiles, pps, slab);         \
+                           (const unsigned short*)dy_planes, dy_pe, out, g, ci_tiles, co_tiles, pps, slab, dw, arr);         \
     } while (0)
         if (nplanes == 3) {
             if (bm == 128 && bn == 128) PWG(128, 128, 3);
@@ -1237,7 +1244,7 @@ extern "C" int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_
     }
     int rc = sc_check_launch("conv2d_wgrad_planes");
     if (rc) return rc;
-    if (splits > 1) {
+    if (splits > 1 && !arr) {
         ScProfScope prof2("slab_reduce", st, 0, 4.0 * (double)slab * (splits + 1));
         sc_launch_slab_reduce((const float*)ws, dw, slab, splits, slab, st);
         rc = sc_check_launch("conv2d_wgrad_planes_reduce");

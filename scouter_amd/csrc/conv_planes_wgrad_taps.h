@@ -23,7 +23,8 @@ template <int NP, int NACC_>
 __global__ __launch_bounds__(256, 1) void pwgrad_taps_kernel(const unsigned short* __restrict__ x_planes, long x_pe,
                                                              const unsigned short* __restrict__ dy_planes, long dy_pe,
                                                              float* __restrict__ out, ConvGeom g, int ci_tiles,
-                                                             int co_tiles, long pix_per_split, long slab) {
+                                                             int co_tiles, long pix_per_split, long slab,
+                                                             float* __restrict__ dw, unsigned* __restrict__ arrival) {
     constexpr int BM = 64, BN = 64, BK = 32, NACC = NP == 3 ? NACC_ : 1;
     constexpr int RING = 256;                                   // X pixel rows resident per plane (8 units of 32)
     constexpr int XPL = RING * BM * 2 + 128;                    // plane image + its zero row (row index 256)
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(256, 1) void pwgrad_taps_kernel(const unsigned shor
     const int wm = wave >> 1, wn = wave & 1;
     int bid, split_id;
     wgrad_block_coords(bid, split_id);
+    const int tile_id = bid;
     const int co_t = bid % co_tiles; bid /= co_tiles;
     const int ci_t = bid % ci_tiles;
     const int grp = bid / ci_tiles;
@@ -372,6 +374,10 @@ __global__ __launch_bounds__(256, 1) void pwgrad_taps_kernel(const unsigned shor
         for (int e = 0; e < 16; ++e) {
             const int ci = ci0 + wm * 32 + mfma32_row(e, lane);
             const int co = grp * g.Ng + co0 + wn * 32 + l31;
-            o[(long)t * g.Cg * g.N + (long)ci * g.N + co] = NACC == 2 ? acc[t][e] + accl[NACC == 2 ? t : 0][e] : acc[t][e];
+            slab_store(o + (long)t * g.Cg * g.N + (long)ci * g.N + co,
+                       NACC == 2 ? acc[t][e] + accl[NACC == 2 ? t : 0][e] : acc[t][e], arrival != nullptr);
         }
+    if (arrival)        // the last workgroup of this tile sums the slabs itself (conv_common.h slab_tile_finish)
+        slab_tile_finish(out, dw, slab, gridDim.y, arrival + tile_id, 9, (long)g.Cg * g.N, (long)ci0 * g.N, BM, g.N,
+                         grp * g.Ng + co0, BN);
 }

@@ -13,7 +13,8 @@ typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
 template <int BM, int BN, int WM, int WN, int MODE>     // MODE 1: padded taps, 2: 1x1 (see wgrad_kernel)
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restrict__ act, const float* __restrict__ dy,
                                                             float* __restrict__ out, ConvGeom g, int ci_tiles,
-                                                            int co_tiles, long pix_per_split, long slab) {
+                                                            int co_tiles, long pix_per_split, long slab, float* __restrict__ dw,
+                                                            unsigned* __restrict__ arrival) {
     constexpr int KP = 64;                                 // pixels per chunk
     constexpr int LDP = KP + 8;                            // LDS row stride (bf16): 16-byte aligned rows
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
@@ -25,6 +26,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     int bid, split_id;
     wgrad_block_coords(bid, split_id);
+    const int tile_id = bid;
     const int co_t = bid % co_tiles; bid /= co_tiles;
     const int ci_t = bid % ci_tiles; bid /= ci_tiles;
     const int grp = bid % g.groups;
@@ -182,7 +184,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int co = grp * g.Ng + co0 + wn * WN + j * 32 + l31;
-                o[(long)ci * g.N + co] = acc[i][j][e];
+                slab_store(o + (long)ci * g.N + co, acc[i][j][e], arrival != nullptr);
             }
         }
+    if (arrival)
+        slab_tile_finish(out + (long)tap * g.Cg * g.N, dw + (long)tap * g.Cg * g.N, slab, gridDim.y, arrival + tile_id, 1, 0,
+                         (long)ci0 * g.N, BM, g.N, grp * g.Ng + co0, BN);
 }

@@ -13,7 +13,8 @@
 template <int BN>       // output-channel tile; input-channel tile is the whole group (32)
 __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const float* __restrict__ act, const float* __restrict__ dy,
                                                             float* __restrict__ out, ConvGeom g, int co_tiles,
-                                                            long pix_per_split, long slab) {
+                                                            long pix_per_split, long slab, float* __restrict__ dw,
+                                                            unsigned* __restrict__ arrival) {
     constexpr int BM = 32, CH = 32;                    // chunk = 32 pixels = 16 MFMA k-steps of 2
     constexpr int NWN = BN / 32, WK = 4 / NWN, SPW = 16 / WK, BI = BN / 32;
     constexpr int A_T = CH * BM;                       // floats per tap tile
@@ -25,6 +26,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const float* __restr
     const int wn = wave % NWN, wk = wave / NWN;
     int bid, split_id;
     wgrad_block_coords(bid, split_id);
+    const int tile_id = bid;
     const int co_t = bid % co_tiles, grp = bid / co_tiles;
     const int co0 = co_t * BN;
     const long mbeg = (long)split_id * pix_per_split;
@@ -128,8 +130,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const float* __restr
             float v = red[e];
 #pragma unroll
             for (int k = 1; k < WK; ++k) v += red[k * BM * BN + e];
-            o[((long)t * g.Cg + e / BN) * g.N + grp * g.Ng + co0 + e % BN] = v;
+            slab_store(o + ((long)t * g.Cg + e / BN) * g.N + grp * g.Ng + co0 + e % BN, v, arrival != nullptr);
         }
         __syncthreads();
     }
+    if (arrival)        // the last workgroup of this tile sums the slabs itself (conv_common.h slab_tile_finish)
+        slab_tile_finish(out, dw, slab, gridDim.y, arrival + tile_id, 9, (long)g.Cg * g.N, 0, BM, g.N, grp * g.Ng + co0, BN);
 }

@@ -75,7 +75,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        ws_before = set(K._ws)
+        ws_before, arr_before = set(K._ws), set(K._arrival)
         with torch.cuda.graph(self.graph):
             self.logp, self.stats = self._eager(self.x, self.y)
         # Every scratch buffer the captured kernels may address stays alive as long as the graph does: the
@@ -85,8 +85,11 @@ class GraphedTrainStep:
         self._pinned_ws = list(K._ws.values())
         sp = getattr(self.model, "_wsplitter", None)          # plane-weight tables / plane buffers of the captured key
         self._pinned_ws += sp.buffers() if sp is not None else []
+        self._pinned_ws += list(K._arrival.values())          # arrival counters of the split-K weight gradients
         for key in set(K._ws) - ws_before:        # scratch allocated from the graph's private pool: never hand it to
             del K._ws[key]                        # eager code that happens to run on a stream with the same handle
+        for key in set(K._arrival) - arr_before:
+            del K._arrival[key]
         self._shape = (tuple(images.shape), tuple(labels.shape))
         # the capture pass itself only RECORDED a step; the host-side step mirror advanced though: take that back
         for gi, _ in enumerate(self.optimizer.param_groups):

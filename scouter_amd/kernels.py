@@ -52,6 +52,26 @@ def workspace(nbytes, device):
     return w
 
 
+_arrival = {}
+ARRIVAL_SLOTS = 1 << 16
+# SCOUTER_SLAB_FUSE=0: the separate slab-sum launch after every split-K weight gradient (rounds 1-3)
+SLAB_FUSE = os.environ.get("SCOUTER_SLAB_FUSE", "1") == "1"
+
+
+def arrival_counters(device):
+    """Per-(device, stream) buffer of zeroed 32-bit arrival counters for the split-K weight-gradient kernels: with it the
+    LAST workgroup of an output tile sums the tile's slabs inside the kernel (include/scouter_hip.h `arrival`) -- no
+    slab-sum launch.  The kernels leave it zero; it is never part of the shared scratch (which tests poison and other
+    kernels overwrite)."""
+    if not SLAB_FUSE:
+        return None
+    key = (device.type, device.index, _stream())
+    a = _arrival.get(key)
+    if a is None:
+        a = _arrival[key] = torch.zeros(ARRIVAL_SLOTS, dtype=torch.int32, device=device)
+    return a
+
+
 def hwio(weight):
     """Physical HWIO view [kh, kw, Cin/g, Cout] of a logical-OIHW conv weight; relayouts (once) if needed."""
     v = weight.permute(2, 3, 1, 0)
@@ -571,8 +591,10 @@ def conv2d_wgrad_planes(xp, dyp, dw_hwio, pad, groups=1):
             return plan < 64 or (kh == 3 and kw == 3 and pad == 1 and W <= 63 and
                                  2 * B * H * W * max(Cin, Cout) < (1 << 31))
         ws = workspace(L.scouter_conv2d_wgrad_planes_workspace_bytes(B, H, W, Cin, Cout, kh, kw, groups, plan), xp.device)
+        arr = arrival_counters(xp.device)
         _native.check(L.scouter_conv2d_wgrad_planes(_p(xp), _p(dyp), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, pad, groups,
-                                                    nplanes, plan, _p(ws), ws.numel(), _stream()), "conv2d_wgrad_planes")
+                                                    nplanes, plan, _p(ws), ws.numel(), _p(arr), ARRIVAL_SLOTS if arr is not None else 0,
+                                                    _stream()), "conv2d_wgrad_planes")
         return True
 
     launch(_pick_tile(("pwgrad", nplanes, B, H, W, Cin, Cout, kh, kw, pad, groups), launch, _PWGRAD_PLANS))
@@ -657,8 +679,9 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
             return True
         need = L.scouter_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, plan)
         ws = workspace(need, x.device)
+        arr = arrival_counters(x.device)
         _native.check(fn(_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, plan, _p(ws),
-                         ws.numel(), st), "conv2d_wgrad")
+                         ws.numel(), _p(arr), ARRIVAL_SLOTS if arr is not None else 0, st), "conv2d_wgrad")
         return True
 
     launch(_pick_tile(("wgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, _WGRAD_PLANS))
