@@ -195,6 +195,11 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
             "measured": "hipEvents around each launch, median of 8 batches x 20 launches after 200 warm-up launches"}
 
 
+# `sustained` (TFLOP/s, reported BESIDE `peak`, never instead of it): what a pure-MFMA burn with RANDOM operands that change
+# from MFMA to MFMA delivers on this chip for >= 300 ms right after training steps (tools_dev/clocks.py,
+# profiles/r04_clocks.txt): the fp32 MFMA holds 2.40 GHz (154 TFLOP/s = 0.98 of nominal), the bf16 MFMA is power-managed down
+# to 1.88 GHz with real data (1 886 TFLOP/s = 0.754 of the 2 500 nominal; 2.39 GHz / 2 497 only with constant operands), and
+# the plane kernels themselves run at 1.62-1.88 GHz (cycle stamps inside pwgrad_taps_kernel, tools_dev/pwt_stamps.py).
 PMC_TRAFFIC_FILE = "r04_pmc_hbm_traffic.json"
 PMC_MFMA_FILE = "r04_pmc_mfma_util.json"
 # Kernel classes of the roofline object: bench label prefixes (the library's hipEvent scopes) and the rocprofv3 kernel-name
@@ -204,20 +209,21 @@ CLASSES = {
     "fp32_mfma_conv": {
         "labels": ("igemm_fwd<", "igemm_dgrad<", "igemm_dgrad+bn_bwd<", "wgrad<", "wgrad_taps"),
         "rocprof": ("void igemm_kernel<", "void wgrad_kernel<", "void wgrad_taps_kernel<"),
-        "peak": 157.3, "what": "fp32 implicit-GEMM convolutions (forward, input gradient incl. the fused BatchNorm-backward "
+        "peak": 157.3, "sustained": 154.0, "what": "fp32 implicit-GEMM convolutions (forward, input gradient incl. the fused BatchNorm-backward "
                                "epilogue, weight gradient), v_mfma_f32_32x32x2_f32"},
     "bf16x3_plane_conv": {
         "labels": ("pconv_fwd<bf16x3>", "pconv_dgrad<bf16x3>", "pwgrad<bf16x3>"),
-        "rocprof": ("void pconv_kernel<", "void phalo_kernel<", "void pwgrad_kernel<", "void ppersist_kernel<"),
-        "peak": 2500.0 / 6.0, "what": "grouped 3x3 convolutions on exact three-way bf16 operand splits: 6 x "
+        "rocprof": ("void pconv_kernel<", "void phalo_kernel<", "void pwgrad_kernel<", "void ppersist_kernel<",
+                    "void pwgrad_taps_kernel<"),
+        "peak": 2500.0 / 6.0, "sustained": 1886.0 / 6.0, "what": "grouped 3x3 convolutions on exact three-way bf16 operand splits: 6 x "
                                       "v_mfma_f32_32x32x16_bf16 per fp32-grade product, fp32 accumulate; peak = 2500 / 6 "
                                       "TFLOP/s of algorithmic work"},
     "bf16_mfma_conv": {
         "labels": ("igemm_fwd_bf16<", "igemm_dgrad_bf16<", "igemm_dgrad_bf16+bn_bwd<", "wgrad_bf16", "pconv_fwd<bf16>",
                    "pconv_dgrad<bf16>", "pwgrad<bf16>"),
         "rocprof": ("void igemm_bf16_kernel<", "void wgrad_bf16_kernel<", "void pconv_kernel<", "void phalo_kernel<",
-                    "void pwgrad_kernel<"),
-        "peak": 2500.0, "what": "bf16-input convolutions (--precision bf16), v_mfma_f32_32x32x16_bf16, fp32 accumulate"},
+                    "void pwgrad_kernel<", "void pwgrad_taps_kernel<", "void ppersist_kernel<"),
+        "peak": 2500.0, "sustained": 1886.0, "what": "bf16-input convolutions (--precision bf16), v_mfma_f32_32x32x16_bf16, fp32 accumulate"},
 }
 
 
@@ -402,7 +408,26 @@ def main():
         model.set_side_stream(True)
     loss_val = float(losses[0].detach())
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dp_info = None
     if dist.is_initialized():
+        # what explains a scaling curve: the group size RCCL actually ran with, every rank's own time, and
+        # the time the compute stream spent WAITING for the gradient all-reduces (hipEvents around the waits, a few extra steps)
+        net.measure_exposed = True
+        for _ in range(5):
+            step(eager=True)
+        fence()
+        exposed = net.exposed_allreduce_ms()
+        net.measure_exposed = False
+        mine = torch.tensor([dt, exposed if exposed is not None else -1.0], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        ms = [1e3 * float(t[0]) / a.steps for t in every]
+        ex = [float(t[1]) for t in every]
+        dp_info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                   "ms_per_step_by_rank": [round(v, 3) for v in ms], "ms_per_step_spread": round(max(ms) - min(ms), 3),
+                   "allreduce_exposed_ms": round(max(ex), 4), "allreduce_exposed_ms_by_rank": [round(v, 4) for v in ex],
+                   "gradient_bytes_per_step": int(model.grad_arena().numel * 4), "buckets": 5,
+                   "buffer_broadcast": "asynchronous, issued at the end of the previous backward"}
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
@@ -433,7 +458,9 @@ def main():
             classes[cname] = {"kernels": c["what"], "instances": sorted(rows), "gflop_per_step": round(fl, 1),
                               "ms_per_step": round(ms, 4), "launches_per_step": nl, "avg_launch_us": round(1e3 * ms / nl, 2),
                               "achieved": round(fl / ms, 2), "peak": round(c["peak"], 1), "unit": "TFLOP/s",
-                              "frac": round(fl / ms / c["peak"], 4), "pmc_mfma_busy": busy,
+                              "frac": round(fl / ms / c["peak"], 4),
+                              "peak_at_sustained_clock": round(c["sustained"], 1),
+                              "frac_of_sustained": round(fl / ms / c["sustained"], 4), "pmc_mfma_busy": busy,
                               "algorithmic_bytes_per_launch": round(by / nl), "traffic": traffic,
                               "traffic_over_algorithmic": round(traffic / (by / nl), 2) if traffic and by else None,
                               "pmc_source": src or None}
@@ -476,6 +503,8 @@ def main():
                            "launch": "hipGraph replay (one captured graph per step)" if graphed is not None else "eager",
                            "final_loss": round(loss_val, 5)},
                 "roofline": roofline, "kernels": kern}
+        if dp_info is not None:
+            line["data_parallel"] = dp_info
         if world == 1 and not a.no_prof:
             line["xslot_roofline"] = xslot_roofline(device)
             # the reference's default geometry (--img_size 260 -> 9 x 9 = 81 tokens, reference train.py:39)

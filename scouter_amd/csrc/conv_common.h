@@ -52,8 +52,11 @@ void sc_launch_slab_reduce(const float* part, float* dst, long n, int splits, lo
 //     resets the counter to 0 (the caller's buffer is zero on entry and left zero) and
 //   * reads all partials back with agent-scope atomic loads (sc1: past the local L2), 8 bytes each, eight in flight.
 // `arrival` == NULL: the caller launches slab_reduce_kernel as before (plain stores).
+#ifndef SC_SLAB_MODE
+#define SC_SLAB_MODE 1      // 0: write-through atomic stores + sc1 atomic loads (first version: -17 % images/sec, kept for the A/B);
+#endif                      // 1: plain stores + agent-scope release fence, acquire fence + plain vector loads
 __device__ __forceinline__ void slab_store(float* p, float v, bool coherent) {
-    if (coherent) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (SC_SLAB_MODE == 0 && coherent) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
 
@@ -62,6 +65,7 @@ __device__ __forceinline__ void slab_tile_finish(const float* ws, float* dw, lon
                                                  int ntaps, long tap_stride, long row0, int nrows, long row_stride, int col0,
                                                  int ncols) {
     __shared__ int s_last;
+    if (SC_SLAB_MODE == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // partials leave this XCD's L2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -71,6 +75,26 @@ __device__ __forceinline__ void slab_tile_finish(const float* ws, float* dw, lon
     }
     __syncthreads();
     if (!s_last) return;
+    if (SC_SLAB_MODE == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // nothing stale from this XCD's L2
+        const int quads = ncols >> 2, per_tap = nrows * quads;
+        for (int e = threadIdx.x; e < ntaps * per_tap; e += blockDim.x) {
+            const int t = e / per_tap, r = (e - t * per_tap) / quads, c4 = e % quads;
+            const long a = (long)t * tap_stride + row0 + (long)r * row_stride + col0 + 4 * c4;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            int k = 0;
+            for (; k + 8 <= splits; k += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(ws + (long)(k + u) * slab + a);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < splits; ++k) s += *(const f32x4*)(ws + (long)k * slab + a);
+            *(f32x4*)(dw + a) = s;
+        }
+        return;
+    }
     typedef unsigned long long u64;
     const int pairs = ncols >> 1, per_tap = nrows * pairs;
     for (int e = threadIdx.x; e < ntaps * per_tap; e += blockDim.x) {

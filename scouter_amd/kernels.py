@@ -54,8 +54,14 @@ def workspace(nbytes, device):
 
 _arrival = {}
 ARRIVAL_SLOTS = 1 << 16
-# SCOUTER_SLAB_FUSE=0: the separate slab-sum launch after every split-K weight gradient (rounds 1-3)
-SLAB_FUSE = os.environ.get("SCOUTER_SLAB_FUSE", "1") == "1"
+# SCOUTER_SLAB_FUSE=1: the split-K slabs are summed INSIDE the weight-gradient kernels by the last workgroup of a tile to
+# arrive (csrc/conv_common.h slab_tile_finish) instead of a slab-sum launch per layer.  Built, bit-
+# reproducible and green under the poisoned-workspace tests -- and measured 17-25 % SLOWER on the step (interleaved A/B on one
+# box, 2 x 60 steps each: 4 113 / 4 128 img/s with the separate launches; 3 432 / 3 461 with write-through stores + sc1 loads,
+# 3 121 / 3 122 with plain stores + agent-scope release / acquire fences): a layer has 4-64 output tiles, so 4-64 workgroups
+# walk `splits` x 16 KB of uncached partials each (~100 us tails) while the 10-us slab_reduce launch it replaces spreads the
+# same bytes over every CU.  Off by default; kept as a documented option.
+SLAB_FUSE = os.environ.get("SCOUTER_SLAB_FUSE", "0") == "1"
 
 
 def arrival_counters(device):

@@ -575,3 +575,47 @@ def test_downsample_batchnorm_applied_in_the_last_apply_pass_and_planes_only_out
     d_full = kk.sa_bn_bwd(dout, a, dgap, x0, sv, True, planes=3)
     d_only = kk.sa_bn_bwd(dout, a, dgap, x0, sv, True, planes=3, keep_f32=False)
     assert d_only.f32 is None and torch.equal(d_only.planes, d_full.planes)
+
+
+@pytest.mark.parametrize("case", [(8, 56, 56, 32, 64, 3, 1, 1), (6, 28, 28, 128, 256, 1, 0, 1), (4, 28, 28, 128, 256, 3, 1, 2)])
+def test_in_kernel_slab_sum_option(case, monkeypatch):
+    """SCOUTER_SLAB_FUSE=1 (off by default: measured slower, kernels.SLAB_FUSE): the last workgroup of
+    an output tile sums the split-K slabs inside the weight-gradient kernel.  Same result as the separate slab-sum launch to
+    fp32 rounding (another association order), deterministic, arrival counters left zero, scratch poisoned in between."""
+    B, H, W, Cin, Cout, k, pad, g = case
+    kk = K()
+    rng = np.random.default_rng(sum(case))
+    x = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((B, H, W, Cout)).astype(np.float32)).cuda()
+    ref = torch.empty((k, k, Cin // g, Cout), dtype=torch.float32, device="cuda")
+    monkeypatch.setattr(kk, "SLAB_FUSE", False)
+    kk.conv2d_wgrad(x, dy, ref, 1, pad, g)
+    monkeypatch.setattr(kk, "SLAB_FUSE", True)
+    outs = []
+    for poison in (float("nan"), 1e30):
+        for w in kk._ws.values():
+            w.view(torch.float32)[:w.numel() // 4].fill_(poison)
+        dw = torch.full_like(ref, float("nan"))
+        kk.conv2d_wgrad(x, dy, dw, 1, pad, g)
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    sc = float(ref.abs().max())
+    assert float((outs[0] - ref).abs().max()) <= 1e-5 * sc
+    for a in kk._arrival.values():
+        assert int(a.abs().sum()) == 0
+    if (Cin // g) % 64 == 0 and (Cout // g) % 64 == 0:               # the plane kernels, incl. the tap-fused plan
+        xp, dyp = kk.planes_split(x, 3), kk.planes_split(dy, 3)
+        key = ("pwgrad", 3, B, H, W, Cin, Cout, k, k, pad, g)
+        try:
+            for plan in (-1, 64) if k == 3 else (-1,):
+                kk._tile_cache[key] = plan
+                monkeypatch.setattr(kk, "SLAB_FUSE", False)
+                r3 = torch.empty_like(ref); kk.conv2d_wgrad_planes(xp, dyp, r3, pad, g)
+                monkeypatch.setattr(kk, "SLAB_FUSE", True)
+                d3 = torch.full_like(ref, float("nan")); kk.conv2d_wgrad_planes(xp, dyp, d3, pad, g)
+                d3b = torch.full_like(ref, float("nan")); kk.conv2d_wgrad_planes(xp, dyp, d3b, pad, g)
+                assert torch.equal(d3, d3b)
+                assert float((d3 - r3).abs().max()) <= 1e-5 * sc, plan
+        finally:
+            kk._tile_cache.pop(key, None)
