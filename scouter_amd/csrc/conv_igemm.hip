@@ -13,9 +13,20 @@
 #include "conv_common.h"
 #include "conv_wgrad_bf16.h"
 #include "conv_wgrad_taps.h"
+#include "conv_pw_persist.h"
 
 #include <stdlib.h>
 #include <type_traits>
+
+#ifdef IGEMM_STAMPS    // dev builds (tools_dev/igemm_stamps.sh): per workgroup {start, first fragments, K loop done, end, XCC / CU id}
+__device__ long long* g_igemm_stamps = nullptr;
+extern "C" int scouter_dev_set_igemm_stamps(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_stamps), &p, sizeof(p));
+}
+#define IG_STAMP(k) if (g_igemm_stamps && threadIdx.x == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_igemm_stamps[8L * blockIdx.x + (k)] = (long long)wall_clock64(); }
+#else
+#define IG_STAMP(k)
+#endif
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;   // k-contiguous tiles: 36-float rows -> conflict-free ds_read_b128, 16B aligned
@@ -61,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     const int n0 = nt_id * BN;
     const int cpt = g.Cg / BK;                 // K chunks per filter tap
     const int KT = g.R * g.S * cpt;
+    IG_STAMP(0)
     EpiPre<(WM / (64 / (WN / 4)) <= 8 ? WM / (64 / (WN / 4)) : 1)> epre;
     epre.on = false;
     if constexpr (DGRAD && FUSE) igemm_epilogue_prefetch<BM, BN, WM, WN>(epre, g, addend, m0, n0, grp, fz);
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     if (KT > 1) { load_a(1); load_b(1); }
     __syncthreads();
     frag_a(0, P0{}); frag_b(0, P0{});
+    IG_STAMP(1)
     // one K-tile; the LDS buffer index is a compile-time constant (the loop is unrolled by two) so that every LDS
     // address is a register + immediate -- no per-tile VALU address arithmetic
     auto tile = [&](int kt, auto CUR) {
@@ -310,11 +323,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
         if (kt + 1 < KT) tile(kt + 1, P1{});
     }
 #undef SB
+    IG_STAMP(2)
 
     // ---- epilogue (conv_common.h): LDS-staged vector stores, fused bias / addend / ReLU / BatchNorm statistics
     static_assert(4 * WM * (WN + 4) <= 2 * T::STAGE, "epilogue staging fits in the K-loop LDS");
     igemm_epilogue<BM, BN, WM, WN, DGRAD && FUSE, true>(acc, lds, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz,
                                                         &epre);
+#ifdef IGEMM_STAMPS
+    if (g_igemm_stamps && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g_igemm_stamps[8L * blockIdx.x + 3] = (long long)wall_clock64();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_igemm_stamps[8L * blockIdx.x + 4] = (long long)(((xcc & 0xf) << 16) | (hw & 0xffff));
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -627,12 +652,62 @@ static void launch_igemm(const float* src, const float* w, const float* bias, co
     else launch_igemm_s<BM, BN, WM, WN, DGRAD, false, false>(src, w, bias, addend, dst, bn_part, g, relu, st, fz);
 }
 
+// ---- tile 4: persistent pointwise kernel with the weights resident in LDS (conv_pw_persist.h)
+struct PwpPlan { int ks, bn, wg_per_col, waves_m; };
+static bool pwp_geom_ok(const ConvGeom& g) {                 // (g as for the GEMM: Cg = K, Ng = N)
+    return g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.H == g.Ho && g.W == g.Wo && g.groups == 1 &&
+           (g.Cg == 64 || g.Cg == 128 || g.Cg == 256) && g.Ng % 64 == 0 && g.M * g.Cg * 4 < (1L << 31) &&
+           g.M * g.Ng * 4 < (1L << 31);
+}
+static PwpPlan pwp_plan(const ConvGeom& g) {
+    PwpPlan p;
+    p.ks = g.Cg / 64;
+    const int cap = 256 / p.ks;                              // columns whose [K][BN] fp32 tile fits 64 KB
+    p.bn = (cap >= 256 && g.Ng % 256 == 0) ? 256 : ((cap >= 128 && g.Ng % 128 == 0) ? 128 : 64);
+    const int colgroups = g.Ng / p.bn;
+    int w = (256 / colgroups) & ~7;
+    p.wg_per_col = w < 8 ? 8 : w;
+    p.waves_m = p.bn >= 256 ? 1 : 2;
+    return p;
+}
+template <bool DGRAD>
+static void launch_pwp(const float* src, const float* w, const float* addend, float* dst, double* bn_part, const ConvGeom& g,
+                       hipStream_t st) {
+    const PwpPlan p = pwp_plan(g);
+    const int mtiles = sc_cdiv(g.M, 64), grid = p.wg_per_col * (g.Ng / p.bn);
+    const size_t lds = (size_t)g.Cg * p.bn * 4 + 4 * 16384;
+#define PWP(KS_, BN_)                                                                                              \
+    do {                                                                                                           \
+        if (DGRAD ? addend != nullptr : bn_part != nullptr) {                                                      \
+            auto kern = pwp_kernel<KS_, BN_, DGRAD, true>;                                                         \
+            static bool attr_set = false;                                                                          \
+            if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4 * 16384); attr_set = true; } \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, src, w, addend, dst, bn_part, g.M, g.Ng, mtiles, \
+                               p.wg_per_col);                                                                      \
+        } else {                                                                                                   \
+            auto kern = pwp_kernel<KS_, BN_, DGRAD, false>;                                                        \
+            static bool attr_set = false;                                                                          \
+            if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4 * 16384); attr_set = true; } \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, src, w, addend, dst, bn_part, g.M, g.Ng, mtiles, \
+                               p.wg_per_col);                                                                      \
+        }                                                                                                          \
+    } while (0)
+    if (p.ks == 1 && p.bn == 256) PWP(1, 256);
+    else if (p.ks == 1 && p.bn == 128) PWP(1, 128);
+    else if (p.ks == 1) PWP(1, 64);
+    else if (p.ks == 2 && p.bn == 128) PWP(2, 128);
+    else if (p.ks == 2) PWP(2, 64);
+    else PWP(4, 64);
+#undef PWP
+}
+
 // tile choice: largest tile that still fills the chip (>= ~1.5 rounds of 256 CUs x 2 blocks); Ng is a multiple of 32
 static bool igemm_tile_ok(const ConvGeom& g, int t) {
     return (t == 0 && g.Ng % 128 == 0) || ((t == 1 || t == 2) && g.Ng % 64 == 0) || t == 3;
 }
 // hint >= 0: the caller's (autotuned) choice if legal for this shape; otherwise the static heuristic
-static int igemm_tile(const ConvGeom& g, int hint = -1) {     // 0: 128x128  1: 128x64  2: 64x64  3: 128x32
+static int igemm_tile(const ConvGeom& g, int hint = -1) {     // 0: 128x128  1: 128x64  2: 64x64  3: 128x32  4: persistent
+    if (hint == 4 && pwp_geom_ok(g)) return 4;
     if (hint >= 0 && hint <= 3 && igemm_tile_ok(g, hint)) return hint;
     auto blocks = [&](int bm, int bn) { return (long)sc_cdiv(g.M, bm) * (g.Ng / bn) * g.groups; };
     const long want = 768;
@@ -648,6 +723,15 @@ static int dispatch_igemm(const float* src, const float* w, const float* bias, c
                           const BnBwdFuse& fz = BnBwdFuse{}) {
     SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 28),
                    "conv2d: more than 2^31 output pixels or an image above 2^28 elements is not supported");
+    if (tile == 4) {
+        // (the caller named the persistent kernel: its partial-row layout differs, so an unsupported request is an error,
+        // never a silent re-route)
+        SC_UNSUPPORTED(pwp_geom_ok(g) && !bias && !relu && !fz.part1 && (DGRAD || !addend),
+                       "conv2d: tile 4 (persistent pointwise kernel) covers 1x1 / stride 1 / groups 1 convolutions with 64, 128 "
+                       "or 256 GEMM-K channels, no bias / ReLU / fused BatchNorm backward (forward: no addend)");
+        launch_pwp<DGRAD>(src, w, addend, dst, bn_part, g, st);
+        return sc_check_launch(DGRAD ? "conv2d_dgrad(persistent)" : "conv2d_fwd(persistent)");
+    }
     switch (tile) {
         case 0: launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
         case 1: launch_igemm<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
@@ -675,7 +759,9 @@ extern "C" int scouter_conv2d_fwd_bn_partial_rows(int B, int H, int W, int Cin, 
                                                   int pad, int groups, int tile_hint) {
     ConvGeom g;
     if (conv_fwd_geom(g, B, H, W, Cin, Cout, kh, kw, stride, pad, groups) != SC_OK) return 0;
-    return sc_cdiv(g.M, igemm_tile(g, tile_hint) == 2 ? 64 : 128);
+    const int t = igemm_tile(g, tile_hint);
+    if (t == 4) { const PwpPlan p = pwp_plan(g); return p.wg_per_col * p.waves_m; }    // one row per (workgroup, wave row)
+    return sc_cdiv(g.M, t == 2 ? 64 : 128);
 }
 
 extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* addend,
@@ -690,7 +776,8 @@ extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const floa
         sc_set_error("conv2d_fwd: per-group channels must be multiples of 32 (got %d -> %d)", Cin / groups, Cout / groups);
         return rc;
     }
-    static const char* names[4] = {"igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>"};
+    static const char* names[5] = {"igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>",
+                                   "igemm_fwd<persistent>"};
     const int tile = igemm_tile(g, tile_hint);
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
                      4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
@@ -711,7 +798,7 @@ extern "C" int scouter_conv2d_dgrad_bn_partial_rows(int B, int H, int W, int Cin
                                                     int pad, int groups, int tile_hint) {
     if (!(groups > 0 && Cin % groups == 0 && Cout % groups == 0)) return 0;
     const ConvGeom g = dgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
-    return sc_cdiv(g.M, igemm_tile(g, tile_hint) == 2 ? 64 : 128);
+    return sc_cdiv(g.M, igemm_tile(g, tile_hint == 4 ? -1 : tile_hint) == 2 ? 64 : 128);   // (tile 4 has no fused epilogue)
 }
 
 extern "C" int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, const float* addend, float* dx, int B,
@@ -727,12 +814,12 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, c
     SC_UNSUPPORTED(Cig % 32 == 0 && Cog % 32 == 0, "conv2d_dgrad: per-group channels must be multiples of 32");
     const int Ho = conv_out(H, kh, stride, pad), Wo = conv_out(W, kw, stride, pad);
     const ConvGeom g = dgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
-    static const char* names[4] = {"igemm_dgrad<128x128>", "igemm_dgrad<128x64>", "igemm_dgrad<64x64>",
-                                   "igemm_dgrad<128x32>"};
+    static const char* names[5] = {"igemm_dgrad<128x128>", "igemm_dgrad<128x64>", "igemm_dgrad<64x64>",
+                                   "igemm_dgrad<128x32>", "igemm_dgrad<persistent>"};
     // with the BatchNorm-backward reductions in the epilogue the kernel is a different piece of work (it also reads the
     // BatchNorm input(s), the addend and the ReLU bits -- co-bound by HBM on the short-K layers): its own profile row
-    static const char* names_bn[4] = {"igemm_dgrad+bn_bwd<128x128>", "igemm_dgrad+bn_bwd<128x64>",
-                                      "igemm_dgrad+bn_bwd<64x64>", "igemm_dgrad+bn_bwd<128x32>"};
+    static const char* names_bn[5] = {"igemm_dgrad+bn_bwd<128x128>", "igemm_dgrad+bn_bwd<128x64>",
+                                      "igemm_dgrad+bn_bwd<64x64>", "igemm_dgrad+bn_bwd<128x32>", "igemm_dgrad+bn_bwd<?>"};
     const int tile = igemm_tile(g, tile_hint);
     const double out_elems = (double)g.M * Cin;
     ScProfScope prof(part1 ? names_bn[tile] : names[tile], (hipStream_t)stream,

@@ -1,0 +1,229 @@
+// Persistent pointwise (1x1, stride 1) fp32 convolution with the weight tile RESIDENT in LDS -- forward and plain input
+// gradient of the short-K layers (K = 64 / 128 / 256 input channels of the GEMM: layer1 / layer2 of the bottleneck nets).
+//
+// Why (VERDICT r2 / r3 "the persistent weight-resident short-K 1x1 kernel"): these layers are HBM-co-bound -- 64 -> 256 at
+// 56 x 56, batch 70: 7.2 GFLOP = 46 us of fp32 MFMA against 281 MB = 51 us of HBM -- and igemm_kernel runs them at 110-117 us.
+// Workgroup stamps (tools_dev/igemm_stamps.py) show why: a 64 x 64 workgroup lives 7.8 us for 0.85 us of matrix work --
+// 2.1 us waiting for its operands, 2.3 us in a K loop it shares with two other resident workgroups, 3.5 us in the LDS-staged
+// epilogue until its stores have retired; with three workgroups per CU the latencies are only half hidden.  Here ONE
+// workgroup per CU stays for the whole launch:
+//   * B (the weights, [K][BN] fp32 <= 64 KB) is loaded into LDS once;
+//   * A streams through a four-slot LDS ring of [64 rows][64 k] stages filled by LDS-DMA three stages ahead (no VGPR round
+//     trip; 48 KB in flight per CU: the HBM latency-bandwidth product), slot index = stage mod 4 is a compile-time constant
+//     of the four-way unrolled stage loop, so every LDS address is a lane offset + an immediate;
+//   * 16-byte chunk c of row r sits at chunk c ^ (r & 15) (applied on the DMA's source side): the k-contiguous
+//     ds_read_b128 fragment reads are bank-conflict free without padded rows;
+//   * the epilogue stores straight from the MFMA accumulators (a lane holds one column: 32 lanes = one 128-byte line per row),
+//     fire and forget -- no LDS staging, no barrier; BatchNorm statistics accumulate lane-locally in fp64 over ALL tiles of
+//     the workgroup and leave as ONE partial row per (workgroup, wave row): wg x (1 | 2) rows instead of M / 64;
+//   * counted waits: before a stage's stores are issued the NEXT stage's DMA has landed (vmcnt counts loads and stores in
+//     order -- waiting after the stores would wait for their HBM round trip).
+// Same arithmetic as igemm_kernel (exact-fp32 MFMA, the same K order per output element: bit-identical outputs).
+#pragma once
+#include "conv_common.h"
+
+#include <type_traits>
+
+__device__ __forceinline__ void pwp_dma16(__amdgpu_buffer_rsrc_t rs, char* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void pwp_store(__amdgpu_buffer_rsrc_t rs, float v, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+}
+__device__ __forceinline__ float pwp_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+
+// KS = K / 64; BN = output columns per workgroup (KS * BN <= 256: the weight tile fits 64 KB); DGRAD: B = W^T.
+// STATS: forward -- fused BatchNorm statistics (bn_part != NULL); input gradient -- an addend is added (addend != NULL).
+// grid = wg_per_col * (N / BN) workgroups; workgroup (p, cg) owns M tiles p, p + wg_per_col, ... of column group cg.
+template <int KS, int BN, bool DGRAD, bool STATS>
+__global__ __launch_bounds__(256, 1) void pwp_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
+                                                     const float* __restrict__ addend, float* __restrict__ dst,
+                                                     double* __restrict__ bn_part, long M, int N, int mtiles,
+                                                     int wg_per_col) {
+    constexpr int K = 64 * KS;
+    constexpr int WAVES_N = BN >= 256 ? 4 : 2, WAVES_M = 4 / WAVES_N;
+    constexpr int WM = 64 / WAVES_M, WN = BN / WAVES_N, MT = WM / 32, NT = WN / 32;
+    constexpr int WBYTES = K * BN * 4, SLOT = 64 * 64 * 4;
+    static_assert(WBYTES <= 65536 && (KS == 1 || KS == 2 || KS == 4), "weight tile must fit 64 KB");
+    extern __shared__ __attribute__((aligned(1024))) char pwp_lds[];
+    float* Wl = (float*)pwp_lds;
+    char* ring = pwp_lds + WBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int colgroups = N / BN;
+    // workgroups of one M range (same p) share an XCD (dispatch is round-robin over the eight XCDs): A is read from HBM once
+    const int L = blockIdx.x;
+    const int cg = (L >> 3) % colgroups, p = (L & 7) + 8 * ((L >> 3) / colgroups);
+    const int n0 = cg * BN;
+    const int n_my = p < mtiles ? (mtiles - p + wg_per_col - 1) / wg_per_col : 0;
+    const int nstage4 = (n_my * KS + 3) / 4;                    // groups of four stages
+
+    // ---- operands
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)(M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (unsigned)(M * N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)(DGRAD && addend ? addend : dst), 0,
+                                                                          (unsigned)(M * N * 4), 0x00020000);
+    unsigned a_voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * (wave + 4 * j) + (lane >> 4), c = (lane & 15) ^ (r & 15);
+        a_voff[j] = (unsigned)((r * K + c * 4) * 4);
+    }
+    // global stage G = tile G / KS of this workgroup, k chunk G % KS
+    auto issue = [&](int G, int slot) __attribute__((always_inline)) {
+        const int ti = G / KS, kc = G % KS;
+        const long m0 = (long)__builtin_amdgcn_readfirstlane(p + ti * wg_per_col) * 64;
+        const long off = (m0 * K + kc * 64) * 4;
+        const int soff = off > 0x7fffffffL ? 0x7fffffff : (int)off;            // (beyond the tensor: reads zeros)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pwp_dma16(rs_a, ring + slot * SLOT + (wave + 4 * j) * 1024, a_voff[j], soff);
+    };
+    issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);
+    // weights -> LDS [k][BN] (dgrad: transposed, B[k = co][n = ci] = W[ci][co])
+    for (int e = tid; e < K * BN / 4; e += 256) {
+        if (!DGRAD) {
+            const int k = e / (BN / 4), c4 = e % (BN / 4);
+            *(f32x4*)(Wl + k * BN + 4 * c4) = *(const f32x4*)(wgt + (long)k * N + n0 + 4 * c4);
+        } else {
+            const int n = e / (K / 4), k4 = e % (K / 4);
+            const f32x4 v = *(const f32x4*)(wgt + (long)(n0 + n) * K + 4 * k4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Wl[(4 * k4 + q) * BN + n] = v[q];
+        }
+    }
+
+    // ---- fragment geometry
+    const int x = l31 & 15;
+    unsigned aoff[2][2][2];                                      // [32-k sub-tile u][half pp][q]: byte offset inside a slot
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                aoff[u][pp][q] = (unsigned)((wm * WM + l31) * 256 + (((u * 8 + h * 4 + 2 * pp + q) ^ x) << 4));
+    const int boff = h * 16 * BN + wn * WN + l31;               // float index of the lane's B column, k = 16 h
+    // epilogue addressing: lane -> column l31 of a 32-column block, rows (e & 3) + 8 (e >> 2) + 4 h of a 32-row block
+    const unsigned o_voff = (unsigned)(((long)(wm * WM + 4 * h) * N + n0 + wn * WN + l31) * 4);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    double s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
+
+    f32x4 fa[2][MT][2];
+    float fb[2][8][NT];
+    auto frags = [&](int buf, auto SL, auto KC, int u, int pp) __attribute__((always_inline)) {
+        constexpr int slot = decltype(SL)::value, kc = decltype(KC)::value;
+        const char* As = ring + slot * SLOT;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) fa[buf][i][q] = *(const f32x4*)(As + i * 8192 + aoff[u][pp][q]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[buf][s][j] = Wl[boff + (kc * 64 + u * 32 + 8 * pp + s) * BN + j * 32];
+    };
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fa[buf][i][s >> 2][s & 3], fb[buf][s][j], acc[i][j]);
+    };
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    // tile `ti` of this workgroup is complete in the accumulators: store it (+ addend), take the statistics, clear
+    auto epilogue = [&](int ti) __attribute__((always_inline)) {
+        const long m0 = (long)__builtin_amdgcn_readfirstlane(p + ti * wg_per_col) * 64;
+        const long rowbytes = (long)N * 4;
+        if (DGRAD && STATS) {                                    // (DGRAD: STATS = "has an addend") the shortcut gradient: every load first, then the stores
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long off = (m0 + i * 32 + (e & 3) + 8 * (e >> 2)) * rowbytes;
+                    const int soff = off > 0x7fffffffL ? 0x7fffffff : (int)off;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j][e] += pwp_load(rs_d, o_voff + j * 128, soff);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long off = (m0 + i * 32 + (e & 3) + 8 * (e >> 2)) * rowbytes;
+                const int soff = off > 0x7fffffffL ? 0x7fffffff : (int)off;        // rows beyond M: dropped by the range check
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float v = acc[i][j][e];
+                    pwp_store(rs_o, v, o_voff + j * 128, soff);
+                    if (!DGRAD && STATS) {
+                        const double d = (double)v;
+                        s1[j] += d;
+                        s2[j] = __builtin_fma(d, d, s2[j]);
+                    }
+                    acc[i][j][e] = 0.f;
+                }
+            }
+    };
+    using Z0 = std::integral_constant<int, 0>;
+    using Z1 = std::integral_constant<int, 1>;
+    using Z2 = std::integral_constant<int, 2>;
+    using Z3 = std::integral_constant<int, 3>;
+    auto stage = [&](int base, auto SL) __attribute__((always_inline)) {
+        constexpr int S = decltype(SL)::value, kc = S % KS;
+        using KC = std::integral_constant<int, kc>;
+        const int G = 4 * base + S;
+        // four halves of eight k-steps; fragments of half n + 1 are read while half n multiplies
+        frags(0, SL, KC{}, 0, 0);
+        SB();
+        frags(1, SL, KC{}, 0, 1);
+        mma(0); SB();
+        frags(0, SL, KC{}, 1, 0);
+        mma(1); SB();
+        frags(1, SL, KC{}, 1, 1);
+        mma(0); SB();
+        mma(1); SB();
+        // the NEXT stage's DMA (issued three stages ago) must have landed BEFORE this stage's stores enter the queue: vmcnt is
+        // in order over loads and stores -- only the two younger DMA stages (8 instructions) may still be in flight
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (kc == KS - 1 && G / KS < n_my) epilogue(G / KS);
+        __builtin_amdgcn_s_barrier();                            // slot S is free, slot S + 1 is visible to every wave
+        SB();
+        issue(G + 4, S);
+    };
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");           // stage 0 has landed (three younger stages in flight)
+    __syncthreads();                                             // ... and the weight tile is in LDS
+    for (int base = 0; base < nstage4; ++base) {
+        stage(base, Z0{});
+        stage(base, Z1{});
+        stage(base, Z2{});
+        stage(base, Z3{});
+    }
+#undef SB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!DGRAD && STATS) {
+        // one partial row per (workgroup, wave row): lanes h = 0 / 1 hold disjoint rows of the same column
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const double t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+            if (h == 0) {
+                double* o = bn_part + ((long)(p * WAVES_M + wm) * N + n0 + wn * WN + j * 32 + l31) * 2;
+                o[0] = t1;
+                o[1] = t2;
+            }
+        }
+    }
+}

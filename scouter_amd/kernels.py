@@ -294,6 +294,14 @@ def _tile_legal(ng, t):
     return (t == 0 and ng % 128 == 0) or (t in (1, 2) and ng % 64 == 0) or t == 3
 
 
+def _pw_persist_legal(M, K_, N_, kh, kw, stride, pad, groups, plain):
+    """tile 4 = persistent pointwise kernel with the weight tile resident in LDS (csrc/conv_pw_persist.h): 1x1 / stride 1 /
+    groups 1, GEMM-K of 64 / 128 / 256 channels, 64-multiples of output columns, plain epilogue (forward: optional
+    BatchNorm statistics; input gradient: optional addend), byte offsets within 31 bits."""
+    return bool(plain and kh == 1 and kw == 1 and stride == 1 and pad == 0 and groups == 1 and K_ in (64, 128, 256) and
+                N_ % 64 == 0 and 4 * M * max(K_, N_) < (1 << 31))
+
+
 def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, relu=False, bn_stats=False,
                precision="fp32"):
     """bn_stats=True: the epilogue also produces the per-tile fp64 channel sums BatchNorm needs; returns
@@ -314,6 +322,9 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
 
     def launch(tile, dry=False, part=None):
         if dry:
+            if tile == 4:
+                return not bf16 and _pw_persist_legal(B * H * W, Cin, Cout, kh, kw, stride, pad, groups,
+                                                      bias is None and addend is None and not relu)
             return _tile_legal(Cout // groups, tile)
         if bf16:
             _native.check(L.scouter_conv2d_fwd_bf16(_p(x), _p(wt), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
@@ -325,7 +336,9 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
                           "conv2d_fwd")
         return True
 
-    tile = _pick_tile(("fwd", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch)
+    tile = _pick_tile(("fwd", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, (0, 1, 2, 3, 4))
+    if tile == 4 and not launch(4, dry=True):        # (the table's entry is for the plain epilogue; this call has bias / addend / ReLU)
+        tile = -1
     part, rows = None, 0
     if bn_stats:
         rows = L.scouter_conv2d_fwd_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
@@ -349,6 +362,8 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
 
     def launch(tile, dry=False, fuse=_NO_FUSE):
         if dry:
+            if tile == 4:        # (GEMM-K of the input gradient = Cout)
+                return not bf16 and _pw_persist_legal(B * H * W, Cout, Cin, kh, kw, stride, pad, groups, True)
             return _tile_legal(Cin // groups, tile)
         fn = L.scouter_conv2d_dgrad_bnbwd_bf16 if bf16 else L.scouter_conv2d_dgrad_bnbwd_f32
         _native.check(fn(_p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile,
@@ -360,7 +375,7 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
         # different tile wins than for the plain input gradient); partials sized for the most rows while timing
         def launch_fused(tile, dry=False):
             if dry:
-                return launch(tile, dry=True)
+                return tile != 4 and launch(tile, dry=True)          # (the persistent kernel has no fused epilogue)
             if not post.applied:
                 post.alloc(-(-B * H * W // 64), x_shape)
             return launch(tile, fuse=post.args())
@@ -371,7 +386,7 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
         post.alloc(-(-B * H * W // (64 if tile == 2 else 128)), x_shape)
         launch(tile, fuse=post.args())
     else:
-        launch(_pick_tile(("dgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch))
+        launch(_pick_tile(("dgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, (0, 1, 2, 3, 4)))
     return dx
 
 

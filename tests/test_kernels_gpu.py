@@ -619,3 +619,67 @@ def test_in_kernel_slab_sum_option(case, monkeypatch):
                 assert float((d3 - r3).abs().max()) <= 1e-5 * sc, plan
         finally:
             kk._tile_cache.pop(key, None)
+
+
+@pytest.mark.parametrize("case", [(3, 20, 20, 64, 256), (2, 13, 11, 64, 64), (5, 9, 9, 128, 512), (2, 17, 15, 256, 64),
+                                  (70, 14, 14, 256, 128), (1, 5, 5, 128, 128), (9, 28, 28, 64, 128)])
+def test_persistent_pointwise_kernel(case):
+    """Tile 4 (csrc/conv_pw_persist.h: weights resident in LDS, A through an LDS-DMA ring, direct stores, statistics
+    accumulated per workgroup): forward bit-identical to the implicit-GEMM kernel (same K order per output element), fused
+    BatchNorm partial rows sum to the output's fp64 column sums, input gradient (+ addend) bit-identical; ragged M (the last
+    tile's rows beyond M must neither be stored nor counted) with a guard band behind the output."""
+    B, H, W, Cin, Cout = case
+    kk = K()
+    rng = np.random.default_rng(sum(case))
+    M = B * H * W
+    x = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((1, 1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)).cuda()
+    L = kk._native.lib()
+    st = kk._stream()
+
+    def fwd(tile, guard=False):
+        rows = L.scouter_conv2d_fwd_bn_partial_rows(B, H, W, Cin, Cout, 1, 1, 1, 0, 1, tile)
+        part = torch.full((rows, Cout, 2), float("nan"), dtype=torch.float64, device="cuda")
+        buf = torch.full((M * Cout + 4096,), 777.0, device="cuda")
+        y = buf[:M * Cout].view(B, H, W, Cout)
+        kk._native.check(L.scouter_conv2d_fwd_f32(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), part.data_ptr(), B, H, W,
+                                                  Cin, Cout, 1, 1, 1, 0, 1, 0, tile, st), "fwd")
+        torch.cuda.synchronize()
+        assert bool((buf[M * Cout:] == 777.0).all()), "stores beyond the output tensor"
+        return y, part
+    y2, p2 = fwd(2)
+    y4, p4 = fwd(4)
+    assert torch.equal(y2, y4)
+    yd = y4.double().view(-1, Cout)
+    s = p4.sum(0)
+    torch.testing.assert_close(s[:, 0], yd.sum(0), rtol=1e-11, atol=1e-9)
+    torch.testing.assert_close(s[:, 1], (yd * yd).sum(0), rtol=1e-11, atol=1e-9)
+    # the wrapper: statistics of tile 4 feed the BatchNorm like any other tile's
+    key = ("fwd", False, B, H, W, Cin, Cout, 1, 1, 1, 0, 1)
+    try:
+        kk._tile_cache[key] = 4
+        yw, (pw, rw) = kk.conv2d_fwd(x, w, None, None, 1, 0, 1, False, True)
+        assert torch.equal(yw, y4) and rw == p4.shape[0]
+        yb = kk.conv2d_fwd(x, w, torch.ones(Cout, device="cuda"), None, 1, 0, 1, True)     # bias + ReLU: not tile 4's business
+        assert torch.equal(yb, torch.relu(y4 + 1.0))
+    finally:
+        kk._tile_cache.pop(key, None)
+    # input gradient of the transposed problem: dX [M, Cin] = dY [M, Cout] W^T, with and without the shortcut gradient
+    if Cout in (64, 128, 256) and Cin % 64 == 0:
+        dy = torch.from_numpy(rng.standard_normal((B, H, W, Cout)).astype(np.float32)).cuda()
+        add = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).cuda()
+        for a in (None, add):
+            outs = []
+            for tile in (2, 4):
+                buf = torch.full((M * Cin + 4096,), 777.0, device="cuda")
+                dx = buf[:M * Cin].view(B, H, W, Cin)
+                kk._native.check(L.scouter_conv2d_dgrad_f32(dy.data_ptr(), w.data_ptr(), None if a is None else a.data_ptr(),
+                                                            dx.data_ptr(), B, H, W, Cin, Cout, 1, 1, 1, 0, 1, tile, st), "dgrad")
+                torch.cuda.synchronize()
+                assert bool((buf[M * Cin:] == 777.0).all())
+                outs.append(dx)
+            assert torch.equal(outs[0], outs[1]), ("dgrad", a is not None)
+    # a request the persistent kernel does not cover is refused, not re-routed
+    rc = L.scouter_conv2d_fwd_f32(x.data_ptr(), w.data_ptr(), torch.ones(Cout, device="cuda").data_ptr(), None, y4.data_ptr(), None,
+                                  B, H, W, Cin, Cout, 1, 1, 1, 0, 1, 0, 4, st)
+    assert rc != 0
