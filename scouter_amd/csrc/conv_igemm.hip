@@ -701,6 +701,42 @@ static void launch_pwp(const float* src, const float* w, const float* addend, fl
 #undef PWP
 }
 
+// the input gradient with the fused BatchNorm-backward epilogue on the persistent skeleton (pwp_fused_kernel)
+static PwpPlan pwp_fused_plan(const ConvGeom& g) {
+    PwpPlan p;
+    p.ks = g.Cg / 64;
+    const int cap = p.ks == 4 ? 64 : 128;                    // 32 x 64 wave tiles at most (epilogue operands stay in registers)
+    p.bn = (cap >= 128 && g.Ng % 128 == 0) ? 128 : 64;
+    const int colgroups = g.Ng / p.bn;
+    int w = (256 / colgroups) & ~7;
+    p.wg_per_col = w < 8 ? 8 : w;
+    p.waves_m = 2;
+    return p;
+}
+static void launch_pwp_fused(const float* src, const float* w, const float* addend, float* dst, const ConvGeom& g,
+                             hipStream_t st, const BnBwdFuse& fz) {
+    const PwpPlan p = pwp_fused_plan(g);
+    const int mtiles = sc_cdiv(g.M, 64), grid = p.wg_per_col * (g.Ng / p.bn);
+    const size_t lds = (size_t)g.Cg * p.bn * 4 + 4 * 16384;
+    const long mask_words = ((g.M * g.Ng / 4 + 63) / 64) * 4;
+#define PWF(KS_, BN_, TWO_)                                                                                        \
+    do {                                                                                                           \
+        auto kern = pwp_fused_kernel<KS_, BN_, TWO_>;                                                              \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4 * 16384); attr_set = true; } \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, src, w, addend, dst, g.M, g.Ng, mtiles, p.wg_per_col, fz, \
+                           mask_words);                                                                            \
+    } while (0)
+#define PWF2(KS_, BN_) do { if (fz.part2) PWF(KS_, BN_, true); else PWF(KS_, BN_, false); } while (0)
+    if (p.ks == 1 && p.bn == 128) PWF2(1, 128);
+    else if (p.ks == 1) PWF2(1, 64);
+    else if (p.ks == 2 && p.bn == 128) PWF2(2, 128);
+    else if (p.ks == 2) PWF2(2, 64);
+    else PWF2(4, 64);
+#undef PWF2
+#undef PWF
+}
+
 // tile choice: largest tile that still fills the chip (>= ~1.5 rounds of 256 CUs x 2 blocks); Ng is a multiple of 32
 static bool igemm_tile_ok(const ConvGeom& g, int t) {
     return (t == 0 && g.Ng % 128 == 0) || ((t == 1 || t == 2) && g.Ng % 64 == 0) || t == 3;
@@ -726,10 +762,11 @@ static int dispatch_igemm(const float* src, const float* w, const float* bias, c
     if (tile == 4) {
         // (the caller named the persistent kernel: its partial-row layout differs, so an unsupported request is an error,
         // never a silent re-route)
-        SC_UNSUPPORTED(pwp_geom_ok(g) && !bias && !relu && !fz.part1 && (DGRAD || !addend),
+        SC_UNSUPPORTED(pwp_geom_ok(g) && !bias && !relu && (DGRAD || (!addend && !fz.part1)),
                        "conv2d: tile 4 (persistent pointwise kernel) covers 1x1 / stride 1 / groups 1 convolutions with 64, 128 "
-                       "or 256 GEMM-K channels, no bias / ReLU / fused BatchNorm backward (forward: no addend)");
-        launch_pwp<DGRAD>(src, w, addend, dst, bn_part, g, st);
+                       "or 256 GEMM-K channels, no bias / ReLU (forward: no addend)");
+        if (DGRAD && fz.part1) launch_pwp_fused(src, w, addend, dst, g, st, fz);
+        else launch_pwp<DGRAD>(src, w, addend, dst, bn_part, g, st);
         return sc_check_launch(DGRAD ? "conv2d_dgrad(persistent)" : "conv2d_fwd(persistent)");
     }
     switch (tile) {
@@ -798,7 +835,9 @@ extern "C" int scouter_conv2d_dgrad_bn_partial_rows(int B, int H, int W, int Cin
                                                     int pad, int groups, int tile_hint) {
     if (!(groups > 0 && Cin % groups == 0 && Cout % groups == 0)) return 0;
     const ConvGeom g = dgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
-    return sc_cdiv(g.M, igemm_tile(g, tile_hint == 4 ? -1 : tile_hint) == 2 ? 64 : 128);   // (tile 4 has no fused epilogue)
+    const int t = igemm_tile(g, tile_hint);
+    if (t == 4) { const PwpPlan p = pwp_fused_plan(g); return p.wg_per_col * p.waves_m; }   // one row per (workgroup, wave row)
+    return sc_cdiv(g.M, t == 2 ? 64 : 128);
 }
 
 extern "C" int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, const float* addend, float* dx, int B,
@@ -819,7 +858,7 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, c
     // with the BatchNorm-backward reductions in the epilogue the kernel is a different piece of work (it also reads the
     // BatchNorm input(s), the addend and the ReLU bits -- co-bound by HBM on the short-K layers): its own profile row
     static const char* names_bn[5] = {"igemm_dgrad+bn_bwd<128x128>", "igemm_dgrad+bn_bwd<128x64>",
-                                      "igemm_dgrad+bn_bwd<64x64>", "igemm_dgrad+bn_bwd<128x32>", "igemm_dgrad+bn_bwd<?>"};
+                                      "igemm_dgrad+bn_bwd<64x64>", "igemm_dgrad+bn_bwd<128x32>", "igemm_dgrad+bn_bwd<persistent>"};
     const int tile = igemm_tile(g, tile_hint);
     const double out_elems = (double)g.M * Cin;
     ScProfScope prof(part1 ? names_bn[tile] : names[tile], (hipStream_t)stream,

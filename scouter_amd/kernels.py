@@ -375,15 +375,16 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
         # different tile wins than for the plain input gradient); partials sized for the most rows while timing
         def launch_fused(tile, dry=False):
             if dry:
-                return tile != 4 and launch(tile, dry=True)          # (the persistent kernel has no fused epilogue)
+                return launch(tile, dry=True)
             if not post.applied:
-                post.alloc(-(-B * H * W // 64), x_shape)
+                post.alloc(max(-(-B * H * W // 64), 512), x_shape)   # (the most rows any tile writes; tile 4: <= 512)
             return launch(tile, fuse=post.args())
         tile = _pick_tile(("dgrad+bn", len(post.entries), addend is not None, bf16, B, H, W, Cin, Cout, kh, kw, stride,
-                           pad, groups), launch_fused)
+                           pad, groups), launch_fused, (0, 1, 2, 3, 4))
         if tile < 0:                              # autotuning disabled: name a tile, the partial rows depend on it
             tile = 2 if (Cin // groups) % 64 == 0 else 3
-        post.alloc(-(-B * H * W // (64 if tile == 2 else 128)), x_shape)
+        rows = L.scouter_conv2d_dgrad_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
+        post.alloc(rows, x_shape)
         launch(tile, fuse=post.args())
     else:
         launch(_pick_tile(("dgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, (0, 1, 2, 3, 4)))

@@ -429,7 +429,10 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
     (2, 9, 9, 128, 128, 3, 1, 2, False, False),      # radix conv: finishes bn1 (ragged last M tile)
     (5, 7, 7, 64, 32, 1, 0, 1, False, True),
     (9, 12, 12, 64, 64, 3, 1, 1, True, False),
-    (45, 28, 27, 128, 128, 3, 1, 2, True, True)])     # > 256 plane tiles: the persistent kernel's second round
+    (45, 28, 27, 128, 128, 3, 1, 2, True, True),      # > 256 plane tiles: the persistent kernel's second round
+    (7, 13, 11, 256, 128, 1, 0, 1, True, True),       # persistent fused kernel: K = 128, two column groups, ragged M
+    (3, 9, 9, 512, 256, 1, 0, 1, False, True),        # K = 256: 32 x 32 wave tiles, eight column groups
+    (11, 28, 28, 64, 64, 1, 0, 1, False, False)])     # K = 64, N = 64: one column group, no shortcut gradient
 def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision, monkeypatch):
     """conv dgrad with a BnBwdFuse == conv dgrad, then ReLU mask, then the BatchNorm backward's own reduction: the masked
     gradient bit for bit (every tile), the fp64 partial sums to 1e-10, dx / dgamma / dbeta of the BatchNorm(s) to fp32
@@ -473,6 +476,8 @@ def test_input_gradient_epilogue_finishes_batchnorm_backward(case, precision, mo
 
     tiles = (kk._plane_tiles(Cin // g, 3, kk._halo_ok(k, k, 1, pad, H, W, 2)) if precision == "planes"
              else [t for t in range(4) if kk._tile_legal(Cin // g, t)])
+    if precision == "fp32" and kk._pw_persist_legal(B * H * W, Cout, Cin, k, k, 1, pad, g, True):
+        tiles = list(tiles) + [4]              # the persistent pointwise kernel carries the fused epilogue too
     if precision == "planes" and k * k * (Cout // g // 32) < 2:
         tiles = [t for t in tiles if t != 6]              # (the persistent tile needs two K-tiles)
     for t in tiles:
