@@ -208,7 +208,8 @@ PMC_MFMA_FILE = "r04_pmc_mfma_util.json"
 CLASSES = {
     "fp32_mfma_conv": {
         "labels": ("igemm_fwd<", "igemm_dgrad<", "igemm_dgrad+bn_bwd<", "wgrad<", "wgrad_taps"),
-        "rocprof": ("void igemm_kernel<", "void wgrad_kernel<", "void wgrad_taps_kernel<"),
+        "rocprof": ("void igemm_kernel<", "void wgrad_kernel<", "void wgrad_taps_kernel<", "void pwp_kernel<",
+                    "void pwp_fused_kernel<"),
         "peak": 157.3, "sustained": 154.0, "what": "fp32 implicit-GEMM convolutions (forward, input gradient incl. the fused BatchNorm-backward "
                                "epilogue, weight gradient), v_mfma_f32_32x32x2_f32"},
     "bf16x3_plane_conv": {

@@ -665,6 +665,7 @@ def test_persistent_pointwise_kernel(case):
         kk._tile_cache[key] = 4
         yw, (pw, rw) = kk.conv2d_fwd(x, w, None, None, 1, 0, 1, False, True)
         assert torch.equal(yw, y4) and rw == p4.shape[0]
+        assert torch.equal(kk.conv2d_fwd(x, w, None, None, 1, 0, 1, False, False), y4)     # eval forward: no statistics
         yb = kk.conv2d_fwd(x, w, torch.ones(Cout, device="cuda"), None, 1, 0, 1, True)     # bias + ReLU: not tile 4's business
         assert torch.equal(yb, torch.relu(y4 + 1.0))
     finally:
