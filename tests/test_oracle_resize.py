@@ -70,7 +70,11 @@ def test_readers_and_host_transform(tmp_path):
     s = tr[4]
     assert s["image"].dtype == torch.uint8 and s["image"].shape == (10, 9, 3) and int(s["label"]) == 1
     batch = collate_raw([tr[0], tr[5]])
-    assert isinstance(batch["image"], list) and batch["label"].tolist() == [0, 1] and batch["label"].dtype == torch.int64
+    from scouter_amd.dataset.transform_func import PackedImages
+    # (round 4: the frames of a batch travel packed in ONE buffer -- one pinned allocation, one H2D copy -- indexable like a list)
+    assert isinstance(batch["image"], PackedImages) and len(batch["image"]) == 2
+    assert torch.equal(batch["image"][0], tr[0]["image"]) and torch.equal(batch["image"][1], tr[5]["image"])
+    assert batch["label"].tolist() == [0, 1] and batch["label"].dtype == torch.int64
     # ---- CUB-200 layout
     root = tmp_path / "cub"
     (root / "images" / "001.a").mkdir(parents=True)
