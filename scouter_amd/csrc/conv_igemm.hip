@@ -381,6 +381,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     if (mend > g.M) mend = g.M;
     const int KT = (int)((mend - mbeg + BK - 1) / BK);
     const int hw = g.Ho * g.Wo;
+#ifdef IGEMM_STAMPS
+    if (g_igemm_stamps && threadIdx.x == 0) { g_igemm_stamps[8L * (blockIdx.x + (long)gridDim.x * blockIdx.y) + 0] = (long long)wall_clock64(); }
+#undef IG_STAMP
+#define IG_STAMP(k) if (g_igemm_stamps && threadIdx.x == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_igemm_stamps[8L * (blockIdx.x + (long)gridDim.x * blockIdx.y) + (k)] = (long long)wall_clock64(); }
+#endif
 
     // per-thread pixel state of its A rows, advanced by BK pixels per chunk without divisions
     int pb[AI], py[AI], px[AI];
@@ -533,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     }
     __syncthreads();
     if (KT > 0) frag(0, P0{});
+    IG_STAMP(1)
     auto chunk = [&](int kt, auto CUR) {              // LDS buffer index is a compile-time constant (loop unrolled by 2)
         constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
         const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
@@ -553,6 +559,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
         if (kt + 1 < KT) chunk(kt + 1, P1{});
     }
 #undef SB
+    IG_STAMP(2)
     float* o = out + (long)split_id * slab + (long)tap * g.Cg * g.N;
     const bool coh = arrival != nullptr;               // partial tiles leave write-through: another workgroup sums them
     if (WK == 1) {
@@ -587,6 +594,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     if (coh)
         slab_tile_finish(out + (long)tap * g.Cg * g.N, dw + (long)tap * g.Cg * g.N, slab, gridDim.y, arrival + tile_id, 1, 0,
                          (long)ci0 * g.N, BM, g.N, grp * g.Ng + co0, BN);
+#ifdef IGEMM_STAMPS
+    if (g_igemm_stamps && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g_igemm_stamps[8L * (blockIdx.x + (long)gridDim.x * blockIdx.y) + 3] = (long long)wall_clock64();
+        g_igemm_stamps[8L * (blockIdx.x + (long)gridDim.x * blockIdx.y) + 5] = KT;
+    }
+#endif
 }
 
 // Sums the split slabs in a fixed order (deterministic).  Block = 8 float4 columns x 32 split-lanes: each lane adds
