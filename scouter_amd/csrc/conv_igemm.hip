@@ -895,7 +895,7 @@ struct WgradPlan { int bm, bn, ci_tiles, co_tiles, splits; long pix_per_split, t
 // plan_hint < 0: the static plan below.  Otherwise (autotuned by the caller, include/scouter_hip.h) bits 0-1 select the
 // block budget {512, 1024, 2048, 4096} that sets the split count and bits 4-5 halve the ci / co tile edge -- smaller
 // output tiles give more parallelism without split-K slabs, which pays for the short-K (7x7, 14x14) layers.
-static WgradPlan wgrad_plan(const ConvGeom& g, int plan_hint, bool chunk64 = false) {
+static WgradPlan wgrad_plan(const ConvGeom& g, int plan_hint, bool chunk64 = false, int min_tile = 32) {
     WgradPlan p;
     p.bm = (g.Cg % 128 == 0) ? 128 : (g.Cg % 64 == 0 ? 64 : 32);
     p.bn = (g.Ng % 128 == 0) ? 128 : (g.Ng % 64 == 0 ? 64 : 32);
@@ -905,8 +905,10 @@ static WgradPlan wgrad_plan(const ConvGeom& g, int plan_hint, bool chunk64 = fal
         if ((plan_hint & 16) && p.bm > 32) p.bm >>= 1;
         if ((plan_hint & 32) && p.bn > 32) p.bn >>= 1;
     }
-    p.ci_tiles = g.Cg / p.bm;
-    p.co_tiles = g.Ng / p.bn;
+    if (p.bm < min_tile) p.bm = min_tile;                 // (bf16 kernel: ragged 64-wide tiles over 32-channel groups)
+    if (p.bn < min_tile) p.bn = min_tile;
+    p.ci_tiles = sc_cdiv(g.Cg, p.bm);
+    p.co_tiles = sc_cdiv(g.Ng, p.bn);
     p.tiles = (long)p.ci_tiles * p.co_tiles * g.groups * g.R * g.S;
     // enough blocks to fill 256 CUs x 2 blocks twice over, but few splits for big weight tensors: every split costs a
     // full-size slab write + read in the reduction kernel
@@ -1063,8 +1065,11 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
 }
 
 // bf16 matrix inputs (conv_wgrad_bf16.h).  Supported: "same" stride-1 convolutions whose per-group channel counts are
-// multiples of 64 (everything in ResNeSt except the 32-channel stem / first grouped layer); SC_ERR_UNSUPPORTED tells the
-// caller to use the fp32 kernel for that layer.  Same workspace as scouter_conv2d_wgrad_f32.
+// multiples of 32; SC_ERR_UNSUPPORTED tells the caller to use the fp32 kernel for that layer.  32-channel groups (the
+// ResNeSt stem and its first grouped layer) run on RAGGED 64-wide tiles: the tile reads 64 channels from the group's first
+// one -- the upper 32 are the neighbouring group's / pixel's values -- and the rows / columns past the group are dropped at
+// the store (at bf16 matrix rates the doubled tile is free, and 4x faster than the fp32 kernel these layers used).
+// Same workspace as scouter_conv2d_wgrad_f32.
 extern "C" int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin,
                                          int Cout, int kh, int kw, int stride, int pad, int groups, int plan_hint,
                                          void* ws, size_t ws_bytes, void* arrival, int arrival_slots, void* stream) {
@@ -1073,10 +1078,10 @@ extern "C" int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float*
     ConvGeom g = wgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
     const bool same = stride == 1 && g.Ho == H && g.Wo == W;
     const int mode = !same ? 0 : (kh == 1 && kw == 1 && pad == 0) ? 2 : (64 / g.Wo + 1 < g.Ho ? 1 : 0);
-    SC_UNSUPPORTED(mode != 0 && g.Cg % 64 == 0 && g.Ng % 64 == 0 && g.M < (1L << 31),
+    SC_UNSUPPORTED(mode != 0 && g.Cg % 32 == 0 && g.Ng % 32 == 0 && g.M < (1L << 31),
                    "conv2d_wgrad_bf16: shape not covered by the bf16 kernel");
-    WgradPlan p = wgrad_plan(g, plan_hint, true);
-    if (p.bm < 64 || p.bn < 64) p = wgrad_plan(g, plan_hint & 3, true);      // the bf16 kernel has no 32-wide tiles
+    const bool ragged = g.Cg % 64 != 0 || g.Ng % 64 != 0;
+    WgradPlan p = wgrad_plan(g, plan_hint, true, 64);                        // the bf16 kernel has no 32-wide tiles
     const long slab = (long)kh * kw * g.Cg * Cout;
     const size_t need = p.splits > 1 ? (size_t)p.splits * slab * sizeof(float) : 0;
     if (need > ws_bytes || (need && !ws)) {
@@ -1085,7 +1090,7 @@ extern "C" int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float*
     }
     hipStream_t st = (hipStream_t)stream;
     float* out = p.splits > 1 ? (float*)ws : dw;
-    unsigned* arr = p.splits > 1 && arrival && p.tiles <= arrival_slots ? (unsigned*)arrival : nullptr;
+    unsigned* arr = p.splits > 1 && arrival && p.tiles <= arrival_slots && !ragged ? (unsigned*)arrival : nullptr;
     dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
     int rc;
     {

@@ -69,15 +69,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
         b_row[i] = 4 * cq; b_pq[i] = pq;
         b_voff[i] = (unsigned)((4 * pq * (long)g.N + grp * g.Ng + co0 + 4 * cq) * 4);
     }
-    auto records = [&](long m_chunk, int row_elems) {
-        long n = (mend - m_chunk) * (long)row_elems * 4;
+    // bytes the descriptor may touch from pixel `first`: up to this split's last pixel and (ragged tiles read one pixel
+    // past a valid one) never beyond the tensor's last pixel
+    auto records = [&](long m_chunk, long first, int row_elems) {
+        long px = mend - m_chunk;
+        if (px > g.M - first) px = g.M - first;
+        const long n = px * (long)row_elems * 4;
         return (unsigned)(n < 0 ? 0 : (n > 0x7fffffffL ? 0x7fffffffL : n));
     };
     f32x4 ra[AP][4], rb[BP][4];
     long a_m = mbeg, b_m = mbeg;
     auto load_a = [&]() {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(act + (a_m + tapoff) * g.C), 0,
-                                                                            records(a_m, g.C), 0x00020000);
+                                                                            records(a_m, a_m + tapoff, g.C), 0x00020000);
         unsigned long long vmask = ~0ull;
         if (MODE == 1) {
             const int iy = qy1 - g.pad + r, ix = qx1 - g.pad + q;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
     };
     auto load_b = [&]() {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + b_m * g.N), 0,
-                                                                            records(b_m, g.N), 0x00020000);
+                                                                            records(b_m, b_m, g.N), 0x00020000);
 #pragma unroll
         for (int i = 0; i < BP; ++i)
 #pragma unroll
@@ -183,8 +187,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
             const int ci = ci0 + wm * WM + i * 32 + mfma32_row(e, lane);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int co = grp * g.Ng + co0 + wn * WN + j * 32 + l31;
-                slab_store(o + (long)ci * g.N + co, acc[i][j][e], arrival != nullptr);
+                const int cl = co0 + wn * WN + j * 32 + l31, co = grp * g.Ng + cl;
+                if (ci < g.Cg && cl < g.Ng)             // (ragged tiles over 32-channel groups: the rest is not this group's)
+                    slab_store(o + (long)ci * g.N + co, acc[i][j][e], arrival != nullptr);
             }
         }
     if (arrival)

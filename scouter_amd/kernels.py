@@ -689,10 +689,10 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
     L = _native.lib()
     st = _stream()
 
-    # bf16 matrix inputs where the bf16 kernel applies (same-size stride-1 convolutions, 64-multiples of channels per
-    # group); the remaining layers (32-channel stem, strided convolutions) keep the fp32 kernel
+    # bf16 matrix inputs where the bf16 kernel applies (same-size stride-1 convolutions, 32-multiples of channels per
+    # group -- 32-channel groups on ragged 64-wide tiles); the remaining layers (strided convolutions) keep the fp32 kernel
     same = stride == 1 and dy.shape[1] == H and dy.shape[2] == W
-    bf16 = (precision == "bf16" and same and cg % 64 == 0 and (Cout // groups) % 64 == 0 and
+    bf16 = (precision == "bf16" and same and cg % 32 == 0 and (Cout // groups) % 32 == 0 and
             B * H * W >= BF16_MIN_PIXELS and ((kh == 1 and kw == 1 and pad == 0) or 64 // W + 1 < H))
     fn = L.scouter_conv2d_wgrad_bf16 if bf16 else L.scouter_conv2d_wgrad_f32
 

@@ -381,7 +381,10 @@ def _bf16_round(t):
     (2, 14, 14, 64, 128, 3, 1, 1, 2), (3, 9, 7, 128, 64, 1, 1, 0, 1), (2, 12, 12, 32, 32, 3, 1, 1, 1),
     (1, 8, 8, 256, 256, 3, 1, 1, 2), (2, 10, 10, 64, 64, 3, 2, 1, 1), (5, 7, 7, 192, 96, 1, 1, 0, 1),
     (3, 14, 14, 128, 128, 3, 1, 1, 1), (2, 28, 28, 64, 128, 3, 1, 1, 1), (7, 7, 7, 128, 256, 1, 1, 0, 1),
-    (2, 70, 70, 64, 64, 3, 1, 1, 1)])
+    (2, 70, 70, 64, 64, 3, 1, 1, 1),
+    # 32-channel groups: the weight gradient's ragged 64-wide tiles (stem / first grouped layer of ResNeSt; 96 = 64 + 32)
+    (3, 17, 19, 64, 128, 3, 1, 1, 2), (2, 23, 21, 32, 64, 3, 1, 1, 1), (5, 9, 11, 96, 32, 1, 1, 0, 1),
+    (4, 30, 30, 64, 192, 3, 1, 1, 2)])
 def test_conv_bf16_inputs_fp32_accumulate(cfg):
     """bf16 mode: the kernels must equal an exact convolution of the bf16-ROUNDED operands (fp32 accumulation error
     only), for the forward (+ fused BN statistics) and the stride-1 input gradient."""
@@ -408,9 +411,9 @@ def test_conv_bf16_inputs_fp32_accumulate(cfg):
             dx_ref = torch.autograd.grad(F.conv2d(xr, _bf16_round(w), None, stride, pad, 1, groups), xr, _bf16_round(dy))[0]
             dx = kk.conv2d_dgrad(nhwc(dy), wd, tuple(xd.shape), None, stride, pad, groups, precision="bf16")
             np.testing.assert_allclose(from_nhwc(dx).numpy(), dx_ref.numpy(), atol=2e-5 * float(dx_ref.abs().max()), rtol=1e-5)
-        # weight gradient: bf16 kernel where it applies (same-size, 64-multiples), fp32 kernel elsewhere
+        # weight gradient: bf16 kernel where it applies (same-size, 32-multiples per group), fp32 kernel elsewhere
         dy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
-        uses_bf16 = stride == 1 and (Cin // groups) % 64 == 0 and (Cout // groups) % 64 == 0 and (k == 1 or 64 // W + 1 < H)
+        uses_bf16 = stride == 1 and (k == 1 or 64 // W + 1 < H)
         xs, dys = (_bf16_round(x), _bf16_round(dy)) if uses_bf16 else (x, dy)
         wr = w.clone().requires_grad_(True)
         dw_ref = torch.autograd.grad(F.conv2d(xs, wr, None, stride, pad, 1, groups), wr, dys)[0]
