@@ -85,12 +85,26 @@ int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, const float*
  * LDS and multiplied on v_mfma_f32_32x32x16_bf16.  The forward takes the weights pre-transposed to bf16
  * [kh*kw][Cout][Cin/groups] (scouter_conv2d_weight_bf16t, 2*kh*kw*Cin/groups*Cout bytes); dgrad reads the fp32 HWIO
  * weights directly (stride 1 only: strided input gradients stay on the fp32 kernel).  wgrad_bf16 covers same-size
- * stride-1 convolutions with per-group channels that are multiples of 64 and returns SC_ERR_UNSUPPORTED otherwise
- * (callers then use scouter_conv2d_wgrad_f32); it shares that function's workspace. */
+ * stride-1 convolutions with per-group channels that are multiples of 32 (32-channel groups on ragged 64-wide tiles) and
+ * returns SC_ERR_UNSUPPORTED otherwise (callers then use scouter_conv2d_wgrad_f32); it shares that function's workspace.
+ *
+ * ACTIVATION STORAGE (`*_io` entry points, round 4): under --precision bf16 the widest tensors of a bottleneck -- the conv3 /
+ * downsample-convolution outputs and the block outputs (timm/models/resnest.py:128-143: `out = self.bn3(self.conv3(out))`,
+ * `out += residual`, `out = self.act3(out)`) -- may be STORED as bf16.  The typed entry points take untyped pointers plus
+ * an `io` bit set: SCOUTER_IO_X_BF16 (1) the main input, SCOUTER_IO_Y_BF16 (2) the output, SCOUTER_IO_R_BF16 (4) the
+ * residual; values are widened on load and rounded RNE on store, all arithmetic (and every gradient tensor) stays fp32;
+ * a bf16-stored convolution input holds exactly the values the kernel rounds an fp32 input to, so the product is the
+ * same bits.  io = 0 is the fp32 entry point. */
+#define SCOUTER_IO_X_BF16 1
+#define SCOUTER_IO_Y_BF16 2
+#define SCOUTER_IO_R_BF16 4
 int scouter_conv2d_weight_bf16t(const float* w, void* wt, int kh, int kw, int Cin, int Cout, int groups, void* stream);
 int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, const float* bias, const float* addend, float* y,
                             double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
                             int pad, int groups, int relu, int tile_hint, void* stream);
+int scouter_conv2d_fwd_bf16_io(const void* x, const void* wt_bf16, const float* bias, const float* addend, void* y,
+                               double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                               int pad, int groups, int relu, int tile_hint, int io, void* stream);
 int scouter_conv2d_dgrad_bf16(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,
                               int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
                               void* stream);
@@ -98,9 +112,18 @@ int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, const float
                                     int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
                                     const void* relu_mask, const float* x1, const float* saved1, double* part1,
                                     const float* x2, const float* saved2, double* part2, void* stream);
+/* x_io: bit 0 -- x1 is stored as bf16, bit 1 -- x2 is (the BatchNorm inputs the fused epilogue reads) */
+int scouter_conv2d_dgrad_bnbwd_bf16_io(const float* dy, const float* w, const float* addend, float* dx, int B, int H,
+                                       int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups,
+                                       int tile_hint, const void* relu_mask, const void* x1, const float* saved1,
+                                       double* part1, const void* x2, const float* saved2, double* part2, int x_io,
+                                       void* stream);
 int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
                               int kw, int stride, int pad, int groups, int plan_hint, void* ws, size_t ws_bytes,
                               void* arrival, int arrival_slots, void* stream);
+int scouter_conv2d_wgrad_bf16_io(const void* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                                 int kh, int kw, int stride, int pad, int groups, int plan_hint, void* ws,
+                                 size_t ws_bytes, void* arrival, int arrival_slots, int io, void* stream);
 /* plan_hint: -1 = built-in plan; otherwise bits 0-1 = block budget {512,1024,2048,4096} (sets the split-K count),
  * bit 4 / bit 5 = halve the ci / co tile edge.  Every plan is deterministic; different plans sum the pixels in a
  * different order (results differ in the last bits), so a caller that autotunes keeps its choice for the whole run.
@@ -138,6 +161,13 @@ int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, 
                        int training, int relu, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
                        const double* ext_partial, int ext_rows, unsigned long long* relu_mask_out, void* planes_out,
                        int nplanes, const float* residual_bn_saved, void* ws, size_t ws_bytes, void* stream);
+/* typed storage (see ACTIVATION STORAGE above): x / y / residual per `io`; a bf16 x needs ext_partial in training mode
+ * (its batch statistics are those of the producing convolution's fp32 accumulators) */
+int scouter_bn_fwd_io(const void* x, void* y, const void* residual, long M, int C, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                      int training, int relu, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
+                      const double* ext_partial, int ext_rows, unsigned long long* relu_mask_out, void* planes_out,
+                      int nplanes, const float* residual_bn_saved, int io, void* ws, size_t ws_bytes, void* stream);
 /* y == NULL in scouter_bn_fwd_f32: with planes_out the apply pass writes the planes only (every consumer reads planes: 6
  * instead of 10 bytes per element); without, statistics / running-stat update only.  scouter_bn_apply_f32: the apply pass alone
  * from a saved block [4][C] = {mean, rstd, scale, shift} (contiguous rows, as written through the four *_out pointers). */
@@ -151,6 +181,11 @@ int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, cons
                        const float* scale, const unsigned long long* relu_mask, long M, int C, int training,
                        float* dgamma, float* dbeta, float* dx, float* gout, const double* ext_partial, int ext_rows,
                        void* ws, size_t ws_bytes, void* stream);
+/* io & SCOUTER_IO_X_BF16: the BatchNorm input x is stored as bf16 (dy, dx, gout stay fp32) */
+int scouter_bn_bwd_io(const float* dy, const float* ymask, const void* x, const float* mean, const float* rstd,
+                      const float* scale, const unsigned long long* relu_mask, long M, int C, int training,
+                      float* dgamma, float* dbeta, float* dx, float* gout, const double* ext_partial, int ext_rows,
+                      int io, void* ws, size_t ws_bytes, void* stream);
 /* out[c] = alpha * sum_m a[m][c] * (b ? b[m][c] : 1)  -- bias gradients, d(initial_slots) */
 int scouter_colsum_f32(const float* a, const float* b, float* out, long M, int C, float alpha, void* ws,
                        size_t ws_bytes, void* stream);
@@ -176,6 +211,8 @@ int scouter_bn_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, con
                                float* dbeta, float* dx, void* ws, size_t ws_bytes, void* stream);
 int scouter_avgpool_fwd_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride, int pad,
                             int ceil_mode, int count_include_pad, void* stream);
+int scouter_avgpool_fwd_io(const void* x, float* y, int B, int H, int W, int C, int k, int stride, int pad,
+                           int ceil_mode, int count_include_pad, int io, void* stream);    /* io: SCOUTER_IO_X_BF16 */
 int scouter_avgpool_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, int k, int stride, int pad,
                             int ceil_mode, int count_include_pad, void* stream);
 int scouter_transpose_f32(const float* in, float* out, int batch, int rows, int cols, void* stream);

@@ -199,11 +199,17 @@ def head_forward(P, feat, target, cfg, aux=None):
 # even) before an exact product -- what the build's precision="bf16" mode computes (fp32 accumulation, fp32 storage):
 #   forward : conv(rb(x), rb(w))                       when the layer has >= BF16_MIN_PIXELS output pixels
 #   dgrad   : conv_transpose(rb(dy), rb(w))            stride-1 layers with >= BF16_MIN_PIXELS input pixels
-#   wgrad   : wgrad(rb(x), rb(dy))                     same-size stride-1 layers, per-group channels multiples of 64
-# everything else (tiny attention FCs on the pooled vector, strided gradients, the 32-channel stem's weight gradient,
-# the xSlot head) stays exact.
+#   wgrad   : wgrad(rb(x), rb(dy))                     same-size stride-1 layers, per-group channels multiples of 32
+# everything else (tiny attention FCs on the pooled vector, strided gradients, the xSlot head) stays exact.
 CONV_INPUT_ROUNDING = None
 BF16_MIN_PIXELS = 1024
+# ACTIVATION_STORAGE = "bf16" (with CONV_INPUT_ROUNDING = "bf16"): what the build's bf16 activation storage computes
+# (scouter_amd SlotModel.set_activation_storage) -- in every ResNeSt bottleneck but the network's last one whose output
+# has >= BF16_MIN_PIXELS pixels, the conv3 / downsample-convolution outputs and the block output are STORED rounded to
+# bf16: the BatchNorm after conv3 (and the downsample one) takes its batch statistics from the unrounded convolution
+# result and normalises the rounded values; the block output is rounded after the ReLU.  Gradients are not rounded
+# (straight-through).
+ACTIVATION_STORAGE = None
 
 
 def _rb(t):
@@ -227,7 +233,7 @@ class _RoundedConv(torch.autograd.Function):
         Cout, cg, kh, kw = w.shape
         dgrad_bf16 = stride == 1 and B * H * W >= BF16_MIN_PIXELS
         same = stride == 1 and dy.shape[2] == H and dy.shape[3] == W
-        wgrad_bf16 = (same and cg % 64 == 0 and (Cout // groups) % 64 == 0 and B * H * W >= BF16_MIN_PIXELS and
+        wgrad_bf16 = (same and cg % 32 == 0 and (Cout // groups) % 32 == 0 and B * H * W >= BF16_MIN_PIXELS and
                       ((kh == 1 and kw == 1 and pad == 0) or 64 // W + 1 < H))
         dx = torch.nn.grad.conv2d_input(x.shape, _rb(w) if dgrad_bf16 else w, _rb(dy) if dgrad_bf16 else dy, stride, pad,
                                         1, groups)
@@ -259,6 +265,30 @@ def _bn(P, name, x, training):
     return y
 
 
+def _rb_ste(t):
+    """round to bf16 in the forward, identity in the backward (a storage rounding)"""
+    return t + (_rb(t) - t).detach()
+
+
+def _bn_stored(P, name, x, training):
+    """BatchNorm of a convolution output that is STORED as bf16 (ACTIVATION_STORAGE): statistics (and the running-stat
+    update) from the unrounded x, the affine map applied to the rounded values."""
+    w, b = P[name + ".weight"], P[name + ".bias"]
+    if training:
+        n = x.numel() // x.shape[1]
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        with torch.no_grad():
+            P[name + ".running_mean"].mul_(0.9).add_(0.1 * mean)
+            P[name + ".running_var"].mul_(0.9).add_(0.1 * var * (n / max(n - 1, 1)))
+        if (name + ".num_batches_tracked") in P:
+            P[name + ".num_batches_tracked"] += 1
+    else:
+        mean, var = P[name + ".running_mean"], P[name + ".running_var"]
+    sc = (w * torch.rsqrt(var + 1e-5)).view(1, -1, 1, 1)
+    return (_rb_ste(x) - mean.view(1, -1, 1, 1)) * sc + b.view(1, -1, 1, 1)
+
+
 def _split_attn(P, name, x, training):
     """SplitAttnConv2d.forward, radix 2, cardinality 1 (split_attn.py:54-80, RadixSoftmax :20-28)."""
     x = _conv(x, P[name + ".conv.weight"], None, 1, 1, 1, 2)
@@ -274,20 +304,25 @@ def _split_attn(P, name, x, training):
     return (x5 * a).sum(dim=1)
 
 
-def _resnest_block(P, name, x, stride, training):
+def _resnest_block(P, name, x, stride, training, last=False):
     """ResNestBottleneck.forward with avd=True, avd_first=False (resnest.py:111-143); `is_first` is never set
-    by ResNet._make_layer so avd pooling exists only when stride > 1 (:76-80)."""
+    by ResNet._make_layer so avd pooling exists only when stride > 1 (:76-80).  last: the network's last block (never
+    stored as bf16, see ACTIVATION_STORAGE)."""
     out = _relu(name + ".bn1", _bn(P, name + ".bn1", _conv(x, P[name + ".conv1.weight"]), training))
     out = _split_attn(P, name + ".conv2", out, training)
     if stride > 1:
         out = F.avg_pool2d(out, 3, stride, padding=1)
-    out = _bn(P, name + ".bn3", _conv(out, P[name + ".conv3.weight"]), training)
+    stored = (ACTIVATION_STORAGE == "bf16" and not last and
+              out.shape[0] * out.shape[2] * out.shape[3] >= BF16_MIN_PIXELS)
+    bn = _bn_stored if stored else _bn
+    out = bn(P, name + ".bn3", _conv(out, P[name + ".conv3.weight"]), training)
     residual = x
     if (name + ".downsample.1.weight") in P:          # downsample_avg (resnet.py:292-306)
         if stride > 1:
             residual = F.avg_pool2d(residual, 2, stride, ceil_mode=True, count_include_pad=False)
-        residual = _bn(P, name + ".downsample.2", _conv(residual, P[name + ".downsample.1.weight"]), training)
-    return _relu(name + ".bn3", out + residual)
+        residual = bn(P, name + ".downsample.2", _conv(residual, P[name + ".downsample.1.weight"]), training)
+    y = _relu(name + ".bn3", out + residual)
+    return _rb_ste(y) if stored else y
 
 
 def _basic_block(P, name, x, stride, training):
@@ -319,7 +354,11 @@ def backbone_features(P, x, arch, training, prefix="backbone."):
     for li, nblocks in enumerate(cfg["layers"]):
         for bi in range(nblocks):
             stride = 2 if (li > 0 and bi == 0) else 1
-            x = block(P, f"{prefix}layer{li + 1}.{bi}", x, stride, training)
+            if cfg["kind"] == "resnest":
+                x = block(P, f"{prefix}layer{li + 1}.{bi}", x, stride, training,
+                          last=li == len(cfg["layers"]) - 1 and bi == nblocks - 1)
+            else:
+                x = block(P, f"{prefix}layer{li + 1}.{bi}", x, stride, training)
     return x
 
 

@@ -31,7 +31,7 @@ static int col_blocks(long M, const ColGeom& g) {
 
 // Per-block partial column sums of up to two quantities produced by `F(row, col4) -> (float4 u, float4 v)`.
 // partial layout: [block][C][2] doubles.
-template <int MODE>   // 0: (x, x*x)   1: (g, g*xhat) with g = dy*(mask>0)   2: (x, 0)   3: (a*b, 0)
+template <int MODE, bool XB = false>   // 0: (x, x*x)   1: (g, g*xhat) with g = dy*(mask>0)   2: (x, 0)   3: (a*b, 0)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
                                                              const float* __restrict__ p2,
                                                              const float* __restrict__ mean,
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 #pragma unroll
                     for (int k = 0; k < 4; ++k) a[k] = y[k] > 0.f ? a[k] : 0.f;
                 }
-                f32x4 x = *(const f32x4*)(p2 + off);
+                const f32x4 x = sc_load4<XB>(p2, off);             // (XB: the BatchNorm input is stored as bf16)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { s[k] += a[k]; t[k] += (double)a[k] * ((x[k] - mu[k]) * rs[k]); }
             } else if (MODE == 2) {
@@ -181,21 +181,22 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
     shift_o[c] = beta ? beta[c] : 0.f;        // applied as (x - mean) * scale + beta: no cancellation when |mean| >> std
 }
 
-__global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ x,
+template <bool XB = false, bool YB = false, bool RB = false>     // storage types of x / y / res (bf16 or fp32)
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const void* __restrict__ x,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
-                                                              const float* __restrict__ res, float* __restrict__ y,
+                                                              const void* __restrict__ res, void* __restrict__ y,
                                                               unsigned long long* __restrict__ mbits, long n4, int C,
                                                               int relu, unsigned short* __restrict__ planes,
                                                               int nplanes, const float* __restrict__ res_bn) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
-        f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
+        f32x4 v = sc_load4_nt<XB>(x, i * 4);
         const f32x4 a = *(const f32x4*)(scale + c), b = *(const f32x4*)(shift + c), mu = *(const f32x4*)(mean + c);
         v = bn_affine(v, mu, a, b);
         if (res) {
-            f32x4 r = *(const f32x4*)(res + i * 4);
+            f32x4 r = sc_load4<RB>(res, i * 4);
             // the residual is the RAW output of the downsample convolution: its BatchNorm is applied here (saved block
             // [mean, rstd, scale, shift][C]) -- the same fma the stand-alone apply pass uses, so the sum is bit-identical
             if (res_bn) r = bn_affine(r, *(const f32x4*)(res_bn + c), *(const f32x4*)(res_bn + 2 * C + c),
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         }
-        if (y) *(f32x4*)(y + i * 4) = v;                               // (NULL: the consumers read the planes only)
+        if (y) sc_store4<YB>(y, i * 4, v);                            // (NULL: the consumers read the planes only)
         if (planes) store_planes4(planes, n4 * 4, nplanes, i, v);     // operand planes of the consuming plane convolution
     }
 }
@@ -236,8 +237,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 }
 
 // dx = gamma*rstd * (g - c1 - xhat*c2),  g = dy * (ymask > 0);  optionally also writes g (the residual-branch grad)
+template <bool XB = false>                                   // XB: the BatchNorm input x is stored as bf16
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
-                                                           const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const void* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ scale, const float* __restrict__ c1,
                                                            const float* __restrict__ c2,
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
         }
-        const f32x4 xv = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
+        const f32x4 xv = sc_load4_nt<XB>(x, i * 4);
         const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), sc = *(const f32x4*)(scale + c);
         const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c);
         const f32x4 xh = (xv - mu) * rs;
@@ -456,7 +458,8 @@ __device__ __forceinline__ float avg_div(const PoolGeom& g, int oy, int ox) {
     return (float)((y1 - y0) * (x1 - x0));
 }
 
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <bool XB = false>                                   // XB: the input is stored as bf16 (output fp32)
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const void* __restrict__ x, float* __restrict__ y,
                                                           PoolGeom g) {
     const int c4n = g.C / 4;
     const long n = (long)g.B * g.Ho * g.Wo * c4n;
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
             for (int kx = 0; kx < g.k; ++kx) {
                 const int ix = ox * g.stride - g.pad + kx;
                 if (ix < 0 || ix >= g.W) continue;
-                acc += *(const f32x4*)(x + (((long)b * g.H + iy) * g.W + ix) * g.C + c);
+                acc += sc_load4<XB>(x, (((long)b * g.H + iy) * g.W + ix) * g.C + c);
             }
         }
         *(f32x4*)(y + i * 4) = acc / avg_div(g, oy, ox);
@@ -675,26 +678,32 @@ extern "C" size_t scouter_colreduce_workspace_bytes(long M, int C) { (void)M; re
 
 extern "C" size_t scouter_relu_mask_words(long n) { return (size_t)((n / 4 + 63) / 64) * 4; }
 
-extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
-                                  const float* beta, float* running_mean, float* running_var, float momentum,
-                                  float eps, int training, int relu, float* mean_out, float* rstd_out,
-                                  float* scale_out, float* shift_out, const double* ext_partial, int ext_rows,
-                                  unsigned long long* relu_mask_out, void* planes_out, int nplanes,
-                                  const float* residual_bn_saved, void* ws, size_t ws_bytes, void* stream) {
+// `io` (SC_IO_X_BF16 | SC_IO_Y_BF16 | SC_IO_R_BF16): storage type of x / y / residual.  A bf16 x carries the values the
+// apply pass normalises; its batch statistics must come from the producing convolution's fp32 accumulators (ext_partial)
+extern "C" int scouter_bn_fwd_io(const void* x, void* y, const void* residual, long M, int C, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, float momentum,
+                                 float eps, int training, int relu, float* mean_out, float* rstd_out,
+                                 float* scale_out, float* shift_out, const double* ext_partial, int ext_rows,
+                                 unsigned long long* relu_mask_out, void* planes_out, int nplanes,
+                                 const float* residual_bn_saved, int io, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(x && mean_out && rstd_out && scale_out && shift_out, "bn_fwd: null pointer");   // y == NULL: statistics only
+    SC_REQUIRE((io & ~7) == 0, "bn_fwd: unknown io bits %d", io);
+    SC_UNSUPPORTED(!(io & SC_IO_X_BF16) || !training || ext_partial,
+                   "bn_fwd: a bf16-stored input needs the batch statistics of its producer (ext_partial)");
     SC_REQUIRE(!residual_bn_saved || residual, "bn_fwd: residual_bn_saved without residual");
     SC_REQUIRE(!planes_out || nplanes == 1 || nplanes == 3, "bn_fwd: planes_out needs 1 or 3 planes");
     SC_REQUIRE(!relu_mask_out || relu, "bn_fwd: relu_mask_out without relu");
     SC_REQUIRE(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
     COL_CHECKS("bn_fwd")
     hipStream_t st = (hipStream_t)stream;
-    ScProfScope prof("bn_fwd(stats+finalize+apply)", st, 0, (ext_partial ? 8.0 : 12.0) * M * C);
+    ScProfScope prof("bn_fwd(stats+finalize+apply)", st, 0,
+                     ((ext_partial ? 0.0 : 4.0) + ((io & SC_IO_X_BF16) ? 2.0 : 4.0) + ((io & SC_IO_Y_BF16) ? 2.0 : 4.0)) * M * C);
     const double* part = (const double*)ws;
     int nparts = nb;
     if (training && ext_partial) { part = ext_partial; nparts = ext_rows; }     // statistics came from the conv epilogue
     else if (training)
-        hipLaunchKernelGGL(colsum_partial_kernel<0>, pgrid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, (double*)ws, g);
+        hipLaunchKernelGGL(colsum_partial_kernel<0>, pgrid, dim3(256), 0, st, (const float*)x, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, (double*)ws, g);
     if (fin_narrow(C, nparts))
         hipLaunchKernelGGL(bn_stats_finalize_kernel<1>, dim3(C), dim3(256), 0, st, part, nparts, M, C, gamma, beta,
                            running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out, shift_out);
@@ -702,11 +711,35 @@ extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residua
         hipLaunchKernelGGL(bn_stats_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, part, nparts, M, C, gamma, beta,
                            running_mean, running_var, momentum, eps, training, mean_out, rstd_out, scale_out, shift_out);
     const long n4 = M * C / 4;
-    if (y || planes_out)       // neither: the consumer applies (x - mean) * scale + shift itself (fused split attention)
-        hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, scale_out,
-                               shift_out, residual, y, relu_mask_out, n4, C, relu, (unsigned short*)planes_out, nplanes,
-                               residual_bn_saved);
+    if (y || planes_out) {     // neither: the consumer applies (x - mean) * scale + shift itself (fused split attention)
+#define SSA(XB_, YB_, RB_)                                                                                            \
+        hipLaunchKernelGGL((scale_shift_act_kernel<XB_, YB_, RB_>), dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, \
+                           scale_out, shift_out, residual, y, relu_mask_out, n4, C, relu, (unsigned short*)planes_out, \
+                           nplanes, residual_bn_saved)
+        switch (io & 7) {
+            case 0: SSA(false, false, false); break;
+            case 1: SSA(true, false, false); break;
+            case 2: SSA(false, true, false); break;
+            case 3: SSA(true, true, false); break;
+            case 4: SSA(false, false, true); break;
+            case 5: SSA(true, false, true); break;
+            case 6: SSA(false, true, true); break;
+            default: SSA(true, true, true); break;
+        }
+#undef SSA
+    }
     return sc_check_launch("bn_fwd");
+}
+
+extern "C" int scouter_bn_fwd_f32(const float* x, float* y, const float* residual, long M, int C, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum,
+                                  float eps, int training, int relu, float* mean_out, float* rstd_out,
+                                  float* scale_out, float* shift_out, const double* ext_partial, int ext_rows,
+                                  unsigned long long* relu_mask_out, void* planes_out, int nplanes,
+                                  const float* residual_bn_saved, void* ws, size_t ws_bytes, void* stream) {
+    return scouter_bn_fwd_io(x, y, residual, M, C, gamma, beta, running_mean, running_var, momentum, eps, training, relu,
+                             mean_out, rstd_out, scale_out, shift_out, ext_partial, ext_rows, relu_mask_out, planes_out,
+                             nplanes, residual_bn_saved, 0, ws, ws_bytes, stream);
 }
 
 // the apply pass alone: y = [relu]((x - mean) * scale + shift) from a saved [4][C] block (mean, rstd, scale, shift)
@@ -714,16 +747,20 @@ extern "C" int scouter_bn_apply_f32(const float* x, const float* bn_saved, float
                                     void* stream) {
     SC_REQUIRE(x && bn_saved && y && M > 0 && C > 0 && C % 4 == 0, "bn_apply: bad arguments");
     const long n4 = M * C / 4;
-    hipLaunchKernelGGL(scale_shift_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, bn_saved,
-                       bn_saved + 2 * C, bn_saved + 3 * C, nullptr, y, nullptr, n4, C, relu, nullptr, 0, nullptr);
+    hipLaunchKernelGGL((scale_shift_act_kernel<false, false, false>), dim3(ew_blocks(n4)), dim3(256), 0,
+                       (hipStream_t)stream, x, bn_saved, bn_saved + 2 * C, bn_saved + 3 * C, nullptr, y, nullptr, n4, C,
+                       relu, nullptr, 0, nullptr);
     return sc_check_launch("bn_apply");
 }
 
-extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean,
-                                  const float* rstd, const float* scale, const unsigned long long* relu_mask, long M,
-                                  int C, int training, float* dgamma, float* dbeta, float* dx, float* gout,
-                                  const double* ext_partial, int ext_rows, void* ws, size_t ws_bytes, void* stream) {
+// `io` & SC_IO_X_BF16: the BatchNorm input x is stored as bf16 (gradients stay fp32)
+extern "C" int scouter_bn_bwd_io(const float* dy, const float* ymask, const void* x, const float* mean,
+                                 const float* rstd, const float* scale, const unsigned long long* relu_mask, long M,
+                                 int C, int training, float* dgamma, float* dbeta, float* dx, float* gout,
+                                 const double* ext_partial, int ext_rows, int io, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(dy && x && mean && rstd && scale && dx, "bn_bwd: null pointer");
+    SC_REQUIRE((io & ~SC_IO_X_BF16) == 0, "bn_bwd: unsupported io bits %d (only the input x may be bf16)", io);
+    const bool xb = (io & SC_IO_X_BF16) != 0;
     SC_REQUIRE(!ext_partial || (ext_rows > 0 && !ymask && !relu_mask && !gout),
                "bn_bwd: with ext_partial dy is the already masked gradient (no ymask / relu_mask / gout)");
     COL_CHECKS("bn_bwd")
@@ -737,32 +774,47 @@ extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const flo
     hipStream_t st = (hipStream_t)stream;
     ScProfScope prof(ext_partial ? "bn_bwd(finalize+apply)" : "bn_bwd(reduce+finalize+apply)", st, 0,
                      ((ext_partial ? 12.0 : (ymask && !relu_mask ? 28.0 : 20.0)) + (gout ? 4.0 : 0.0) +
-                      (relu_mask ? 0.25 : 0.0)) * M * C);
-    if (!ext_partial && M <= (long)g.rpb * 24) {                 // few row passes: everything in one launch
+                      (relu_mask ? 0.25 : 0.0) - (xb ? (ext_partial ? 2.0 : 4.0) : 0.0)) * M * C);
+    if (!ext_partial && M <= (long)g.rpb * 24 && !xb) {          // few row passes: everything in one launch
         // 16-channel slabs (4 threads per row, 64 rows per pass) when the channel count allows: C / 16 workgroups with one or
         // two passes each instead of ONE workgroup walking up to 24 dependent passes (14 us on every block's critical path)
         ColGeom gs = g;
         int slabs = pgrid.y;
         if (C % 16 == 0 && C >= 32) { gs.cslab = 16; gs.tpr = 4; gs.rpb = 64; slabs = C / 16; }
-        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, slabs), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale,
+        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, slabs), dim3(256), 0, st, dy, ymask, (const float*)x, mean, rstd, scale,
                            relu_mask, training, dgamma, dbeta, dx, gout, gs);
         return sc_check_launch("bn_bwd");
     }
     const double* part = (const double*)ws;
     int nparts = nb;
     if (ext_partial) { part = ext_partial; nparts = ext_rows; }   // reduced by the epilogue of the kernel that produced dy
+    else if (xb)
+        hipLaunchKernelGGL((colsum_partial_kernel<1, true>), pgrid, dim3(256), 0, st, dy, ymask, (const float*)x, mean, rstd,
+                           relu_mask, (double*)ws, g);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, x, mean, rstd, relu_mask,
-                           (double*)ws, g);
+        hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, (const float*)x, mean, rstd,
+                           relu_mask, (double*)ws, g);
     if (fin_narrow(C, nparts))
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<1>, dim3(C), dim3(256), 0, st, part, nparts, M, C, training, dgamma, dbeta, c1, c2);
     else
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, part, nparts, M, C, training, dgamma,
                            dbeta, c1, c2);
     const long n4 = M * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale, c1,
-                       c2, relu_mask, dx, gout, n4, C);
+    if (xb)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale,
+                           c1, c2, relu_mask, dx, gout, n4, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale,
+                           c1, c2, relu_mask, dx, gout, n4, C);
     return sc_check_launch("bn_bwd");
+}
+
+extern "C" int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, const float* mean,
+                                  const float* rstd, const float* scale, const unsigned long long* relu_mask, long M,
+                                  int C, int training, float* dgamma, float* dbeta, float* dx, float* gout,
+                                  const double* ext_partial, int ext_rows, void* ws, size_t ws_bytes, void* stream) {
+    return scouter_bn_bwd_io(dy, ymask, x, mean, rstd, scale, relu_mask, M, C, training, dgamma, dbeta, dx, gout,
+                             ext_partial, ext_rows, 0, ws, ws_bytes, stream);
 }
 
 // ---- split attention fused with its BatchNorm (bn0), backward (timm/models/layers/split_attn.py:62-80 + bn0/act0).
@@ -1017,11 +1069,19 @@ extern "C" int scouter_maxpool_bwd_f32(const float* dy, const unsigned char* arg
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)B * H * W * C / 4)), dim3(256), 0, st, dy, argmax, dx, g);
     return sc_check_launch("maxpool_bwd");
 }
+// `io` & SC_IO_X_BF16: x is stored as bf16 (the pooled tensor is always fp32)
+extern "C" int scouter_avgpool_fwd_io(const void* x, float* y, int B, int H, int W, int C, int k, int stride, int pad,
+                                      int ceil_mode, int count_include_pad, int io, void* stream) {
+    POOL_SETUP("avgpool_fwd")
+    SC_REQUIRE((io & ~SC_IO_X_BF16) == 0, "avgpool_fwd: unsupported io bits %d (only the input may be bf16)", io);
+    const dim3 grid(ew_blocks((long)B * g.Ho * g.Wo * C / 4));
+    if (io & SC_IO_X_BF16) hipLaunchKernelGGL(avgpool_fwd_kernel<true>, grid, dim3(256), 0, st, x, y, g);
+    else hipLaunchKernelGGL(avgpool_fwd_kernel<false>, grid, dim3(256), 0, st, x, y, g);
+    return sc_check_launch("avgpool_fwd");
+}
 extern "C" int scouter_avgpool_fwd_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride, int pad,
                                        int ceil_mode, int count_include_pad, void* stream) {
-    POOL_SETUP("avgpool_fwd")
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_blocks((long)B * g.Ho * g.Wo * C / 4)), dim3(256), 0, st, x, y, g);
-    return sc_check_launch("avgpool_fwd");
+    return scouter_avgpool_fwd_io(x, y, B, H, W, C, k, stride, pad, ceil_mode, count_include_pad, 0, stream);
 }
 extern "C" int scouter_avgpool_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, int k, int stride,
                                        int pad, int ceil_mode, int count_include_pad, void* stream) {

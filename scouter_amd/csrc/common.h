@@ -93,6 +93,50 @@ __device__ __forceinline__ void store_planes4(unsigned short* __restrict__ plane
     }
 }
 
+// ---- activation storage type (round 4: --precision bf16 keeps the 4g-wide tensors of a bottleneck -- conv3 / downsample
+// outputs and the block outputs -- as bf16 in HBM).  The kernels that touch them take an `io` bit set next to untyped
+// pointers; values are widened / RNE-rounded (v_cvt_pk_bf16_f32) at the load / store, all arithmetic stays fp32.
+#define SC_IO_X_BF16 1       // the main input (x / src)
+#define SC_IO_Y_BF16 2       // the output (y / dst)
+#define SC_IO_R_BF16 4       // the residual / second input
+typedef __bf16 sc_bf16x4 __attribute__((ext_vector_type(4)));
+template <bool BF>
+__device__ __forceinline__ f32x4 sc_load4(const void* __restrict__ p, long elem) {
+    if constexpr (BF) {
+        const sc_bf16x4 h = *(const sc_bf16x4*)((const __bf16*)p + elem);
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else {
+        return *(const f32x4*)((const float*)p + elem);
+    }
+}
+template <bool BF>
+__device__ __forceinline__ f32x4 sc_load4_nt(const void* __restrict__ p, long elem) {       // streamed once: non-temporal
+    if constexpr (BF) {
+        const sc_bf16x4 h = __builtin_nontemporal_load((const sc_bf16x4*)((const __bf16*)p + elem));
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else {
+        return __builtin_nontemporal_load((const f32x4*)((const float*)p + elem));
+    }
+}
+template <bool BF>
+__device__ __forceinline__ void sc_store4(void* __restrict__ p, long elem, f32x4 v) {
+    if constexpr (BF) {
+        sc_bf16x4 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[k] = (__bf16)v[k];
+        *(sc_bf16x4*)((__bf16*)p + elem) = h;
+    } else {
+        *(f32x4*)((float*)p + elem) = v;
+    }
+}
+// run-time flag variants for epilogues (a wave-uniform branch per access)
+__device__ __forceinline__ f32x4 sc_load4_rt(const void* __restrict__ p, long elem, bool bf) {
+    return bf ? sc_load4<true>(p, elem) : sc_load4<false>(p, elem);
+}
+__device__ __forceinline__ void sc_store4_rt(void* __restrict__ p, long elem, f32x4 v, bool bf) {
+    if (bf) sc_store4<true>(p, elem, v); else sc_store4<false>(p, elem, v);
+}
+
 // BatchNorm apply, one expression for EVERY kernel that evaluates it (apply pass, fused split-attention passes and
 // their backward): (x - mean) * scale + shift as an explicit fma, so the ReLU sign of an element is the same bit
 // wherever it is recomputed.

@@ -35,18 +35,24 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
 // forward / dgrad.  Block = 4 waves, tile BM x BN x KT (KT = 64, or 32 for 32-channel groups), 2 LDS stages,
 // LDS rows of KT+8 bf16 (16-byte aligned, conflict-free 16-byte fragment reads).
 // ----------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int KT_, bool DGRAD>
-__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restrict__ src, const void* __restrict__ wgt,
+// A_BF16: the A operand (the forward's input activation) is STORED as bf16 (round 4, activation storage): 16-byte loads
+// carry eight k-values straight into LDS, no conversion.  dst_bf16 (run time): the output tensor is stored as bf16 -- the
+// fused BatchNorm statistics still come from the fp32 accumulators.
+template <int BM, int BN, int WM, int WN, int KT_, bool DGRAD, bool A_BF16 = false>
+__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const void* __restrict__ src, const void* __restrict__ wgt,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ addend, float* __restrict__ dst,
                                                             double* __restrict__ bn_part, ConvGeom g, int relu,
-                                                            int mtiles, int ntiles, BnBwdFuse fz) {
+                                                            int mtiles, int ntiles, BnBwdFuse fz, int dst_bf16) {
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     constexpr int LDH = KT_ + 8;                          // LDS row stride in bf16
     constexpr int A_H = BM * LDH, B_H = BN * LDH, STAGE_H = A_H + B_H;
     constexpr int TPR = KT_ / 4;                          // threads per operand row when loading fp32 float4 along k
     constexpr int RPI = 256 / TPR;                        // rows per load instruction
-    constexpr int AI = BM / RPI, BI = BN / RPI;
+    constexpr int AEL = A_BF16 ? 8 : 4, AES = A_BF16 ? 2 : 4;   // A: elements per 16-byte load, bytes per element
+    constexpr int ATPR = KT_ / AEL, ARPI = 256 / ATPR;    // A: threads per row, rows per load instruction
+    constexpr int AI = (BM + ARPI - 1) / ARPI, BI = BN / RPI;
+    static_assert(!(A_BF16 && DGRAD), "bf16-stored A operands: forward only (gradients are stored as fp32)");
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
     extern __shared__ __attribute__((aligned(16))) __bf16 ldsh[];      // max(2 stages, epilogue staging) bytes
 
@@ -69,12 +75,12 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restr
     const int blk_rem = (int)((unsigned)m0 - (unsigned)blk_b * (unsigned)hw);
     const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
     const int rows_valid = (int)(g.M - m0 < BM ? g.M - m0 : BM);
-    const int a_col = (tid % TPR) * 4;
+    const int a_col = (tid % ATPR) * AEL;
     unsigned a_mask[AI], a_voff[AI], a_veff[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int rowoff = tid / TPR + RPI * i;
-        const bool okm = rowoff < rows_valid;
+        const int rowoff = tid / ATPR + ARPI * i;
+        const bool okm = rowoff < rows_valid && rowoff < BM;
         const int tx = blk_x + rowoff, qx = fast_div(tx, g.inv_wo), x = tx - qx * g.Wo;
         const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho), y = ty - qy * g.Ho;
         const int ay = DGRAD ? y + g.pad : y * g.stride - g.pad, ax = DGRAD ? x + g.pad : x * g.stride - g.pad;
@@ -84,13 +90,13 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restr
         a_mask[i] = okm ? mask : 0u;
         const int rel = okm ? qy * g.H * g.W : 0;
         const int e = DGRAD ? (rel + ay * g.W + ax) * g.C : (rel + (ay + g.pad) * g.W + (ax + g.pad)) * g.C;
-        a_voff[i] = (unsigned)(e + grp * g.Cg + a_col) * 4u;
+        a_voff[i] = (unsigned)(e + grp * g.Cg + a_col) * (unsigned)AES;
         a_veff[i] = OOB;
     }
     const long img_elems = (long)g.H * g.W * g.C;
     const long shift = DGRAD ? ((long)(g.R - 1) * g.W + (g.S - 1)) * g.C : ((long)g.pad * g.W + g.pad) * g.C;
-    const __amdgpu_buffer_rsrc_t rs_a =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)blk_b * img_elems - shift), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)src + ((long)blk_b * img_elems - shift) * AES), 0, 0x7fffffff, 0x00020000);
     // ---- B rows (n = output column of the GEMM, k contiguous)
     //   fwd  : bf16 W^T [tap][co][Cg]      : 8 bf16 (16 B) per load, KT/8 threads per row
     //   dgrad: fp32 W   [tap][ci][Cout]    : rows n = ci, k = co within the group, float4 per load
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < AI; ++i) a_veff[i] = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB;
         }
-        const int soff = (int)((DGRAD ? shift + toff : toff) * 4);
+        const int soff = (int)((DGRAD ? shift + toff : toff) * AES);
 #pragma unroll
         for (int i = 0; i < AI; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_veff[i], soff, 0));
@@ -137,7 +143,11 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restr
     auto store_a = [&](int buf) {
         __bf16* As = ldsh + buf * STAGE_H;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) *(bf16x4*)(As + (tid / TPR + RPI * i) * LDH + a_col) = to_bf16x4(ra[i]);
+        for (int i = 0; i < AI; ++i) {
+            if (BM % ARPI != 0 && tid / ATPR + ARPI * i >= BM) continue;      // (tiles shorter than one load instruction)
+            if constexpr (A_BF16) *(bf16x8*)(As + (tid / ATPR + ARPI * i) * LDH + a_col) = __builtin_bit_cast(bf16x8, ra[i]);
+            else *(bf16x4*)(As + (tid / ATPR + ARPI * i) * LDH + a_col) = to_bf16x4(ra[i]);
+        }
     };
     auto store_b = [&](int buf) {
         __bf16* Bs = ldsh + buf * STAGE_H + A_H;
@@ -198,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const float* __restr
         tile(kt, P0{});
         if (kt + 1 < KT) tile(kt + 1, P1{});
     }
-    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)ldsh, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
+    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)ldsh, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz,
+                                          nullptr, dst_bf16 != 0);
 }
 
 // W (HWIO fp32 [taps][Cin/groups][Cout]) -> bf16 W^T [taps][Cout][Cin/groups]
@@ -213,8 +224,8 @@ __global__ __launch_bounds__(256) void weight_bf16t_kernel(const float* __restri
 }
 
 template <int BM, int BN, int WM, int WN, bool DGRAD>
-static void launch_bf16(const float* src, const void* w, const float* bias, const float* addend, float* dst,
-                        double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz) {
+static void launch_bf16(const void* src, const void* w, const float* bias, const float* addend, float* dst,
+                        double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz, int io) {
     const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
     dim3 grid(mtiles * ntiles * g.groups);
     ConvGeom gg = g;
@@ -226,22 +237,30 @@ static void launch_bf16(const float* src, const void* w, const float* bias, cons
         size_t lds = (size_t)2 * (BM + BN) * (kt + 8) * 2;
         if (lds < epi) lds = epi;
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, src, w, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, src, w, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz,
+                           (io & SC_IO_Y_BF16) ? 1 : 0);
     };
+    if constexpr (!DGRAD) {
+        if (io & SC_IO_X_BF16) {
+            if (g.Cg % 64 == 0) go(igemm_bf16_kernel<BM, BN, WM, WN, 64, false, true>, 64);
+            else go(igemm_bf16_kernel<BM, BN, WM, WN, 32, false, true>, 32);
+            return;
+        }
+    }
     if (g.Cg % 64 == 0) go(igemm_bf16_kernel<BM, BN, WM, WN, 64, DGRAD>, 64);
     else go(igemm_bf16_kernel<BM, BN, WM, WN, 32, DGRAD>, 32);
 }
 template <bool DGRAD>
-static int dispatch_bf16(const float* src, const void* w, const float* bias, const float* addend, float* dst,
+static int dispatch_bf16(const void* src, const void* w, const float* bias, const float* addend, float* dst,
                          double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st,
-                         const BnBwdFuse& fz = BnBwdFuse{}) {
+                         const BnBwdFuse& fz = BnBwdFuse{}, int io = 0) {
     SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 28),
                    "conv2d_bf16: more than 2^31 output pixels or an image above 2^28 elements is not supported");
     switch (tile) {
-        case 0: launch_bf16<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
-        case 1: launch_bf16<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
-        case 2: launch_bf16<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
-        default: launch_bf16<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 0: launch_bf16<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
+        case 1: launch_bf16<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
+        case 2: launch_bf16<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
+        default: launch_bf16<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
     }
     return sc_check_launch(DGRAD ? "conv2d_dgrad_bf16" : "conv2d_fwd_bf16");
 }
@@ -266,10 +285,14 @@ extern "C" int scouter_conv2d_weight_bf16t(const float* w, void* wt, int kh, int
     return sc_check_launch("conv2d_weight_bf16t");
 }
 
-extern "C" int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, const float* bias, const float* addend,
-                                       float* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh,
-                                       int kw, int stride, int pad, int groups, int relu, int tile_hint, void* stream) {
+// `io`: SC_IO_X_BF16 -- x is stored as bf16 (the values the kernel would round to anyway: same result, half the bytes);
+// SC_IO_Y_BF16 -- y is stored as bf16 (RNE of the fp32 result; bn_partial still sums the fp32 accumulators)
+extern "C" int scouter_conv2d_fwd_bf16_io(const void* x, const void* wt_bf16, const float* bias, const float* addend,
+                                          void* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh,
+                                          int kw, int stride, int pad, int groups, int relu, int tile_hint, int io,
+                                          void* stream) {
     SC_REQUIRE(x && wt_bf16 && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_bf16: null pointer or empty shape");
+    SC_REQUIRE((io & ~(SC_IO_X_BF16 | SC_IO_Y_BF16)) == 0, "conv2d_fwd_bf16: unknown io bits %d", io);
     SC_REQUIRE(!(bn_partial && relu), "conv2d_fwd_bf16: fused BatchNorm statistics are taken before any activation");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_fwd_bf16: channels not divisible by groups");
     const int Cg = Cin / groups, Ng = Cout / groups;
@@ -280,16 +303,25 @@ extern "C" int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, cons
     static const char* names[4] = {"igemm_fwd_bf16<128x128>", "igemm_fwd_bf16<128x64>", "igemm_fwd_bf16<64x64>", "igemm_fwd_bf16<128x32>"};
     const int tile = bf16_tile(g, tile_hint);
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
-                     4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
-    return dispatch_bf16<false>(x, wt_bf16, bias, addend, y, bn_partial, g, relu, tile, (hipStream_t)stream);
+                     ((io & SC_IO_X_BF16) ? 2.0 : 4.0) * B * H * W * Cin + ((io & SC_IO_Y_BF16) ? 2.0 : 4.0) * g.M * Cout);
+    return dispatch_bf16<false>(x, wt_bf16, bias, addend, (float*)y, bn_partial, g, relu, tile, (hipStream_t)stream,
+                                BnBwdFuse{}, io);
+}
+extern "C" int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, const float* bias, const float* addend,
+                                       float* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh,
+                                       int kw, int stride, int pad, int groups, int relu, int tile_hint, void* stream) {
+    return scouter_conv2d_fwd_bf16_io(x, wt_bf16, bias, addend, y, bn_partial, B, H, W, Cin, Cout, kh, kw, stride, pad,
+                                      groups, relu, tile_hint, 0, stream);
 }
 
-extern "C" int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, const float* addend, float* dx, int B,
-                                               int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
-                                               int groups, int tile_hint, const void* relu_mask, const float* x1,
-                                               const float* saved1, double* part1, const float* x2,
-                                               const float* saved2, double* part2, void* stream) {
+// `x_io`: bit 0 -- x1 is stored as bf16, bit 1 -- x2 is (the BatchNorm inputs the epilogue reads; gradients are fp32)
+extern "C" int scouter_conv2d_dgrad_bnbwd_bf16_io(const float* dy, const float* w, const float* addend, float* dx, int B,
+                                                  int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                                  int groups, int tile_hint, const void* relu_mask, const void* x1,
+                                                  const float* saved1, double* part1, const void* x2,
+                                                  const float* saved2, double* part2, int x_io, void* stream) {
     SC_REQUIRE(dy && w && dx && B > 0, "conv2d_dgrad_bf16: null pointer or empty shape");
+    SC_REQUIRE((x_io & ~3) == 0, "conv2d_dgrad_bf16: unknown x_io bits %d", x_io);
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad_bf16: channels not divisible by groups");
     SC_REQUIRE(!part1 || (x1 && saved1), "conv2d_dgrad_bf16: fused BatchNorm backward needs x1 and saved1");
     SC_REQUIRE(!part2 || (part1 && x2 && saved2), "conv2d_dgrad_bf16: second fused BatchNorm needs the first, x2 and saved2");
@@ -303,8 +335,17 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, 
     const int tile = bf16_tile(g, tile_hint);
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw,
                      4.0 * ((double)B * Ho * Wo * Cout + (double)g.M * Cin));
-    const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, x1, saved1, part1, x2, saved2, part2};
+    const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, (const float*)x1, saved1, part1,
+                       (const float*)x2, saved2, part2, x_io};
     return dispatch_bf16<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream, fz);
+}
+extern "C" int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, const float* addend, float* dx, int B,
+                                               int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                               int groups, int tile_hint, const void* relu_mask, const float* x1,
+                                               const float* saved1, double* part1, const float* x2,
+                                               const float* saved2, double* part2, void* stream) {
+    return scouter_conv2d_dgrad_bnbwd_bf16_io(dy, w, addend, dx, B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile_hint,
+                                              relu_mask, x1, saved1, part1, x2, saved2, part2, 0, stream);
 }
 
 extern "C" int scouter_conv2d_dgrad_bf16(const float* dy, const float* w, const float* addend, float* dx, int B, int H,

@@ -132,6 +132,7 @@ struct BnBwdFuse {
     const unsigned long long* mask;                        // may be NULL: no ReLU between the BatchNorm and the consumer
     const float* x1; const float* sv1; double* part1;      // BatchNorm input, saved [4][C] block, partial rows [mt][C][2]
     const float* x2; const float* sv2; double* part2;      // second BatchNorm (may be NULL)
+    int io;                                                // bit 0 / 1: x1 / x2 is STORED as bf16 (bf16-input kernels only)
 };
 
 // Operands of the fused BatchNorm-backward epilogue that do not depend on the GEMM (shortcut gradient, BatchNorm inputs):
@@ -173,7 +174,8 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
                                                const float* __restrict__ bias, const float* __restrict__ addend,
                                                float* __restrict__ dst, double* __restrict__ bn_part, int relu,
                                                long m0, int n0, int grp, int mt_id, const BnBwdFuse* fz = nullptr,
-                                               const EpiPre<(WM / (64 / (WN / 4)) <= 8 ? WM / (64 / (WN / 4)) : 1)>* pre = nullptr) {
+                                               const EpiPre<(WM / (64 / (WN / 4)) <= 8 ? WM / (64 / (WN / 4)) : 1)>* pre = nullptr,
+                                               bool dst_bf16 = false) {
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -257,12 +259,12 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
                 const long off = m * g.N + ncol;
                 if (fz->mask) relu_mask_apply(v, fz->mask, off >> 2);
                 f32x4 xa;
-                if constexpr (PREF) xa = pre->x1[rr]; else xa = *(const f32x4*)(fz->x1 + off);
+                if constexpr (PREF) xa = pre->x1[rr]; else xa = sc_load4_rt(fz->x1, off, (fz->io & 1) != 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * ((xa[e] - mu1[e]) * rs1[e]); }
                 if (bwd2) {
                     f32x4 xb;
-                    if constexpr (PREF) xb = pre->x2[rr]; else xb = *(const f32x4*)(fz->x2 + off);
+                    if constexpr (PREF) xb = pre->x2[rr]; else xb = sc_load4_rt(fz->x2, off, (fz->io & 2) != 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) cq2[e] += (double)v[e] * ((xb[e] - mu2[e]) * rs2[e]);
                 }
@@ -276,7 +278,7 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        *(f32x4*)(dst + m * g.N + ncol) = v;
+        sc_store4_rt(dst, m * g.N + ncol, v, dst_bf16);
     }
     if (bn_part) {
         // Fused batch statistics of the tile just written: lanes sharing a column quad (stride QPR) are combined by

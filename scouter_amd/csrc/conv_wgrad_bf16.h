@@ -10,8 +10,10 @@
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WM, int WN, int MODE>     // MODE 1: padded taps, 2: 1x1 (see wgrad_kernel)
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restrict__ act, const float* __restrict__ dy,
+// A_BF16: the activation X is STORED as bf16 (round 4): the same 4-pixel x 4-channel patches as four 8-byte loads, no
+// conversion -- the values are the ones the fp32 path rounds to.
+template <int BM, int BN, int WM, int WN, int MODE, bool A_BF16 = false>     // MODE 1: padded taps, 2: 1x1 (see wgrad_kernel)
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const void* __restrict__ act, const float* __restrict__ dy,
                                                             float* __restrict__ out, ConvGeom g, int ci_tiles,
                                                             int co_tiles, long pix_per_split, long slab, float* __restrict__ dw,
                                                             unsigned* __restrict__ arrival) {
@@ -20,6 +22,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     constexpr int A_H = BM * LDP, B_H = BN * LDP, STAGE_H = A_H + B_H;
     constexpr int AP = BM / 64, BP = BN / 64;              // (channel-quad, pixel-quad) patches per thread
+    constexpr int AES = A_BF16 ? 2 : 4;                    // bytes per stored activation element
     static_assert((BM / WM) * (BN / WN) == 4 && BM % 64 == 0 && BN % 64 == 0, "tile config");
     extern __shared__ __attribute__((aligned(16))) __bf16 ldsw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
     for (int i = 0; i < AP; ++i) {
         const int p = tid + 256 * i, cq = (p & 7) + 8 * (p >> 7), pq = (p >> 3) & 15;
         a_row[i] = 4 * cq; a_pq[i] = pq;
-        a_voff[i] = (unsigned)((4 * pq * (long)g.C + grp * g.Cg + ci0 + 4 * cq) * 4);
+        a_voff[i] = (unsigned)((4 * pq * (long)g.C + grp * g.Cg + ci0 + 4 * cq) * AES);
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
@@ -71,17 +74,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
     }
     // bytes the descriptor may touch from pixel `first`: up to this split's last pixel and (ragged tiles read one pixel
     // past a valid one) never beyond the tensor's last pixel
-    auto records = [&](long m_chunk, long first, int row_elems) {
+    auto records = [&](long m_chunk, long first, int row_elems, int es) {
         long px = mend - m_chunk;
         if (px > g.M - first) px = g.M - first;
-        const long n = px * (long)row_elems * 4;
+        const long n = px * (long)row_elems * es;
         return (unsigned)(n < 0 ? 0 : (n > 0x7fffffffL ? 0x7fffffffL : n));
     };
     f32x4 ra[AP][4], rb[BP][4];
+    wg_bf16x4 rah[AP][4];                                  // (A_BF16: the patches arrive as bf16)
     long a_m = mbeg, b_m = mbeg;
     auto load_a = [&]() {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(act + (a_m + tapoff) * g.C), 0,
-                                                                            records(a_m, a_m + tapoff, g.C), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)act + (a_m + tapoff) * g.C * AES), 0, records(a_m, a_m + tapoff, g.C, AES), 0x00020000);
         unsigned long long vmask = ~0ull;
         if (MODE == 1) {
             const int iy = qy1 - g.pad + r, ix = qx1 - g.pad + q;
@@ -96,15 +100,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
         for (int i = 0; i < AP; ++i)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                unsigned vo = a_voff[i] + (unsigned)(rr * g.C * 4);
+                unsigned vo = a_voff[i] + (unsigned)(rr * g.C * AES);
                 if (MODE == 1) vo = ((vmask >> (4 * a_pq[i] + rr)) & 1ull) ? vo : OOB;
-                ra[i][rr] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+                if constexpr (A_BF16) rah[i][rr] = __builtin_bit_cast(wg_bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 0, 0));
+                else ra[i][rr] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
             }
         a_m += KP;
     };
     auto load_b = [&]() {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + b_m * g.N), 0,
-                                                                            records(b_m, b_m, g.N), 0x00020000);
+                                                                            records(b_m, b_m, g.N, 4), 0x00020000);
 #pragma unroll
         for (int i = 0; i < BP; ++i)
 #pragma unroll
@@ -122,11 +127,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const float* __restr
             *(wg_bf16x4*)(T + (row + e) * LDP + 4 * pq) = o;
         }
     };
+    auto store_th = [&](__bf16* T, const wg_bf16x4 (&v)[4], int row, int pq) {  // the same transpose of bf16 patches
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            wg_bf16x4 o;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) o[rr] = v[rr][e];
+            *(wg_bf16x4*)(T + (row + e) * LDP + 4 * pq) = o;
+        }
+    };
     auto store_ab = [&](int buf) {
         __bf16* As = ldsw + buf * STAGE_H;
         __bf16* Bs = As + A_H;
 #pragma unroll
-        for (int i = 0; i < AP; ++i) store_t(As, ra[i], a_row[i], a_pq[i]);
+        for (int i = 0; i < AP; ++i) {
+            if constexpr (A_BF16) store_th(As, rah[i], a_row[i], a_pq[i]);
+            else store_t(As, ra[i], a_row[i], a_pq[i]);
+        }
 #pragma unroll
         for (int i = 0; i < BP; ++i) store_t(Bs, rb[i], b_row[i], b_pq[i]);
     };

@@ -11,6 +11,9 @@ import torch
 from . import _native
 
 F32 = torch.float32
+BF16 = torch.bfloat16
+# storage-type bits of the typed entry points (include/scouter_hip.h SCOUTER_IO_*)
+IO_X_BF16, IO_Y_BF16, IO_R_BF16 = 1, 2, 4
 _ws = {}
 
 
@@ -26,12 +29,13 @@ def _stream():
 
 
 def _chk(t, name, dtype=F32):
+    """dtype: the storage type the callee accepts, or a tuple of them (typed-storage entry points)."""
     if t is None:
         return
     if not t.is_cuda:
         raise RuntimeError("scouter_amd: %s is on %s -- the xSlot path runs on a HIP device only (no CPU fallback)"
                            % (name, t.device))
-    if t.dtype != dtype:
+    if t.dtype != dtype and not (isinstance(dtype, tuple) and t.dtype in dtype):
         raise RuntimeError("scouter_amd: %s must be %s (got %s)" % (name, dtype, t.dtype))
     if not t.is_contiguous():
         raise RuntimeError("scouter_amd: %s must be contiguous" % name)
@@ -259,7 +263,7 @@ class BnBwdFuse:
     def alloc(self, rows, x_shape):
         for x, saved in self.entries:
             assert tuple(x.shape) == tuple(x_shape), (tuple(x.shape), tuple(x_shape))
-            _chk(x, "BatchNorm input"); _chk(saved, "BatchNorm saved block")
+            _chk(x, "BatchNorm input", (F32, BF16)); _chk(saved, "BatchNorm saved block")
         C = x_shape[-1]
         self.rows = rows
         self.parts = [torch.empty((rows, C, 2), dtype=torch.float64, device=self.entries[0][0].device)
@@ -271,6 +275,10 @@ class BnBwdFuse:
         x2, s2 = self.entries[1] if len(self.entries) > 1 else (None, None)
         return (_p(self.mask), _p(x1), _p(s1), _p(self.parts[0]), _p(x2), _p(s2),
                 _p(self.parts[1]) if len(self.entries) > 1 else None)
+
+    def x_io(self):
+        """bit i: the BatchNorm input of entry i is STORED as bf16 (only the bf16-input kernels' epilogue reads those)"""
+        return sum(1 << i for i, (x, _) in enumerate(self.entries) if x.dtype == BF16)
 
 
 _NO_FUSE = (None,) * 7
@@ -303,18 +311,26 @@ def _pw_persist_legal(M, K_, N_, kh, kw, stride, pad, groups, plain):
 
 
 def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, relu=False, bn_stats=False,
-               precision="fp32"):
+               precision="fp32", out_dtype=F32):
     """bn_stats=True: the epilogue also produces the per-tile fp64 channel sums BatchNorm needs; returns
-    (y, (partial, rows)) and `bn_fwd(..., stats=(partial, rows))` then skips its own statistics pass."""
-    _chk(x, "x"); _chk(w_hwio, "weight"); _chk(bias, "bias"); _chk(addend, "addend")
+    (y, (partial, rows)) and `bn_fwd(..., stats=(partial, rows))` then skips its own statistics pass.
+    Activation storage (precision "bf16" only, layers the bf16 kernel runs): x may be a bfloat16 tensor -- the values the
+    kernel rounds an fp32 input to, so the product is the same bits -- and out_dtype=torch.bfloat16 stores y rounded (the
+    statistics still come from the fp32 accumulators)."""
+    _chk(x, "x", (F32, BF16)); _chk(w_hwio, "weight"); _chk(bias, "bias"); _chk(addend, "addend")
     B, H, W, Cin = x.shape
     kh, kw, cg, Cout = w_hwio.shape
     assert cg * groups == Cin, (x.shape, w_hwio.shape, groups)
-    y = torch.empty((B, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout), dtype=F32, device=x.device)
     L = _native.lib()
     st = _stream()
 
-    bf16 = precision == "bf16" and y.numel() // Cout >= BF16_MIN_PIXELS
+    Ho, Wo = conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad)
+    bf16 = precision == "bf16" and B * Ho * Wo >= BF16_MIN_PIXELS
+    if (x.dtype != F32 or out_dtype != F32) and not bf16:
+        raise RuntimeError("scouter_amd: bf16-stored activations are an option of the bf16-input kernels (precision "
+                           "'bf16', >= %d output pixels); got precision %r, %d pixels" % (BF16_MIN_PIXELS, precision, B * Ho * Wo))
+    y = torch.empty((B, Ho, Wo, Cout), dtype=out_dtype, device=x.device)
+    io = (IO_X_BF16 if x.dtype == BF16 else 0) | (IO_Y_BF16 if out_dtype == BF16 else 0)
     wt = None
     if bf16:                      # W^T as bf16 [taps][Cout][Cin/groups], rebuilt per call (weights change every step)
         wt = torch.empty((kh * kw, Cout, cg), dtype=torch.bfloat16, device=x.device)
@@ -327,8 +343,8 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
                                                       bias is None and addend is None and not relu)
             return _tile_legal(Cout // groups, tile)
         if bf16:
-            _native.check(L.scouter_conv2d_fwd_bf16(_p(x), _p(wt), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
-                                                    Cout, kh, kw, stride, pad, groups, int(relu), tile, st),
+            _native.check(L.scouter_conv2d_fwd_bf16_io(_p(x), _p(wt), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
+                                                       Cout, kh, kw, stride, pad, groups, int(relu), tile, io, st),
                           "conv2d_fwd_bf16")
         else:
             _native.check(L.scouter_conv2d_fwd_f32(_p(x), _p(w_hwio), _p(bias), _p(addend), _p(y), _p(part), B, H, W,
@@ -336,6 +352,7 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
                           "conv2d_fwd")
         return True
 
+    # (typed storage shares the fp32-storage key: the table is tuned on that; half the bytes move no tile boundary far)
     tile = _pick_tile(("fwd", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, (0, 1, 2, 3, 4))
     if tile == 4 and not launch(4, dry=True):        # (the table's entry is for the plain epilogue; this call has bias / addend / ReLU)
         tile = -1
@@ -365,12 +382,19 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
             if tile == 4:        # (GEMM-K of the input gradient = Cout)
                 return not bf16 and _pw_persist_legal(B * H * W, Cout, Cin, kh, kw, stride, pad, groups, True)
             return _tile_legal(Cin // groups, tile)
-        fn = L.scouter_conv2d_dgrad_bnbwd_bf16 if bf16 else L.scouter_conv2d_dgrad_bnbwd_f32
-        _native.check(fn(_p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile,
-                         *fuse, st), "conv2d_dgrad")
+        if bf16:
+            _native.check(L.scouter_conv2d_dgrad_bnbwd_bf16_io(
+                _p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile, *fuse,
+                post.x_io() if fuse is not _NO_FUSE else 0, st), "conv2d_dgrad")
+        else:
+            _native.check(L.scouter_conv2d_dgrad_bnbwd_f32(
+                _p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile, *fuse, st),
+                "conv2d_dgrad")
         return True
 
-    if _fuse_wanted(post, kh):
+    # (BatchNorm inputs stored as bf16: only the bf16-input kernel's epilogue reads them; otherwise that BatchNorm's own
+    #  backward -- typed -- does the reduction)
+    if _fuse_wanted(post, kh) and (bf16 or post.x_io() == 0):
         # the fused launch is tuned as what it is (its epilogue reads one or two more tensors: on the short-K layers a
         # different tile wins than for the plain input gradient); partials sized for the most rows while timing
         def launch_fused(tile, dry=False):
@@ -392,7 +416,6 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
 
 
 # ---- convolution on pre-split bf16 operand planes (csrc/conv_planes.hip)
-BF16 = torch.bfloat16
 
 
 class PlaneTensor:
@@ -683,7 +706,7 @@ _PWGRAD_PLANS = _WGRAD_PLANS + ((64, 65, 66, 67) if len(_WGRAD_PLANS) > 1 else (
 def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
     """Writes dW (HWIO, contiguous, e.g. a slice of the flat gradient arena).  The (tile, split-K) plan is autotuned
     once per layer shape and kept for the run (see _WGRAD_PLANS)."""
-    _chk(x, "x"); _chk(dy, "dy"); _chk(dw_hwio, "dw")
+    _chk(x, "x", (F32, BF16)); _chk(dy, "dy"); _chk(dw_hwio, "dw")
     B, H, W, Cin = x.shape
     kh, kw, cg, Cout = dw_hwio.shape
     L = _native.lib()
@@ -694,7 +717,9 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
     same = stride == 1 and dy.shape[1] == H and dy.shape[2] == W
     bf16 = (precision == "bf16" and same and cg % 32 == 0 and (Cout // groups) % 32 == 0 and
             B * H * W >= BF16_MIN_PIXELS and ((kh == 1 and kw == 1 and pad == 0) or 64 // W + 1 < H))
-    fn = L.scouter_conv2d_wgrad_bf16 if bf16 else L.scouter_conv2d_wgrad_f32
+    if x.dtype != F32 and not bf16:
+        raise RuntimeError("scouter_amd: a bf16-stored activation needs the bf16-input weight-gradient kernel "
+                           "(precision 'bf16', same-size stride-1 layer); got %s" % (tuple(x.shape),))
 
     def launch(plan, dry=False):
         if dry:
@@ -702,8 +727,12 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
         need = L.scouter_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, plan)
         ws = workspace(need, x.device)
         arr = arrival_counters(x.device)
-        _native.check(fn(_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, plan, _p(ws),
-                         ws.numel(), _p(arr), ARRIVAL_SLOTS if arr is not None else 0, st), "conv2d_wgrad")
+        args = (_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, plan, _p(ws), ws.numel(),
+                _p(arr), ARRIVAL_SLOTS if arr is not None else 0)
+        if bf16:
+            _native.check(L.scouter_conv2d_wgrad_bf16_io(*args, IO_X_BF16 if x.dtype == BF16 else 0, st), "conv2d_wgrad")
+        else:
+            _native.check(L.scouter_conv2d_wgrad_f32(*args, st), "conv2d_wgrad")
         return True
 
     launch(_pick_tile(("wgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, _WGRAD_PLANS))
@@ -745,16 +774,16 @@ def _col_ws(M, C, device):
 def bn_stats(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, stats=None):
     """Finalises the BatchNorm statistics only (running stats updated in training): returns saved = [4, C] (mean, rstd,
     scale, shift).  The consumer applies (x - mean) * scale + shift itself (fused split attention)."""
-    _chk(x, "x")
+    _chk(x, "x", (F32, BF16))      # (a bf16-stored x is never read: its statistics are `stats` / the running ones)
     C = x.shape[-1]
     M = x.numel() // C
     saved = torch.empty((4, C), dtype=F32, device=x.device)
     ws = _col_ws(M, C, x.device)
-    _native.check(_native.lib().scouter_bn_fwd_f32(
+    _native.check(_native.lib().scouter_bn_fwd_io(
         _p(x), None, None, M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
         int(training), 0, _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]),
-        _p(stats[0]) if stats else None, stats[1] if stats else 0, None, None, 0, None, _p(ws), ws.numel(),
-        _stream()), "bn_stats")
+        _p(stats[0]) if stats else None, stats[1] if stats else 0, None, None, 0, None,
+        IO_X_BF16 if x.dtype == BF16 else 0, _p(ws), ws.numel(), _stream()), "bn_stats")
     return saved
 
 
@@ -769,14 +798,17 @@ def bn_apply(x, saved, relu):
 
 
 def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=None, momentum=0.1, eps=1e-5,
-           stats=None, want_mask=False, planes=0, residual_bn=None, keep_f32=True):
+           stats=None, want_mask=False, planes=0, residual_bn=None, keep_f32=True, out_dtype=F32):
     """x: [..., C] NHWC.  Returns (y, saved) with saved = (mean, rstd, scale, shift) packed as one [4, C] tensor.
     stats = (partial, rows) from conv2d_fwd(bn_stats=True) replaces the statistics pass over x.
-    want_mask (with relu): returns (y, saved, mask) -- the 1-bit/element sign mask bn_bwd takes instead of y."""
-    _chk(x, "x"); _chk(residual, "residual")
+    want_mask (with relu): returns (y, saved, mask) -- the 1-bit/element sign mask bn_bwd takes instead of y.
+    x / residual may be bfloat16-stored tensors and out_dtype=torch.bfloat16 stores y rounded (activation storage)."""
+    _chk(x, "x", (F32, BF16)); _chk(residual, "residual", (F32, BF16))
     C = x.shape[-1]
     M = x.numel() // C
-    y = torch.empty_like(x) if keep_f32 or not planes else None      # keep_f32=False: planes only
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device) if keep_f32 or not planes else None   # keep_f32=False: planes only
+    io = ((IO_X_BF16 if x.dtype == BF16 else 0) | (IO_Y_BF16 if out_dtype == BF16 else 0) |
+          (IO_R_BF16 if residual is not None and residual.dtype == BF16 else 0))
     saved = torch.empty((4, C), dtype=F32, device=x.device)
     ws = _col_ws(M, C, x.device)
     mask = None
@@ -784,10 +816,10 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=N
         assert relu
         mask = torch.empty(_native.lib().scouter_relu_mask_words(x.numel()), dtype=torch.int64, device=x.device)
     yp = torch.empty((planes,) + tuple(x.shape), dtype=BF16, device=x.device) if planes else None
-    _native.check(_native.lib().scouter_bn_fwd_f32(
+    _native.check(_native.lib().scouter_bn_fwd_io(
         _p(x), _p(y), _p(residual), M, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps,
         int(training), int(relu), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(saved[3]),
-        _p(stats[0]) if stats else None, stats[1] if stats else 0, _p(mask), _p(yp), planes, _p(residual_bn), _p(ws),
+        _p(stats[0]) if stats else None, stats[1] if stats else 0, _p(mask), _p(yp), planes, _p(residual_bn), io, _p(ws),
         ws.numel(), _stream()), "bn_fwd")
     if planes:
         y = PlaneTensor(y, yp)
@@ -798,21 +830,22 @@ def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=Fal
     """ReLU sign from `mask` (bits written by bn_fwd(want_mask=True)) or from the activation `ymask`; both None: no ReLU.
     ext = (partial, rows) from a BnBwdFuse: dy is the already masked gradient, its sums are reduced -- no reduction
     pass, no mask, and the masked gradient `gout` is dy itself."""
-    _chk(dy, "dy"); _chk(ymask, "ymask"); _chk(x, "x")
+    _chk(dy, "dy"); _chk(ymask, "ymask"); _chk(x, "x", (F32, BF16))
     C = x.shape[-1]
     M = x.numel() // C
-    dx = torch.empty_like(x)
+    dx = torch.empty(x.shape, dtype=F32, device=x.device)          # (x may be bf16-stored; gradients are fp32)
     ws = _col_ws(M, C, x.device)
+    io = IO_X_BF16 if x.dtype == BF16 else 0
     if ext is not None:
         part, rows = ext
-        _native.check(_native.lib().scouter_bn_bwd_f32(
+        _native.check(_native.lib().scouter_bn_bwd_io(
             _p(dy), None, _p(x), _p(saved[0]), _p(saved[1]), _p(saved[2]), None, M, C, int(training), _p(dgamma),
-            _p(dbeta), _p(dx), None, _p(part), rows, _p(ws), ws.numel(), _stream()), "bn_bwd")
+            _p(dbeta), _p(dx), None, _p(part), rows, io, _p(ws), ws.numel(), _stream()), "bn_bwd")
         return dx, (dy if want_gout else None)
-    gout = torch.empty_like(x) if want_gout else None
-    _native.check(_native.lib().scouter_bn_bwd_f32(
+    gout = torch.empty(x.shape, dtype=F32, device=x.device) if want_gout else None
+    _native.check(_native.lib().scouter_bn_bwd_io(
         _p(dy), _p(ymask), _p(x), _p(saved[0]), _p(saved[1]), _p(saved[2]), _p(mask), M, C, int(training), _p(dgamma),
-        _p(dbeta), _p(dx), _p(gout), None, 0, _p(ws), ws.numel(), _stream()), "bn_bwd")
+        _p(dbeta), _p(dx), _p(gout), None, 0, io, _p(ws), ws.numel(), _stream()), "bn_bwd")
     return dx, gout
 
 
@@ -887,12 +920,14 @@ def bn_maxpool_bwd(dy, arg, x, saved, training, dgamma=None, dbeta=None, k=3, st
 
 
 def avgpool_fwd(x, k, stride, pad, ceil_mode, count_include_pad):
-    _chk(x, "x")
+    """x may be a bfloat16-stored activation; the pooled tensor is fp32."""
+    _chk(x, "x", (F32, BF16))
     B, H, W, C = x.shape
     y = torch.empty((B, pool_out(H, k, stride, pad, ceil_mode), pool_out(W, k, stride, pad, ceil_mode), C), dtype=F32,
                     device=x.device)
-    _native.check(_native.lib().scouter_avgpool_fwd_f32(_p(x), _p(y), B, H, W, C, k, stride, pad, int(ceil_mode),
-                                                        int(count_include_pad), _stream()), "avgpool_fwd")
+    _native.check(_native.lib().scouter_avgpool_fwd_io(_p(x), _p(y), B, H, W, C, k, stride, pad, int(ceil_mode),
+                                                       int(count_include_pad), IO_X_BF16 if x.dtype == BF16 else 0,
+                                                       _stream()), "avgpool_fwd")
     return y
 
 

@@ -74,9 +74,11 @@ class Conv2d(nn.Module):
         return bool(self.planes_in() and self.planes_dy() and cg % 64 == 0 and ng % 64 == 0
                     and 2 * self.padding == self.kernel_size - 1)
 
-    def fwd(self, x, save, relu=False, addend=None, bn_stats=False):
-        """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd."""
+    def fwd(self, x, save, relu=False, addend=None, bn_stats=False, out_dtype=None):
+        """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd.
+        out_dtype=torch.bfloat16: the output is STORED as bf16 (activation storage of the bf16 mode, kernels.conv2d_fwd)."""
         if isinstance(x, K.PlaneTensor):
+            assert out_dtype in (None, K.F32), "plane convolutions write fp32"
             k = self.kernel_size
             want_wd = save and self.planes_dy() > 0
             ws, self._wsplit = self._wsplit, None
@@ -91,7 +93,7 @@ class Conv2d(nn.Module):
             return y, ((x.f32 if x.f32 is not None else tuple(x.shape), wd,
                         x.planes if self.planes_wgrad() else None) if save else None)
         y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
-                         bn_stats, precision=self.precision)
+                         bn_stats, precision=self.precision, out_dtype=out_dtype or K.F32)
         if self._capture is not None and relu:
             self._capture[0][self._capture[1]] = y
         return y, (x if save else None)
@@ -190,8 +192,10 @@ class BatchNorm2d(nn.Module):
         self._dg = self._db = None
         self._capture = None                 # test instrumentation: (dict, key) -> the ReLU'd output is stored there
 
-    def fwd(self, x, save, relu=False, residual=None, tracked=None, planes=0, residual_bn=None, keep_f32=True):
-        """x may be the (tensor, stats) pair a conv produced with bn_stats=True.  planes = 1 / 3: the output is a
+    def fwd(self, x, save, relu=False, residual=None, tracked=None, planes=0, residual_bn=None, keep_f32=True,
+            out_dtype=None):
+        """x may be the (tensor, stats) pair a conv produced with bn_stats=True.  out_dtype=torch.bfloat16: the output is
+        stored as bf16 (x / residual may be bf16-stored too: kernels.bn_fwd).  planes = 1 / 3: the output is a
         K.PlaneTensor (fp32 + bf16 operand planes for the plane convolution that consumes it).  residual_bn: `residual`
         is the raw output of the downsample convolution and this the saved block of ITS BatchNorm (stats_only): both
         BatchNorms are applied in this one pass."""
@@ -203,7 +207,8 @@ class BatchNorm2d(nn.Module):
                              % (tuple(x.shape),))
         out = K.bn_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, relu,
                        residual, self.momentum, self.eps, stats if self.training else None,
-                       want_mask=bool(relu and save), planes=planes, residual_bn=residual_bn, keep_f32=keep_f32)
+                       want_mask=bool(relu and save), planes=planes, residual_bn=residual_bn, keep_f32=keep_f32,
+                       out_dtype=out_dtype or K.F32)
         if self.training and tracked is not None:
             tracked.append(self.num_batches_tracked)
         if self._capture is not None and relu:

@@ -18,6 +18,9 @@ from ..timm.models import create_model
 from .utils.position_encode import build_position_encoding
 from .utils.slot_attention import SlotAttention
 
+# bf16 activation storage under --precision bf16 (SlotModel.set_activation_storage); SCOUTER_BF16_STORAGE=0: fp32 storage
+BF16_STORAGE_DEFAULT = os.environ.get("SCOUTER_BF16_STORAGE", "1") != "0"
+
 
 class Identical(nn.Module):
     def forward(self, x):
@@ -105,6 +108,22 @@ class SlotModel(nn.Module):
         for mod in self.backbone.modules():
             if isinstance(mod, Conv2d):
                 mod.precision = precision
+        self.set_activation_storage("bf16" if precision == "bf16" and BF16_STORAGE_DEFAULT else "fp32")
+
+    def set_activation_storage(self, storage):
+        """"bf16" (the default under precision "bf16"; SCOUTER_BF16_STORAGE=0 turns it off): every ResNeSt bottleneck but
+        the last stores its 4x-wide tensors -- conv3 / downsample-convolution outputs and the block output -- as bf16 in
+        HBM (half the bytes of the passes that dominate BASELINE configs[4]); arithmetic and every gradient stay fp32.
+        The oracle emulates it with oracle.torch_oracle.ACTIVATION_STORAGE."""
+        if storage not in ("fp32", "bf16"):
+            raise ValueError("activation storage must be fp32 or bf16, got %r" % storage)
+        if storage == "bf16" and self.precision != "bf16":
+            raise ValueError("bf16 activation storage is an option of precision 'bf16'")
+        from ..timm.models.resnest import ResNestBottleneck
+        blocks = [m for m in self.backbone.modules() if isinstance(m, ResNestBottleneck)]
+        for i, blk in enumerate(blocks):
+            blk.store_bf16 = storage == "bf16" and i + 1 < len(blocks)
+        self.activation_storage = storage if blocks else "fp32"
 
     def set_planes(self, nplanes):
         """3 (default): the grouped 3x3 convolutions of the split-attention blocks run on the bf16 matrix cores over

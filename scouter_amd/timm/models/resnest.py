@@ -2,6 +2,7 @@
 Mirrors timm/models/resnest.py:58-143 and :161-189 of the reference."""
 import torch.nn as nn
 
+from ... import kernels as K
 from ...nn_hip import Act, BatchNorm2d, Conv2d
 from .layers.split_attn import SplitAttnConv2d
 from .resnet import AvgPool2dSpec, ResNet, BRANCH_FWD, BRANCH_BWD
@@ -25,14 +26,30 @@ class ResNestBottleneck(nn.Module):
         self.bn3 = BatchNorm2d(planes * 4)
         self.act3 = Act()
         self.downsample = downsample
+        # bf16 activation storage (SlotModel.set_precision("bf16"); never the network's last block, whose output feeds the
+        # fp32 head): conv3 / downsample outputs and the block output -- the 4x-wide tensors -- are stored as bf16
+        self.store_bf16 = False
+
+    def _storage(self, x):
+        """Storage type of this block's wide tensors for an input batch x: bf16 where the bf16-input kernels run
+        (their pixel-count rule), fp32 otherwise.  The next block's conv1 sees the same pixel count, so a bf16-stored
+        output is always read by a bf16-input kernel."""
+        if not (self.store_bf16 and self.conv3.precision == "bf16"):
+            return None
+        B, H, W, _ = x.shape
+        if self.avd_last is not None:
+            H, W = K.pool_out(H, 3, self.avd_last.s, 1), K.pool_out(W, 3, self.avd_last.s, 1)
+        return K.BF16 if B * H * W >= K.BF16_MIN_PIXELS else None
 
     def zero_init_last_bn(self):
         nn.init.zeros_(self.bn3.weight)
 
     def fwd(self, x, save, tracked):
         res, rbn, kd = (x, None, None)
+        odt = self._storage(x)
         if self.downsample is not None:       # (on its own stream next to the main branch, Downsample.fwd_async)
-            res, rbn, kd, hnd = self.downsample.fwd_async(x, save, tracked, BRANCH_FWD and self.conv1.use_side_stream)
+            res, rbn, kd, hnd = self.downsample.fwd_async(x, save, tracked, BRANCH_FWD and self.conv1.use_side_stream,
+                                                          out_dtype=odt)
         c1, k1 = self.conv1.fwd(x, save, bn_stats=self.bn1.training)
         t1 = c1[0] if isinstance(c1, tuple) else c1
         conv = self.conv2.conv                   # (all three of its kernels on planes: no fp32 copy of h1 is written)
@@ -40,10 +57,10 @@ class ResNestBottleneck(nn.Module):
                               keep_f32=not conv.planes_only(t1.shape[1], t1.shape[2]))
         sa, ksa = self.conv2.fwd(h1, save, tracked)
         p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
-        c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training)
+        c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training, out_dtype=odt)
         if self.downsample is not None:
             self.downsample.fwd_join(x.device, hnd)
-        out, b3 = self.bn3.fwd(c3, save, relu=True, residual=res, tracked=tracked, residual_bn=rbn)
+        out, b3 = self.bn3.fwd(c3, save, relu=True, residual=res, tracked=tracked, residual_bn=rbn, out_dtype=odt)
         return out, ((k1, b1, ksa, tuple(sa.shape), k3, b3, kd) if save else None)
 
     def out_fuse(self, ctx):

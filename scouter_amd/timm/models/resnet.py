@@ -36,17 +36,18 @@ class AvgPool2dSpec(nn.Module):
 class Downsample(nn.Sequential):
     """downsample_conv: [conv1x1(stride), bn]   downsample_avg: [pool | Identity, conv1x1, bn]"""
 
-    def fwd(self, x, save, tracked):
+    def fwd(self, x, save, tracked, out_dtype=None):
         """-> (raw convolution output, saved block of the BatchNorm, ctx): the BatchNorm itself is applied by the
         block's last BatchNorm pass together with its own (BatchNorm2d.fwd residual_bn) -- the normalised shortcut is
-        never stored.  ctx[1] has the layout of a BatchNorm2d context (x, mask = None, saved, training)."""
+        never stored.  ctx[1] has the layout of a BatchNorm2d context (x, mask = None, saved, training).
+        out_dtype: storage type of the raw output (bf16 activation storage, ResNestBottleneck.fwd)."""
         mods = list(self)
         pool = None
         if len(mods) == 3:
             pool = mods[0] if isinstance(mods[0], AvgPool2dSpec) else None
             mods = mods[1:]
         xin = pool.fwd(x) if pool is not None else x
-        c, c_conv = mods[0].fwd(xin, save, bn_stats=mods[1].training)
+        c, c_conv = mods[0].fwd(xin, save, bn_stats=mods[1].training, out_dtype=out_dtype)
         craw, saved = mods[1].stats_only(c, tracked, relu_follows=False)
         c_bn = (craw, None, saved, mods[1].training)
         return craw, saved, ((c_conv, c_bn, pool, tuple(x.shape)) if save else None)
@@ -54,12 +55,12 @@ class Downsample(nn.Sequential):
     # ---- the branch on its own stream ("branch": never behind the backlog of weight gradients), next to the block's
     # main branch whose many small launches leave the GPU idle in between.  Measured on the benchmark step (3 x 120 steps,
     # interleaved, one box): forward +0.5 % (3 970 -> 3 991), backward +1.6 % (3 947 -> 4 011).
-    def fwd_async(self, x, save, tracked, on):
+    def fwd_async(self, x, save, tracked, on, out_dtype=None):
         """-> (raw output, saved block, ctx, handle); handle goes to fwd_join (no per-call state on the module)."""
         if not on:
-            return self.fwd(x, save, tracked) + (None,)
+            return self.fwd(x, save, tracked, out_dtype) + (None,)
         with K.side_stream(x.device, x, enabled=True, which="branch"):
-            craw, saved, ctx = self.fwd(x, save, tracked)
+            craw, saved, ctx = self.fwd(x, save, tracked, out_dtype)
         made = [craw, saved] + ([ctx[0][0] if isinstance(ctx[0], tuple) else ctx[0]] if ctx is not None else [])
         return craw, saved, ctx, [t for t in made if torch.is_tensor(t) and t is not x]
 

@@ -351,11 +351,12 @@ def test_bf16_mode_sits_inside_the_bf16_noise_of_the_reference_arithmetic():
     out, (loss, nll, area) = mb(images.cuda(), labels.cuda())
     loss.backward()
     torch.cuda.synchronize()
-    O.CONV_INPUT_ROUNDING = "bf16"
+    assert mb.activation_storage == "bf16"          # (the default of the bf16 mode; emulated by the oracle below)
+    O.CONV_INPUT_ROUNDING = O.ACTIVATION_STORAGE = "bf16"
     try:
         emu_out, emu_losses, _, emu_leaves, _ = oracle_run(case, torch.float64)
     finally:
-        O.CONV_INPUT_ROUNDING = None
+        O.CONV_INPUT_ROUNDING = O.ACTIVATION_STORAGE = None
     _, tru_losses, _, tru_leaves, _ = oracle_run(case, torch.float64)
     truth = g["f64_log_probs"]
     err_hip = float(np.abs(out.detach().cpu().numpy() - truth).max())
@@ -491,6 +492,7 @@ def test_bf16_mode_resnest50d_300_slots():
     inserted (evaluated in fp64) against the exact fp64 truth."""
     m, P, images, labels, cfg = _synthetic_model("resnest50d", 100, 3, 3, 4, 224, 1300, well_conditioned_head=True)
     m.set_precision("bf16")
+    assert m.activation_storage == "bf16" and sum(b.store_bf16 for b in m.backbone.modules() if hasattr(b, "store_bf16")) == 15
     out, (loss, nll, area) = m(images.cuda(), labels.cuda())
     loss.backward()
     torch.cuda.synchronize()
@@ -501,12 +503,12 @@ def test_bf16_mode_resnest50d_300_slots():
         keys = O.trainable_keys(Pd)
         leaves = {k: Pd[k].clone().requires_grad_(True) for k in keys}
         Q = dict(Pd); Q.update(leaves)
-        O.CONV_INPUT_ROUNDING = rounding
+        O.CONV_INPUT_ROUNDING = O.ACTIVATION_STORAGE = rounding      # (operand rounding + bf16 activation storage)
         try:
             o, ls = O.slot_model_forward(Q, images.double(), labels, cfg, training=True)
             ls[0].backward()
         finally:
-            O.CONV_INPUT_ROUNDING = None
+            O.CONV_INPUT_ROUNDING = O.ACTIVATION_STORAGE = None
         return o.detach(), ls, leaves
     tru_out, tru_losses, tru = run(None)
     emu_out, emu_losses, emu = run("bf16")

@@ -1,0 +1,201 @@
+"""bf16 ACTIVATION STORAGE of the bf16 mode (-m gpu): the typed (`*_io`) entry points of include/scouter_hip.h.
+
+Storage is not arithmetic: a kernel that reads a bf16-stored tensor must give, BIT FOR BIT, what the fp32-storage kernel
+gives on the widened tensor, and a kernel that stores bf16 must store the RNE rounding of what the fp32-storage kernel
+writes.  Every test below is that statement for one entry point (torch's .float() / .to(bfloat16) are the widening and
+the RNE rounding).  The model-level effect is covered by tests/test_model_gpu.py (oracle ACTIVATION_STORAGE emulation)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+def K():
+    from scouter_amd import kernels
+    return kernels
+
+
+@pytest.fixture(autouse=True)
+def _every_layer_on_the_bf16_kernels(monkeypatch):
+    monkeypatch.setattr(K(), "BF16_MIN_PIXELS", 1)       # (the model keeps layers under 1024 pixels on the fp32 kernels)
+
+
+def _rand(rng, *shape, scale=1.0):
+    return torch.from_numpy(rng.standard_normal(shape) * scale).float().cuda()
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, pad, groups
+    (3, 20, 19, 256, 64, 1, 0, 1),      # conv1 of a bottleneck: bf16-stored block input (K = 256)
+    (5, 17, 17, 64, 256, 1, 0, 1),      # conv3: bf16-stored output, 128-wide tiles
+    (2, 28, 28, 128, 512, 1, 0, 1),
+    (4, 23, 9, 96, 64, 1, 0, 1),        # K = 96: the 32-channel K tile
+    (2, 24, 24, 64, 128, 3, 1, 2)])     # a 3x3 layer through the same kernel
+def test_conv_forward_typed_storage(case):
+    B, H, W, Cin, Cout, k, pad, groups = case
+    kk = K()
+    rng = np.random.default_rng(sum(case))
+    xh = _rand(rng, B, H, W, Cin).to(BF16)
+    w = _rand(rng, k, k, Cin // groups, Cout, scale=0.1)
+    key = ("fwd", True, B, H, W, Cin, Cout, k, k, 1, pad, groups)
+    for tile in (0, 1, 2, 3):
+        if not kk._tile_legal(Cout // groups, tile):
+            continue
+        kk._tile_cache[key] = tile
+        y32, (p32, rows) = kk.conv2d_fwd(xh.float(), w, None, None, 1, pad, groups, False, bn_stats=True, precision="bf16")
+        yx, (px, _) = kk.conv2d_fwd(xh, w, None, None, 1, pad, groups, False, bn_stats=True, precision="bf16")
+        assert torch.equal(yx, y32) and torch.equal(px, p32), "bf16-stored input: tile %d" % tile
+        yo, (po, _) = kk.conv2d_fwd(xh, w, None, None, 1, pad, groups, False, bn_stats=True, precision="bf16",
+                                    out_dtype=BF16)
+        assert yo.dtype == BF16 and torch.equal(yo, y32.to(BF16)), "bf16-stored output: tile %d" % tile
+        assert torch.equal(po, p32), "the statistics are those of the fp32 accumulators"
+    del kk._tile_cache[key]
+    with pytest.raises(RuntimeError, match="bf16-stored activations"):
+        kk.conv2d_fwd(xh, w, None, None, 1, pad, groups, precision="fp32")
+
+
+def _stats_of(x):
+    """[1, C, 2] fp64 partial sums (sum, sum of squares) as a convolution epilogue hands them over"""
+    xd = x.double().reshape(-1, x.shape[-1])
+    return torch.stack([xd.sum(0), (xd * xd).sum(0)], dim=1).unsqueeze(0).contiguous(), 1
+
+
+@pytest.mark.parametrize("shape", [(3, 14, 14, 256), (2, 9, 7, 64), (5, 28, 28, 512)])
+@pytest.mark.parametrize("with_res", ["none", "plain", "downsample"])
+def test_batchnorm_apply_typed_storage(shape, with_res):
+    kk = K()
+    rng = np.random.default_rng(shape[0] + shape[3] + len(with_res))
+    C = shape[-1]
+    x = _rand(rng, *shape)                      # the convolution result
+    xh = x.to(BF16)                             # ... as stored
+    gamma, beta = _rand(rng, C).abs() + 0.5, _rand(rng, C)
+    res = _rand(rng, *shape).to(BF16) if with_res != "none" else None
+    rbn = None
+    if with_res == "downsample":                # raw downsample-convolution output + the saved block of its BatchNorm
+        rbn = kk.bn_stats(res.float(), _rand(rng, C).abs() + 0.5, _rand(rng, C), torch.zeros(C, device="cuda"),
+                          torch.ones(C, device="cuda"), True)
+    stats = _stats_of(x)                        # statistics of the UNROUNDED result
+
+    def run(xin, rin, out_dtype):
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        y, saved, mask = kk.bn_fwd(xin, gamma, beta, rm, rv, True, True, rin, stats=stats, want_mask=True,
+                                   residual_bn=rbn, out_dtype=out_dtype)
+        return y, saved, mask, rm, rv
+    ref = run(xh.float(), None if res is None else res.float(), torch.float32)
+    got = run(xh, res, torch.float32)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    got16 = run(xh, res, BF16)
+    assert got16[0].dtype == BF16 and torch.equal(got16[0], ref[0].to(BF16))
+    assert torch.equal(got16[2], ref[2]), "the ReLU sign bits come from the unrounded value"
+    # eval mode (running statistics): no producer statistics needed
+    rm, rv = _rand(rng, C) * 0.1, _rand(rng, C).abs() + 0.5
+    ye = kk.bn_fwd(xh, gamma, beta, rm, rv, False, True, res, out_dtype=BF16)[0]
+    ye_ref = kk.bn_fwd(xh.float(), gamma, beta, rm, rv, False, True, None if res is None else res.float())[0]
+    assert torch.equal(ye, ye_ref.to(BF16))
+    with pytest.raises(RuntimeError, match="statistics of its producer"):
+        kk.bn_fwd(xh, gamma, beta, rm, rv, True, True)
+
+
+@pytest.mark.parametrize("shape", [(3, 14, 14, 256), (2, 9, 7, 64), (6, 28, 28, 512), (2, 31, 5, 128)])
+def test_batchnorm_backward_typed_storage(shape):
+    kk = K()
+    rng = np.random.default_rng(shape[0] * 7 + shape[3])
+    C = shape[-1]
+    xh = _rand(rng, *shape).to(BF16)
+    gamma, beta = _rand(rng, C).abs() + 0.5, _rand(rng, C)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    _, saved, mask = kk.bn_fwd(xh, gamma, beta, rm, rv, True, True, stats=_stats_of(xh.float()), want_mask=True)
+    dy = _rand(rng, *shape)
+    outs = []
+    for xin in (xh.float(), xh):
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dx, gout = kk.bn_bwd(dy, None, xin, saved, True, dg, db, want_gout=True, mask=mask)     # own reduction pass
+        outs.append((dx, gout, dg, db))
+    for a, b in zip(*outs):
+        assert a.dtype == torch.float32 and torch.equal(a, b)
+    # producer-reduced sums (ext): finalize + apply only
+    g = outs[0][1]
+    xhat = (xh.double() - saved[0].double()) * saved[1].double()
+    part = torch.stack([g.double().reshape(-1, C).sum(0), (g.double() * xhat).reshape(-1, C).sum(0)], 1).unsqueeze(0).contiguous()
+    ext = []
+    for xin in (xh.float(), xh):
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        ext.append(kk.bn_bwd(g, None, xin, saved, True, dg, db, ext=(part, 1))[0])
+    assert torch.equal(ext[0], ext[1])
+    np.testing.assert_allclose(ext[0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_avgpool_typed_storage():
+    kk = K()
+    rng = np.random.default_rng(5)
+    for shape, (k, s, p, ceil, cip) in (((3, 28, 28, 256), (2, 2, 0, True, False)), ((2, 15, 13, 64), (2, 2, 0, True, False)),
+                                        ((2, 14, 14, 128), (3, 2, 1, False, True))):
+        xh = _rand(rng, *shape).to(BF16)
+        assert torch.equal(kk.avgpool_fwd(xh, k, s, p, ceil, cip), kk.avgpool_fwd(xh.float(), k, s, p, ceil, cip))
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, pad, groups
+    (3, 20, 19, 256, 64, 1, 0, 1), (2, 28, 28, 512, 128, 1, 0, 1), (4, 23, 9, 96, 64, 1, 0, 1), (2, 24, 24, 64, 128, 3, 1, 2),
+    (2, 30, 30, 128, 128, 3, 1, 1)])
+def test_weight_gradient_typed_storage(case):
+    B, H, W, Cin, Cout, k, pad, groups = case
+    kk = K()
+    rng = np.random.default_rng(sum(case) + 1)
+    xh = _rand(rng, B, H, W, Cin).to(BF16)
+    dy = _rand(rng, B, H, W, Cout)
+    key = ("wgrad", True, B, H, W, Cin, Cout, k, k, 1, pad, groups)
+    for plan in (-1, 0, 17, 34, 51):
+        kk._tile_cache[key] = plan
+        dw32 = torch.zeros(k, k, Cin // groups, Cout, device="cuda")
+        dwh = torch.zeros_like(dw32)
+        kk.conv2d_wgrad(xh.float(), dy, dw32, 1, pad, groups, precision="bf16")
+        kk.conv2d_wgrad(xh, dy, dwh, 1, pad, groups, precision="bf16")
+        assert torch.equal(dw32, dwh), "plan %d" % plan
+    del kk._tile_cache[key]
+    with pytest.raises(RuntimeError, match="bf16-stored activation"):
+        kk.conv2d_wgrad(xh, dy, dwh, 1, pad, groups, precision="fp32")
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin (= channels of the block output whose gradient is produced), Cout, two BatchNorms?, shortcut addend?
+    (3, 20, 19, 256, 64, True, True), (5, 14, 14, 512, 128, False, True), (2, 28, 28, 256, 128, True, False),
+    (7, 13, 11, 128, 32, False, False)])
+def test_fused_batchnorm_backward_epilogue_reads_typed_storage(case, monkeypatch):
+    """conv1's input-gradient kernel finishing the previous block's bn3 (+ downsample BatchNorm) sums from bf16-stored
+    BatchNorm inputs == the same launch on the widened inputs: masked gradient and fp64 partial sums bit for bit."""
+    B, H, W, Cin, Cout, two, with_add = case
+    kk = K()
+    monkeypatch.setattr(kk, "BN_BWD_FUSE", 15)
+    rng = np.random.default_rng(sum(case[:5]))
+    shape = (B, H, W, Cin)
+    dy = _rand(rng, B, H, W, Cout)
+    w = _rand(rng, 1, 1, Cin, Cout, scale=0.1)
+    add = _rand(rng, *shape) if with_add else None
+    gamma, beta = _rand(rng, Cin).abs() + 0.5, _rand(rng, Cin)
+    xs = [_rand(rng, *shape).to(BF16) for _ in range(2 if two else 1)]
+    ctxs = []
+    for i, xh in enumerate(xs):
+        rm, rv = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda")
+        if i == 0:
+            _, saved, mask = kk.bn_fwd(xh, gamma, beta, rm, rv, True, True, stats=_stats_of(xh.float()), want_mask=True)
+        else:
+            saved = kk.bn_stats(xh, gamma, beta, rm, rv, True, stats=_stats_of(xh.float()))
+        ctxs.append(saved)
+    res = []
+    for widen in (True, False):
+        post = kk.BnBwdFuse(mask, [((x.float() if widen else x), s) for x, s in zip(xs, ctxs)])
+        dx = kk.conv2d_dgrad(dy, w, shape, add, 1, 0, 1, precision="bf16", post=post)
+        assert post.applied
+        res.append((dx, post.parts, post.rows))
+    assert torch.equal(res[0][0], res[1][0]) and res[0][2] == res[1][2]
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    # the fp32-input kernel's epilogue does not read bf16 storage: the fuse is left to the BatchNorm's own (typed) backward
+    post = kk.BnBwdFuse(mask, [(x, s) for x, s in zip(xs, ctxs)])
+    kk.conv2d_dgrad(dy, w, shape, add, 1, 0, 1, precision="fp32", post=post)
+    assert not post.applied
