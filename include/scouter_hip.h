@@ -112,16 +112,23 @@ int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, const float
                                     int Cin, int Cout, int kh, int kw, int stride, int pad, int groups, int tile_hint,
                                     const void* relu_mask, const float* x1, const float* saved1, double* part1,
                                     const float* x2, const float* saved2, double* part2, void* stream);
-/* x_io: bit 0 -- x1 is stored as bf16, bit 1 -- x2 is (the BatchNorm inputs the fused epilogue reads) */
-int scouter_conv2d_dgrad_bnbwd_bf16_io(const float* dy, const float* w, const float* addend, float* dx, int B, int H,
+/* io bits of the typed input gradient: 1 -- x1 is stored as bf16, 2 -- x2 is (the BatchNorm inputs the fused epilogue
+ * reads), 4 -- the addend is, 8 -- dy is (the values the kernel rounds an fp32 dy to: same result), 16 -- dx is */
+#define SCOUTER_DGRAD_IO_X1 1
+#define SCOUTER_DGRAD_IO_X2 2
+#define SCOUTER_DGRAD_IO_ADDEND 4
+#define SCOUTER_DGRAD_IO_DY 8
+#define SCOUTER_DGRAD_IO_DX 16
+int scouter_conv2d_dgrad_bnbwd_bf16_io(const void* dy, const float* w, const void* addend, void* dx, int B, int H,
                                        int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int groups,
                                        int tile_hint, const void* relu_mask, const void* x1, const float* saved1,
-                                       double* part1, const void* x2, const float* saved2, double* part2, int x_io,
+                                       double* part1, const void* x2, const float* saved2, double* part2, int io,
                                        void* stream);
 int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
                               int kw, int stride, int pad, int groups, int plan_hint, void* ws, size_t ws_bytes,
                               void* arrival, int arrival_slots, void* stream);
-int scouter_conv2d_wgrad_bf16_io(const void* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+/* io: SCOUTER_IO_X_BF16 -- x is stored as bf16, SCOUTER_IO_R_BF16 -- dy is */
+int scouter_conv2d_wgrad_bf16_io(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,
                                  int kh, int kw, int stride, int pad, int groups, int plan_hint, void* ws,
                                  size_t ws_bytes, void* arrival, int arrival_slots, int io, void* stream);
 /* plan_hint: -1 = built-in plan; otherwise bits 0-1 = block budget {512,1024,2048,4096} (sets the split-K count),
@@ -181,10 +188,11 @@ int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, cons
                        const float* scale, const unsigned long long* relu_mask, long M, int C, int training,
                        float* dgamma, float* dbeta, float* dx, float* gout, const double* ext_partial, int ext_rows,
                        void* ws, size_t ws_bytes, void* stream);
-/* io & SCOUTER_IO_X_BF16: the BatchNorm input x is stored as bf16 (dy, dx, gout stay fp32) */
+/* io: SCOUTER_IO_X_BF16 -- the BatchNorm input x is stored as bf16; SCOUTER_IO_Y_BF16 -- dx is stored as bf16 (for a dx
+ * read only by bf16-input convolution kernels, which round it the same way: same results); dy and gout are fp32 */
 int scouter_bn_bwd_io(const float* dy, const float* ymask, const void* x, const float* mean, const float* rstd,
                       const float* scale, const unsigned long long* relu_mask, long M, int C, int training,
-                      float* dgamma, float* dbeta, float* dx, float* gout, const double* ext_partial, int ext_rows,
+                      float* dgamma, float* dbeta, void* dx, float* gout, const double* ext_partial, int ext_rows,
                       int io, void* ws, size_t ws_bytes, void* stream);
 /* out[c] = alpha * sum_m a[m][c] * (b ? b[m][c] : 1)  -- bias gradients, d(initial_slots) */
 int scouter_colsum_f32(const float* a, const float* b, float* out, long M, int C, float alpha, void* ws,

@@ -237,14 +237,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 }
 
 // dx = gamma*rstd * (g - c1 - xhat*c2),  g = dy * (ymask > 0);  optionally also writes g (the residual-branch grad)
-template <bool XB = false>                                   // XB: the BatchNorm input x is stored as bf16
+template <bool XB = false, bool YB = false>                 // XB / YB: the BatchNorm input x / the gradient dx is stored as bf16
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                            const void* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ scale, const float* __restrict__ c1,
                                                            const float* __restrict__ c2,
                                                            const unsigned long long* __restrict__ mbits,
-                                                           float* __restrict__ dx, float* __restrict__ gout, long n4,
+                                                           void* __restrict__ dx, float* __restrict__ gout, long n4,
                                                            int C) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), sc = *(const f32x4*)(scale + c);
         const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c);
         const f32x4 xh = (xv - mu) * rs;
-        *(f32x4*)(dx + i * 4) = sc * (g - k1 - xh * k2);
+        sc_store4<YB>(dx, i * 4, sc * (g - k1 - xh * k2));
         if (gout) *(f32x4*)(gout + i * 4) = g;
     }
 }
@@ -753,14 +753,15 @@ extern "C" int scouter_bn_apply_f32(const float* x, const float* bn_saved, float
     return sc_check_launch("bn_apply");
 }
 
-// `io` & SC_IO_X_BF16: the BatchNorm input x is stored as bf16 (gradients stay fp32)
+// `io`: SC_IO_X_BF16 -- the BatchNorm input x is stored as bf16; SC_IO_Y_BF16 -- dx is stored as bf16 (RNE; for a dx whose
+// only readers are bf16-input convolution kernels, which round it the same way).  dy and gout are fp32.
 extern "C" int scouter_bn_bwd_io(const float* dy, const float* ymask, const void* x, const float* mean,
                                  const float* rstd, const float* scale, const unsigned long long* relu_mask, long M,
-                                 int C, int training, float* dgamma, float* dbeta, float* dx, float* gout,
+                                 int C, int training, float* dgamma, float* dbeta, void* dx, float* gout,
                                  const double* ext_partial, int ext_rows, int io, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(dy && x && mean && rstd && scale && dx, "bn_bwd: null pointer");
-    SC_REQUIRE((io & ~SC_IO_X_BF16) == 0, "bn_bwd: unsupported io bits %d (only the input x may be bf16)", io);
-    const bool xb = (io & SC_IO_X_BF16) != 0;
+    SC_REQUIRE((io & ~(SC_IO_X_BF16 | SC_IO_Y_BF16)) == 0, "bn_bwd: unsupported io bits %d (x and dx may be bf16)", io);
+    const bool xb = (io & SC_IO_X_BF16) != 0, yb = (io & SC_IO_Y_BF16) != 0;
     SC_REQUIRE(!ext_partial || (ext_rows > 0 && !ymask && !relu_mask && !gout),
                "bn_bwd: with ext_partial dy is the already masked gradient (no ymask / relu_mask / gout)");
     COL_CHECKS("bn_bwd")
@@ -774,15 +775,15 @@ extern "C" int scouter_bn_bwd_io(const float* dy, const float* ymask, const void
     hipStream_t st = (hipStream_t)stream;
     ScProfScope prof(ext_partial ? "bn_bwd(finalize+apply)" : "bn_bwd(reduce+finalize+apply)", st, 0,
                      ((ext_partial ? 12.0 : (ymask && !relu_mask ? 28.0 : 20.0)) + (gout ? 4.0 : 0.0) +
-                      (relu_mask ? 0.25 : 0.0) - (xb ? (ext_partial ? 2.0 : 4.0) : 0.0)) * M * C);
-    if (!ext_partial && M <= (long)g.rpb * 24 && !xb) {          // few row passes: everything in one launch
+                      (relu_mask ? 0.25 : 0.0) - (xb ? (ext_partial ? 2.0 : 4.0) : 0.0) - (yb ? 2.0 : 0.0)) * M * C);
+    if (!ext_partial && M <= (long)g.rpb * 24 && !xb && !yb) {   // few row passes: everything in one launch
         // 16-channel slabs (4 threads per row, 64 rows per pass) when the channel count allows: C / 16 workgroups with one or
         // two passes each instead of ONE workgroup walking up to 24 dependent passes (14 us on every block's critical path)
         ColGeom gs = g;
         int slabs = pgrid.y;
         if (C % 16 == 0 && C >= 32) { gs.cslab = 16; gs.tpr = 4; gs.rpb = 64; slabs = C / 16; }
         hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, slabs), dim3(256), 0, st, dy, ymask, (const float*)x, mean, rstd, scale,
-                           relu_mask, training, dgamma, dbeta, dx, gout, gs);
+                           relu_mask, training, dgamma, dbeta, (float*)dx, gout, gs);
         return sc_check_launch("bn_bwd");
     }
     const double* part = (const double*)ws;
@@ -800,12 +801,14 @@ extern "C" int scouter_bn_bwd_io(const float* dy, const float* ymask, const void
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, part, nparts, M, C, training, dgamma,
                            dbeta, c1, c2);
     const long n4 = M * C / 4;
-    if (xb)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale,
-                           c1, c2, relu_mask, dx, gout, n4, C);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, scale,
-                           c1, c2, relu_mask, dx, gout, n4, C);
+#define BBA(XB_, YB_)                                                                                                 \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<XB_, YB_>), dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, \
+                       scale, c1, c2, relu_mask, dx, gout, n4, C)
+    if (xb && yb) BBA(true, true);
+    else if (xb) BBA(true, false);
+    else if (yb) BBA(false, true);
+    else BBA(false, false);
+#undef BBA
     return sc_check_launch("bn_bwd");
 }
 

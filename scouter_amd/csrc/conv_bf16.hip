@@ -35,8 +35,8 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
 // forward / dgrad.  Block = 4 waves, tile BM x BN x KT (KT = 64, or 32 for 32-channel groups), 2 LDS stages,
 // LDS rows of KT+8 bf16 (16-byte aligned, conflict-free 16-byte fragment reads).
 // ----------------------------------------------------------------------------------------------------------------
-// A_BF16: the A operand (the forward's input activation) is STORED as bf16 (round 4, activation storage): 16-byte loads
-// carry eight k-values straight into LDS, no conversion.  dst_bf16 (run time): the output tensor is stored as bf16 -- the
+// A_BF16: the A operand (the forward's input activation, the input gradient's dy) is STORED as bf16 (round 4, activation
+// storage): 16-byte loads carry eight k-values straight into LDS, no conversion.  dst_bf16 (run time): the output tensor is stored as bf16 -- the
 // fused BatchNorm statistics still come from the fp32 accumulators.
 template <int BM, int BN, int WM, int WN, int KT_, bool DGRAD, bool A_BF16 = false>
 __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const void* __restrict__ src, const void* __restrict__ wgt,
@@ -52,7 +52,6 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const void* __restri
     constexpr int AEL = A_BF16 ? 8 : 4, AES = A_BF16 ? 2 : 4;   // A: elements per 16-byte load, bytes per element
     constexpr int ATPR = KT_ / AEL, ARPI = 256 / ATPR;    // A: threads per row, rows per load instruction
     constexpr int AI = (BM + ARPI - 1) / ARPI, BI = BN / RPI;
-    static_assert(!(A_BF16 && DGRAD), "bf16-stored A operands: forward only (gradients are stored as fp32)");
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
     extern __shared__ __attribute__((aligned(16))) __bf16 ldsh[];      // max(2 stages, epilogue staging) bytes
 
@@ -208,6 +207,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const void* __restri
         tile(kt, P0{});
         if (kt + 1 < KT) tile(kt + 1, P1{});
     }
+    // (the fp32 kernels request the fused epilogue's operands at workgroup start; here that was measured to LOSE -- 140
+    //  instead of 82 registers, fewer resident workgroups of a kernel that lives on loads in flight: 6.3 -> 7.0 ms per step
+    //  on BASELINE configs[4])
     igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)ldsh, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz,
                                           nullptr, dst_bf16 != 0);
 }
@@ -240,12 +242,10 @@ static void launch_bf16(const void* src, const void* w, const float* bias, const
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, src, w, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz,
                            (io & SC_IO_Y_BF16) ? 1 : 0);
     };
-    if constexpr (!DGRAD) {
-        if (io & SC_IO_X_BF16) {
-            if (g.Cg % 64 == 0) go(igemm_bf16_kernel<BM, BN, WM, WN, 64, false, true>, 64);
-            else go(igemm_bf16_kernel<BM, BN, WM, WN, 32, false, true>, 32);
-            return;
-        }
+    if (io & SC_IO_X_BF16) {
+        if (g.Cg % 64 == 0) go(igemm_bf16_kernel<BM, BN, WM, WN, 64, DGRAD, true>, 64);
+        else go(igemm_bf16_kernel<BM, BN, WM, WN, 32, DGRAD, true>, 32);
+        return;
     }
     if (g.Cg % 64 == 0) go(igemm_bf16_kernel<BM, BN, WM, WN, 64, DGRAD>, 64);
     else go(igemm_bf16_kernel<BM, BN, WM, WN, 32, DGRAD>, 32);
@@ -314,14 +314,15 @@ extern "C" int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, cons
                                       groups, relu, tile_hint, 0, stream);
 }
 
-// `x_io`: bit 0 -- x1 is stored as bf16, bit 1 -- x2 is (the BatchNorm inputs the epilogue reads; gradients are fp32)
-extern "C" int scouter_conv2d_dgrad_bnbwd_bf16_io(const float* dy, const float* w, const float* addend, float* dx, int B,
+// `io` (SCOUTER_DGRAD_IO_*): 1 / 2 -- x1 / x2 (the BatchNorm inputs the epilogue reads) are stored as bf16, 4 -- the addend
+// is, 8 -- dy is (the values the kernel rounds an fp32 dy to), 16 -- dx is
+extern "C" int scouter_conv2d_dgrad_bnbwd_bf16_io(const void* dy, const float* w, const void* addend, void* dx, int B,
                                                   int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
                                                   int groups, int tile_hint, const void* relu_mask, const void* x1,
                                                   const float* saved1, double* part1, const void* x2,
-                                                  const float* saved2, double* part2, int x_io, void* stream) {
+                                                  const float* saved2, double* part2, int io, void* stream) {
     SC_REQUIRE(dy && w && dx && B > 0, "conv2d_dgrad_bf16: null pointer or empty shape");
-    SC_REQUIRE((x_io & ~3) == 0, "conv2d_dgrad_bf16: unknown x_io bits %d", x_io);
+    SC_REQUIRE((io & ~31) == 0, "conv2d_dgrad_bf16: unknown io bits %d", io);
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad_bf16: channels not divisible by groups");
     SC_REQUIRE(!part1 || (x1 && saved1), "conv2d_dgrad_bf16: fused BatchNorm backward needs x1 and saved1");
     SC_REQUIRE(!part2 || (part1 && x2 && saved2), "conv2d_dgrad_bf16: second fused BatchNorm needs the first, x2 and saved2");
@@ -334,10 +335,11 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_bf16_io(const float* dy, const float* 
     static const char* names[4] = {"igemm_dgrad_bf16<128x128>", "igemm_dgrad_bf16<128x64>", "igemm_dgrad_bf16<64x64>", "igemm_dgrad_bf16<128x32>"};
     const int tile = bf16_tile(g, tile_hint);
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw,
-                     4.0 * ((double)B * Ho * Wo * Cout + (double)g.M * Cin));
+                     ((io & 8) ? 2.0 : 4.0) * B * Ho * Wo * Cout + ((io & 16) ? 2.0 : 4.0) * g.M * Cin);
     const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, (const float*)x1, saved1, part1,
-                       (const float*)x2, saved2, part2, x_io};
-    return dispatch_bf16<true>(dy, w, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream, fz);
+                       (const float*)x2, saved2, part2, io & 7};
+    return dispatch_bf16<true>(dy, w, nullptr, (const float*)addend, (float*)dx, nullptr, g, 0, tile, (hipStream_t)stream,
+                               fz, ((io & 8) ? SC_IO_X_BF16 : 0) | ((io & 16) ? SC_IO_Y_BF16 : 0));
 }
 extern "C" int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, const float* addend, float* dx, int B,
                                                int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,

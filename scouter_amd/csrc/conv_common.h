@@ -132,7 +132,7 @@ struct BnBwdFuse {
     const unsigned long long* mask;                        // may be NULL: no ReLU between the BatchNorm and the consumer
     const float* x1; const float* sv1; double* part1;      // BatchNorm input, saved [4][C] block, partial rows [mt][C][2]
     const float* x2; const float* sv2; double* part2;      // second BatchNorm (may be NULL)
-    int io;                                                // bit 0 / 1: x1 / x2 is STORED as bf16 (bf16-input kernels only)
+    int io;                                                // bit 0 / 1 / 2: x1 / x2 / the addend is STORED as bf16 (bf16-input kernels only)
 };
 
 // Operands of the fused BatchNorm-backward epilogue that do not depend on the GEMM (shortcut gradient, BatchNorm inputs):
@@ -159,9 +159,9 @@ __device__ __forceinline__ void igemm_epilogue_prefetch(EpiPre<(WM / (64 / (WN /
             for (int rr = 0; rr < NR; ++rr) {
                 const long m = m0 + wm * WM + rr * RPP + qrow;
                 const long off = (m < g.M ? m : 0) * g.N + ncol;      // (rows beyond M: any valid address, never used)
-                pre.add[rr] = addend ? *(const f32x4*)(addend + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-                pre.x1[rr] = *(const f32x4*)(fz.x1 + off);
-                pre.x2[rr] = fz.part2 ? *(const f32x4*)(fz.x2 + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+                pre.add[rr] = addend ? sc_load4_rt(addend, off, (fz.io & 4) != 0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                pre.x1[rr] = sc_load4_rt(fz.x1, off, (fz.io & 1) != 0);
+                pre.x2[rr] = fz.part2 ? sc_load4_rt(fz.x2, off, (fz.io & 2) != 0) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }
@@ -248,11 +248,12 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
         const long m = m0 + wm * WM + row;
         if (m >= g.M) continue;
         f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
+        const bool add_bf16 = BWD && fz != nullptr && (fz->io & 4) != 0;
         if constexpr (PREF) {
             if (pref) v += pre->add[rr];
-            else if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
+            else if (addend) v += sc_load4_rt(addend, m * g.N + ncol, add_bf16);
         } else {
-            if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
+            if (addend) v += sc_load4_rt(addend, m * g.N + ncol, add_bf16);
         }
         if constexpr (BWD) {
             if (bwd) {

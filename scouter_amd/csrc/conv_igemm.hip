@@ -1070,14 +1070,14 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
 // one -- the upper 32 are the neighbouring group's / pixel's values -- and the rows / columns past the group are dropped at
 // the store (at bf16 matrix rates the doubled tile is free, and 4x faster than the fp32 kernel these layers used).
 // Same workspace as scouter_conv2d_wgrad_f32.
-// `io` & SC_IO_X_BF16: the activation x is stored as bf16 (dy stays fp32)
-extern "C" int scouter_conv2d_wgrad_bf16_io(const void* x, const float* dy, float* dw, int B, int H, int W, int Cin,
+// `io`: SC_IO_X_BF16 -- the activation x is stored as bf16, SC_IO_R_BF16 -- dy is
+extern "C" int scouter_conv2d_wgrad_bf16_io(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
                                             int Cout, int kh, int kw, int stride, int pad, int groups, int plan_hint,
                                             void* ws, size_t ws_bytes, void* arrival, int arrival_slots, int io,
                                             void* stream) {
     SC_REQUIRE(x && dy && dw && B > 0, "conv2d_wgrad_bf16: null pointer or empty shape");
-    SC_REQUIRE((io & ~SC_IO_X_BF16) == 0, "conv2d_wgrad_bf16: unsupported io bits %d (only x may be bf16)", io);
-    const bool xb = (io & SC_IO_X_BF16) != 0;
+    SC_REQUIRE((io & ~(SC_IO_X_BF16 | SC_IO_R_BF16)) == 0, "conv2d_wgrad_bf16: unsupported io bits %d (x and dy may be bf16)", io);
+    const bool xb = (io & SC_IO_X_BF16) != 0, db = (io & SC_IO_R_BF16) != 0;
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_wgrad_bf16: channels not divisible by groups");
     ConvGeom g = wgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
     const bool same = stride == 1 && g.Ho == H && g.Wo == W;
@@ -1099,7 +1099,7 @@ extern "C" int scouter_conv2d_wgrad_bf16_io(const void* x, const float* dy, floa
     int rc;
     {
     ScProfScope prof("wgrad_bf16", st, 2.0 * g.M * Cout * g.Cg * kh * kw,
-                     (xb ? 2.0 : 4.0) * B * H * W * Cin + 4.0 * g.M * Cout);
+                     (xb ? 2.0 : 4.0) * B * H * W * Cin + (db ? 2.0 : 4.0) * g.M * Cout);
 #define WGK(KERN)                                                                                                   \
     do {                                                                                                            \
         auto kern = KERN;                                                                                           \
@@ -1110,10 +1110,14 @@ extern "C" int scouter_conv2d_wgrad_bf16_io(const void* x, const float* dy, floa
 #define WGH(BM_, BN_, WM_, WN_)                                                                                     \
     do {                                                                                                            \
         const size_t lds = (size_t)2 * (BM_ + BN_) * 72 * 2;                                                        \
-        if (mode == 2 && xb) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 2, true>));                                 \
-        else if (mode == 2) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 2, false>));                                 \
-        else if (xb) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 1, true>));                                         \
-        else WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 1, false>));                                                \
+        if (mode == 2 && xb && db) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 2, true, true>));                     \
+        else if (mode == 2 && xb) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 2, true, false>));                     \
+        else if (mode == 2 && db) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 2, false, true>));                     \
+        else if (mode == 2) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 2, false, false>));                          \
+        else if (xb && db) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 1, true, true>));                             \
+        else if (xb) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 1, true, false>));                                  \
+        else if (db) WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 1, false, true>));                                  \
+        else WGK((wgrad_bf16_kernel<BM_, BN_, WM_, WN_, 1, false, false>));                                         \
     } while (0)
     if (p.bm == 128 && p.bn == 128) WGH(128, 128, 64, 64);
     else if (p.bm == 128 && p.bn == 64) WGH(128, 64, 64, 32);

@@ -12,8 +12,9 @@ typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
 
 // A_BF16: the activation X is STORED as bf16 (round 4): the same 4-pixel x 4-channel patches as four 8-byte loads, no
 // conversion -- the values are the ones the fp32 path rounds to.
-template <int BM, int BN, int WM, int WN, int MODE, bool A_BF16 = false>     // MODE 1: padded taps, 2: 1x1 (see wgrad_kernel)
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const void* __restrict__ act, const float* __restrict__ dy,
+// B_BF16: the same for dy.
+template <int BM, int BN, int WM, int WN, int MODE, bool A_BF16 = false, bool B_BF16 = false>     // MODE 1: padded taps, 2: 1x1
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const void* __restrict__ act, const void* __restrict__ dy,
                                                             float* __restrict__ out, ConvGeom g, int ci_tiles,
                                                             int co_tiles, long pix_per_split, long slab, float* __restrict__ dw,
                                                             unsigned* __restrict__ arrival) {
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const void* __restri
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     constexpr int A_H = BM * LDP, B_H = BN * LDP, STAGE_H = A_H + B_H;
     constexpr int AP = BM / 64, BP = BN / 64;              // (channel-quad, pixel-quad) patches per thread
-    constexpr int AES = A_BF16 ? 2 : 4;                    // bytes per stored activation element
+    constexpr int AES = A_BF16 ? 2 : 4, BES = B_BF16 ? 2 : 4;    // bytes per stored activation / gradient element
     static_assert((BM / WM) * (BN / WN) == 4 && BM % 64 == 0 && BN % 64 == 0, "tile config");
     extern __shared__ __attribute__((aligned(16))) __bf16 ldsw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const void* __restri
     for (int i = 0; i < BP; ++i) {
         const int p = tid + 256 * i, cq = (p & 7) + 8 * (p >> 7), pq = (p >> 3) & 15;
         b_row[i] = 4 * cq; b_pq[i] = pq;
-        b_voff[i] = (unsigned)((4 * pq * (long)g.N + grp * g.Ng + co0 + 4 * cq) * 4);
+        b_voff[i] = (unsigned)((4 * pq * (long)g.N + grp * g.Ng + co0 + 4 * cq) * BES);
     }
     // bytes the descriptor may touch from pixel `first`: up to this split's last pixel and (ragged tiles read one pixel
     // past a valid one) never beyond the tensor's last pixel
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const void* __restri
         return (unsigned)(n < 0 ? 0 : (n > 0x7fffffffL ? 0x7fffffffL : n));
     };
     f32x4 ra[AP][4], rb[BP][4];
-    wg_bf16x4 rah[AP][4];                                  // (A_BF16: the patches arrive as bf16)
+    wg_bf16x4 rah[AP][4], rbh[BP][4];                      // (A_BF16 / B_BF16: the patches arrive as bf16)
     long a_m = mbeg, b_m = mbeg;
     auto load_a = [&]() {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -108,14 +109,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const void* __restri
         a_m += KP;
     };
     auto load_b = [&]() {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + b_m * g.N), 0,
-                                                                            records(b_m, b_m, g.N, 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)dy + b_m * g.N * BES), 0, records(b_m, b_m, g.N, BES), 0x00020000);
 #pragma unroll
         for (int i = 0; i < BP; ++i)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                rb[i][rr] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          rs, b_voff[i] + (unsigned)(rr * g.N * 4), 0, 0));
+            for (int rr = 0; rr < 4; ++rr) {
+                const unsigned vo = b_voff[i] + (unsigned)(rr * g.N * BES);
+                if constexpr (B_BF16) rbh[i][rr] = __builtin_bit_cast(wg_bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 0, 0));
+                else rb[i][rr] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+            }
         b_m += KP;
     };
     auto store_t = [&](__bf16* T, const f32x4 (&v)[4], int row, int pq) {      // 4x4 transpose, four 8-byte row writes
@@ -145,7 +148,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const void* __restri
             else store_t(As, ra[i], a_row[i], a_pq[i]);
         }
 #pragma unroll
-        for (int i = 0; i < BP; ++i) store_t(Bs, rb[i], b_row[i], b_pq[i]);
+        for (int i = 0; i < BP; ++i) {
+            if constexpr (B_BF16) store_th(Bs, rbh[i], b_row[i], b_pq[i]);
+            else store_t(Bs, rb[i], b_row[i], b_pq[i]);
+        }
     };
     f32x16 acc[MT][NT];
 #pragma unroll

@@ -14,6 +14,7 @@ F32 = torch.float32
 BF16 = torch.bfloat16
 # storage-type bits of the typed entry points (include/scouter_hip.h SCOUTER_IO_*)
 IO_X_BF16, IO_Y_BF16, IO_R_BF16 = 1, 2, 4
+DGRAD_IO_ADDEND, DGRAD_IO_DY, DGRAD_IO_DX = 4, 8, 16          # (SCOUTER_DGRAD_IO_*; bits 1 / 2: BnBwdFuse.x_io)
 _ws = {}
 
 
@@ -364,18 +365,27 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     return (y, (part, rows)) if bn_stats else y
 
 
-def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, precision="fp32", post=None):
+def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, precision="fp32", post=None,
+                 out_dtype=F32):
     """post (BnBwdFuse): the tensor produced is the gradient of a BatchNorm+ReLU block output -- the epilogue masks it
-    and reduces that BatchNorm's backward sums (see BnBwdFuse)."""
-    _chk(dy, "dy"); _chk(w_hwio, "weight"); _chk(addend, "addend")
+    and reduces that BatchNorm's backward sums (see BnBwdFuse).
+    Gradient storage (bf16-input kernel only): dy may be a bfloat16-stored tensor (the values the kernel rounds an fp32
+    dy to: same result), the addend too, and out_dtype=torch.bfloat16 stores dx rounded."""
+    _chk(dy, "dy", (F32, BF16)); _chk(w_hwio, "weight"); _chk(addend, "addend", (F32, BF16))
     B, H, W, Cin = x_shape
     kh, kw, cg, Cout = w_hwio.shape
-    dx = torch.empty(x_shape, dtype=F32, device=dy.device)
+    dx = torch.empty(x_shape, dtype=out_dtype, device=dy.device)
     L = _native.lib()
     st = _stream()
 
     # strided input gradients (resnet18) and tiny layers stay on the fp32 kernel
     bf16 = precision == "bf16" and stride == 1 and B * H * W >= BF16_MIN_PIXELS
+    io = ((DGRAD_IO_DY if dy.dtype == BF16 else 0) | (DGRAD_IO_DX if out_dtype == BF16 else 0) |
+          (DGRAD_IO_ADDEND if addend is not None and addend.dtype == BF16 else 0))
+    if io and not bf16:
+        raise RuntimeError("scouter_amd: bf16-stored gradients are an option of the bf16-input kernels (precision 'bf16', "
+                           "stride 1, >= %d pixels); got precision %r, stride %d, %d pixels"
+                           % (BF16_MIN_PIXELS, precision, stride, B * H * W))
 
     def launch(tile, dry=False, fuse=_NO_FUSE):
         if dry:
@@ -385,7 +395,7 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
         if bf16:
             _native.check(L.scouter_conv2d_dgrad_bnbwd_bf16_io(
                 _p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile, *fuse,
-                post.x_io() if fuse is not _NO_FUSE else 0, st), "conv2d_dgrad")
+                io | (post.x_io() if fuse is not _NO_FUSE else 0), st), "conv2d_dgrad")
         else:
             _native.check(L.scouter_conv2d_dgrad_bnbwd_f32(
                 _p(dy), _p(w_hwio), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile, *fuse, st),
@@ -706,7 +716,7 @@ _PWGRAD_PLANS = _WGRAD_PLANS + ((64, 65, 66, 67) if len(_WGRAD_PLANS) > 1 else (
 def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
     """Writes dW (HWIO, contiguous, e.g. a slice of the flat gradient arena).  The (tile, split-K) plan is autotuned
     once per layer shape and kept for the run (see _WGRAD_PLANS)."""
-    _chk(x, "x", (F32, BF16)); _chk(dy, "dy"); _chk(dw_hwio, "dw")
+    _chk(x, "x", (F32, BF16)); _chk(dy, "dy", (F32, BF16)); _chk(dw_hwio, "dw")
     B, H, W, Cin = x.shape
     kh, kw, cg, Cout = dw_hwio.shape
     L = _native.lib()
@@ -717,8 +727,8 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
     same = stride == 1 and dy.shape[1] == H and dy.shape[2] == W
     bf16 = (precision == "bf16" and same and cg % 32 == 0 and (Cout // groups) % 32 == 0 and
             B * H * W >= BF16_MIN_PIXELS and ((kh == 1 and kw == 1 and pad == 0) or 64 // W + 1 < H))
-    if x.dtype != F32 and not bf16:
-        raise RuntimeError("scouter_amd: a bf16-stored activation needs the bf16-input weight-gradient kernel "
+    if (x.dtype != F32 or dy.dtype != F32) and not bf16:
+        raise RuntimeError("scouter_amd: a bf16-stored activation / gradient needs the bf16-input weight-gradient kernel "
                            "(precision 'bf16', same-size stride-1 layer); got %s" % (tuple(x.shape),))
 
     def launch(plan, dry=False):
@@ -730,7 +740,8 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
         args = (_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, kh, kw, stride, pad, groups, plan, _p(ws), ws.numel(),
                 _p(arr), ARRIVAL_SLOTS if arr is not None else 0)
         if bf16:
-            _native.check(L.scouter_conv2d_wgrad_bf16_io(*args, IO_X_BF16 if x.dtype == BF16 else 0, st), "conv2d_wgrad")
+            _native.check(L.scouter_conv2d_wgrad_bf16_io(
+                *args, (IO_X_BF16 if x.dtype == BF16 else 0) | (IO_R_BF16 if dy.dtype == BF16 else 0), st), "conv2d_wgrad")
         else:
             _native.check(L.scouter_conv2d_wgrad_f32(*args, st), "conv2d_wgrad")
         return True
@@ -826,16 +837,17 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training, relu, residual=N
     return (y, saved, mask) if want_mask else (y, saved)
 
 
-def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=False, mask=None, ext=None):
+def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=False, mask=None, ext=None, dx_dtype=F32):
     """ReLU sign from `mask` (bits written by bn_fwd(want_mask=True)) or from the activation `ymask`; both None: no ReLU.
     ext = (partial, rows) from a BnBwdFuse: dy is the already masked gradient, its sums are reduced -- no reduction
-    pass, no mask, and the masked gradient `gout` is dy itself."""
+    pass, no mask, and the masked gradient `gout` is dy itself.  dx_dtype=torch.bfloat16: dx is stored as bf16 (for a dx
+    read only by bf16-input convolution kernels, which round it the same way)."""
     _chk(dy, "dy"); _chk(ymask, "ymask"); _chk(x, "x", (F32, BF16))
     C = x.shape[-1]
     M = x.numel() // C
-    dx = torch.empty(x.shape, dtype=F32, device=x.device)          # (x may be bf16-stored; gradients are fp32)
+    dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)     # (x may be bf16-stored)
     ws = _col_ws(M, C, x.device)
-    io = IO_X_BF16 if x.dtype == BF16 else 0
+    io = (IO_X_BF16 if x.dtype == BF16 else 0) | (IO_Y_BF16 if dx_dtype == BF16 else 0)
     if ext is not None:
         part, rows = ext
         _native.check(_native.lib().scouter_bn_bwd_io(

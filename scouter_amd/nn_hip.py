@@ -8,6 +8,7 @@ see a single contiguous buffer.  Modules keep the reference's parameter / buffer
 interchangeable; conv weights have the reference's logical (Cout, Cin/g, kh, kw) shape
 over an HWIO physical layout."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -20,6 +21,10 @@ class Act(nn.Module):
 
     def forward(self, x):   # pragma: no cover - activation is fused into the neighbouring kernel
         raise RuntimeError("activation is fused; call the parent module")
+
+
+# bf16 storage of the gradients that only bf16-input convolution kernels read (Conv2d.grad_storage); SCOUTER_BF16_GRADS=0: fp32
+GRAD_STORAGE_BF16 = os.environ.get("SCOUTER_BF16_GRADS", "1") != "0"
 
 
 class Conv2d(nn.Module):
@@ -73,6 +78,17 @@ class Conv2d(nn.Module):
         cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
         return bool(self.planes_in() and self.planes_dy() and cg % 64 == 0 and ng % 64 == 0
                     and 2 * self.padding == self.kernel_size - 1)
+
+    def grad_storage(self, B, H, W):
+        """Storage type for this layer's OUTPUT gradient (B x H x W output pixels): bf16 when both of its readers -- the
+        input-gradient and the weight-gradient kernel -- are the bf16-input ones, which round an fp32 gradient to exactly
+        the stored values (so this storage changes no result); None (fp32) otherwise."""
+        cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
+        k = self.kernel_size
+        ok = (GRAD_STORAGE_BF16 and self.precision == "bf16" and not self.planes and self.bias is None and
+              self.stride == 1 and 2 * self.padding == k - 1 and B * H * W >= K.BF16_MIN_PIXELS and
+              cg % 32 == 0 and ng % 32 == 0 and (k == 1 or 64 // W + 1 < H))
+        return K.BF16 if ok else None
 
     def fwd(self, x, save, relu=False, addend=None, bn_stats=False, out_dtype=None):
         """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd.
@@ -240,12 +256,14 @@ class BatchNorm2d(nn.Module):
         BatchNorms fed by the same gradient -- the downsample branch)."""
         return K.BnBwdFuse(ctx[1], [(c[0], c[2]) for c in (ctx,) + more])
 
-    def bwd(self, dy, ctx, want_gout=False, fused=None):
-        """fused = BnBwdFuse.ext(i): dy is already masked and its sums are reduced (by the producer's epilogue)."""
+    def bwd(self, dy, ctx, want_gout=False, fused=None, dx_dtype=None):
+        """fused = BnBwdFuse.ext(i): dy is already masked and its sums are reduced (by the producer's epilogue).
+        dx_dtype=torch.bfloat16: dx is stored as bf16 (Conv2d.grad_storage of the convolution in front)."""
         x, mask, saved, training = ctx
         if fused is not None:
-            return K.bn_bwd(dy, None, x, saved, training, self._dg, self._db, want_gout, ext=fused)
-        return K.bn_bwd(dy, None, x, saved, training, self._dg, self._db, want_gout, mask=mask)
+            return K.bn_bwd(dy, None, x, saved, training, self._dg, self._db, want_gout, ext=fused,
+                            dx_dtype=dx_dtype or K.F32)
+        return K.bn_bwd(dy, None, x, saved, training, self._dg, self._db, want_gout, mask=mask, dx_dtype=dx_dtype or K.F32)
 
 
 class LinearParams(nn.Module):

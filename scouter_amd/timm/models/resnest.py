@@ -74,7 +74,9 @@ class ResNestBottleneck(nn.Module):
         the bn3 / downsample sums are reduced); post: the previous block's, for conv1's input-gradient epilogue."""
         k1, b1, ksa, sa_shape, k3, b3, kd = ctx
         own = own if own is not None and own.applied else None
-        dc3, dres = self.bn3.bwd(dout, b3, want_gout=True, fused=own.ext(0) if own else None)
+        # (dc3 / dc1 / the downsample gradient are read by bf16-input kernels only: stored as bf16 where those run)
+        dc3, dres = self.bn3.bwd(dout, b3, want_gout=True, fused=own.ext(0) if own else None,
+                                 dx_dtype=self.conv3.grad_storage(*dout.shape[:3]))
         dxres = dres
         if self.downsample is not None:       # the branch's backward next to the main branch's (Downsample.bwd_async)
             dxres, hnd = self.downsample.bwd_async(dres, kd, need_dx, own.ext(1) if own else None,
@@ -83,7 +85,8 @@ class ResNestBottleneck(nn.Module):
         dsa = self.avd_last.bwd(dp, sa_shape) if self.avd_last is not None else dp
         f1 = BatchNorm2d.fuse(b1)
         dh1 = self.conv2.bwd(dsa, ksa, post=f1)
-        dc1, _ = self.bn1.bwd(dh1, b1, fused=f1.ext(0) if f1.applied else None)
+        dc1, _ = self.bn1.bwd(dh1, b1, fused=f1.ext(0) if f1.applied else None,
+                              dx_dtype=self.conv1.grad_storage(*dh1.shape[:3]))
         if self.downsample is not None:
             dxres = self.downsample.bwd_join(dxres, dres.device, hnd)
         return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None)

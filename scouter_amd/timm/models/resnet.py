@@ -90,7 +90,7 @@ class Downsample(nn.Sequential):
     def bwd(self, dy, ctx, need_dx, fused=None):
         c_conv, c_bn, pool, x_shape = ctx
         mods = list(self)[-2:]
-        dc, _ = mods[1].bwd(dy, c_bn, fused=fused)
+        dc, _ = mods[1].bwd(dy, c_bn, fused=fused, dx_dtype=mods[0].grad_storage(*dy.shape[:3]))
         dx = mods[0].bwd(dc, c_conv, need_dx)
         if dx is not None and pool is not None:
             dx = pool.bwd(dx, x_shape)

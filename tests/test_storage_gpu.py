@@ -199,3 +199,57 @@ def test_fused_batchnorm_backward_epilogue_reads_typed_storage(case, monkeypatch
     post = kk.BnBwdFuse(mask, [(x, s) for x, s in zip(xs, ctxs)])
     kk.conv2d_dgrad(dy, w, shape, add, 1, 0, 1, precision="fp32", post=post)
     assert not post.applied
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, pad, groups
+    (3, 20, 19, 64, 256, 1, 0, 1), (2, 28, 28, 128, 512, 1, 0, 1), (4, 23, 9, 96, 64, 1, 0, 1), (2, 24, 24, 64, 128, 3, 1, 2)])
+def test_gradients_read_only_by_bf16_kernels_may_be_stored_as_bf16(case):
+    """dc = BatchNorm-backward output in front of a convolution whose input- and weight-gradient kernels are the bf16-input
+    ones: stored as bf16 it is exactly what those kernels round an fp32 dc to -- dx and dW bit for bit the same."""
+    B, H, W, Cin, Cout, k, pad, groups = case
+    kk = K()
+    rng = np.random.default_rng(sum(case) + 2)
+    C = Cout
+    x = _rand(rng, B, H, W, Cin)
+    w = _rand(rng, k, k, Cin // groups, Cout, scale=0.1)
+    y = _rand(rng, B, H, W, C)                          # the convolution output = BatchNorm input
+    gamma, beta = _rand(rng, C).abs() + 0.5, _rand(rng, C)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    _, saved, mask = kk.bn_fwd(y, gamma, beta, rm, rv, True, True, want_mask=True)
+    dout = _rand(rng, B, H, W, C)
+    dc32, _ = kk.bn_bwd(dout, None, y, saved, True, None, None, mask=mask)
+    dc16, _ = kk.bn_bwd(dout, None, y, saved, True, None, None, mask=mask, dx_dtype=BF16)
+    assert dc16.dtype == BF16 and torch.equal(dc16, dc32.to(BF16))
+    dx32 = kk.conv2d_dgrad(dc32, w, tuple(x.shape), None, 1, pad, groups, precision="bf16")
+    dx16 = kk.conv2d_dgrad(dc16, w, tuple(x.shape), None, 1, pad, groups, precision="bf16")
+    assert torch.equal(dx32, dx16)
+    dw32, dw16 = torch.zeros_like(w), torch.zeros_like(w)
+    kk.conv2d_wgrad(x, dc32, dw32, 1, pad, groups, precision="bf16")
+    kk.conv2d_wgrad(x, dc16, dw16, 1, pad, groups, precision="bf16")
+    assert torch.equal(dw32, dw16)
+    kk.conv2d_wgrad(x.to(BF16), dc16, dw16, 1, pad, groups, precision="bf16")           # both operands bf16-stored
+    kk.conv2d_wgrad(x.to(BF16).float(), dc32, dw32, 1, pad, groups, precision="bf16")
+    assert torch.equal(dw32, dw16)
+    with pytest.raises(RuntimeError, match="bf16-stored gradients"):
+        kk.conv2d_dgrad(dc16, w, tuple(x.shape), None, 1, pad, groups, precision="fp32")
+
+
+def test_gradient_storage_changes_no_bit_of_the_model(monkeypatch):
+    """Whole model (resnest26d + xSlot, precision bf16, batch 8 x 224 x 224 so that layer1-3 run the bf16 kernels): with the
+    gradients in front of conv1 / conv3 / the downsample convolutions stored as bf16 (nn_hip.Conv2d.grad_storage) every
+    output and every parameter gradient is the same bits as with fp32 storage."""
+    import test_model_gpu as T
+    from scouter_amd import nn_hip
+    monkeypatch.undo()                                   # (the model's own pixel rule, not the kernel tests' override)
+    res = []
+    for flag in (False, True):
+        monkeypatch.setattr(nn_hip, "GRAD_STORAGE_BF16", flag)
+        m, P, images, labels, cfg = T._synthetic_model("resnest26d", 10, 1, 3, 8, 224, 1900)
+        m.set_precision("bf16")
+        out, (loss, nll, area) = m(images.cuda(), labels.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), m.grad_arena().flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float(res[0][1].abs().max()) > 0
