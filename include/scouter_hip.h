@@ -189,8 +189,9 @@ int scouter_bn_bwd_f32(const float* dy, const float* ymask, const float* x, cons
                        float* dgamma, float* dbeta, float* dx, float* gout, const double* ext_partial, int ext_rows,
                        void* ws, size_t ws_bytes, void* stream);
 /* io: SCOUTER_IO_X_BF16 -- the BatchNorm input x is stored as bf16; SCOUTER_IO_Y_BF16 -- dx is stored as bf16 (for a dx
- * read only by bf16-input convolution kernels, which round it the same way: same results); dy and gout are fp32 */
-int scouter_bn_bwd_io(const float* dy, const float* ymask, const void* x, const float* mean, const float* rstd,
+ * read only by bf16-input convolution kernels, which round it the same way: same results); SCOUTER_IO_R_BF16 -- dy is
+ * stored as bf16 (the masked block-output gradient of scouter_conv2d_dgrad_bnbwd_bf16_io; gout must be NULL) */
+int scouter_bn_bwd_io(const void* dy, const float* ymask, const void* x, const float* mean, const float* rstd,
                       const float* scale, const unsigned long long* relu_mask, long M, int C, int training,
                       float* dgamma, float* dbeta, void* dx, float* gout, const double* ext_partial, int ext_rows,
                       int io, void* ws, size_t ws_bytes, void* stream);

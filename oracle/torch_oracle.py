@@ -207,8 +207,11 @@ BF16_MIN_PIXELS = 1024
 # (scouter_amd SlotModel.set_activation_storage) -- in every ResNeSt bottleneck but the network's last one whose output
 # has >= BF16_MIN_PIXELS pixels, the conv3 / downsample-convolution outputs and the block output are STORED rounded to
 # bf16: the BatchNorm after conv3 (and the downsample one) takes its batch statistics from the unrounded convolution
-# result and normalises the rounded values; the block output is rounded after the ReLU.  Gradients are not rounded
-# (straight-through).
+# result and normalises the rounded values; the block output is rounded after the ReLU (straight-through for the
+# gradient).  The same blocks store the gradient of their output -- masked by the ReLU, i.e. the gradient of
+# `out + residual` -- as bf16: it is rounded once where it is formed and both branches (the bn3 backward and the
+# shortcut) read the rounded value.  (The other bf16-stored gradients -- in front of conv1 / conv3 / the downsample
+# convolution -- hold exactly what the bf16-operand kernels round to anyway: CONV_INPUT_ROUNDING covers them.)
 ACTIVATION_STORAGE = None
 
 
@@ -270,6 +273,17 @@ def _rb_ste(t):
     return t + (_rb(t) - t).detach()
 
 
+class _GradRound(torch.autograd.Function):
+    """identity whose incoming gradient is rounded to bf16 (a gradient tensor stored as bf16)"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
 def _bn_stored(P, name, x, training):
     """BatchNorm of a convolution output that is STORED as bf16 (ACTIVATION_STORAGE): statistics (and the running-stat
     update) from the unrounded x, the affine map applied to the rounded values."""
@@ -321,7 +335,10 @@ def _resnest_block(P, name, x, stride, training, last=False):
         if stride > 1:
             residual = F.avg_pool2d(residual, 2, stride, ceil_mode=True, count_include_pad=False)
         residual = bn(P, name + ".downsample.2", _conv(residual, P[name + ".downsample.1.weight"]), training)
-    y = _relu(name + ".bn3", out + residual)
+    pre = out + residual
+    if stored:
+        pre = _GradRound.apply(pre)
+    y = _relu(name + ".bn3", pre)
     return _rb_ste(y) if stored else y
 
 

@@ -31,7 +31,7 @@ static int col_blocks(long M, const ColGeom& g) {
 
 // Per-block partial column sums of up to two quantities produced by `F(row, col4) -> (float4 u, float4 v)`.
 // partial layout: [block][C][2] doubles.
-template <int MODE, bool XB = false>   // 0: (x, x*x)   1: (g, g*xhat) with g = dy*(mask>0)   2: (x, 0)   3: (a*b, 0)
+template <int MODE, bool XB = false, bool DB = false>   // 0: (x, x*x)   1: (g, g*xhat) with g = dy*(mask>0)   2: (x, 0)   3: (a*b, 0)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
                                                              const float* __restrict__ p2,
                                                              const float* __restrict__ mean,
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         }
         for (; r < g.M; r += rstep) {
             const long off = r * g.C + c;
-            f32x4 a = *(const f32x4*)(p0 + off);
+            f32x4 a = sc_load4<(MODE == 1 && DB)>(p0, off);            // (DB: dy of MODE 1 is stored as bf16)
             if (MODE == 0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { s[k] += a[k]; t[k] += (double)a[k] * a[k]; }
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 }
 
 // dx = gamma*rstd * (g - c1 - xhat*c2),  g = dy * (ymask > 0);  optionally also writes g (the residual-branch grad)
-template <bool XB = false, bool YB = false>                 // XB / YB: the BatchNorm input x / the gradient dx is stored as bf16
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+template <bool XB = false, bool YB = false, bool DB = false>   // XB / YB / DB: x / dx / dy is stored as bf16
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dy, const float* __restrict__ ymask,
                                                            const void* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ scale, const float* __restrict__ c1,
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int C) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
-        f32x4 g = __builtin_nontemporal_load((const f32x4*)(dy + i * 4));
+        f32x4 g = sc_load4_nt<DB>(dy, i * 4);
         if (mbits) {
             relu_mask_apply(g, mbits, i);
         } else if (ymask) {
@@ -754,14 +754,16 @@ extern "C" int scouter_bn_apply_f32(const float* x, const float* bn_saved, float
 }
 
 // `io`: SC_IO_X_BF16 -- the BatchNorm input x is stored as bf16; SC_IO_Y_BF16 -- dx is stored as bf16 (RNE; for a dx whose
-// only readers are bf16-input convolution kernels, which round it the same way).  dy and gout are fp32.
-extern "C" int scouter_bn_bwd_io(const float* dy, const float* ymask, const void* x, const float* mean,
+// only readers are bf16-input convolution kernels, which round it the same way); SC_IO_R_BF16 -- dy is stored as bf16 (the
+// masked block-output gradient written by scouter_conv2d_dgrad_bnbwd_bf16_io).  gout is fp32.
+extern "C" int scouter_bn_bwd_io(const void* dy, const float* ymask, const void* x, const float* mean,
                                  const float* rstd, const float* scale, const unsigned long long* relu_mask, long M,
                                  int C, int training, float* dgamma, float* dbeta, void* dx, float* gout,
                                  const double* ext_partial, int ext_rows, int io, void* ws, size_t ws_bytes, void* stream) {
     SC_REQUIRE(dy && x && mean && rstd && scale && dx, "bn_bwd: null pointer");
-    SC_REQUIRE((io & ~(SC_IO_X_BF16 | SC_IO_Y_BF16)) == 0, "bn_bwd: unsupported io bits %d (x and dx may be bf16)", io);
-    const bool xb = (io & SC_IO_X_BF16) != 0, yb = (io & SC_IO_Y_BF16) != 0;
+    SC_REQUIRE((io & ~7) == 0, "bn_bwd: unknown io bits %d", io);
+    const bool xb = (io & SC_IO_X_BF16) != 0, yb = (io & SC_IO_Y_BF16) != 0, db = (io & SC_IO_R_BF16) != 0;
+    SC_UNSUPPORTED(!db || !gout, "bn_bwd: a bf16-stored dy is the already masked gradient (no separate gout)");
     SC_REQUIRE(!ext_partial || (ext_rows > 0 && !ymask && !relu_mask && !gout),
                "bn_bwd: with ext_partial dy is the already masked gradient (no ymask / relu_mask / gout)");
     COL_CHECKS("bn_bwd")
@@ -775,39 +777,48 @@ extern "C" int scouter_bn_bwd_io(const float* dy, const float* ymask, const void
     hipStream_t st = (hipStream_t)stream;
     ScProfScope prof(ext_partial ? "bn_bwd(finalize+apply)" : "bn_bwd(reduce+finalize+apply)", st, 0,
                      ((ext_partial ? 12.0 : (ymask && !relu_mask ? 28.0 : 20.0)) + (gout ? 4.0 : 0.0) +
-                      (relu_mask ? 0.25 : 0.0) - (xb ? (ext_partial ? 2.0 : 4.0) : 0.0) - (yb ? 2.0 : 0.0)) * M * C);
-    if (!ext_partial && M <= (long)g.rpb * 24 && !xb && !yb) {   // few row passes: everything in one launch
+                      (relu_mask ? 0.25 : 0.0) - (xb ? (ext_partial ? 2.0 : 4.0) : 0.0) - (yb ? 2.0 : 0.0) -
+                      (db ? (ext_partial ? 2.0 : 4.0) : 0.0)) * M * C);
+    if (!ext_partial && M <= (long)g.rpb * 24 && !xb && !yb && !db) {   // few row passes: everything in one launch
         // 16-channel slabs (4 threads per row, 64 rows per pass) when the channel count allows: C / 16 workgroups with one or
         // two passes each instead of ONE workgroup walking up to 24 dependent passes (14 us on every block's critical path)
         ColGeom gs = g;
         int slabs = pgrid.y;
         if (C % 16 == 0 && C >= 32) { gs.cslab = 16; gs.tpr = 4; gs.rpb = 64; slabs = C / 16; }
-        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, slabs), dim3(256), 0, st, dy, ymask, (const float*)x, mean, rstd, scale,
-                           relu_mask, training, dgamma, dbeta, (float*)dx, gout, gs);
+        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, slabs), dim3(256), 0, st, (const float*)dy, ymask, (const float*)x, mean,
+                           rstd, scale, relu_mask, training, dgamma, dbeta, (float*)dx, gout, gs);
         return sc_check_launch("bn_bwd");
     }
     const double* part = (const double*)ws;
     int nparts = nb;
     if (ext_partial) { part = ext_partial; nparts = ext_rows; }   // reduced by the epilogue of the kernel that produced dy
-    else if (xb)
-        hipLaunchKernelGGL((colsum_partial_kernel<1, true>), pgrid, dim3(256), 0, st, dy, ymask, (const float*)x, mean, rstd,
-                           relu_mask, (double*)ws, g);
-    else
-        hipLaunchKernelGGL(colsum_partial_kernel<1>, pgrid, dim3(256), 0, st, dy, ymask, (const float*)x, mean, rstd,
-                           relu_mask, (double*)ws, g);
+#define CSP(XB_, DB_)                                                                                                 \
+        hipLaunchKernelGGL((colsum_partial_kernel<1, XB_, DB_>), pgrid, dim3(256), 0, st, (const float*)dy, ymask,          \
+                           (const float*)x, mean, rstd, relu_mask, (double*)ws, g)
+    else if (xb && db) CSP(true, true);
+    else if (xb) CSP(true, false);
+    else if (db) CSP(false, true);
+    else CSP(false, false);
+#undef CSP
     if (fin_narrow(C, nparts))
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<1>, dim3(C), dim3(256), 0, st, part, nparts, M, C, training, dgamma, dbeta, c1, c2);
     else
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, part, nparts, M, C, training, dgamma,
                            dbeta, c1, c2);
     const long n4 = M * C / 4;
-#define BBA(XB_, YB_)                                                                                                 \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<XB_, YB_>), dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean, rstd, \
-                       scale, c1, c2, relu_mask, dx, gout, n4, C)
-    if (xb && yb) BBA(true, true);
-    else if (xb) BBA(true, false);
-    else if (yb) BBA(false, true);
-    else BBA(false, false);
+#define BBA(XB_, YB_, DB_)                                                                                            \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<XB_, YB_, DB_>), dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean,    \
+                       rstd, scale, c1, c2, relu_mask, dx, gout, n4, C)
+    switch ((xb ? 1 : 0) | (yb ? 2 : 0) | (db ? 4 : 0)) {
+        case 0: BBA(false, false, false); break;
+        case 1: BBA(true, false, false); break;
+        case 2: BBA(false, true, false); break;
+        case 3: BBA(true, true, false); break;
+        case 4: BBA(false, false, true); break;
+        case 5: BBA(true, false, true); break;
+        case 6: BBA(false, true, true); break;
+        default: BBA(true, true, true); break;
+    }
 #undef BBA
     return sc_check_launch("bn_bwd");
 }

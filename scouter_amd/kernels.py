@@ -370,16 +370,23 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
     """post (BnBwdFuse): the tensor produced is the gradient of a BatchNorm+ReLU block output -- the epilogue masks it
     and reduces that BatchNorm's backward sums (see BnBwdFuse).
     Gradient storage (bf16-input kernel only): dy may be a bfloat16-stored tensor (the values the kernel rounds an fp32
-    dy to: same result), the addend too, and out_dtype=torch.bfloat16 stores dx rounded."""
+    dy to: same result), the addend too; out_dtype=torch.bfloat16 stores dx rounded WHEN the fused epilogue runs (dx is
+    then the masked block-output gradient, read by that BatchNorm's backward and as the previous block's addend) -- check
+    dx.dtype."""
     _chk(dy, "dy", (F32, BF16)); _chk(w_hwio, "weight"); _chk(addend, "addend", (F32, BF16))
     B, H, W, Cin = x_shape
     kh, kw, cg, Cout = w_hwio.shape
-    dx = torch.empty(x_shape, dtype=out_dtype, device=dy.device)
     L = _native.lib()
     st = _stream()
 
     # strided input gradients (resnet18) and tiny layers stay on the fp32 kernel
     bf16 = precision == "bf16" and stride == 1 and B * H * W >= BF16_MIN_PIXELS
+    # (BatchNorm inputs stored as bf16: only the bf16-input kernel's epilogue reads them; otherwise that BatchNorm's own
+    #  backward -- typed -- does the reduction)
+    fuse = _fuse_wanted(post, kh) and (bf16 or post.x_io() == 0)
+    if out_dtype == BF16 and not (fuse and bf16):
+        out_dtype = F32           # (bf16 storage is for the MASKED block-output gradient the fused epilogue writes)
+    dx = torch.empty(x_shape, dtype=out_dtype, device=dy.device)
     io = ((DGRAD_IO_DY if dy.dtype == BF16 else 0) | (DGRAD_IO_DX if out_dtype == BF16 else 0) |
           (DGRAD_IO_ADDEND if addend is not None and addend.dtype == BF16 else 0))
     if io and not bf16:
@@ -402,9 +409,7 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
                 "conv2d_dgrad")
         return True
 
-    # (BatchNorm inputs stored as bf16: only the bf16-input kernel's epilogue reads them; otherwise that BatchNorm's own
-    #  backward -- typed -- does the reduction)
-    if _fuse_wanted(post, kh) and (bf16 or post.x_io() == 0):
+    if fuse:
         # the fused launch is tuned as what it is (its epilogue reads one or two more tensors: on the short-K layers a
         # different tile wins than for the plain input gradient); partials sized for the most rows while timing
         def launch_fused(tile, dry=False):
@@ -842,12 +847,15 @@ def bn_bwd(dy, ymask, x, saved, training, dgamma=None, dbeta=None, want_gout=Fal
     ext = (partial, rows) from a BnBwdFuse: dy is the already masked gradient, its sums are reduced -- no reduction
     pass, no mask, and the masked gradient `gout` is dy itself.  dx_dtype=torch.bfloat16: dx is stored as bf16 (for a dx
     read only by bf16-input convolution kernels, which round it the same way)."""
-    _chk(dy, "dy"); _chk(ymask, "ymask"); _chk(x, "x", (F32, BF16))
+    _chk(dy, "dy", (F32, BF16)); _chk(ymask, "ymask"); _chk(x, "x", (F32, BF16))
     C = x.shape[-1]
     M = x.numel() // C
     dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)     # (x may be bf16-stored)
     ws = _col_ws(M, C, x.device)
-    io = (IO_X_BF16 if x.dtype == BF16 else 0) | (IO_Y_BF16 if dx_dtype == BF16 else 0)
+    io = ((IO_X_BF16 if x.dtype == BF16 else 0) | (IO_Y_BF16 if dx_dtype == BF16 else 0) |
+          (IO_R_BF16 if dy.dtype == BF16 else 0))
+    if dy.dtype == BF16 and ext is None and want_gout:
+        raise RuntimeError("scouter_amd: a bf16-stored dy is the already masked gradient (its producer fused the mask)")
     if ext is not None:
         part, rows = ext
         _native.check(_native.lib().scouter_bn_bwd_io(

@@ -114,9 +114,10 @@ class Conv2d(nn.Module):
             self._capture[0][self._capture[1]] = y
         return y, (x if save else None)
 
-    def bwd(self, dy, ctx, need_dx=True, addend=None, post=None):
+    def bwd(self, dy, ctx, need_dx=True, addend=None, post=None, dx_dtype=None):
         """post (K.BnBwdFuse): the input gradient is the gradient of a BatchNorm(+ReLU) output -- its producer finishes
-        that BatchNorm's backward reductions in the epilogue (only when dx is computed at all)."""
+        that BatchNorm's backward reductions in the epilogue (only when dx is computed at all).  dx_dtype=torch.bfloat16:
+        that masked gradient is stored as bf16 when the bf16-input kernel fuses (kernels.conv2d_dgrad; check dx.dtype)."""
         wd = xp = None
         if isinstance(ctx, tuple):
             x, wd, xp = ctx
@@ -150,7 +151,7 @@ class Conv2d(nn.Module):
         if not need_dx:
             return dx
         return K.conv2d_dgrad(dy, K.hwio(self.weight), xshape, addend, self.stride, self.padding, self.groups,
-                              precision=self.precision, post=post)
+                              precision=self.precision, post=post, out_dtype=dx_dtype or K.F32)
 
 
 class StemConv2d(Conv2d):

@@ -1,11 +1,20 @@
 """ResNeSt bottleneck (radix 2, cardinality 1, avd after the split-attention conv, avg-pool downsample).
 Mirrors timm/models/resnest.py:58-143 and :161-189 of the reference."""
+import os
+
+import torch
 import torch.nn as nn
 
 from ... import kernels as K
 from ...nn_hip import Act, BatchNorm2d, Conv2d
 from .layers.split_attn import SplitAttnConv2d
 from .resnet import AvgPool2dSpec, ResNet, BRANCH_FWD, BRANCH_BWD
+
+
+# bf16 storage of the masked block-output gradients (the residual-stream gradient) next to the bf16-stored activations;
+# SCOUTER_BF16_GRAD_STREAM=0: fp32.  Unlike Conv2d.grad_storage this one rounds values that fp32 arithmetic reads (the
+# BatchNorm backward, the shortcut addend): the oracle emulates it (oracle.torch_oracle.ACTIVATION_STORAGE).
+GRAD_STREAM_BF16 = os.environ.get("SCOUTER_BF16_GRAD_STREAM", "1") != "0"
 
 
 class ResNestBottleneck(nn.Module):
@@ -89,7 +98,11 @@ class ResNestBottleneck(nn.Module):
                               dx_dtype=self.conv1.grad_storage(*dh1.shape[:3]))
         if self.downsample is not None:
             dxres = self.downsample.bwd_join(dxres, dres.device, hnd)
-        return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None)
+        # the block-INPUT gradient this produces is the previous block's masked output gradient (post): stored as bf16 where
+        # that block stores its activations as bf16 (same rule: ResNestBottleneck._storage of the previous block)
+        gdt = K.BF16 if (post is not None and need_dx and GRAD_STREAM_BF16 and isinstance(k1, torch.Tensor) and
+                         k1.dtype == K.BF16) else None
+        return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None, dx_dtype=gdt)
 
 
 def _resnest(name, layers, pretrained, num_classes, in_chans, **kwargs):

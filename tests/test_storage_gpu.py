@@ -253,3 +253,47 @@ def test_gradient_storage_changes_no_bit_of_the_model(monkeypatch):
         res.append((out.detach().clone(), m.grad_arena().flat.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert float(res[0][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("case", [(3, 20, 19, 256, 64, True, True), (5, 14, 14, 512, 128, False, True), (2, 28, 28, 256, 128, True, False)])
+def test_masked_block_gradient_stored_as_bf16(case, monkeypatch):
+    """The residual-stream gradient: conv1's fused input-gradient epilogue stores the masked gradient g as bf16 (= RNE of the
+    fp32-storage launch's g, same partial sums), takes a bf16-stored shortcut addend, and the BatchNorm backward / the
+    next epilogue read the stored g like the widened tensor."""
+    B, H, W, Cin, Cout, two, with_add = case
+    kk = K()
+    monkeypatch.setattr(kk, "BN_BWD_FUSE", 15)
+    rng = np.random.default_rng(sum(case[:5]) + 3)
+    shape = (B, H, W, Cin)
+    dy = _rand(rng, B, H, W, Cout)
+    w = _rand(rng, 1, 1, Cin, Cout, scale=0.1)
+    add = _rand(rng, *shape).to(BF16) if with_add else None
+    gamma, beta = _rand(rng, Cin).abs() + 0.5, _rand(rng, Cin)
+    xs = [_rand(rng, *shape).to(BF16) for _ in range(2 if two else 1)]
+    saved = []
+    for i, xh in enumerate(xs):
+        rm, rv = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda")
+        if i == 0:
+            _, sv, mask = kk.bn_fwd(xh, gamma, beta, rm, rv, True, True, stats=_stats_of(xh.float()), want_mask=True)
+        else:
+            sv = kk.bn_stats(xh, gamma, beta, rm, rv, True, stats=_stats_of(xh.float()))
+        saved.append(sv)
+    out = []
+    for typed in (False, True):
+        post = kk.BnBwdFuse(mask, list(zip(xs, saved)))
+        g = kk.conv2d_dgrad(dy, w, shape, (add if typed else add.float()) if with_add else None, 1, 0, 1, precision="bf16",
+                            post=post, out_dtype=BF16 if typed else torch.float32)
+        assert post.applied and g.dtype == (BF16 if typed else torch.float32)
+        dg, db = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+        gin = g if typed else g.to(BF16).float()         # what the fp32-storage chain would see had g been rounded
+        dc, dres = kk.bn_bwd(gin, None, xs[0], saved[0], True, dg, db, want_gout=True, ext=post.ext(0), dx_dtype=BF16)
+        assert dres is gin
+        out.append((g, post.parts, dc, dg, db))
+    assert torch.equal(out[1][0], out[0][0].to(BF16))
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b), "the sums are those of the unrounded masked gradient"
+    for a, b in zip(out[0][2:], out[1][2:]):
+        assert torch.equal(a, b)
+    # without the fused epilogue the gradient is not a block-output gradient: fp32 storage, whatever was asked
+    plain = kk.conv2d_dgrad(dy, w, shape, None, 1, 0, 1, precision="bf16", out_dtype=BF16)
+    assert plain.dtype == torch.float32
