@@ -90,6 +90,17 @@ class Conv2d(nn.Module):
               cg % 32 == 0 and ng % 32 == 0 and (k == 1 or 64 // W + 1 < H))
         return K.BF16 if ok else None
 
+    def act_storage(self, B, H, W):
+        """Storage type for this layer's INPUT activation (B x H x W pixels) when nothing else reads it: bf16 when the
+        forward and the weight-gradient kernel are the bf16-input ones (which round an fp32 input to exactly the stored
+        values: no result changes); None (fp32) otherwise."""
+        cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
+        k = self.kernel_size
+        ok = (GRAD_STORAGE_BF16 and self.precision == "bf16" and not self.planes and self.stride == 1 and
+              2 * self.padding == k - 1 and B * H * W >= K.BF16_MIN_PIXELS and cg % 32 == 0 and ng % 32 == 0 and
+              (k == 1 or 64 // W + 1 < H))
+        return K.BF16 if ok else None
+
     def fwd(self, x, save, relu=False, addend=None, bn_stats=False, out_dtype=None):
         """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd.
         out_dtype=torch.bfloat16: the output is STORED as bf16 (activation storage of the bf16 mode, kernels.conv2d_fwd)."""

@@ -33,6 +33,12 @@ class AvgPool2dSpec(nn.Module):
         return K.avgpool_bwd(dy, x_shape, self.k, self.s, self.p, self.ceil, self.cip)
 
 
+def _map_of(c):
+    """(B, H, W) of a convolution result that may come as (tensor, statistics)"""
+    t = c[0] if isinstance(c, tuple) else c
+    return tuple(t.shape[:3])
+
+
 class Downsample(nn.Sequential):
     """downsample_conv: [conv1x1(stride), bn]   downsample_avg: [pool | Identity, conv1x1, bn]"""
 
@@ -197,10 +203,11 @@ class ResNet(nn.Module):
         ctx = []
         if isinstance(self.conv1, nn.Sequential):
             s = self.conv1
+            # (bf16 mode: the two stem activations are read by bf16-input kernels only -- stored as bf16, same results)
             c, k0 = s[0].fwd(x_nchw, save, bn_stats=s[1].training)
-            h, b0 = s[1].fwd(c, save, relu=True, tracked=tracked)
+            h, b0 = s[1].fwd(c, save, relu=True, tracked=tracked, out_dtype=s[3].act_storage(*_map_of(c)))
             c, k1 = s[3].fwd(h, save, bn_stats=s[4].training)
-            h, b1 = s[4].fwd(c, save, relu=True, tracked=tracked)
+            h, b1 = s[4].fwd(c, save, relu=True, tracked=tracked, out_dtype=s[6].act_storage(*_map_of(c)))
             c, k2 = s[6].fwd(h, save, bn_stats=self.bn1.training)
             ctx.append((k0, b0, k1, b1, k2))
         else:
@@ -276,7 +283,7 @@ class ResNet(nn.Module):
             k0, b0, k1, b1, k2 = ctx[0]
             f = BatchNorm2d.fuse(b1)
             dh = s[6].bwd(dc, k2, True, post=f)
-            dc, _ = s[4].bwd(dh, b1, fused=f.ext(0) if f.applied else None)
+            dc, _ = s[4].bwd(dh, b1, fused=f.ext(0) if f.applied else None, dx_dtype=s[3].grad_storage(*dh.shape[:3]))
             f = BatchNorm2d.fuse(b0)
             dh = s[3].bwd(dc, k1, True, post=f)
             dc, _ = s[1].bwd(dh, b0, fused=f.ext(0) if f.applied else None)
