@@ -235,6 +235,15 @@ int scouter_transpose_f32(const float* in, float* out, int batch, int rows, int 
  * in the d(attention) pass -- g = (dout * a + dgap / HW) * [bn0(x0) > 0] is affine in (a, dgap), constants of an image,
  * so its BatchNorm-backward sums follow from them and the reduction pass over (dout, x0) is skipped. */
 size_t scouter_sa_workspace_bytes(int B, int HW, int C2);
+/* typed storage of the radix convolution's raw output x / x0 (SCOUTER_IO_X_BF16) and of the attention-weighted sum `out`
+ * (SCOUTER_IO_Y_BF16) -- see ACTIVATION STORAGE above */
+int scouter_sa_reduce_io(const void* x, const float* dout, const float* bn_saved, float* out, double* bn_sums_out, int B,
+                         int HW, int Cp, int mode, int io, void* ws, size_t ws_bytes, void* stream);
+int scouter_sa_bn_bwd_io(const float* dout, const float* a, const float* dgap, const void* x0, const float* bn_saved,
+                         const double* bn_sums, int B, int HW, int Cp, int training, float* dgamma, float* dbeta,
+                         float* dx, void* dx_planes, int nplanes, int io, void* ws, size_t ws_bytes, void* stream);
+int scouter_sa_apply_fwd_io(const void* x, const float* a, const float* bn_saved, void* out, int B, int HW, int Cp, int io,
+                            void* stream);
 int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out, double* bn_sums_out,
                           int B, int HW, int Cp, int mode, void* ws, size_t ws_bytes, void* stream);
 int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0, const float* bn_saved,
@@ -313,6 +322,10 @@ int scouter_planes_split_weight_f32(const float* w_hwio, void* w_fwd, void* w_dg
 size_t scouter_planes_split_weights_row_bytes(void);
 int scouter_planes_split_weights_multi(const void* table, int nrows, long total, int nplanes, void* stream);
 int scouter_conv2d_fwd_planes_bn_partial_rows(int B, int H, int W, int kh, int kw, int stride, int pad);
+/* io & SCOUTER_IO_Y_BF16: y is stored as bf16 (tiles 0-5; the persistent tile 6 writes fp32 only) */
+int scouter_conv2d_fwd_planes_io(const void* x_planes, const void* w_planes, const float* bias, const float* addend,
+                                 void* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                                 int stride, int pad, int groups, int relu, int nplanes, int tile, int io, void* stream);
 int scouter_conv2d_fwd_planes(const void* x_planes, const void* w_planes, const float* bias, const float* addend,
                               float* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                               int stride, int pad, int groups, int relu, int nplanes, int tile, void* stream);

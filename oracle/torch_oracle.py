@@ -205,9 +205,9 @@ CONV_INPUT_ROUNDING = None
 BF16_MIN_PIXELS = 1024
 # ACTIVATION_STORAGE = "bf16" (with CONV_INPUT_ROUNDING = "bf16"): what the build's bf16 activation storage computes
 # (scouter_amd SlotModel.set_activation_storage) -- in every ResNeSt bottleneck but the network's last one whose output
-# has >= BF16_MIN_PIXELS pixels, the conv3 / downsample-convolution outputs and the block output are STORED rounded to
-# bf16: the BatchNorm after conv3 (and the downsample one) takes its batch statistics from the unrounded convolution
-# result and normalises the rounded values; the block output is rounded after the ReLU (straight-through for the
+# has >= BF16_MIN_PIXELS pixels, the outputs of the radix convolution (conv2.conv), of conv3 and of the downsample
+# convolution and the block output are STORED rounded to bf16: the BatchNorm after such a convolution takes its batch
+# statistics from the unrounded convolution result and normalises the rounded values; the block output is rounded after the ReLU (straight-through for the
 # gradient).  The same blocks store the gradient of their output -- masked by the ReLU, i.e. the gradient of
 # `out + residual` -- as bf16: it is rounded once where it is formed and both branches (the bn3 backward and the
 # shortcut) read the rounded value.  (The other bf16-stored gradients -- in front of conv1 / conv3 / the downsample
@@ -303,10 +303,11 @@ def _bn_stored(P, name, x, training):
     return (_rb_ste(x) - mean.view(1, -1, 1, 1)) * sc + b.view(1, -1, 1, 1)
 
 
-def _split_attn(P, name, x, training):
-    """SplitAttnConv2d.forward, radix 2, cardinality 1 (split_attn.py:54-80, RadixSoftmax :20-28)."""
+def _split_attn(P, name, x, training, stored=False):
+    """SplitAttnConv2d.forward, radix 2, cardinality 1 (split_attn.py:54-80, RadixSoftmax :20-28).
+    stored: the radix convolution's output is STORED as bf16 (ACTIVATION_STORAGE)."""
     x = _conv(x, P[name + ".conv.weight"], None, 1, 1, 1, 2)
-    x = _relu(name + ".bn0", _bn(P, name + ".bn0", x, training))
+    x = _relu(name + ".bn0", (_bn_stored if stored else _bn)(P, name + ".bn0", x, training))
     B, RC, H, W = x.shape
     x5 = x.reshape(B, 2, RC // 2, H, W)
     gap = x5.sum(dim=1).mean(dim=(2, 3), keepdim=True)
@@ -323,7 +324,8 @@ def _resnest_block(P, name, x, stride, training, last=False):
     by ResNet._make_layer so avd pooling exists only when stride > 1 (:76-80).  last: the network's last block (never
     stored as bf16, see ACTIVATION_STORAGE)."""
     out = _relu(name + ".bn1", _bn(P, name + ".bn1", _conv(x, P[name + ".conv1.weight"]), training))
-    out = _split_attn(P, name + ".conv2", out, training)
+    stored2 = (ACTIVATION_STORAGE == "bf16" and not last and out.shape[0] * out.shape[2] * out.shape[3] >= BF16_MIN_PIXELS)
+    out = _split_attn(P, name + ".conv2", out, training, stored2)
     if stride > 1:
         out = F.avg_pool2d(out, 3, stride, padding=1)
     stored = (ACTIVATION_STORAGE == "bf16" and not last and

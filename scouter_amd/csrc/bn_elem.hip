@@ -849,9 +849,10 @@ __device__ __forceinline__ f32x4 sa_bn_g(const float* __restrict__ dout, const f
     for (int k = 0; k < 4; ++k) gg[k] = v[k] > 0.f ? gg[k] : 0.f;
     return gg;
 }
+template <bool XB = false>                                   // XB: x0 is stored as bf16
 __global__ __launch_bounds__(256) void sa_bn_bwd_partial_kernel(const float* __restrict__ dout, const float* __restrict__ a,
                                                                 const float* __restrict__ dgap,
-                                                                const float* __restrict__ x0,
+                                                                const void* __restrict__ x0,
                                                                 const float* __restrict__ bn,   // [4][C2]
                                                                 double* __restrict__ part, ColGeom g, int HW, int Cp,
                                                                 float inv_hw) {
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_partial_kernel(const float* __r
         const long rstep = (long)gridDim.x * g.rpb;
         for (long r = (long)blockIdx.x * g.rpb + rl; r < g.M; r += rstep) {
             const int b = (int)((unsigned)r / (unsigned)HW);      // M < 2^31 (host check); HBM-bound pass
-            const f32x4 x = *(const f32x4*)(x0 + r * g.C + c);
+            const f32x4 x = sc_load4<XB>(x0, r * g.C + c);
             const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, g.C, Cp, inv_hw, x, mu, sc, sh);
             const f32x4 xh = (x - mu) * rs;
 #pragma unroll
@@ -887,9 +888,10 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_partial_kernel(const float* __r
     }
 }
 
+template <bool XB = false>                                   // XB: x0 is stored as bf16
 __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ a,
                                                               const float* __restrict__ dgap,
-                                                              const float* __restrict__ x0, const float* __restrict__ bn,
+                                                              const void* __restrict__ x0, const float* __restrict__ bn,
                                                               const float* __restrict__ c1, const float* __restrict__ c2,
                                                               float* __restrict__ dx, long n4, int C, int HW, int Cp,
                                                               float inv_hw, unsigned short* __restrict__ planes,
@@ -901,7 +903,7 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __res
         const int b = (int)((unsigned)r / (unsigned)HW);
         const f32x4 mu = *(const f32x4*)(bn + c), rs = *(const f32x4*)(bn + C + c);
         const f32x4 sc = *(const f32x4*)(bn + 2 * C + c), sh = *(const f32x4*)(bn + 3 * C + c);
-        const f32x4 x = __builtin_nontemporal_load((const f32x4*)(x0 + i * 4));
+        const f32x4 x = sc_load4_nt<XB>(x0, i * 4);
         const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, C, Cp, inv_hw, x, mu, sc, sh);
         const f32x4 xh = (x - mu) * rs;
         const f32x4 o = sc * (gg - *(const f32x4*)(c1 + c) - xh * *(const f32x4*)(c2 + c));
@@ -941,12 +943,15 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_sums_kernel(const double* __res
     c2[c] = training ? (float)(t / (double)M) : 0.f;
 }
 
-extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0,
-                                     const float* bn_saved, const double* bn_sums, int B, int HW, int Cp, int training,
-                                     float* dgamma, float* dbeta, float* dx, void* dx_planes, int nplanes, void* ws,
-                                     size_t ws_bytes, void* stream) {
+// `io` & SC_IO_X_BF16: x0 (the raw radix-convolution output) is stored as bf16
+extern "C" int scouter_sa_bn_bwd_io(const float* dout, const float* a, const float* dgap, const void* x0,
+                                    const float* bn_saved, const double* bn_sums, int B, int HW, int Cp, int training,
+                                    float* dgamma, float* dbeta, float* dx, void* dx_planes, int nplanes, int io, void* ws,
+                                    size_t ws_bytes, void* stream) {
     SC_REQUIRE(dout && a && dgap && x0 && bn_saved && (dx || dx_planes) && B > 0 && HW > 0 && Cp % 4 == 0,
                "sa_bn_bwd: bad arguments");
+    SC_REQUIRE((io & ~SC_IO_X_BF16) == 0, "sa_bn_bwd: unsupported io bits %d (only x0 may be bf16)", io);
+    const bool xb = (io & SC_IO_X_BF16) != 0;
     const long M = (long)B * HW;
     const int C = 2 * Cp;
     SC_UNSUPPORTED(M < (1L << 31), "sa_bn_bwd: more than 2^31 pixels per batch");
@@ -960,20 +965,31 @@ extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const fl
     float* c2 = c1 + C;
     hipStream_t st = (hipStream_t)stream;
     ScProfScope prof(bn_sums ? "sa_bn_bwd(finalize+apply)" : "sa_bn_bwd(reduce+finalize+apply)", st, 0,
-                     ((bn_sums ? 8.0 : 12.0) * C + (bn_sums ? 4.0 : 8.0) * Cp) * M);
+                     ((bn_sums ? 8.0 : 12.0) * C + (bn_sums ? 4.0 : 8.0) * Cp - (xb ? (bn_sums ? 2.0 : 4.0) * C : 0.0)) * M);
     if (bn_sums) {
         hipLaunchKernelGGL(sa_bn_bwd_sums_kernel, dim3(sc_cdiv((long)C * SBS_L, 256)), dim3(256), 0, st, bn_sums, a, dgap, B, C, Cp,
                            1.f / HW, M, training, dgamma, dbeta, c1, c2);
     } else {
-        hipLaunchKernelGGL(sa_bn_bwd_partial_kernel, pgrid, dim3(256), 0, st, dout, a, dgap, x0, bn_saved, (double*)ws, g,
-                           HW, Cp, 1.f / HW);
+        if (xb) hipLaunchKernelGGL(sa_bn_bwd_partial_kernel<true>, pgrid, dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
+                                   (double*)ws, g, HW, Cp, 1.f / HW);
+        else hipLaunchKernelGGL(sa_bn_bwd_partial_kernel<false>, pgrid, dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
+                                (double*)ws, g, HW, Cp, 1.f / HW);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nb, M, C,
                            training, dgamma, dbeta, c1, c2);
     }
     const long n4 = M * C / 4;
-    hipLaunchKernelGGL(sa_bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved, c1, c2,
-                       dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);
+    if (xb) hipLaunchKernelGGL(sa_bn_bwd_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
+                               c1, c2, dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);
+    else hipLaunchKernelGGL(sa_bn_bwd_apply_kernel<false>, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
+                            c1, c2, dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);
     return sc_check_launch("sa_bn_bwd");
+}
+extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0,
+                                     const float* bn_saved, const double* bn_sums, int B, int HW, int Cp, int training,
+                                     float* dgamma, float* dbeta, float* dx, void* dx_planes, int nplanes, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    return scouter_sa_bn_bwd_io(dout, a, dgap, x0, bn_saved, bn_sums, B, HW, Cp, training, dgamma, dbeta, dx, dx_planes,
+                                nplanes, 0, ws, ws_bytes, stream);
 }
 
 // out[c] = alpha * sum_m a[m][c] (* b[m][c] when b != NULL)

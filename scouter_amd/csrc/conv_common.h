@@ -132,7 +132,8 @@ struct BnBwdFuse {
     const unsigned long long* mask;                        // may be NULL: no ReLU between the BatchNorm and the consumer
     const float* x1; const float* sv1; double* part1;      // BatchNorm input, saved [4][C] block, partial rows [mt][C][2]
     const float* x2; const float* sv2; double* part2;      // second BatchNorm (may be NULL)
-    int io;                                                // bit 0 / 1 / 2: x1 / x2 / the addend is STORED as bf16 (bf16-input kernels only)
+    int io;                                                // bit 0 / 1 / 2: x1 / x2 / the addend is STORED as bf16 (bf16-input kernels only);
+                                                           // bit 3: the OUTPUT is (plane forward kernels, which have no other flag)
 };
 
 // Operands of the fused BatchNorm-backward epilogue that do not depend on the GEMM (shortcut gradient, BatchNorm inputs):
@@ -279,7 +280,7 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        sc_store4_rt(dst, m * g.N + ncol, v, dst_bf16);
+        sc_store4_rt(dst, m * g.N + ncol, v, dst_bf16 || (fz != nullptr && (fz->io & 8) != 0));
     }
     if (bn_part) {
         // Fused batch statistics of the tile just written: lanes sharing a column quad (stride QPR) are combined by

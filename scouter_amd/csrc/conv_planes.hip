@@ -811,12 +811,15 @@ extern "C" int scouter_conv2d_fwd_planes_bn_partial_rows(int B, int H, int W, in
 }
 
 // x_planes: [nplanes][B*H*W][Cin] bf16; w_planes: scouter_planes_split_weight_f32's forward layout.
-extern "C" int scouter_conv2d_fwd_planes(const void* x_planes, const void* w_planes, const float* bias,
-                                         const float* addend, float* y, double* bn_partial, int B, int H, int W, int Cin,
-                                         int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int nplanes,
-                                         int tile, void* stream) {
+// `io` & SC_IO_Y_BF16: y is stored as bf16 (RNE of the fp32 result; bn_partial still sums the fp32 accumulators); tiles 0-5
+extern "C" int scouter_conv2d_fwd_planes_io(const void* x_planes, const void* w_planes, const float* bias,
+                                            const float* addend, void* y, double* bn_partial, int B, int H, int W, int Cin,
+                                            int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int nplanes,
+                                            int tile, int io, void* stream) {
     SC_REQUIRE(x_planes && w_planes && y && B > 0 && H > 0 && W > 0 && (nplanes == 1 || nplanes == 3),
                "conv2d_fwd_planes: bad arguments");
+    SC_REQUIRE((io & ~SC_IO_Y_BF16) == 0, "conv2d_fwd_planes: unsupported io bits %d (only y may be bf16)", io);
+    SC_UNSUPPORTED(!(io & SC_IO_Y_BF16) || tile != 6, "conv2d_fwd_planes: the persistent tile 6 writes fp32 only");
     SC_REQUIRE(!(bn_partial && (relu & 1)), "conv2d_fwd_planes: fused BatchNorm statistics are taken before any activation");
     SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_fwd_planes: channels not divisible by groups");
     const int Cg = Cin / groups, Ng = Cout / groups;
@@ -828,9 +831,19 @@ extern "C" int scouter_conv2d_fwd_planes(const void* x_planes, const void* w_pla
     SC_UNSUPPORTED(g.M < (1L << 31) && (long)nplanes * a_pe * 2 < (1L << 31) + ((long)H * W * Cin * 2) &&
                    (long)H * W * Cin < (1L << 28), "conv2d_fwd_planes: tensor too large for 32-bit plane offsets");
     ScProfScope prof(nplanes == 3 ? "pconv_fwd<bf16x3>" : "pconv_fwd<bf16>", (hipStream_t)stream,
-                     2.0 * g.M * Cout * Cg * kh * kw, 2.0 * nplanes * ((double)a_pe) + 4.0 * (double)g.M * Cout);
-    return dispatch_pconv<false>(x_planes, a_pe, w_planes, w_pe, bias, addend, y, bn_partial, g, relu, nplanes, tile,
-                                 (hipStream_t)stream);
+                     2.0 * g.M * Cout * Cg * kh * kw,
+                     2.0 * nplanes * ((double)a_pe) + ((io & SC_IO_Y_BF16) ? 2.0 : 4.0) * (double)g.M * Cout);
+    BnBwdFuse fz{};
+    fz.io = (io & SC_IO_Y_BF16) ? 8 : 0;             // (the shared block epilogue reads the output's storage type here)
+    return dispatch_pconv<false>(x_planes, a_pe, w_planes, w_pe, bias, addend, (float*)y, bn_partial, g, relu, nplanes, tile,
+                                 (hipStream_t)stream, fz);
+}
+extern "C" int scouter_conv2d_fwd_planes(const void* x_planes, const void* w_planes, const float* bias,
+                                         const float* addend, float* y, double* bn_partial, int B, int H, int W, int Cin,
+                                         int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int nplanes,
+                                         int tile, void* stream) {
+    return scouter_conv2d_fwd_planes_io(x_planes, w_planes, bias, addend, y, bn_partial, B, H, W, Cin, Cout, kh, kw, stride,
+                                        pad, groups, relu, nplanes, tile, 0, stream);
 }
 
 // dy_planes: [nplanes][B*Ho*Wo][Cout]; w_planes: the dgrad layout.  Stride-1 convolutions only.

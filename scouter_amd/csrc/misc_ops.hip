@@ -19,8 +19,8 @@ static inline int ew_blocks(long n) { long b = (n + 255) / 256; return (int)(b >
 //   sum g xhat  = sum_b  a[b,c] * S2 + dgap[b,c'] / HW * S4,     S2 = sum_hw dout * m * xhat,  S4 = sum_hw m * xhat
 // with m = [bn0(x0) > 0]: the separate reduction pass of scouter_sa_bn_bwd_f32 over (dout, x0) disappears.
 // partial planes: [1 + 4][B][nsplit][C2] doubles (plane 0 = the column sums as before).
-template <bool WITH_W, bool STATS>
-__global__ __launch_bounds__(256) void sa_colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <bool WITH_W, bool STATS, bool XB = false>      // XB: x (the raw radix-convolution output) is stored as bf16
+__global__ __launch_bounds__(256) void sa_colsum_partial_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bn,
                                                                 double* __restrict__ part, int HW, int C2, int Cp,
                                                                 int tpr, int rpb, int rows_per_split, long plane) {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void sa_colsum_partial_kernel(const float* __r
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[q][k] = 0.0;
-    const float* xb = x + (long)b * HW * C2;
+    const long xb0 = (long)b * HW * C2;
     const float* wb = WITH_W ? w + (long)b * HW * Cp : nullptr;
     f32x4 mu = {0, 0, 0, 0}, rs = {1, 1, 1, 1}, sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
     if (bn) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void sa_colsum_partial_kernel(const float* __r
         sc = *(const f32x4*)(bn + 2 * C2 + c); sh = *(const f32x4*)(bn + 3 * C2 + c);
     }
     for (int r = r0 + rl; r < r1; r += rpb) {
-        const f32x4 xr = *(const f32x4*)(xb + (long)r * C2 + c);
+        const f32x4 xr = sc_load4<XB>(x, xb0 + (long)r * C2 + c);
         f32x4 v = xr, hv = xr;
         if (bn) {
             hv = bn_affine(xr, mu, sc, sh);                      // (the sign of THIS value is the ReLU mask everywhere)
@@ -158,15 +158,16 @@ __global__ void radix_softmax_bwd_kernel(const float* __restrict__ a, const floa
 }
 
 // out[b,hw,c] = x[b,hw,c]*a[b,c] + x[b,hw,Cp+c]*a[b,Cp+c]
-__global__ __launch_bounds__(256) void sa_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
-                                                           const float* __restrict__ bn, float* __restrict__ out,
+template <bool XB = false, bool YB = false>              // storage of x (raw convolution output) / out: bf16 or fp32
+__global__ __launch_bounds__(256) void sa_apply_fwd_kernel(const void* __restrict__ x, const float* __restrict__ a,
+                                                           const float* __restrict__ bn, void* __restrict__ out,
                                                            long n4, int HW, int Cp) {
     const int c4n = Cp / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
         const long row = i / c4n;                 // b*HW + hw
         const int b = (int)(row / HW);
-        f32x4 x0 = *(const f32x4*)(x + row * 2 * Cp + c), x1 = *(const f32x4*)(x + row * 2 * Cp + Cp + c);
+        f32x4 x0 = sc_load4<XB>(x, row * 2 * Cp + c), x1 = sc_load4<XB>(x, row * 2 * Cp + Cp + c);
         if (bn) {                                 // x is the raw convolution output: relu(bn0(x)) on the fly
             const int C2 = 2 * Cp;
             x0 = bn_affine(x0, *(const f32x4*)(bn + c), *(const f32x4*)(bn + 2 * C2 + c), *(const f32x4*)(bn + 3 * C2 + c));
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void sa_apply_fwd_kernel(const float* __restri
             for (int k = 0; k < 4; ++k) { x0[k] = fmaxf(x0[k], 0.f); x1[k] = fmaxf(x1[k], 0.f); }
         }
         const f32x4 a0 = *(const f32x4*)(a + (long)b * 2 * Cp + c), a1 = *(const f32x4*)(a + (long)b * 2 * Cp + Cp + c);
-        *(f32x4*)(out + i * 4) = x0 * a0 + x1 * a1;
+        sc_store4<YB>(out, i * 4, x0 * a0 + x1 * a1);
     }
 }
 // dx[b,hw,r*Cp+c] = dout[b,hw,c]*a[b,r*Cp+c] + dgap[b,c]*inv_hw
@@ -212,31 +213,45 @@ extern "C" size_t scouter_sa_workspace_bytes(int B, int HW, int C2) { (void)HW; 
 // mode 0: gap[b][c]  = mean_hw (x[.,c] + x[.,Cp+c])          (out: [B][Cp])
 // mode 1: da[b][c2]  = sum_hw dout[b,hw,c2 % Cp] * x[b,hw,c2] (out: [B][2Cp]); with bn_sums_out (needs bn_saved) also
 //         the per-image statistics [B][2Cp][4] (fp64) that let scouter_sa_bn_bwd_f32 skip its reduction pass
-extern "C" int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out,
-                                     double* bn_sums_out, int B, int HW, int Cp, int mode, void* ws, size_t ws_bytes,
-                                     void* stream) {
+// `io` & SC_IO_X_BF16: x (the raw radix-convolution output) is stored as bf16
+extern "C" int scouter_sa_reduce_io(const void* x, const float* dout, const float* bn_saved, float* out,
+                                    double* bn_sums_out, int B, int HW, int Cp, int mode, int io, void* ws, size_t ws_bytes,
+                                    void* stream) {
     const int C2 = 2 * Cp;
     int tpr, rpb, ns, rps;
     SC_REQUIRE(x && out && B > 0 && HW > 0, "sa_reduce: bad arguments");
+    SC_REQUIRE((io & ~SC_IO_X_BF16) == 0, "sa_reduce: unsupported io bits %d (only x may be bf16)", io);
+    const bool xb = (io & SC_IO_X_BF16) != 0;
     SC_REQUIRE(!bn_sums_out || (mode == 1 && bn_saved), "sa_reduce: bn_sums_out needs mode 1 and bn_saved");
     SC_UNSUPPORTED(sa_plan(HW, C2, &tpr, &rpb, &ns, &rps) == 0, "sa_reduce: unsupported channel count %d", C2);
     const long plane = (long)B * ns * C2;
     if (!ws || ws_bytes < (size_t)(bn_sums_out ? 5 : 1) * plane * sizeof(double)) { sc_set_error("sa_reduce: workspace too small"); return SC_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(ns, B);
+#define SCP(W_, S_, DOUT_)                                                                                            \
+    do {                                                                                                              \
+        if (xb) hipLaunchKernelGGL((sa_colsum_partial_kernel<W_, S_, true>), grid, dim3(256), 0, st, x, DOUT_, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane); \
+        else hipLaunchKernelGGL((sa_colsum_partial_kernel<W_, S_, false>), grid, dim3(256), 0, st, x, DOUT_, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane); \
+    } while (0)
     if (mode == 0) {
-        hipLaunchKernelGGL((sa_colsum_partial_kernel<false, false>), grid, dim3(256), 0, st, x, nullptr, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane);
+        SCP(false, false, (const float*)nullptr);
         hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * Cp * SA_FL, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 1, 1.f / HW);
     } else if (bn_sums_out) {
         SC_REQUIRE(dout, "sa_reduce: dout missing");
-        hipLaunchKernelGGL((sa_colsum_partial_kernel<true, true>), grid, dim3(256), 0, st, x, dout, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane);
+        SCP(true, true, dout);
         hipLaunchKernelGGL(sa_dattn_stats_finalize_kernel, dim3(sc_cdiv((long)B * C2 * SA_FL, 256)), dim3(256), 0, st, (const double*)ws, out, bn_sums_out, B, ns, C2, plane);
     } else {
         SC_REQUIRE(dout, "sa_reduce: dout missing");
-        hipLaunchKernelGGL((sa_colsum_partial_kernel<true, false>), grid, dim3(256), 0, st, x, dout, bn_saved, (double*)ws, HW, C2, Cp, tpr, rpb, rps, plane);
+        SCP(true, false, dout);
         hipLaunchKernelGGL(sa_colsum_finalize_kernel, dim3(sc_cdiv((long)B * C2 * SA_FL, 256)), dim3(256), 0, st, (const double*)ws, out, B, ns, C2, Cp, 0, 1.f);
     }
+#undef SCP
     return sc_check_launch("sa_reduce");
+}
+extern "C" int scouter_sa_reduce_f32(const float* x, const float* dout, const float* bn_saved, float* out,
+                                     double* bn_sums_out, int B, int HW, int Cp, int mode, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    return scouter_sa_reduce_io(x, dout, bn_saved, out, bn_sums_out, B, HW, Cp, mode, 0, ws, ws_bytes, stream);
 }
 extern "C" int scouter_radix_softmax_fwd_f32(const float* z, float* a, int B, int Cp, void* stream) {
     hipLaunchKernelGGL(radix_softmax_fwd_kernel, dim3(sc_cdiv((long)B * Cp, 256)), dim3(256), 0, (hipStream_t)stream, z, a, B, Cp);
@@ -246,12 +261,25 @@ extern "C" int scouter_radix_softmax_bwd_f32(const float* a, const float* da, fl
     hipLaunchKernelGGL(radix_softmax_bwd_kernel, dim3(sc_cdiv((long)B * Cp, 256)), dim3(256), 0, (hipStream_t)stream, a, da, dz, B, Cp);
     return sc_check_launch("radix_softmax_bwd");
 }
+// `io`: SC_IO_X_BF16 -- x is stored as bf16, SC_IO_Y_BF16 -- out is
+extern "C" int scouter_sa_apply_fwd_io(const void* x, const float* a, const float* bn_saved, void* out, int B, int HW,
+                                       int Cp, int io, void* stream) {
+    SC_REQUIRE(Cp % 4 == 0, "sa_apply: Cp %% 4 != 0");
+    SC_REQUIRE((io & ~(SC_IO_X_BF16 | SC_IO_Y_BF16)) == 0, "sa_apply: unknown io bits %d", io);
+    const long n4 = (long)B * HW * Cp / 4;
+    const dim3 grid(ew_blocks(n4));
+    hipStream_t st = (hipStream_t)stream;
+    switch (io & 3) {
+        case 0: hipLaunchKernelGGL((sa_apply_fwd_kernel<false, false>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
+        case 1: hipLaunchKernelGGL((sa_apply_fwd_kernel<true, false>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
+        case 2: hipLaunchKernelGGL((sa_apply_fwd_kernel<false, true>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
+        default: hipLaunchKernelGGL((sa_apply_fwd_kernel<true, true>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
+    }
+    return sc_check_launch("sa_apply_fwd");
+}
 extern "C" int scouter_sa_apply_fwd_f32(const float* x, const float* a, const float* bn_saved, float* out, int B, int HW,
                                         int Cp, void* stream) {
-    SC_REQUIRE(Cp % 4 == 0, "sa_apply: Cp %% 4 != 0");
-    const long n4 = (long)B * HW * Cp / 4;
-    hipLaunchKernelGGL(sa_apply_fwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, a, bn_saved, out, n4, HW, Cp);
-    return sc_check_launch("sa_apply_fwd");
+    return scouter_sa_apply_fwd_io(x, a, bn_saved, out, B, HW, Cp, 0, stream);
 }
 extern "C" int scouter_sa_apply_bwd_f32(const float* dout, const float* a, const float* dgap, float* dx, int B, int HW,
                                         int Cp, void* stream) {

@@ -555,14 +555,17 @@ def _halo_ok(kh, kw, stride, pad, H, W, mode=3):
 
 
 def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, addend=None, relu=False, bn_stats=False,
-                      tile=None):
-    """xp: activation planes [np, B, H, W, Cin]; wf: forward weight planes.  Returns y (fp32 NHWC) or (y, stats).
-    tile None: autotuned once per layer shape (bit-identical results for every tile)."""
+                      tile=None, out_dtype=F32):
+    """xp: activation planes [np, B, H, W, Cin]; wf: forward weight planes.  Returns y (NHWC) or (y, stats).
+    tile None: autotuned once per layer shape (bit-identical results for every tile).  out_dtype=torch.bfloat16: y is
+    stored as bf16 (the statistics still come from the fp32 accumulators)."""
     nplanes, B, H, W, Cin = xp.shape
     Cout = wf.shape[2]
-    y = torch.empty((B, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout), dtype=F32, device=xp.device)
+    y = torch.empty((B, conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad), Cout), dtype=out_dtype, device=xp.device)
     L = _native.lib()
     cands = _plane_tiles(Cout // groups, nplanes, False)
+    if out_dtype == BF16:
+        cands = tuple(t for t in cands if t != 6)      # (the persistent tile's register epilogue writes fp32 only)
     if tile is None and _halo_ok(kh, kw, stride, pad, H, W, 1) and H * W >= HALO_FWD_MIN_PIXELS:
         tile = 5                                   # static rule (see HALO_TILE): no timing, same bits for every batch
     if tile == 5:
@@ -581,8 +584,9 @@ def conv2d_fwd_planes(xp, wf, kh, kw, stride=1, pad=0, groups=1, bias=None, adde
             if scratch[0] is None:
                 scratch[0] = torch.empty(((M + 255) // 256 * 4, Cout, 2), dtype=torch.float64, device=xp.device)
             part = scratch[0]
-        _native.check(L.scouter_conv2d_fwd_planes(_p(xp), _p(wf), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
-                                                  Cout, kh, kw, stride, pad, groups, int(relu), nplanes, t, _stream()),
+        _native.check(L.scouter_conv2d_fwd_planes_io(_p(xp), _p(wf), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
+                                                     Cout, kh, kw, stride, pad, groups, int(relu), nplanes, t,
+                                                     IO_Y_BF16 if out_dtype == BF16 else 0, _stream()),
                       "conv2d_fwd_planes")
         return True
     if tile is None:
@@ -985,23 +989,27 @@ def _sa_ws(B, HW, C2, device):
 def sa_gap(x, bn=None):
     """x: [B, H, W, 2C'] -> gap [B, C'] = mean_hw(h[..., :C'] + h[..., C':]), h = x, or relu(bn(x)) on the fly when `bn`
     (the [4, 2C'] block of bn_stats) is given and x is the raw convolution output."""
+    _chk(x, "x", (F32, BF16))
     B, H, W, C2 = x.shape
     out = torch.empty((B, C2 // 2), dtype=F32, device=x.device)
     ws = _sa_ws(B, H * W, C2, x.device)
-    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), None, _p(bn), _p(out), None, B, H * W, C2 // 2, 0, _p(ws),
-                                                      ws.numel(), _stream()), "sa_gap")
+    _native.check(_native.lib().scouter_sa_reduce_io(_p(x), None, _p(bn), _p(out), None, B, H * W, C2 // 2, 0,
+                                                     IO_X_BF16 if x.dtype == BF16 else 0, _p(ws), ws.numel(), _stream()),
+                  "sa_gap")
     return out
 
 
 def sa_dattn(x, dout, bn=None, want_stats=False):
     """da[b, r*C'+c] = sum_hw dout[b,hw,c] * h[b,hw,r*C'+c]   (h as in sa_gap).  want_stats (needs bn): returns
     (da, sums) with the per-image statistics [B, 2C', 4] (fp64) that let sa_bn_bwd skip its reduction pass."""
+    _chk(x, "x", (F32, BF16)); _chk(dout, "dout")
     B, H, W, C2 = x.shape
     out = torch.empty((B, C2), dtype=F32, device=x.device)
     sums = torch.empty((B, C2, 4), dtype=torch.float64, device=x.device) if want_stats else None
     ws = _sa_ws(B, H * W, C2, x.device)
-    _native.check(_native.lib().scouter_sa_reduce_f32(_p(x), _p(dout), _p(bn), _p(out), _p(sums), B, H * W, C2 // 2, 1,
-                                                      _p(ws), ws.numel(), _stream()), "sa_dattn")
+    _native.check(_native.lib().scouter_sa_reduce_io(_p(x), _p(dout), _p(bn), _p(out), _p(sums), B, H * W, C2 // 2, 1,
+                                                     IO_X_BF16 if x.dtype == BF16 else 0, _p(ws), ws.numel(), _stream()),
+                  "sa_dattn")
     return (out, sums) if want_stats else out
 
 
@@ -1009,13 +1017,15 @@ def sa_bn_bwd(dout, a, dgap, x0, bn, training, dgamma=None, dbeta=None, planes=0
     """Backward of [bn0 -> ReLU -> split-attention weighting / GAP] in one fused chain: returns the gradient w.r.t. the
     radix convolution's raw output x0 [B, H, W, 2C'] (a PlaneTensor when `planes`; keep_f32=False: planes only) and fills
     dgamma / dbeta."""
+    _chk(x0, "x0", (F32, BF16)); _chk(dout, "dout")
     B, H, W, Cp = dout.shape
-    dx = torch.empty_like(x0) if keep_f32 or not planes else None
+    dx = torch.empty(x0.shape, dtype=F32, device=x0.device) if keep_f32 or not planes else None
     dxp = torch.empty((planes,) + tuple(x0.shape), dtype=BF16, device=x0.device) if planes else None
     ws = _col_ws(B * H * W, 2 * Cp, x0.device)
-    _native.check(_native.lib().scouter_sa_bn_bwd_f32(_p(dout), _p(a), _p(dgap), _p(x0), _p(bn), _p(sums), B, H * W, Cp,
-                                                      int(training), _p(dgamma), _p(dbeta), _p(dx), _p(dxp), planes,
-                                                      _p(ws), ws.numel(), _stream()), "sa_bn_bwd")
+    _native.check(_native.lib().scouter_sa_bn_bwd_io(_p(dout), _p(a), _p(dgap), _p(x0), _p(bn), _p(sums), B, H * W, Cp,
+                                                     int(training), _p(dgamma), _p(dbeta), _p(dx), _p(dxp), planes,
+                                                     IO_X_BF16 if x0.dtype == BF16 else 0, _p(ws), ws.numel(), _stream()),
+                  "sa_bn_bwd")
     return PlaneTensor(dx, dxp) if planes else dx
 
 
@@ -1033,11 +1043,14 @@ def radix_softmax_bwd(a, da):
     return dz
 
 
-def sa_apply_fwd(x, a, bn=None):
+def sa_apply_fwd(x, a, bn=None, out_dtype=F32):
+    """x may be bf16-stored; out_dtype=torch.bfloat16 stores the weighted sum as bf16."""
+    _chk(x, "x", (F32, BF16))
     B, H, W, C2 = x.shape
-    out = torch.empty((B, H, W, C2 // 2), dtype=F32, device=x.device)
-    _native.check(_native.lib().scouter_sa_apply_fwd_f32(_p(x), _p(a), _p(bn), _p(out), B, H * W, C2 // 2, _stream()),
-                  "sa_apply_fwd")
+    out = torch.empty((B, H, W, C2 // 2), dtype=out_dtype, device=x.device)
+    _native.check(_native.lib().scouter_sa_apply_fwd_io(
+        _p(x), _p(a), _p(bn), _p(out), B, H * W, C2 // 2,
+        (IO_X_BF16 if x.dtype == BF16 else 0) | (IO_Y_BF16 if out_dtype == BF16 else 0), _stream()), "sa_apply_fwd")
     return out
 
 

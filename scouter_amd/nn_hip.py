@@ -105,7 +105,6 @@ class Conv2d(nn.Module):
         """bn_stats=True (a train-mode BatchNorm follows): returns ((y, stats), ctx) -- see kernels.conv2d_fwd.
         out_dtype=torch.bfloat16: the output is STORED as bf16 (activation storage of the bf16 mode, kernels.conv2d_fwd)."""
         if isinstance(x, K.PlaneTensor):
-            assert out_dtype in (None, K.F32), "plane convolutions write fp32"
             k = self.kernel_size
             want_wd = save and self.planes_dy() > 0
             ws, self._wsplit = self._wsplit, None
@@ -114,7 +113,7 @@ class Conv2d(nn.Module):
             else:
                 wf, wd = K.planes_split_weight(K.hwio(self.weight), self.groups, x.planes.shape[0], fwd=True, dgrad=want_wd)
             y = K.conv2d_fwd_planes(x.planes, wf, k, k, self.stride, self.padding, self.groups, self.bias, addend, relu,
-                                    bn_stats)
+                                    bn_stats, out_dtype=out_dtype or K.F32)
             if self._capture is not None and relu:
                 self._capture[0][self._capture[1]] = y
             return y, ((x.f32 if x.f32 is not None else tuple(x.shape), wd,

@@ -30,11 +30,13 @@ class SplitAttnConv2d(nn.Module):
         self.act1 = Act()
         self.fc2 = Conv2d(attn_chs, mid_chs, 1, bias=True)
 
-    def fwd(self, x, save, tracked=None):
+    def fwd(self, x, save, tracked=None, x0_dtype=None, out_dtype=None):
         """bn0 + ReLU are folded into the two passes that read the radix convolution's output anyway (GAP and the
         attention-weighted sum): only the batch statistics are finalised, the activation relu(bn0(x0)) is never stored --
-        one 8-byte-per-element pass less on the largest tensor of every block, forward and backward."""
-        c, c_conv = self.conv.fwd(x, save, bn_stats=self.bn0.training)
+        one 8-byte-per-element pass less on the largest tensor of every block, forward and backward.
+        x0_dtype / out_dtype = torch.bfloat16 (bf16 activation storage): the raw convolution output x0 -- read four times,
+        twice in each direction -- and the attention-weighted sum are stored as bf16."""
+        c, c_conv = self.conv.fwd(x, save, bn_stats=self.bn0.training, out_dtype=x0_dtype)
         x0, saved0 = self.bn0.stats_only(c, tracked)                             # x0: [B,H,W,2C'] raw conv output
         B = x0.shape[0]
         gap = K.sa_gap(x0, saved0)                                               # split_attn.py:63-68 (+ bn0, act0)
@@ -42,7 +44,7 @@ class SplitAttnConv2d(nn.Module):
         g1, c_bn1 = self.bn1.fwd(z1, save, relu=True, tracked=tracked)
         z2, c_fc2 = self.fc2.fwd(g1, save)
         a = K.radix_softmax_fwd(z2.view(B, -1))                                  # split_attn.py:20-28,75
-        out = K.sa_apply_fwd(x0, a, saved0)                                      # split_attn.py:76-79
+        out = K.sa_apply_fwd(x0, a, saved0, out_dtype=out_dtype or K.F32)        # split_attn.py:76-79
         return out, ((c_conv, x0, saved0, self.bn0.training, c_fc1, c_bn1, c_fc2, a) if save else None)
 
     def bwd(self, dout, ctx, post=None):

@@ -64,7 +64,12 @@ class ResNestBottleneck(nn.Module):
         conv = self.conv2.conv                   # (all three of its kernels on planes: no fp32 copy of h1 is written)
         h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked, planes=conv.planes_in(),
                               keep_f32=not conv.planes_only(t1.shape[1], t1.shape[2]))
-        sa, ksa = self.conv2.fwd(h1, save, tracked)
+        # (stored blocks: the radix convolution's output -- the tensor the split attention reads four times -- as bf16; the
+        #  attention-weighted sum too where conv3 alone reads it: the bf16-input kernels round it the same way)
+        x0dt = K.BF16 if (self.store_bf16 and conv.precision == "bf16" and
+                          t1.shape[0] * t1.shape[1] * t1.shape[2] >= K.BF16_MIN_PIXELS) else None
+        sadt = self.conv3.act_storage(*t1.shape[:3]) if self.avd_last is None else None
+        sa, ksa = self.conv2.fwd(h1, save, tracked, x0_dtype=x0dt, out_dtype=sadt)
         p = self.avd_last.fwd(sa) if self.avd_last is not None else sa
         c3, k3 = self.conv3.fwd(p, save, bn_stats=self.bn3.training, out_dtype=odt)
         if self.downsample is not None:

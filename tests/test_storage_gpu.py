@@ -297,3 +297,59 @@ def test_masked_block_gradient_stored_as_bf16(case, monkeypatch):
     # without the fused epilogue the gradient is not a block-output gradient: fp32 storage, whatever was asked
     plain = kk.conv2d_dgrad(dy, w, shape, None, 1, 0, 1, precision="bf16", out_dtype=BF16)
     assert plain.dtype == torch.float32
+
+
+@pytest.mark.parametrize("shape", [(3, 20, 19, 128), (2, 28, 28, 256), (5, 9, 11, 512)])
+def test_split_attention_passes_typed_storage(shape):
+    """The four passes that read the radix convolution's raw output x0 (GAP, weighted sum, d(attention) + statistics, bn0
+    backward) on a bf16-stored x0 == the same passes on the widened tensor; the weighted sum stored as bf16 == its RNE."""
+    kk = K()
+    B, H, W, C2 = shape
+    Cp = C2 // 2
+    rng = np.random.default_rng(sum(shape))
+    x0 = _rand(rng, *shape).to(BF16)
+    gamma, beta = _rand(rng, C2).abs() + 0.5, _rand(rng, C2)
+    bn = kk.bn_stats(x0, gamma, beta, torch.zeros(C2, device="cuda"), torch.ones(C2, device="cuda"), True,
+                     stats=_stats_of(x0.float()))
+    a = torch.softmax(_rand(rng, B, 2, Cp), dim=1).reshape(B, C2).contiguous()
+    dout, dgap = _rand(rng, B, H, W, Cp), _rand(rng, B, Cp)
+    res = []
+    for x in (x0.float(), x0):
+        gap = kk.sa_gap(x, bn)
+        out = kk.sa_apply_fwd(x, a, bn)
+        da, sums = kk.sa_dattn(x, dout, bn, want_stats=True)
+        da2 = kk.sa_dattn(x, dout, bn)
+        dg, db = torch.zeros(C2, device="cuda"), torch.zeros(C2, device="cuda")
+        dx = kk.sa_bn_bwd(dout, a, dgap, x, bn, True, dg, db, sums=sums)
+        dg2, db2 = torch.zeros(C2, device="cuda"), torch.zeros(C2, device="cuda")
+        dx2 = kk.sa_bn_bwd(dout, a, dgap, x, bn, True, dg2, db2)                     # own reduction pass
+        dxp = kk.sa_bn_bwd(dout, a, dgap, x, bn, True, None, None, planes=1, keep_f32=False, sums=sums)
+        res.append((gap, out, da, sums, da2, dx, dg, db, dx2, dg2, db2, dxp.planes))
+    for i, (p, q) in enumerate(zip(*res)):
+        assert torch.equal(p, q), i
+    out16 = kk.sa_apply_fwd(x0, a, bn, out_dtype=BF16)
+    assert out16.dtype == BF16 and torch.equal(out16, res[0][1].to(BF16))
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 128, 2), (3, 14, 14, 256, 512, 2), (2, 28, 28, 128, 256, 2)])
+def test_plane_forward_stores_bf16(case):
+    """One-plane plane convolution (the bf16 mode's 3x3 layers) writing its output as bf16 == RNE of the fp32-storage launch,
+    same fused statistics, for every tile that supports it; the persistent tile 6 refuses."""
+    B, H, W, Cin, Cout, groups = case
+    kk = K()
+    rng = np.random.default_rng(sum(case))
+    xp = _rand(rng, B, H, W, Cin).to(BF16).unsqueeze(0).contiguous()
+    w = _rand(rng, 3, 3, Cin // groups, Cout, scale=0.1)
+    wf, _ = kk.planes_split_weight(w, groups, 1, fwd=True, dgrad=False)
+    for tile in kk._plane_tiles(Cout // groups, 1, False) + (5,):
+        if tile == 6:
+            with pytest.raises(RuntimeError, match="tile 6"):
+                kk._native.check(kk._native.lib().scouter_conv2d_fwd_planes_io(
+                    xp.data_ptr(), wf.data_ptr(), None, None, xp.data_ptr(), None, B, H, W, Cin, Cout, 3, 3, 1, 1, groups, 0, 1,
+                    6, kk.IO_Y_BF16, None), "conv2d_fwd_planes")
+            continue
+        if tile == 5 and not kk._halo_ok(3, 3, 1, 1, H, W, 1):
+            continue
+        y32, (p32, _) = kk.conv2d_fwd_planes(xp, wf, 3, 3, 1, 1, groups, bn_stats=True, tile=tile)
+        y16, (p16, _) = kk.conv2d_fwd_planes(xp, wf, 3, 3, 1, 1, groups, bn_stats=True, tile=tile, out_dtype=BF16)
+        assert y16.dtype == BF16 and torch.equal(y16, y32.to(BF16)) and torch.equal(p16, p32), "tile %d" % tile
