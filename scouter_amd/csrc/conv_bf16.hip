@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const void* __restri
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ addend, float* __restrict__ dst,
                                                             double* __restrict__ bn_part, ConvGeom g, int relu,
-                                                            int mtiles, int ntiles, BnBwdFuse fz, int dst_bf16) {
+                                                            int mtiles, int ntiles, BnBwdFuse fz, int dst_bf16,
+                                                            int one_stage) {
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     constexpr int LDH = KT_ + 8;                          // LDS row stride in bf16
     constexpr int A_H = BM * LDH, B_H = BN * LDH, STAGE_H = A_H + B_H;
@@ -203,13 +204,26 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const void* __restri
         compute(cur);
         __syncthreads();
     };
-    for (int kt = 0; kt < KT; kt += 2) {
-        tile(kt, P0{});
-        if (kt + 1 < KT) tile(kt + 1, P1{});
+    if (one_stage) {
+        // ONE LDS stage (launched with half the LDS): the next tile waits in registers until this one is consumed -- two
+        // barriers per K-tile, no store / MFMA overlap inside the workgroup, but up to twice the resident workgroups.  For
+        // the short-K launches with a heavy epilogue (fused input gradients) residency is what counts.
+        for (int kt = 0; kt < KT; ++kt) {
+            compute(0);
+            __syncthreads();
+            if (kt + 1 < KT) { store_a(0); store_b(0); }
+            if (kt + 2 < KT) { load_a(kt + 2); load_b(kt + 2); }
+            __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < KT; kt += 2) {
+            tile(kt, P0{});
+            if (kt + 1 < KT) tile(kt + 1, P1{});
+        }
     }
-    // (the fp32 kernels request the fused epilogue's operands at workgroup start; here that was measured to LOSE -- 140
-    //  instead of 82 registers, fewer resident workgroups of a kernel that lives on loads in flight: 6.3 -> 7.0 ms per step
-    //  on BASELINE configs[4])
+    // (the fp32 kernels request the fused epilogue's operands at workgroup start; here both that -- 140 instead of 82
+    //  registers, fewer resident workgroups: 6.3 -> 7.0 ms per step on BASELINE configs[4] -- and issuing them together
+    //  right here in front of the staging -- 4.85 -> 5.03 ms -- were measured to LOSE)
     igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)ldsh, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz,
                                           nullptr, dst_bf16 != 0);
 }
@@ -236,11 +250,19 @@ static void launch_bf16(const void* src, const void* w, const float* bias, const
     gg.inv_ho = 1.0f / (float)g.Ho;
     const size_t epi = (size_t)4 * WM * (WN + 4) * sizeof(float);
     auto go = [&](auto kern, int kt) {
-        size_t lds = (size_t)2 * (BM + BN) * (kt + 8) * 2;
+        // one LDS stage (half the LDS, up to twice the resident workgroups) for launches that live on loads in flight rather
+        // than on the K loop: a single K-tile (the second stage would never be touched), and the fused input gradients with
+        // up to ONE_STAGE_MAX K-tiles in front of their heavy epilogue
+        const int ktiles = g.R * g.S * (g.Cg / kt);
+        // (measured, tools_dev/tune_fused_dgrad_bf16.py: the fused launches of BASELINE configs[4] 4.63 -> 4.20 ms per step
+        //  with one stage up to 8 K-tiles; plain forward / input-gradient launches: no difference beyond noise, kept two-stage)
+        constexpr int ONE_STAGE_MAX = 8;
+        const int one = ktiles <= 1 || (DGRAD && fz.part1 && ktiles <= ONE_STAGE_MAX);
+        size_t lds = (size_t)(one ? 1 : 2) * (BM + BN) * (kt + 8) * 2;
         if (lds < epi) lds = epi;
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, src, w, bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz,
-                           (io & SC_IO_Y_BF16) ? 1 : 0);
+                           (io & SC_IO_Y_BF16) ? 1 : 0, one);
     };
     if (io & SC_IO_X_BF16) {
         if (g.Cg % 64 == 0) go(igemm_bf16_kernel<BM, BN, WM, WN, 64, DGRAD, true>, 64);
