@@ -496,9 +496,11 @@ def main():
                 "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
                 "config": {"workload": "%s, %dx%d, per-GPU batch %d, random init, AdamW lr 1e-4%s"
                                        % (cfg["name"], cfg["img_size"], cfg["img_size"], cfg["batch"],
-                                          "; backbone convolution matrix inputs in bf16 (fp32 accumulate, fp32 storage, "
-                                          "fp32 head)" if bf16 else ""),
+                                          "; backbone convolution matrix inputs in bf16, fp32 accumulate; the wide bottleneck "
+                                          "tensors (block / conv3 / radix-conv outputs, residual-stream gradient) stored as "
+                                          "bf16, statistics / sums / master weights / head fp32" if bf16 else ""),
                            "baseline_config": a.config, "precision": cfg["precision"],
+                           "activation_storage": getattr(model, "activation_storage", "fp32"),
                            "global_batch": world * cfg["batch"], "parallelism": "dp%d" % world,
                            "step": "zero_grad+fwd+loss+bwd(+allreduce)+adamw",
                            "launch": "hipGraph replay (one captured graph per step)" if graphed is not None else "eager",

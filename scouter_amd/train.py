@@ -64,7 +64,7 @@ _CLI = [
     ("resume", "", str, "checkpoint path"),
     ("world_size", 1, int, None), ("local_rank", None, int, None), ("dist_url", "env://", str, None),
     # additions of this build
-    ("precision", "fp32", str, "fp32 | bf16 (backbone convolutions on bf16 matrix inputs, fp32 accumulate/storage)"),
+    ("precision", "fp32", str, "fp32 | bf16 (backbone convolutions on bf16 matrix inputs, fp32 accumulate; wide bottleneck tensors stored as bf16)"),
     ("synthetic_data", True, _flag, "seeded synthetic batches (the benchmark input)"),
     ("synthetic_len", 256, int, "images per synthetic epoch"),
 ]
