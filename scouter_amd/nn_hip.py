@@ -67,11 +67,30 @@ class Conv2d(nn.Module):
         n = self._nplanes()
         return n if n and self.stride == 1 and ng % 32 == 0 and cg % 64 == 0 else 0
 
-    def planes_only(self, H, W):
+    def planes_only(self, H, W, B=None):
         """True if forward, input gradient AND weight gradient of this layer all run on planes for an H x W map: its
-        producers then need not write the fp32 copy of the tensor at all."""
-        return bool(self.bias is None and self.planes_in() and self.planes_dy() and self.planes_wgrad() and
-                    32 // W + 1 < H)
+        producers then need not write the fp32 copy of the tensor at all.  In bf16 mode (ONE plane = the bf16-stored
+        tensor) that also holds when the gradients run on the bf16-input igemm kernels, which read that plane as a
+        bf16-stored activation (32-channel groups: the first grouped layer; needs the batch size for their pixel rule)."""
+        if not (self.bias is None and self.planes_in()):
+            return False
+        if self.planes_dy() and self.planes_wgrad() and 32 // W + 1 < H:
+            return True
+        return bool(B is not None and self._nplanes() == 1 and self._igemm_bf16_grads(B, H, W))
+
+    def _igemm_bf16_grads(self, B, H, W):
+        """input- and weight-gradient both on the bf16-input igemm kernels for a B x H x W map (kernels.conv2d_dgrad /
+        conv2d_wgrad rules): they read bf16-stored operands and round fp32 ones to the same values"""
+        cg, ng = self.in_channels // self.groups, self.out_channels // self.groups
+        k = self.kernel_size
+        return bool(GRAD_STORAGE_BF16 and self.precision == "bf16" and self.bias is None and self.stride == 1 and
+                    2 * self.padding == k - 1 and B * H * W >= K.BF16_MIN_PIXELS and cg % 32 == 0 and ng % 32 == 0 and
+                    (k == 1 or 64 // W + 1 < H))
+
+    def dy_plane_only(self, B, H, W):
+        """bf16 mode, a plane layer whose input gradient does NOT run on planes (32-channel groups): its output gradient
+        can still be handed over as ONE bf16 plane only -- the igemm kernels read it as a bf16-stored tensor."""
+        return bool(self.planes and self._nplanes() == 1 and not self.planes_dy() and self._igemm_bf16_grads(B, H, W))
 
     def planes_wgrad(self):
         """Weight gradient on planes too (same-size convolution, 64-multiples of channels per group)."""
@@ -117,7 +136,7 @@ class Conv2d(nn.Module):
             if self._capture is not None and relu:
                 self._capture[0][self._capture[1]] = y
             return y, ((x.f32 if x.f32 is not None else tuple(x.shape), wd,
-                        x.planes if self.planes_wgrad() else None) if save else None)
+                        x.planes if self.planes_wgrad() or x.f32 is None else None) if save else None)
         y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
                          bn_stats, precision=self.precision, out_dtype=out_dtype or K.F32)
         if self._capture is not None and relu:
@@ -138,6 +157,10 @@ class Conv2d(nn.Module):
             dy, dyp = dy.f32, dy.planes
         xshape = x if isinstance(x, tuple) else tuple(x.shape)       # (a shape only: the producer wrote planes only)
         xt = None if isinstance(x, tuple) else x
+        if xt is None and xp is not None and xp.shape[0] == 1 and not self.planes_wgrad():
+            xt = xp[0]                    # (bf16 mode: the one plane IS the bf16-stored activation of the igemm kernels)
+        if dy is None and dyp is not None and dyp.shape[0] == 1 and wd is None:
+            dy, dyp = dyp[0], None        # (likewise the output gradient, Conv2d.dy_plane_only)
         dev = dy.device if dy is not None else dyp.device
         if need_dx and dyp is not None and wd is not None:
             k = self.kernel_size

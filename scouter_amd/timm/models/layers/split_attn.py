@@ -58,6 +58,9 @@ class SplitAttnConv2d(nn.Module):
         dgap = self.fc1.bwd(dz1, c_fc1, True)
         on_planes = isinstance(c_conv, tuple) and c_conv[1] is not None
         only = on_planes and c_conv[2] is not None and self.conv.planes_only(x0.shape[1], x0.shape[2])
+        planes = self.conv.planes_dy() if on_planes else 0
+        if not planes and self.conv.dy_plane_only(*x0.shape[:3]):
+            planes, only = 1, True       # (bf16 mode, 32-channel groups: the gradient as ONE bf16 plane for the igemm kernels)
         dc = K.sa_bn_bwd(dout, a, dgap.view(B, -1), x0, saved0, training0, self.bn0._dg, self.bn0._db,
-                         planes=self.conv.planes_dy() if on_planes else 0, keep_f32=not only, sums=sums)
+                         planes=planes, keep_f32=not only, sums=sums)
         return self.conv.bwd(dc, c_conv, True, post=post)

@@ -63,7 +63,7 @@ class ResNestBottleneck(nn.Module):
         t1 = c1[0] if isinstance(c1, tuple) else c1
         conv = self.conv2.conv                   # (all three of its kernels on planes: no fp32 copy of h1 is written)
         h1, b1 = self.bn1.fwd(c1, save, relu=True, tracked=tracked, planes=conv.planes_in(),
-                              keep_f32=not conv.planes_only(t1.shape[1], t1.shape[2]))
+                              keep_f32=not conv.planes_only(t1.shape[1], t1.shape[2], t1.shape[0]))
         # (stored blocks: the radix convolution's output -- the tensor the split attention reads four times -- as bf16; the
         #  attention-weighted sum too where conv3 alone reads it: the bf16-input kernels round it the same way)
         x0dt = K.BF16 if (self.store_bf16 and conv.precision == "bf16" and
