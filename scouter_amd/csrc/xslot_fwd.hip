@@ -86,18 +86,20 @@ struct XsS1 {
 };
 // S2: U^T = (X/64)^T A^T.  X is staged TRANSPOSED (Xt[c][j], row stride 32*NJT+4): the contraction index j is
 // contiguous, so one ds_read_b128 feeds four MFMAs like in the other blocks
-template <int NJT>
+// NG <= 4 NJT: live 8-token groups (ceil(N / 8) rounded up by the caller's instantiation): the contraction skips the
+// groups of padded tokens (N = 81: 11 of 12 -- the reference's default 9x9 grid pads to 96 otherwise)
+template <int NJT, int NG>
 struct XsS2 {
     static constexpr int LDT = 32 * NJT + 4;
     const float* base;
     __device__ __forceinline__ XsS2(const XsLds& m, int l31, int hh) : base(m.Xs + l31 * LDT + 4 * hh) {}
     __device__ __forceinline__ const float* operator()(int f) const {
-        return base + (32 * (f / (4 * NJT))) * LDT + 8 * (f % (4 * NJT));
+        return base + (32 * (f / NG)) * LDT + 8 * (f % NG);
     }
     __device__ __forceinline__ void run(const f32x16 (&A)[NJT], f32x16 (&U)[2], const XsFrag& pre) const {
         xs_zero(U[0]); xs_zero(U[1]);
-        xs_stream<8 * NJT>(*this, [&](int f, int e, float a) {
-            const int ct = f / (4 * NJT), g = f % (4 * NJT);
+        xs_stream<2 * NG>(*this, [&](int f, int e, float a) {
+            const int ct = f / NG, g = f % NG;
             U[ct] = mfma32(a, A[g >> 2][4 * (g & 3) + e], U[ct]); }, pre);               // slot_attention.py:59
     }
 };
@@ -138,12 +140,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // folded per slot; element pairs so that the multiply / add become packed-fp32 instructions.  VALU work cannot hide
 // under this wave's own MFMAs (tools_dev/mfma_shadow_bench.hip: they serialise), so it is kept minimal: padded
 // tokens need no mask (their X^T columns are zero), padded slots get c = 0 (finite garbage that is never stored).
-template <int NJT>
+template <int NJT, int NG>
 __device__ __forceinline__ void xs_v1(f32x16 (&A)[NJT], float c) {
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
+            if (4 * jt + (e >> 2) >= NG) continue;           // (elements of padded-token groups: never read, see XsS2)
             f32x2 x = {A[jt][e], A[jt][e + 1]};
             x *= c;
             f32x2 ex = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
@@ -206,20 +209,20 @@ struct XsOut {
 // wave's time.  (The caller issues the workgroup barrier between xs_tile_shared_a and _b.)
 // S1 -> V1 -> S2 of one tile; `next` (if given) is the gate stream that follows: its first fragments and bias
 // accumulators are requested before V1 as well.  LAST (+ writer): attention map, logit partial sums, area.
-template <int NJT, bool LAST>
+template <int NJT, int NG, bool LAST>
 __device__ __forceinline__ void xs_tile_head(const XsLds& m, const f32x16 (&h)[2], const XsTile& t, float tau,
                                              const XsOut& o, f32x16 (&U)[2], bool writer, const XsS3* next,
                                              f32x16 (&G)[4], XsFrag& next_pre) {
     f32x16 A[NJT];
     const XsS1<NJT> s1(m, o.l31, o.hh);
-    const XsS2<NJT> s2(m, o.l31, o.hh);
+    const XsS2<NJT, NG> s2(m, o.l31, o.hh);
     s1.run(h, A, xs_pre(s1));
     if (LAST) XS_STAMP_O(o);
     const XsFrag pre2 = xs_pre(s2);
     if (!LAST) { next->init(G); next_pre = xs_pre(*next); }
     XS_SB();
     const float c = t.iok ? -XS_LOG2E * (tau * xs_recip(t.r)) : 0.f;
-    xs_v1<NJT>(A, c);
+    xs_v1<NJT, NG>(A, c);
     if (LAST) XS_STAMP_O(o);
     s2.run(A, U, pre2);
     if (LAST) XS_STAMP_O(o);
@@ -257,13 +260,13 @@ __device__ __forceinline__ void xs_tile_head(const XsLds& m, const f32x16 (&h)[2
         if (o.lane == 0) o.area_s[t.ti] = asum;
     }
 }
-template <int NJT, bool LAST>
+template <int NJT, int NG, bool LAST>
 __device__ __forceinline__ void xs_tile_own(const XsLds& m, f32x16 (&h)[2], const XsTile& t, float tau, const XsOut& o,
                                             long it_row) {
     f32x16 U[2], G0[4], G1[4];
     const XsS3 s3a(m, 0, o.l31, o.hh), s3b(m, 1, o.l31, o.hh);
     XsFrag pa;
-    xs_tile_head<NJT, LAST>(m, h, t, tau, o, U, true, &s3a, G0, pa);
+    xs_tile_head<NJT, NG, LAST>(m, h, t, tau, o, U, true, &s3a, G0, pa);
     if (!LAST) {
         f32x16 hn0, hn1;
         s3a.run(U, h, G0, pa);
@@ -281,47 +284,63 @@ __device__ __forceinline__ void xs_tile_own(const XsLds& m, f32x16 (&h)[2], cons
         }
     }
 }
-// shared tile, part a: everything up to this wave's half of the new state, parked in the exchange buffer
-template <int NJT, bool LAST>
+// shared tile, part a: everything up to this wave's half of the new state, parked in the exchange buffer.
+// GX (three token tiles: no LDS left for the 16 KB exchange buffer): the halves are exchanged through the `states` rows the
+// wave stores anyway -- the caller's barrier is then a full __syncthreads() (drains the stores) and part b re-reads the
+// partner's half from L2 (same CU, same vector L1: coherent after the barrier).
+template <int NJT, int NG, bool LAST, bool GX>
 __device__ __forceinline__ void xs_tile_shared_a(const XsLds& m, f32x16 (&h)[2], const XsTile& t, float tau,
                                                  const XsOut& o, long it_row) {
     f32x16 U[2], G[4];
     const int gt = o.wave & 1;
     const XsS3 s3(m, gt, o.l31, o.hh);
     XsFrag pg;
-    xs_tile_head<NJT, LAST>(m, h, t, tau, o, U, gt == 0, &s3, G, pg);
+    xs_tile_head<NJT, NG, LAST>(m, h, t, tau, o, U, gt == 0, &s3, G, pg);
     if (!LAST) {
         f32x16 hn;
         s3.run(U, h, G, pg);
         if (gt) xs_v2(G, h[1], hn); else xs_v2(G, h[0], hn);
         XS_SB();
         if (gt) h[1] = hn; else h[0] = hn;
-        float* ex = o.exch + o.wave * 1024 + o.lane * 4;          // [q][lane][4]
+        if constexpr (!GX) {
+            float* ex = o.exch + o.wave * 1024 + o.lane * 4;          // [q][lane][4]
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v;
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = hn[4 * q + e];
-            *(f32x4*)(ex + q * 256) = v;
+                for (int e = 0; e < 4; ++e) v[e] = hn[4 * q + e];
+                *(f32x4*)(ex + q * 256) = v;
+            }
         }
         if (t.iok) xs_store_half(o.states + (it_row + t.i) * XS_D + 32 * gt, hn, o.hh);
     }
 }
 // part b (after the barrier): the partner's half
-__device__ __forceinline__ void xs_tile_shared_b(f32x16 (&h)[2], const XsOut& o) {
+template <bool GX>
+__device__ __forceinline__ void xs_tile_shared_b(f32x16 (&h)[2], const XsOut& o, const XsTile& t, long it_row) {
     const int gt = o.wave & 1;
-    const float* ex = o.exch + (o.wave ^ 1) * 1024 + o.lane * 4;
     f32x16 hp;
+    if constexpr (GX) {
+        const float* sp = o.states + (it_row + (t.iok ? t.i : 0)) * XS_D + 32 * (gt ^ 1) + 4 * o.hh;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *(const f32x4*)(ex + q * 256);
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *(const f32x4*)(sp + 8 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hp[4 * q + e] = v[e];
+            for (int e = 0; e < 4; ++e) hp[4 * q + e] = t.iok ? v[e] : 0.f;         // (padded slots carry nothing)
+        }
+    } else {
+        const float* ex = o.exch + (o.wave ^ 1) * 1024 + o.lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *(const f32x4*)(ex + q * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hp[4 * q + e] = v[e];
+        }
     }
     if (gt) h[0] = hp; else h[1] = hp;
 }
 
-template <int NJT, int TPW>
+template <int NJT, int TPW, int NG = 4 * NJT>
 __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs a) {
 #ifdef XS_TIMING
     int nstamp = 0;
@@ -374,9 +393,11 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
 #pragma unroll
     for (int k = 0; k < WQ; ++k) whr[k] = *(const f32x4*)(a.w_hh + (tid + k * NTHR) * 4);
     // slot tiles: wave w owns tiles w, w+4, ...; the ntiles % 4 leftover tiles go to waves 0.. as whole tiles, or --
-    // when there are one or two of them and the exchange buffer fits (NJT <= 2) -- each is SHARED by a wave pair
+    // when there are one or two of them -- each is SHARED by a wave pair (exchange through LDS, NJT <= 2, or through the
+    // state rows in L2, NJT = 3)
     const int ntiles = (S + 31) >> 5, nfull4 = ntiles >> 2, rem = ntiles & 3;
-    const bool share = NJT <= 2 && (rem == 1 || rem == 2);
+    constexpr bool GX = NJT > 2;                // no LDS for the exchange buffer: through the `states` rows (xs_tile_shared_a)
+    const bool share = (rem == 1 || rem == 2) && (!GX || a.T > 1);
     int tile_id[TPW];
     f32x16 h[TPW][2];
     // initial slots: each wave fetches its tiles as whole 256-byte rows (coalesced; a register-layout gather straight
@@ -427,14 +448,20 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
     float* Hin = H0;
     float* Hout = H1;
     for (int l = 0; l < a.L; ++l) {
-        if (l > 0) {
+        if (l > 0) {              // this layer's weights were requested while the previous layer multiplied (wtr)
             __syncthreads();
-            xs_load_mat(Wt, a.tok_w[l], XS_D, tid, NTHR);
+#pragma unroll
+            for (int k = 0; k < TQ; ++k) { const int c = tid + k * NTHR; *(f32x4*)(Wt + (c >> 4) * XS_LD + (c & 15) * 4) = wtr[k]; }
         }
         __syncthreads();
+        if (l + 1 < a.L) {
+#pragma unroll
+            for (int k = 0; k < TQ; ++k) wtr[k] = *(const f32x4*)(a.tok_w[l + 1] + (tid + k * NTHR) * 4);
+        }
         const bool last = l == a.L - 1;
         for (int tile = wave; tile < NJT * 2; tile += NW) {
             const int jt = tile >> 1, ot = tile & 1;
+            const float bo = a.tok_b[l][32 * ot + l31];          // (requested in front of the MFMAs, used behind them)
             f32x16 acc;
             xs_zero(acc);
 #pragma unroll
@@ -448,7 +475,6 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
                     for (int e = 0; e < 4; ++e) acc = mfma32(av[e], bv[e], acc);
                 }
             const int o = 32 * ot + l31;
-            const float bo = a.tok_b[l][o];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = 32 * jt + mfma32_row(r, lane);
@@ -519,17 +545,18 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
         for (int tt = 0; tt < TPW; ++tt) {
             if (tl[tt].ti < 0) continue;
             if (share && tt == TPW - 1) {
-                if (last) { if (!(wave & 1)) xs_tile_shared_a<NJT, true>(m, h[tt], tl[tt], tau, o, it_row); }
-                else xs_tile_shared_a<NJT, false>(m, h[tt], tl[tt], tau, o, it_row);
+                if (last) { if (!(wave & 1)) xs_tile_shared_a<NJT, NG, true, GX>(m, h[tt], tl[tt], tau, o, it_row); }
+                else xs_tile_shared_a<NJT, NG, false, GX>(m, h[tt], tl[tt], tau, o, it_row);
             } else {
-                if (last) xs_tile_own<NJT, true>(m, h[tt], tl[tt], tau, o, it_row);
-                else xs_tile_own<NJT, false>(m, h[tt], tl[tt], tau, o, it_row);
+                if (last) xs_tile_own<NJT, NG, true>(m, h[tt], tl[tt], tau, o, it_row);
+                else xs_tile_own<NJT, NG, false>(m, h[tt], tl[tt], tau, o, it_row);
             }
             XS_STAMP();
         }
         if (share && !last) {
-            xs_lds_barrier();
-            if (tl[TPW - 1].ti >= 0) xs_tile_shared_b(h[TPW - 1], o);
+            if constexpr (GX) __syncthreads();          // (also drains this wave's stores of its half: the partner reads them)
+            else xs_lds_barrier();
+            if (tl[TPW - 1].ti >= 0) xs_tile_shared_b<GX>(h[TPW - 1], o, tl[TPW - 1], it_row);
         }
     }
     __syncthreads();
@@ -578,24 +605,25 @@ extern "C" int scouter_xslot_fwd_f32(const float* X, const float* PE, const floa
     hipStream_t st = (hipStream_t)stream;
     const double flops = (double)B * (2.0 * L * N * d * d + (double)T * 4.0 * S * N * d + (T - 1) * 12.0 * S * d * d);
     ScProfScope prof("xslot_fwd", st, flops, 4.0 * B * (2.0 * N * d + (double)S * N));
-#define XS_LAUNCH(NJT_, TPW_)                                                                                       \
+#define XS_LAUNCH(NJT_, TPW_, ...)                                                                                  \
     do {                                                                                                            \
-        auto kern = xslot_fwd_kernel<NJT_, TPW_>;                                                                   \
+        auto kern = xslot_fwd_kernel<NJT_, TPW_, ##__VA_ARGS__>;                                                    \
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
         hipLaunchKernelGGL(kern, dim3(B), dim3(NW * 64), lds, st, a);                                               \
     } while (0)
-#define XS_TPW(NJT_)                                   \
-    do {                                               \
-        if (TPW == 1) XS_LAUNCH(NJT_, 1);              \
-        else if (TPW == 2) XS_LAUNCH(NJT_, 2);         \
-        else if (TPW == 3) XS_LAUNCH(NJT_, 3);         \
-        else XS_LAUNCH(NJT_, 4);                       \
+#define XS_TPW(NJT_, ...)                                             \
+    do {                                                              \
+        if (TPW == 1) XS_LAUNCH(NJT_, 1, ##__VA_ARGS__);              \
+        else if (TPW == 2) XS_LAUNCH(NJT_, 2, ##__VA_ARGS__);         \
+        else if (TPW == 3) XS_LAUNCH(NJT_, 3, ##__VA_ARGS__);         \
+        else XS_LAUNCH(NJT_, 4, ##__VA_ARGS__);                       \
     } while (0)
 #ifdef XS_DEV_SINGLE_INST
     XS_LAUNCH(2, 3);      // dev builds (tools_dev/xs_phase_timing.hip): one instantiation compiles much faster
 #else
     if (NJT == 1) XS_TPW(1);
     else if (NJT == 2) XS_TPW(2);
+    else if (N <= 88) XS_TPW(3, 11);      // (the reference's 9x9 grid: the token contraction skips the last 8-token group)
     else XS_TPW(3);
 #endif
 #undef XS_TPW
