@@ -353,3 +353,29 @@ def test_plane_forward_stores_bf16(case):
         y32, (p32, _) = kk.conv2d_fwd_planes(xp, wf, 3, 3, 1, 1, groups, bn_stats=True, tile=tile)
         y16, (p16, _) = kk.conv2d_fwd_planes(xp, wf, 3, 3, 1, 1, groups, bn_stats=True, tile=tile, out_dtype=BF16)
         assert y16.dtype == BF16 and torch.equal(y16, y32.to(BF16)) and torch.equal(p16, p32), "tile %d" % tile
+
+
+def test_eval_forward_and_storage_switch_at_model_level(monkeypatch):
+    """resnest26d in precision bf16, eval mode (running statistics: the BatchNorm passes read bf16-stored inputs without
+    producer statistics): the forward with bf16 storage stays within bf16 noise of the fp32-storage forward, differs from it
+    (proof that the typed kernels ran), and switching the storage back reproduces the fp32-storage bits."""
+    import test_model_gpu as T
+    monkeypatch.undo()
+    m, P, images, labels, cfg = T._synthetic_model("resnest26d", 10, 1, 3, 8, 224, 2100)
+    m.set_precision("bf16")
+    m.eval()
+    with torch.no_grad():
+        o_bf = m(images.cuda(), labels.cuda())[0].clone()
+        m.set_activation_storage("fp32")
+        o_f32 = m(images.cuda(), labels.cuda())[0].clone()
+        m.set_activation_storage("bf16")
+        o_bf2 = m(images.cuda(), labels.cuda())[0].clone()
+        m.set_activation_storage("fp32")
+        o_f32b = m(images.cuda(), labels.cuda())[0].clone()
+    assert torch.isfinite(o_bf).all()
+    assert torch.equal(o_bf, o_bf2) and torch.equal(o_f32, o_f32b)
+    d = float((o_bf - o_f32).abs().max())
+    assert 0.0 < d < 0.5, d
+    with pytest.raises(ValueError, match="precision 'bf16'"):
+        m.set_precision("fp32")
+        m.set_activation_storage("bf16")
