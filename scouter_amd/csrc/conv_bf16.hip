@@ -251,13 +251,14 @@ static void launch_bf16(const void* src, const void* w, const float* bias, const
     const size_t epi = (size_t)4 * WM * (WN + 4) * sizeof(float);
     auto go = [&](auto kern, int kt) {
         // one LDS stage (half the LDS, up to twice the resident workgroups) for launches that live on loads in flight rather
-        // than on the K loop: a single K-tile (the second stage would never be touched), and the fused input gradients with
-        // up to ONE_STAGE_MAX K-tiles in front of their heavy epilogue
+        // than on the K loop: a single K-tile (the second stage would never be touched), and the input gradients with up to
+        // ONE_STAGE_MAX K-tiles (the fused ones in front of their heavy epilogue gain most)
         const int ktiles = g.R * g.S * (g.Cg / kt);
-        // (measured, tools_dev/tune_fused_dgrad_bf16.py: the fused launches of BASELINE configs[4] 4.63 -> 4.20 ms per step
-        //  with one stage up to 8 K-tiles; plain forward / input-gradient launches: no difference beyond noise, kept two-stage)
-        constexpr int ONE_STAGE_MAX = 8;
-        const int one = ktiles <= 1 || (DGRAD && fz.part1 && ktiles <= ONE_STAGE_MAX);
+        // (measured on BASELINE configs[4]: the fused launches 4.63 -> 4.20 ms per step, tools_dev/tune_fused_dgrad_bf16.py;
+        //  all input-gradient launches with one stage up to 32 K-tiles 8.14 -> 7.84 ms of kernel time; the forward
+        //  launches 4.70 -> 4.66: within noise, kept two-stage)
+        constexpr int ONE_STAGE_MAX = 32;
+        const int one = ktiles <= 1 || (DGRAD && ktiles <= ONE_STAGE_MAX);
         size_t lds = (size_t)(one ? 1 : 2) * (BM + BN) * (kt + 8) * 2;
         if (lds < epi) lds = epi;
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
