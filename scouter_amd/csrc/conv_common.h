@@ -160,9 +160,9 @@ __device__ __forceinline__ void igemm_epilogue_prefetch(EpiPre<(WM / (64 / (WN /
             for (int rr = 0; rr < NR; ++rr) {
                 const long m = m0 + wm * WM + rr * RPP + qrow;
                 const long off = (m < g.M ? m : 0) * g.N + ncol;      // (rows beyond M: any valid address, never used)
-                pre.add[rr] = addend ? sc_load4_rt(addend, off, (fz.io & 4) != 0) : f32x4{0.f, 0.f, 0.f, 0.f};
-                pre.x1[rr] = sc_load4_rt(fz.x1, off, (fz.io & 1) != 0);
-                pre.x2[rr] = fz.part2 ? sc_load4_rt(fz.x2, off, (fz.io & 2) != 0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                pre.add[rr] = addend ? *(const f32x4*)(addend + off) : f32x4{0.f, 0.f, 0.f, 0.f};     // (fp32 kernels only:
+                pre.x1[rr] = *(const f32x4*)(fz.x1 + off);                                            //  fp32 storage)
+                pre.x2[rr] = fz.part2 ? *(const f32x4*)(fz.x2 + off) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }
@@ -170,7 +170,10 @@ __device__ __forceinline__ void igemm_epilogue_prefetch(EpiPre<(WM / (64 / (WN /
 
 // Block epilogue.  acc: this wave's (WM x WN) accumulator tiles in MFMA layout; lds: the block's K-loop LDS (free now,
 // at least 4*WM*(WN+4) floats); rows m0.., columns grp*Ng + n0.. of the [M][N] output.
-template <int BM, int BN, int WM, int WN, bool BWD = false, bool BWD_PREFETCH = false>
+// TYPED: the instantiation of the bf16-mode kernels (bf16-input igemm, one-plane plane kernels) -- the storage types of the
+// output / addend / BatchNorm inputs are run-time flags (dst_bf16, fz->io).  The fp32-mode kernels keep TYPED = false: plain
+// fp32 accesses, no flag tests (they cost the parity path 0.5 % of the step when they were unconditional).
+template <int BM, int BN, int WM, int WN, bool BWD = false, bool BWD_PREFETCH = false, bool TYPED = false>
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], float* lds, const ConvGeom& g,
                                                const float* __restrict__ bias, const float* __restrict__ addend,
                                                float* __restrict__ dst, double* __restrict__ bn_part, int relu,
@@ -249,24 +252,30 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
         const long m = m0 + wm * WM + row;
         if (m >= g.M) continue;
         f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
-        const bool add_bf16 = BWD && fz != nullptr && (fz->io & 4) != 0;
+        const bool add_bf16 = TYPED && BWD && fz != nullptr && (fz->io & 4) != 0;
         if constexpr (PREF) {
             if (pref) v += pre->add[rr];
-            else if (addend) v += sc_load4_rt(addend, m * g.N + ncol, add_bf16);
-        } else {
+            else if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
+        } else if constexpr (TYPED) {
             if (addend) v += sc_load4_rt(addend, m * g.N + ncol, add_bf16);
+        } else {
+            if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
         }
         if constexpr (BWD) {
             if (bwd) {
                 const long off = m * g.N + ncol;
                 if (fz->mask) relu_mask_apply(v, fz->mask, off >> 2);
                 f32x4 xa;
-                if constexpr (PREF) xa = pre->x1[rr]; else xa = sc_load4_rt(fz->x1, off, (fz->io & 1) != 0);
+                if constexpr (PREF) xa = pre->x1[rr];
+                else if constexpr (TYPED) xa = sc_load4_rt(fz->x1, off, (fz->io & 1) != 0);
+                else xa = *(const f32x4*)(fz->x1 + off);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * ((xa[e] - mu1[e]) * rs1[e]); }
                 if (bwd2) {
                     f32x4 xb;
-                    if constexpr (PREF) xb = pre->x2[rr]; else xb = sc_load4_rt(fz->x2, off, (fz->io & 2) != 0);
+                    if constexpr (PREF) xb = pre->x2[rr];
+                    else if constexpr (TYPED) xb = sc_load4_rt(fz->x2, off, (fz->io & 2) != 0);
+                    else xb = *(const f32x4*)(fz->x2 + off);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) cq2[e] += (double)v[e] * ((xb[e] - mu2[e]) * rs2[e]);
                 }
@@ -280,7 +289,8 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        sc_store4_rt(dst, m * g.N + ncol, v, dst_bf16 || (fz != nullptr && (fz->io & 8) != 0));
+        if constexpr (TYPED) sc_store4_rt(dst, m * g.N + ncol, v, dst_bf16 || (fz != nullptr && (fz->io & 8) != 0));
+        else *(f32x4*)(dst + m * g.N + ncol) = v;
     }
     if (bn_part) {
         // Fused batch statistics of the tile just written: lanes sharing a column quad (stride QPR) are combined by
