@@ -219,6 +219,54 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const void* __rest
     }
 }
 
+// The same pass when x, the residual (if any) and y are ALL bf16-stored (bn3 + shortcut + ReLU of a stored bottleneck):
+// EIGHT elements per thread, so that every access is 16 bytes again -- the 4-element typed instantiation moves 8 bytes per
+// lane and access and reaches 3.5-4.0 TB/s where the fp32 pass reaches 4.9 (tools_dev/typed_pass_bench.py).  Thread i owns
+// the float4 indices 2i, 2i+1: a wave covers 128 consecutive ones = two mask words per component, the even / odd ballots
+// interleaved on the scalar unit.  Same arithmetic, same bits as the 4-element kernel.
+__global__ __launch_bounds__(256) void scale_shift_act_bf16x8_kernel(const void* __restrict__ x,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     const void* __restrict__ res, void* __restrict__ y,
+                                                                     unsigned long long* __restrict__ mbits, long n8, int C,
+                                                                     int relu, const float* __restrict__ res_bn) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 8) % C);
+        f32x4 v[2], r[2];
+        sc_load8_bf16(x, i * 8, v[0], v[1]);
+        if (res) sc_load8_bf16(res, i * 8, r[0], r[1]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cc = c + 4 * q;
+            v[q] = bn_affine(v[q], *(const f32x4*)(mean + cc), *(const f32x4*)(scale + cc), *(const f32x4*)(shift + cc));
+            if (res) {
+                if (res_bn) r[q] = bn_affine(r[q], *(const f32x4*)(res_bn + cc), *(const f32x4*)(res_bn + 2 * C + cc),
+                                             *(const f32x4*)(res_bn + 3 * C + cc));
+                v[q] += r[q];
+            }
+        }
+        if (relu) {
+            if (mbits) {        // float4 index 2i + q; i - lane is a multiple of 64 -> words (i >> 5) * 4 + k and the next four
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long be = __ballot(v[0][k] > 0.f), bo = __ballot(v[1][k] > 0.f);
+                    if ((threadIdx.x & 63) == 0) {
+                        unsigned long long* w = mbits + ((2 * i) >> 6) * 4 + k;
+                        w[0] = sc_interleave32(be, bo);
+                        if (2 * i + 64 < 2 * n8) w[4] = sc_interleave32(be >> 32, bo >> 32);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[q][k] = fmaxf(v[q][k], 0.f);
+        }
+        sc_store8_bf16(y, i * 8, v[0], v[1]);
+    }
+}
+
 template <int FIN_CH>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, long M, int C,
                                                               int training, float* __restrict__ dgamma,
@@ -262,6 +310,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
         const f32x4 xh = (xv - mu) * rs;
         sc_store4<YB>(dx, i * 4, sc * (g - k1 - xh * k2));
         if (gout) *(f32x4*)(gout + i * 4) = g;
+    }
+}
+
+// all-bf16 storage (dy = the stored masked gradient, x, dx): eight elements per thread, 16-byte accesses (see
+// scale_shift_act_bf16x8_kernel); no mask (a bf16-stored dy is already masked)
+__global__ __launch_bounds__(256) void bn_bwd_apply_bf16x8_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                  void* __restrict__ dx, long n8, int C) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 8) % C);
+        f32x4 g[2], xv[2], o[2];
+        sc_load8_bf16(dy, i * 8, g[0], g[1]);
+        sc_load8_bf16(x, i * 8, xv[0], xv[1]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cc = c + 4 * q;
+            const f32x4 mu = *(const f32x4*)(mean + cc), rs = *(const f32x4*)(rstd + cc), sc = *(const f32x4*)(scale + cc);
+            const f32x4 k1 = *(const f32x4*)(c1 + cc), k2 = *(const f32x4*)(c2 + cc);
+            const f32x4 xh = (xv[q] - mu) * rs;
+            o[q] = sc * (g[q] - k1 - xh * k2);
+        }
+        sc_store8_bf16(dx, i * 8, o[0], o[1]);
     }
 }
 
@@ -716,6 +789,13 @@ extern "C" int scouter_bn_fwd_io(const void* x, void* y, const void* residual, l
         hipLaunchKernelGGL((scale_shift_act_kernel<XB_, YB_, RB_>), dim3(ew_blocks(n4)), dim3(256), 0, st, x, mean_out, \
                            scale_out, shift_out, residual, y, relu_mask_out, n4, C, relu, (unsigned short*)planes_out, \
                            nplanes, residual_bn_saved)
+        const bool all_bf16 = (io & SC_IO_X_BF16) && (io & SC_IO_Y_BF16) && y && (!residual || (io & SC_IO_R_BF16)) &&
+                              !planes_out && C % 8 == 0;
+        if (all_bf16) {
+            const long n8 = n4 / 2;
+            hipLaunchKernelGGL(scale_shift_act_bf16x8_kernel, dim3(ew_blocks(n8)), dim3(256), 0, st, x, mean_out, scale_out,
+                               shift_out, residual, y, relu_mask_out, n8, C, relu, residual_bn_saved);
+        } else
         switch (io & 7) {
             case 0: SSA(false, false, false); break;
             case 1: SSA(true, false, false); break;
@@ -809,6 +889,10 @@ extern "C" int scouter_bn_bwd_io(const void* dy, const float* ymask, const void*
 #define BBA(XB_, YB_, DB_)                                                                                            \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<XB_, YB_, DB_>), dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean,    \
                        rstd, scale, c1, c2, relu_mask, dx, gout, n4, C)
+    if (xb && yb && db && !ymask && !relu_mask && !gout && C % 8 == 0)
+        hipLaunchKernelGGL(bn_bwd_apply_bf16x8_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dy, x, mean, rstd, scale, c1, c2,
+                           dx, n4 / 2, C);
+    else
     switch ((xb ? 1 : 0) | (yb ? 2 : 0) | (db ? 4 : 0)) {
         case 0: BBA(false, false, false); break;
         case 1: BBA(true, false, false); break;

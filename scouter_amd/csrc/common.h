@@ -129,6 +129,33 @@ __device__ __forceinline__ void sc_store4(void* __restrict__ p, long elem, f32x4
         *(f32x4*)((float*)p + elem) = v;
     }
 }
+// eight consecutive bf16-stored elements as ONE 16-byte access (the all-bf16 apply passes, bn_elem.hip)
+typedef __bf16 sc_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void sc_load8_bf16(const void* __restrict__ p, long elem, f32x4& lo, f32x4& hi) {
+    const sc_bf16x8 h = __builtin_nontemporal_load((const sc_bf16x8*)((const __bf16*)p + elem));
+    lo = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    hi = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+}
+__device__ __forceinline__ void sc_store8_bf16(void* __restrict__ p, long elem, f32x4 lo, f32x4 hi) {
+    sc_bf16x8 h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { h[k] = (__bf16)lo[k]; h[4 + k] = (__bf16)hi[k]; }
+    *(sc_bf16x8*)((__bf16*)p + elem) = h;
+}
+// bits of a (even) and b (odd) interleaved: result bit 2l = a bit l, bit 2l+1 = b bit l (l < 32); scalar ALU on ballots
+__device__ __forceinline__ unsigned long long sc_spread32(unsigned long long v) {
+    v &= 0xffffffffull;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffull;
+    v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+__device__ __forceinline__ unsigned long long sc_interleave32(unsigned long long a, unsigned long long b) {
+    return sc_spread32(a) | (sc_spread32(b) << 1);
+}
+
 // run-time flag variants for epilogues (a wave-uniform branch per access)
 __device__ __forceinline__ f32x4 sc_load4_rt(const void* __restrict__ p, long elem, bool bf) {
     return bf ? sc_load4<true>(p, elem) : sc_load4<false>(p, elem);
