@@ -996,6 +996,34 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __res
     }
 }
 
+// bf16 mode with a stored x0 and the gradient handed over as ONE bf16 plane only: eight elements per thread, 16-byte
+// accesses (see scale_shift_act_bf16x8_kernel); same arithmetic as sa_bn_bwd_apply_kernel<true>
+__global__ __launch_bounds__(256) void sa_bn_bwd_apply_bf16x8_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                                                     const float* __restrict__ dgap,
+                                                                     const void* __restrict__ x0, const float* __restrict__ bn,
+                                                                     const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                     long n8, int C, int HW, int Cp, float inv_hw,
+                                                                     unsigned short* __restrict__ plane) {
+    const int c8n = C / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c8n;
+        const int c0 = (int)(i - r * c8n) * 8;
+        const int b = (int)((unsigned)r / (unsigned)HW);
+        f32x4 x[2], o[2];
+        sc_load8_bf16(x0, i * 8, x[0], x[1]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = c0 + 4 * q, cp = c >= Cp ? c - Cp : c;
+            const f32x4 mu = *(const f32x4*)(bn + c), rs = *(const f32x4*)(bn + C + c);
+            const f32x4 sc = *(const f32x4*)(bn + 2 * C + c), sh = *(const f32x4*)(bn + 3 * C + c);
+            const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, C, Cp, inv_hw, x[q], mu, sc, sh);
+            const f32x4 xh = (x[q] - mu) * rs;
+            o[q] = sc * (gg - *(const f32x4*)(c1 + c) - xh * *(const f32x4*)(c2 + c));
+        }
+        sc_store8_bf16(plane, i * 8, o[0], o[1]);
+    }
+}
+
 // Finalize of the split-attention / bn0 backward from the per-image statistics the d(attention) pass produced
 // (misc_ops.hip sa_colsum_partial_kernel<true, true>): one thread per channel sums over the images.
 // (SBS_L lanes per channel share the loop over the images and are added by a fixed-order shuffle tree: one thread per
@@ -1062,7 +1090,10 @@ extern "C" int scouter_sa_bn_bwd_io(const float* dout, const float* a, const flo
                            training, dgamma, dbeta, c1, c2);
     }
     const long n4 = M * C / 4;
-    if (xb) hipLaunchKernelGGL(sa_bn_bwd_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
+    if (xb && !dx && dx_planes && nplanes == 1 && Cp % 8 == 0)
+        hipLaunchKernelGGL(sa_bn_bwd_apply_bf16x8_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
+                           c1, c2, n4 / 2, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes);
+    else if (xb) hipLaunchKernelGGL(sa_bn_bwd_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
                                c1, c2, dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);
     else hipLaunchKernelGGL(sa_bn_bwd_apply_kernel<false>, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
                             c1, c2, dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);

@@ -157,6 +157,14 @@ __global__ void radix_softmax_bwd_kernel(const float* __restrict__ a, const floa
     dz[i1] = a[i1] * (da[i1] - dot);
 }
 
+// the weighted sum of one channel quad -- ONE function for every instantiation, so that the compiler contracts the
+// multiply-adds the same way everywhere (the 8-element bf16 kernel must give the bits of the 4-element one)
+__device__ __forceinline__ f32x4 sa_weighted_sum(f32x4 x0, f32x4 x1, f32x4 a0, f32x4 a1) {
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(x0[k], a0[k], x1[k] * a1[k]);      // (what `x0*a0 + x1*a1` contracted to)
+    return o;
+}
 // out[b,hw,c] = x[b,hw,c]*a[b,c] + x[b,hw,Cp+c]*a[b,Cp+c]
 template <bool XB = false, bool YB = false>              // storage of x (raw convolution output) / out: bf16 or fp32
 __global__ __launch_bounds__(256) void sa_apply_fwd_kernel(const void* __restrict__ x, const float* __restrict__ a,
@@ -177,7 +185,36 @@ __global__ __launch_bounds__(256) void sa_apply_fwd_kernel(const void* __restric
             for (int k = 0; k < 4; ++k) { x0[k] = fmaxf(x0[k], 0.f); x1[k] = fmaxf(x1[k], 0.f); }
         }
         const f32x4 a0 = *(const f32x4*)(a + (long)b * 2 * Cp + c), a1 = *(const f32x4*)(a + (long)b * 2 * Cp + Cp + c);
-        sc_store4<YB>(out, i * 4, x0 * a0 + x1 * a1);
+        sc_store4<YB>(out, i * 4, sa_weighted_sum(x0, x1, a0, a1));
+    }
+}
+// x and out both bf16-stored: eight channels per thread, 16-byte accesses (bn_elem.hip scale_shift_act_bf16x8_kernel);
+// same arithmetic as sa_apply_fwd_kernel<true, true>
+__global__ __launch_bounds__(256) void sa_apply_fwd_bf16x8_kernel(const void* __restrict__ x, const float* __restrict__ a,
+                                                                  const float* __restrict__ bn, void* __restrict__ out,
+                                                                  long n8, int HW, int Cp) {
+    const int c8n = Cp / 8, C2 = 2 * Cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % c8n) * 8;
+        const long row = i / c8n;
+        const int b = (int)(row / HW);
+        f32x4 x0[2], x1[2], o[2];
+        sc_load8_bf16(x, row * C2 + c0, x0[0], x0[1]);
+        sc_load8_bf16(x, row * C2 + Cp + c0, x1[0], x1[1]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = c0 + 4 * q;
+            if (bn) {
+                x0[q] = bn_affine(x0[q], *(const f32x4*)(bn + c), *(const f32x4*)(bn + 2 * C2 + c), *(const f32x4*)(bn + 3 * C2 + c));
+                x1[q] = bn_affine(x1[q], *(const f32x4*)(bn + Cp + c), *(const f32x4*)(bn + 2 * C2 + Cp + c),
+                                  *(const f32x4*)(bn + 3 * C2 + Cp + c));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x0[q][k] = fmaxf(x0[q][k], 0.f); x1[q][k] = fmaxf(x1[q][k], 0.f); }
+            }
+            const f32x4 a0 = *(const f32x4*)(a + (long)b * C2 + c), a1 = *(const f32x4*)(a + (long)b * C2 + Cp + c);
+            o[q] = sa_weighted_sum(x0[q], x1[q], a0, a1);
+        }
+        sc_store8_bf16(out, i * 8, o[0], o[1]);
     }
 }
 // dx[b,hw,r*Cp+c] = dout[b,hw,c]*a[b,r*Cp+c] + dgap[b,c]*inv_hw
@@ -269,6 +306,10 @@ extern "C" int scouter_sa_apply_fwd_io(const void* x, const float* a, const floa
     const long n4 = (long)B * HW * Cp / 4;
     const dim3 grid(ew_blocks(n4));
     hipStream_t st = (hipStream_t)stream;
+    if ((io & 3) == 3 && Cp % 8 == 0) {
+        hipLaunchKernelGGL(sa_apply_fwd_bf16x8_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, x, a, bn_saved, out, n4 / 2, HW, Cp);
+        return sc_check_launch("sa_apply_fwd");
+    }
     switch (io & 3) {
         case 0: hipLaunchKernelGGL((sa_apply_fwd_kernel<false, false>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
         case 1: hipLaunchKernelGGL((sa_apply_fwd_kernel<true, false>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
