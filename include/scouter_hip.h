@@ -218,6 +218,10 @@ int scouter_bn_maxpool_fwd_f32(const float* x, const float* bn_saved, float* y, 
 int scouter_bn_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, const float* x, const float* bn_saved, int B,
                                int H, int W, int C, int k, int stride, int pad, int training, float* dgamma,
                                float* dbeta, float* dx, void* ws, size_t ws_bytes, void* stream);
+/* io & SCOUTER_IO_Y_BF16: dx is stored as bf16 */
+int scouter_bn_maxpool_bwd_io(const float* dy, const unsigned char* argmax, const float* x, const float* bn_saved, int B,
+                              int H, int W, int C, int k, int stride, int pad, int training, float* dgamma,
+                              float* dbeta, void* dx, int io, void* ws, size_t ws_bytes, void* stream);
 int scouter_avgpool_fwd_f32(const float* x, float* y, int B, int H, int W, int C, int k, int stride, int pad,
                             int ceil_mode, int count_include_pad, void* stream);
 int scouter_avgpool_fwd_io(const void* x, float* y, int B, int H, int W, int C, int k, int stride, int pad,

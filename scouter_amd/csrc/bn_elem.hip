@@ -593,10 +593,10 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 // bnx / bn / coef (optional, max pool): the pool input was relu(bn(bnx)) evaluated on the fly in the forward -- the gathered
 // gradient is masked by [bn(bnx) > 0] and pushed through the BatchNorm backward in the same pass:
 // dx = scale * (g - c1 - xhat * c2), coef = [c1 | c2][C] from bn_bwd_finalize_kernel.
-template <int S, bool MAXP>
+template <int S, bool MAXP, bool YB = false>                 // YB: dx is stored as bf16
 __global__ __launch_bounds__(256) void pool_bwd_rows_kernel(const float* __restrict__ dy,
                                                             const unsigned char* __restrict__ arg,
-                                                            float* __restrict__ dx, PoolGeom g, float inv_c4n,
+                                                            void* __restrict__ dx, PoolGeom g, float inv_c4n,
                                                             const float* __restrict__ bnx,
                                                             const float* __restrict__ bn,
                                                             const float* __restrict__ coef) {
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void pool_bwd_rows_kernel(const float* __restr
         const f32x4 xh = (xv - mu) * rs;
         acc = sc * (acc - k1 - xh * k2);
     }
-    *(f32x4*)(dx + off) = acc;
+    sc_store4<YB>(dx, off, acc);
 }
 
 // Reduction pass of the fused BatchNorm + ReLU + max-pool backward: g is non-zero only at the arg-max positions, so
@@ -699,13 +699,18 @@ static bool pool_bwd_rows_ok(const PoolGeom& g) {
     return (g.stride == 1 || g.stride == 2) && xw < (1 << 20) && rows <= 65535;
 }
 template <bool MAXP>
-static bool pool_bwd_rows(const float* dy, const unsigned char* arg, float* dx, const PoolGeom& g, hipStream_t st,
-                          const float* bnx = nullptr, const float* bn = nullptr, const float* coef = nullptr) {
+static bool pool_bwd_rows(const float* dy, const unsigned char* arg, void* dx, const PoolGeom& g, hipStream_t st,
+                          const float* bnx = nullptr, const float* bn = nullptr, const float* coef = nullptr,
+                          bool dx_bf16 = false) {
     const long xw = (long)g.W * (g.C / 4), rows = (long)g.B * g.H;
     if (!pool_bwd_rows_ok(g)) return false;
     dim3 grid((unsigned)((xw + 255) / 256), (unsigned)rows);
     const float inv = 1.0f / (float)(g.C / 4);
-    if (g.stride == 1)
+    if (dx_bf16 && g.stride == 2)
+        hipLaunchKernelGGL((pool_bwd_rows_kernel<2, MAXP, true>), grid, dim3(256), 0, st, dy, arg, dx, g, inv, bnx, bn, coef);
+    else if (dx_bf16)
+        hipLaunchKernelGGL((pool_bwd_rows_kernel<1, MAXP, true>), grid, dim3(256), 0, st, dy, arg, dx, g, inv, bnx, bn, coef);
+    else if (g.stride == 1)
         hipLaunchKernelGGL((pool_bwd_rows_kernel<1, MAXP>), grid, dim3(256), 0, st, dy, arg, dx, g, inv, bnx, bn, coef);
     else
         hipLaunchKernelGGL((pool_bwd_rows_kernel<2, MAXP>), grid, dim3(256), 0, st, dy, arg, dx, g, inv, bnx, bn, coef);
@@ -1179,12 +1184,14 @@ extern "C" int scouter_bn_maxpool_fwd_f32(const float* x, const float* bn_saved,
                        bn_saved);
     return sc_check_launch("bn_maxpool_fwd");
 }
-extern "C" int scouter_bn_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, const float* x,
-                                          const float* bn_saved, int B, int H, int W, int C, int k, int stride, int pad,
-                                          int training, float* dgamma, float* dbeta, float* dx, void* ws,
-                                          size_t ws_bytes, void* stream) {
+// `io` & SC_IO_Y_BF16: dx is stored as bf16 (a dx read by bf16-input convolution kernels only)
+extern "C" int scouter_bn_maxpool_bwd_io(const float* dy, const unsigned char* argmax, const float* x,
+                                         const float* bn_saved, int B, int H, int W, int C, int k, int stride, int pad,
+                                         int training, float* dgamma, float* dbeta, void* dx, int io, void* ws,
+                                         size_t ws_bytes, void* stream) {
     const int ceil_mode = 0, count_include_pad = 0;
     SC_REQUIRE(dy && argmax && x && bn_saved && dx, "bn_maxpool_bwd: null pointer");
+    SC_REQUIRE((io & ~SC_IO_Y_BF16) == 0, "bn_maxpool_bwd: unsupported io bits %d (only dx may be bf16)", io);
     POOL_SETUP("bn_maxpool_bwd")
     SC_UNSUPPORTED(pool_bwd_rows_ok(g), "bn_maxpool_bwd: stride 1 / 2, B*H <= 65535 only");
     const long Mp = (long)B * g.Ho * g.Wo;
@@ -1203,8 +1210,15 @@ extern "C" int scouter_bn_maxpool_bwd_f32(const float* dy, const unsigned char* 
     hipLaunchKernelGGL(bn_maxpool_bwd_partial_kernel, pgrid, dim3(256), 0, st, dy, argmax, x, bn_saved, (double*)ws, g, cg);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nb,
                        (long)B * H * W, C, training, dgamma, dbeta, coef, coef + C);
-    pool_bwd_rows<true>(dy, argmax, dx, g, st, x, bn_saved, coef);
+    pool_bwd_rows<true>(dy, argmax, dx, g, st, x, bn_saved, coef, (io & SC_IO_Y_BF16) != 0);
     return sc_check_launch("bn_maxpool_bwd");
+}
+extern "C" int scouter_bn_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, const float* x,
+                                          const float* bn_saved, int B, int H, int W, int C, int k, int stride, int pad,
+                                          int training, float* dgamma, float* dbeta, float* dx, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    return scouter_bn_maxpool_bwd_io(dy, argmax, x, bn_saved, B, H, W, C, k, stride, pad, training, dgamma, dbeta, dx, 0, ws,
+                                     ws_bytes, stream);
 }
 extern "C" int scouter_maxpool_bwd_f32(const float* dy, const unsigned char* argmax, float* dx, int B, int H, int W,
                                        int C, int k, int stride, int pad, void* stream) {

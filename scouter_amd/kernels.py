@@ -931,15 +931,16 @@ def bn_maxpool_fwd(x, saved, k=3, stride=2, pad=1, want_argmax=True):
     return y, arg
 
 
-def bn_maxpool_bwd(dy, arg, x, saved, training, dgamma=None, dbeta=None, k=3, stride=2, pad=1):
-    """Backward of bn_maxpool_fwd: pooled gradient -> gradient of the BatchNorm input (+ dgamma, dbeta in place)."""
+def bn_maxpool_bwd(dy, arg, x, saved, training, dgamma=None, dbeta=None, k=3, stride=2, pad=1, dx_dtype=F32):
+    """Backward of bn_maxpool_fwd: pooled gradient -> gradient of the BatchNorm input (+ dgamma, dbeta in place).
+    dx_dtype=torch.bfloat16: dx stored as bf16 (read by bf16-input convolution kernels only: Conv2d.grad_storage)."""
     _chk(dy, "dy"); _chk(x, "x")
     B, H, W, C = x.shape
-    dx = torch.empty_like(x)
+    dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
     ws = _col_ws(dy.numel() // C, C, x.device)
-    _native.check(_native.lib().scouter_bn_maxpool_bwd_f32(
+    _native.check(_native.lib().scouter_bn_maxpool_bwd_io(
         _p(dy), _p(arg), _p(x), _p(saved), B, H, W, C, k, stride, pad, int(training), _p(dgamma), _p(dbeta), _p(dx),
-        _p(ws), ws.numel(), _stream()), "bn_maxpool_bwd")
+        IO_Y_BF16 if dx_dtype == BF16 else 0, _p(ws), ws.numel(), _stream()), "bn_maxpool_bwd")
     return dx
 
 

@@ -273,7 +273,9 @@ class ResNet(nn.Module):
             return
         if len(ctx[1]) == 4:
             craw, saved, training1, arg = ctx[1]
-            dc = K.bn_maxpool_bwd(d, arg, craw, saved, training1, self.bn1._dg, self.bn1._db, 3, 2, 1)
+            last = self.conv1[6] if isinstance(self.conv1, nn.Sequential) else None
+            dc = K.bn_maxpool_bwd(d, arg, craw, saved, training1, self.bn1._dg, self.bn1._db, 3, 2, 1,
+                                  dx_dtype=(last.grad_storage(*craw.shape[:3]) if last is not None else None) or K.F32)
         else:
             bb, arg, hshape = ctx[1]
             dh = K.maxpool_bwd(d, arg, hshape, 3, 2, 1)

@@ -379,3 +379,21 @@ def test_eval_forward_and_storage_switch_at_model_level(monkeypatch):
     with pytest.raises(ValueError, match="precision 'bf16'"):
         m.set_precision("fp32")
         m.set_activation_storage("bf16")
+
+
+def test_stem_pool_backward_stores_bf16():
+    """fused BatchNorm + ReLU + max-pool backward writing dx as bf16 == RNE of the fp32-storage launch, same dgamma / dbeta"""
+    kk = K()
+    rng = np.random.default_rng(11)
+    B, H, W, C = 3, 30, 34, 64
+    x = _rand(rng, B, H, W, C)
+    gamma, beta = _rand(rng, C).abs() + 0.5, _rand(rng, C)
+    saved = kk.bn_stats(x, gamma, beta, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), True)
+    p, arg = kk.bn_maxpool_fwd(x, saved, 3, 2, 1, want_argmax=True)
+    dy = _rand(rng, *p.shape)
+    outs = []
+    for dt in (torch.float32, BF16):
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        outs.append((kk.bn_maxpool_bwd(dy, arg, x, saved, True, dg, db, 3, 2, 1, dx_dtype=dt), dg, db))
+    assert outs[1][0].dtype == BF16 and torch.equal(outs[1][0], outs[0][0].to(BF16))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
