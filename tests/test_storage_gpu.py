@@ -397,3 +397,24 @@ def test_stem_pool_backward_stores_bf16():
         outs.append((kk.bn_maxpool_bwd(dy, arg, x, saved, True, dg, db, 3, 2, 1, dx_dtype=dt), dg, db))
     assert outs[1][0].dtype == BF16 and torch.equal(outs[1][0], outs[0][0].to(BF16))
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_residual_stream_gradient_switch(monkeypatch):
+    """SCOUTER_BF16_GRAD_STREAM (resnest.GRAD_STREAM_BF16): with the masked block-output gradient kept in fp32 the step still
+    runs on the typed kernels, the forward is the same bits, and the parameter gradients differ from the default by a
+    bf16-rounding-sized amount only (one rounding per block of a tensor that fp32 arithmetic reads)."""
+    import test_model_gpu as T
+    from scouter_amd.timm.models import resnest as R
+    monkeypatch.undo()
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(R, "GRAD_STREAM_BF16", flag)
+        m, P, images, labels, cfg = T._synthetic_model("resnest26d", 10, 1, 3, 8, 224, 2300)
+        m.set_precision("bf16")
+        out, (loss, nll, area) = m(images.cuda(), labels.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), m.grad_arena().flat.double().clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    rel = float((res[0][1] - res[1][1]).norm() / res[1][1].norm())
+    assert 0.0 < rel < 2e-2, rel
