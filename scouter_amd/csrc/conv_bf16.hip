@@ -1,8 +1,9 @@
 // bf16-input / fp32-accumulate implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the
-// fp32-MFMA rate) -- the mixed-precision mode of BASELINE configs[4] ("bf16").  Tensors stay fp32 in HBM (activations,
+// fp32-MFMA rate) -- the mixed-precision mode of BASELINE configs[4] ("bf16").  By default tensors are fp32 in HBM (activations,
 // gradients, master weights): operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way from the global
 // loads into LDS, so every other kernel of the step (BatchNorm, xSlot, optimizer) is shared with the fp32 path and
-// only the matrix inputs lose precision -- what torch.autocast(bfloat16) does to nn.Conv2d.
+// only the matrix inputs lose precision -- what torch.autocast(bfloat16) does to nn.Conv2d.  The typed (`*_io`) entry
+// points additionally read / write bf16-STORED tensors (A_BF16 loaders, the TYPED epilogue): same products, half the bytes.
 //
 //   forward : Y = X (*) W      A = X rows (pixel, k = (tap, ci) contiguous in ci), B = W^T as bf16 [tap][co][ci]
 //                              (scouter_conv2d_weight_bf16t, one small launch per layer and step)

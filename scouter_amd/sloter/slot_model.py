@@ -71,7 +71,8 @@ class SlotModel(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.use_slot = args.use_slot
-        # "fp32" (parity path) or "bf16": convolution matrix inputs rounded to bf16, fp32 accumulation and storage
+        # "fp32" (parity path) or "bf16": convolution matrix inputs rounded to bf16, fp32 accumulation; the wide bottleneck
+        # tensors stored as bf16 (set_activation_storage)
         self.precision = str(getattr(args, "precision", "fp32"))
         if self.precision not in ("fp32", "bf16"):
             raise ValueError("precision must be fp32 or bf16, got %r" % self.precision)
