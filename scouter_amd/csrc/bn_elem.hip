@@ -224,6 +224,10 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const void* __rest
 // lane and access and reaches 3.5-4.0 TB/s where the fp32 pass reaches 4.9 (tools_dev/typed_pass_bench.py).  Thread i owns
 // the float4 indices 2i, 2i+1: a wave covers 128 consecutive ones = two mask words per component, the even / odd ballots
 // interleaved on the scalar unit.  Same arithmetic, same bits as the 4-element kernel.
+// HOIST: the grid stride is a multiple of C / 8 (power-of-two channel counts), so a thread's eight channels never change:
+// the per-channel parameters are loaded ONCE.  Without it the all-bf16 pass issues ~12 cached parameter loads per 48 bytes
+// of streamed data and is bound by vector-memory INSTRUCTIONS, not bytes (3.5-4.5 TB/s; tools_dev/typed_pass_bench.py).
+template <bool HOIST>
 __global__ __launch_bounds__(256) void scale_shift_act_bf16x8_kernel(const void* __restrict__ x,
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ scale,
@@ -231,18 +235,30 @@ __global__ __launch_bounds__(256) void scale_shift_act_bf16x8_kernel(const void*
                                                                      const void* __restrict__ res, void* __restrict__ y,
                                                                      unsigned long long* __restrict__ mbits, long n8, int C,
                                                                      int relu, const float* __restrict__ res_bn) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 8) % C);
+    const long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 pm[2], ps[2], pb[2], qm[2], qs[2], qb[2];
+    auto params = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cc = c + 4 * q;
+            pm[q] = *(const f32x4*)(mean + cc); ps[q] = *(const f32x4*)(scale + cc); pb[q] = *(const f32x4*)(shift + cc);
+            if (res_bn) {
+                qm[q] = *(const f32x4*)(res_bn + cc); qs[q] = *(const f32x4*)(res_bn + 2 * C + cc);
+                qb[q] = *(const f32x4*)(res_bn + 3 * C + cc);
+            }
+        }
+    };
+    if (HOIST) params((int)((i_first * 8) % C));
+    for (long i = i_first; i < n8; i += (long)gridDim.x * blockDim.x) {
+        if (!HOIST) params((int)((i * 8) % C));
         f32x4 v[2], r[2];
         sc_load8_bf16(x, i * 8, v[0], v[1]);
         if (res) sc_load8_bf16(res, i * 8, r[0], r[1]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int cc = c + 4 * q;
-            v[q] = bn_affine(v[q], *(const f32x4*)(mean + cc), *(const f32x4*)(scale + cc), *(const f32x4*)(shift + cc));
+            v[q] = bn_affine(v[q], pm[q], ps[q], pb[q]);
             if (res) {
-                if (res_bn) r[q] = bn_affine(r[q], *(const f32x4*)(res_bn + cc), *(const f32x4*)(res_bn + 2 * C + cc),
-                                             *(const f32x4*)(res_bn + 3 * C + cc));
+                if (res_bn) r[q] = bn_affine(r[q], qm[q], qs[q], qb[q]);
                 v[q] += r[q];
             }
         }
@@ -315,24 +331,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
 
 // all-bf16 storage (dy = the stored masked gradient, x, dx): eight elements per thread, 16-byte accesses (see
 // scale_shift_act_bf16x8_kernel); no mask (a bf16-stored dy is already masked)
+template <bool HOIST>                                        // (see scale_shift_act_bf16x8_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_apply_bf16x8_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd,
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ c1, const float* __restrict__ c2,
                                                                   void* __restrict__ dx, long n8, int C) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 8) % C);
+    const long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 mu[2], rs[2], sc[2], k1[2], k2[2];
+    auto params = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cc = c + 4 * q;
+            mu[q] = *(const f32x4*)(mean + cc); rs[q] = *(const f32x4*)(rstd + cc); sc[q] = *(const f32x4*)(scale + cc);
+            k1[q] = *(const f32x4*)(c1 + cc); k2[q] = *(const f32x4*)(c2 + cc);
+        }
+    };
+    if (HOIST) params((int)((i_first * 8) % C));
+    for (long i = i_first; i < n8; i += (long)gridDim.x * blockDim.x) {
+        if (!HOIST) params((int)((i * 8) % C));
         f32x4 g[2], xv[2], o[2];
         sc_load8_bf16(dy, i * 8, g[0], g[1]);
         sc_load8_bf16(x, i * 8, xv[0], xv[1]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int cc = c + 4 * q;
-            const f32x4 mu = *(const f32x4*)(mean + cc), rs = *(const f32x4*)(rstd + cc), sc = *(const f32x4*)(scale + cc);
-            const f32x4 k1 = *(const f32x4*)(c1 + cc), k2 = *(const f32x4*)(c2 + cc);
-            const f32x4 xh = (xv[q] - mu) * rs;
-            o[q] = sc * (g[q] - k1 - xh * k2);
+            const f32x4 xh = (xv[q] - mu[q]) * rs[q];
+            o[q] = sc[q] * (g[q] - k1[q] - xh * k2[q]);
         }
         sc_store8_bf16(dx, i * 8, o[0], o[1]);
     }
@@ -798,8 +823,12 @@ extern "C" int scouter_bn_fwd_io(const void* x, void* y, const void* residual, l
                               !planes_out && C % 8 == 0;
         if (all_bf16) {
             const long n8 = n4 / 2;
-            hipLaunchKernelGGL(scale_shift_act_bf16x8_kernel, dim3(ew_blocks(n8)), dim3(256), 0, st, x, mean_out, scale_out,
-                               shift_out, residual, y, relu_mask_out, n8, C, relu, residual_bn_saved);
+            if (256 % (C / 8) == 0)         // (the grid stride, a multiple of 256, is then a multiple of C / 8: see HOIST)
+                hipLaunchKernelGGL(scale_shift_act_bf16x8_kernel<true>, dim3(ew_blocks(n8)), dim3(256), 0, st, x, mean_out,
+                                   scale_out, shift_out, residual, y, relu_mask_out, n8, C, relu, residual_bn_saved);
+            else
+                hipLaunchKernelGGL(scale_shift_act_bf16x8_kernel<false>, dim3(ew_blocks(n8)), dim3(256), 0, st, x, mean_out,
+                                   scale_out, shift_out, residual, y, relu_mask_out, n8, C, relu, residual_bn_saved);
         } else
         switch (io & 7) {
             case 0: SSA(false, false, false); break;
@@ -894,9 +923,12 @@ extern "C" int scouter_bn_bwd_io(const void* dy, const float* ymask, const void*
 #define BBA(XB_, YB_, DB_)                                                                                            \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<XB_, YB_, DB_>), dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean,    \
                        rstd, scale, c1, c2, relu_mask, dx, gout, n4, C)
-    if (xb && yb && db && !ymask && !relu_mask && !gout && C % 8 == 0)
-        hipLaunchKernelGGL(bn_bwd_apply_bf16x8_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dy, x, mean, rstd, scale, c1, c2,
-                           dx, n4 / 2, C);
+    if (xb && yb && db && !ymask && !relu_mask && !gout && C % 8 == 0 && 256 % (C / 8) == 0)
+        hipLaunchKernelGGL(bn_bwd_apply_bf16x8_kernel<true>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dy, x, mean, rstd, scale,
+                           c1, c2, dx, n4 / 2, C);
+    else if (xb && yb && db && !ymask && !relu_mask && !gout && C % 8 == 0)
+        hipLaunchKernelGGL(bn_bwd_apply_bf16x8_kernel<false>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dy, x, mean, rstd, scale,
+                           c1, c2, dx, n4 / 2, C);
     else
     switch ((xb ? 1 : 0) | (yb ? 2 : 0) | (db ? 4 : 0)) {
         case 0: BBA(false, false, false); break;
@@ -1003,6 +1035,7 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __res
 
 // bf16 mode with a stored x0 and the gradient handed over as ONE bf16 plane only: eight elements per thread, 16-byte
 // accesses (see scale_shift_act_bf16x8_kernel); same arithmetic as sa_bn_bwd_apply_kernel<true>
+template <bool HOIST>                                        // (see scale_shift_act_bf16x8_kernel)
 __global__ __launch_bounds__(256) void sa_bn_bwd_apply_bf16x8_kernel(const float* __restrict__ dout, const float* __restrict__ a,
                                                                      const float* __restrict__ dgap,
                                                                      const void* __restrict__ x0, const float* __restrict__ bn,
@@ -1010,20 +1043,31 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_bf16x8_kernel(const float
                                                                      long n8, int C, int HW, int Cp, float inv_hw,
                                                                      unsigned short* __restrict__ plane) {
     const int c8n = C / 8;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 mu[2], rs[2], sc[2], sh[2], k1[2], k2[2];
+    auto params = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = c0 + 4 * q;
+            mu[q] = *(const f32x4*)(bn + c); rs[q] = *(const f32x4*)(bn + C + c);
+            sc[q] = *(const f32x4*)(bn + 2 * C + c); sh[q] = *(const f32x4*)(bn + 3 * C + c);
+            k1[q] = *(const f32x4*)(c1 + c); k2[q] = *(const f32x4*)(c2 + c);
+        }
+    };
+    if (HOIST) params((int)(i_first % c8n) * 8);
+    for (long i = i_first; i < n8; i += (long)gridDim.x * blockDim.x) {
         const long r = i / c8n;
         const int c0 = (int)(i - r * c8n) * 8;
+        if (!HOIST) params(c0);
         const int b = (int)((unsigned)r / (unsigned)HW);
         f32x4 x[2], o[2];
         sc_load8_bf16(x0, i * 8, x[0], x[1]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = c0 + 4 * q, cp = c >= Cp ? c - Cp : c;
-            const f32x4 mu = *(const f32x4*)(bn + c), rs = *(const f32x4*)(bn + C + c);
-            const f32x4 sc = *(const f32x4*)(bn + 2 * C + c), sh = *(const f32x4*)(bn + 3 * C + c);
-            const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, C, Cp, inv_hw, x[q], mu, sc, sh);
-            const f32x4 xh = (x[q] - mu) * rs;
-            o[q] = sc * (gg - *(const f32x4*)(c1 + c) - xh * *(const f32x4*)(c2 + c));
+            const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, C, Cp, inv_hw, x[q], mu[q], sc[q], sh[q]);
+            const f32x4 xh = (x[q] - mu[q]) * rs[q];
+            o[q] = sc[q] * (gg - k1[q] - xh * k2[q]);
         }
         sc_store8_bf16(plane, i * 8, o[0], o[1]);
     }
@@ -1095,9 +1139,12 @@ extern "C" int scouter_sa_bn_bwd_io(const float* dout, const float* a, const flo
                            training, dgamma, dbeta, c1, c2);
     }
     const long n4 = M * C / 4;
-    if (xb && !dx && dx_planes && nplanes == 1 && Cp % 8 == 0)
-        hipLaunchKernelGGL(sa_bn_bwd_apply_bf16x8_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
-                           c1, c2, n4 / 2, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes);
+    if (xb && !dx && dx_planes && nplanes == 1 && Cp % 8 == 0 && 256 % (C / 8) == 0)
+        hipLaunchKernelGGL(sa_bn_bwd_apply_bf16x8_kernel<true>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dout, a, dgap, x0,
+                           bn_saved, c1, c2, n4 / 2, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes);
+    else if (xb && !dx && dx_planes && nplanes == 1 && Cp % 8 == 0)
+        hipLaunchKernelGGL(sa_bn_bwd_apply_bf16x8_kernel<false>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dout, a, dgap, x0,
+                           bn_saved, c1, c2, n4 / 2, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes);
     else if (xb) hipLaunchKernelGGL(sa_bn_bwd_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
                                c1, c2, dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);
     else hipLaunchKernelGGL(sa_bn_bwd_apply_kernel<false>, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,

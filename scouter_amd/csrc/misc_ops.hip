@@ -190,12 +190,27 @@ __global__ __launch_bounds__(256) void sa_apply_fwd_kernel(const void* __restric
 }
 // x and out both bf16-stored: eight channels per thread, 16-byte accesses (bn_elem.hip scale_shift_act_bf16x8_kernel);
 // same arithmetic as sa_apply_fwd_kernel<true, true>
+template <bool HOIST>                   // the grid stride is a multiple of Cp / 8: bn0's parameters are loaded once (bn_elem.hip)
 __global__ __launch_bounds__(256) void sa_apply_fwd_bf16x8_kernel(const void* __restrict__ x, const float* __restrict__ a,
                                                                   const float* __restrict__ bn, void* __restrict__ out,
                                                                   long n8, int HW, int Cp) {
     const int c8n = Cp / 8, C2 = 2 * Cp;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 m0[2], s0[2], b0[2], m1[2], s1[2], b1[2];
+    auto params = [&](int c0) {
+        if (!bn) return;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = c0 + 4 * q;
+            m0[q] = *(const f32x4*)(bn + c); s0[q] = *(const f32x4*)(bn + 2 * C2 + c); b0[q] = *(const f32x4*)(bn + 3 * C2 + c);
+            m1[q] = *(const f32x4*)(bn + Cp + c); s1[q] = *(const f32x4*)(bn + 2 * C2 + Cp + c);
+            b1[q] = *(const f32x4*)(bn + 3 * C2 + Cp + c);
+        }
+    };
+    if (HOIST) params((int)(i_first % c8n) * 8);
+    for (long i = i_first; i < n8; i += (long)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % c8n) * 8;
+        if (!HOIST) params(c0);
         const long row = i / c8n;
         const int b = (int)(row / HW);
         f32x4 x0[2], x1[2], o[2];
@@ -205,9 +220,8 @@ __global__ __launch_bounds__(256) void sa_apply_fwd_bf16x8_kernel(const void* __
         for (int q = 0; q < 2; ++q) {
             const int c = c0 + 4 * q;
             if (bn) {
-                x0[q] = bn_affine(x0[q], *(const f32x4*)(bn + c), *(const f32x4*)(bn + 2 * C2 + c), *(const f32x4*)(bn + 3 * C2 + c));
-                x1[q] = bn_affine(x1[q], *(const f32x4*)(bn + Cp + c), *(const f32x4*)(bn + 2 * C2 + Cp + c),
-                                  *(const f32x4*)(bn + 3 * C2 + Cp + c));
+                x0[q] = bn_affine(x0[q], m0[q], s0[q], b0[q]);
+                x1[q] = bn_affine(x1[q], m1[q], s1[q], b1[q]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { x0[q][k] = fmaxf(x0[q][k], 0.f); x1[q][k] = fmaxf(x1[q][k], 0.f); }
             }
@@ -307,7 +321,10 @@ extern "C" int scouter_sa_apply_fwd_io(const void* x, const float* a, const floa
     const dim3 grid(ew_blocks(n4));
     hipStream_t st = (hipStream_t)stream;
     if ((io & 3) == 3 && Cp % 8 == 0) {
-        hipLaunchKernelGGL(sa_apply_fwd_bf16x8_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, x, a, bn_saved, out, n4 / 2, HW, Cp);
+        if (256 % (Cp / 8) == 0)
+            hipLaunchKernelGGL(sa_apply_fwd_bf16x8_kernel<true>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, x, a, bn_saved, out, n4 / 2, HW, Cp);
+        else
+            hipLaunchKernelGGL(sa_apply_fwd_bf16x8_kernel<false>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, x, a, bn_saved, out, n4 / 2, HW, Cp);
         return sc_check_launch("sa_apply_fwd");
     }
     switch (io & 3) {
