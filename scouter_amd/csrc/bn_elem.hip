@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
     shift_o[c] = beta ? beta[c] : 0.f;        // applied as (x - mean) * scale + beta: no cancellation when |mean| >> std
 }
 
-template <bool XB = false, bool YB = false, bool RB = false>     // storage types of x / y / res (bf16 or fp32)
+// HOIST: the launch's grid stride is a multiple of C / 4, so a thread's four channels never change and the per-channel
+// parameters are loaded once (round 4: these passes issue 3-6 cached parameter loads per 2-3 streamed ones; the bf16
+// instantiations were bound by that instruction stream, not by bytes)
+template <bool XB = false, bool YB = false, bool RB = false, bool HOIST = false>     // storage types of x / y / res (bf16 or fp32)
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const void* __restrict__ x,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ scale,
@@ -190,25 +193,30 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const void* __rest
                                                               unsigned long long* __restrict__ mbits, long n4, int C,
                                                               int relu, unsigned short* __restrict__ planes,
                                                               int nplanes, const float* __restrict__ res_bn) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+    const long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 a, b, mu, qm, qs, qb;
+    auto params = [&](int c) {
+        a = *(const f32x4*)(scale + c); b = *(const f32x4*)(shift + c); mu = *(const f32x4*)(mean + c);
+        if (res && res_bn) { qm = *(const f32x4*)(res_bn + c); qs = *(const f32x4*)(res_bn + 2 * C + c); qb = *(const f32x4*)(res_bn + 3 * C + c); }
+    };
+    if (HOIST) params((int)((i_first * 4) % C));
+    for (long i = i_first; i < n4; i += (long)gridDim.x * blockDim.x) {
+        if (!HOIST) params((int)((i * 4) % C));
         f32x4 v = sc_load4_nt<XB>(x, i * 4);
-        const f32x4 a = *(const f32x4*)(scale + c), b = *(const f32x4*)(shift + c), mu = *(const f32x4*)(mean + c);
         v = bn_affine(v, mu, a, b);
         if (res) {
             f32x4 r = sc_load4<RB>(res, i * 4);
             // the residual is the RAW output of the downsample convolution: its BatchNorm is applied here (saved block
             // [mean, rstd, scale, shift][C]) -- the same fma the stand-alone apply pass uses, so the sum is bit-identical
-            if (res_bn) r = bn_affine(r, *(const f32x4*)(res_bn + c), *(const f32x4*)(res_bn + 2 * C + c),
-                                      *(const f32x4*)(res_bn + 3 * C + c));
+            if (res_bn) r = bn_affine(r, qm, qs, qb);
             v += r;
         }
         if (relu) {
             if (mbits) {        // i - lane is a multiple of 64 (256-thread blocks, grid stride a multiple of 256)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const unsigned long long b = __ballot(v[k] > 0.f);
-                    if ((threadIdx.x & 63) == 0) mbits[(i >> 6) * 4 + k] = b;
+                    const unsigned long long bits = __ballot(v[k] > 0.f);
+                    if ((threadIdx.x & 63) == 0) mbits[(i >> 6) * 4 + k] = bits;
                 }
             }
 #pragma unroll
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 }
 
 // dx = gamma*rstd * (g - c1 - xhat*c2),  g = dy * (ymask > 0);  optionally also writes g (the residual-branch grad)
-template <bool XB = false, bool YB = false, bool DB = false>   // XB / YB / DB: x / dx / dy is stored as bf16
+template <bool XB = false, bool YB = false, bool DB = false, bool HOIST = false>   // XB / YB / DB: x / dx / dy stored as bf16
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dy, const float* __restrict__ ymask,
                                                            const void* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
@@ -310,8 +318,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
                                                            const unsigned long long* __restrict__ mbits,
                                                            void* __restrict__ dx, float* __restrict__ gout, long n4,
                                                            int C) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+    const long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 mu, rs, sc, k1, k2;
+    auto params = [&](int c) {          // (HOIST: see scale_shift_act_kernel)
+        mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); sc = *(const f32x4*)(scale + c);
+        k1 = *(const f32x4*)(c1 + c); k2 = *(const f32x4*)(c2 + c);
+    };
+    if (HOIST) params((int)((i_first * 4) % C));
+    for (long i = i_first; i < n4; i += (long)gridDim.x * blockDim.x) {
+        if (!HOIST) params((int)((i * 4) % C));
         f32x4 g = sc_load4_nt<DB>(dy, i * 4);
         if (mbits) {
             relu_mask_apply(g, mbits, i);
@@ -321,8 +336,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
             for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
         }
         const f32x4 xv = sc_load4_nt<XB>(x, i * 4);
-        const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c), sc = *(const f32x4*)(scale + c);
-        const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c);
         const f32x4 xh = (xv - mu) * rs;
         sc_store4<YB>(dx, i * 4, sc * (g - k1 - xh * k2));
         if (gout) *(f32x4*)(gout + i * 4) = g;
@@ -765,6 +778,20 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 // ---------------------------------------------------------------------------------------------------------------
 static inline bool fin_narrow(int C, int nparts) { return C <= 64 && nparts > 512; }   // see partial_reduce
 static inline int ew_blocks(long n) { long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+// grid for an elementwise pass over n vectors of `cv` = C / 4 (or C / 8) channel groups whose threads keep their channels
+// (HOIST instantiations): the grid stride blocks * 256 must be a multiple of cv; 0 if no such grid (odd channel counts)
+static inline int ew_blocks_hoist(long n, int cv) {
+    int b = ew_blocks(n);
+    if (cv <= 0) return 0;
+    if (256 % cv == 0) return b;
+    if (cv % 256 == 0) {                   // wider rows than a workgroup: a multiple of cv / 256 workgroups
+        const int m = cv / 256;
+        if (b <= 1) return b;              // one workgroup: at most one iteration per thread
+        b = (b + m - 1) / m * m;
+        return b;
+    }
+    return 0;
+}
 
 extern "C" size_t scouter_colreduce_workspace_bytes(long M, int C) { (void)M; return (size_t)MAXB * C * 2 * sizeof(double); }
 
@@ -830,15 +857,26 @@ extern "C" int scouter_bn_fwd_io(const void* x, void* y, const void* residual, l
                 hipLaunchKernelGGL(scale_shift_act_bf16x8_kernel<false>, dim3(ew_blocks(n8)), dim3(256), 0, st, x, mean_out,
                                    scale_out, shift_out, residual, y, relu_mask_out, n8, C, relu, residual_bn_saved);
         } else
+        {
+        const int hb = ew_blocks_hoist(n4, C / 4);
+#define SSH(XB_, YB_, RB_)                                                                                            \
+        do {                                                                                                          \
+            if (hb) hipLaunchKernelGGL((scale_shift_act_kernel<XB_, YB_, RB_, true>), dim3(hb), dim3(256), 0, st, x,    \
+                                       mean_out, scale_out, shift_out, residual, y, relu_mask_out, n4, C, relu,       \
+                                       (unsigned short*)planes_out, nplanes, residual_bn_saved);                      \
+            else SSA(XB_, YB_, RB_);                                                                                  \
+        } while (0)
         switch (io & 7) {
-            case 0: SSA(false, false, false); break;
-            case 1: SSA(true, false, false); break;
-            case 2: SSA(false, true, false); break;
-            case 3: SSA(true, true, false); break;
-            case 4: SSA(false, false, true); break;
-            case 5: SSA(true, false, true); break;
-            case 6: SSA(false, true, true); break;
-            default: SSA(true, true, true); break;
+            case 0: SSH(false, false, false); break;
+            case 1: SSH(true, false, false); break;
+            case 2: SSH(false, true, false); break;
+            case 3: SSH(true, true, false); break;
+            case 4: SSH(false, false, true); break;
+            case 5: SSH(true, false, true); break;
+            case 6: SSH(false, true, true); break;
+            default: SSH(true, true, true); break;
+        }
+#undef SSH
         }
 #undef SSA
     }
@@ -920,9 +958,14 @@ extern "C" int scouter_bn_bwd_io(const void* dy, const float* ymask, const void*
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(sc_cdiv(C, 4)), dim3(256), 0, st, part, nparts, M, C, training, dgamma,
                            dbeta, c1, c2);
     const long n4 = M * C / 4;
+    const int hb4 = ew_blocks_hoist(n4, C / 4);
 #define BBA(XB_, YB_, DB_)                                                                                            \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<XB_, YB_, DB_>), dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x, mean,    \
-                       rstd, scale, c1, c2, relu_mask, dx, gout, n4, C)
+    do {                                                                                                              \
+        if (hb4) hipLaunchKernelGGL((bn_bwd_apply_kernel<XB_, YB_, DB_, true>), dim3(hb4), dim3(256), 0, st, dy, ymask, x,  \
+                                    mean, rstd, scale, c1, c2, relu_mask, dx, gout, n4, C);                           \
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<XB_, YB_, DB_>), dim3(ew_blocks(n4)), dim3(256), 0, st, dy, ymask, x,  \
+                                mean, rstd, scale, c1, c2, relu_mask, dx, gout, n4, C);                               \
+    } while (0)
     if (xb && yb && db && !ymask && !relu_mask && !gout && C % 8 == 0 && 256 % (C / 8) == 0)
         hipLaunchKernelGGL(bn_bwd_apply_bf16x8_kernel<true>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dy, x, mean, rstd, scale,
                            c1, c2, dx, n4 / 2, C);
@@ -1009,7 +1052,7 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_partial_kernel(const float* __r
     }
 }
 
-template <bool XB = false>                                   // XB: x0 is stored as bf16
+template <bool XB = false, bool HOIST = false>               // XB: x0 is stored as bf16; HOIST: see scale_shift_act_kernel
 __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ a,
                                                               const float* __restrict__ dgap,
                                                               const void* __restrict__ x0, const float* __restrict__ bn,
@@ -1018,16 +1061,23 @@ __global__ __launch_bounds__(256) void sa_bn_bwd_apply_kernel(const float* __res
                                                               float inv_hw, unsigned short* __restrict__ planes,
                                                               int nplanes) {
     const int c4n = C / 4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 mu, rs, sc, sh, k1, k2;
+    auto params = [&](int c) {
+        mu = *(const f32x4*)(bn + c); rs = *(const f32x4*)(bn + C + c);
+        sc = *(const f32x4*)(bn + 2 * C + c); sh = *(const f32x4*)(bn + 3 * C + c);
+        k1 = *(const f32x4*)(c1 + c); k2 = *(const f32x4*)(c2 + c);
+    };
+    if (HOIST) params((int)(i_first % c4n) * 4);
+    for (long i = i_first; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long r = i / c4n;
         const int c = (int)(i - r * c4n) * 4, cp = c >= Cp ? c - Cp : c;
         const int b = (int)((unsigned)r / (unsigned)HW);
-        const f32x4 mu = *(const f32x4*)(bn + c), rs = *(const f32x4*)(bn + C + c);
-        const f32x4 sc = *(const f32x4*)(bn + 2 * C + c), sh = *(const f32x4*)(bn + 3 * C + c);
+        if (!HOIST) params(c);
         const f32x4 x = sc_load4_nt<XB>(x0, i * 4);
         const f32x4 gg = sa_bn_g(dout, a, dgap, r, b, c, cp, C, Cp, inv_hw, x, mu, sc, sh);
         const f32x4 xh = (x - mu) * rs;
-        const f32x4 o = sc * (gg - *(const f32x4*)(c1 + c) - xh * *(const f32x4*)(c2 + c));
+        const f32x4 o = sc * (gg - k1 - xh * k2);
         if (dx) *(f32x4*)(dx + i * 4) = o;                              // (NULL: dgrad and wgrad both run on the planes)
         if (planes) store_planes4(planes, n4 * 4, nplanes, i, o);      // A operand of the plane input-gradient kernel
     }
@@ -1145,10 +1195,17 @@ extern "C" int scouter_sa_bn_bwd_io(const float* dout, const float* a, const flo
     else if (xb && !dx && dx_planes && nplanes == 1 && Cp % 8 == 0)
         hipLaunchKernelGGL(sa_bn_bwd_apply_bf16x8_kernel<false>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, dout, a, dgap, x0,
                            bn_saved, c1, c2, n4 / 2, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes);
-    else if (xb) hipLaunchKernelGGL(sa_bn_bwd_apply_kernel<true>, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
-                               c1, c2, dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);
-    else hipLaunchKernelGGL(sa_bn_bwd_apply_kernel<false>, dim3(ew_blocks(n4)), dim3(256), 0, st, dout, a, dgap, x0, bn_saved,
-                            c1, c2, dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes);
+    else {
+        const int hb = ew_blocks_hoist(n4, C / 4);
+#define SBA(XB_, H_, G_)                                                                                              \
+        hipLaunchKernelGGL((sa_bn_bwd_apply_kernel<XB_, H_>), dim3(G_), dim3(256), 0, st, dout, a, dgap, x0, bn_saved, c1, c2, \
+                           dx, n4, C, HW, Cp, 1.f / HW, (unsigned short*)dx_planes, nplanes)
+        if (xb && hb) SBA(true, true, hb);
+        else if (xb) SBA(true, false, ew_blocks(n4));
+        else if (hb) SBA(false, true, hb);
+        else SBA(false, false, ew_blocks(n4));
+#undef SBA
+    }
     return sc_check_launch("sa_bn_bwd");
 }
 extern "C" int scouter_sa_bn_bwd_f32(const float* dout, const float* a, const float* dgap, const float* x0,

@@ -166,21 +166,29 @@ __device__ __forceinline__ f32x4 sa_weighted_sum(f32x4 x0, f32x4 x1, f32x4 a0, f
     return o;
 }
 // out[b,hw,c] = x[b,hw,c]*a[b,c] + x[b,hw,Cp+c]*a[b,Cp+c]
-template <bool XB = false, bool YB = false>              // storage of x (raw convolution output) / out: bf16 or fp32
+// HOIST: the grid stride is a multiple of Cp / 4 -- bn0's parameters of the thread's channels are loaded once (bn_elem.hip)
+template <bool XB = false, bool YB = false, bool HOIST = false>      // storage of x (raw convolution output) / out
 __global__ __launch_bounds__(256) void sa_apply_fwd_kernel(const void* __restrict__ x, const float* __restrict__ a,
                                                            const float* __restrict__ bn, void* __restrict__ out,
                                                            long n4, int HW, int Cp) {
-    const int c4n = Cp / 4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4n = Cp / 4, C2 = 2 * Cp;
+    const long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 m0, s0, b0, m1, s1, b1;
+    auto params = [&](int c) {
+        if (!bn) return;
+        m0 = *(const f32x4*)(bn + c); s0 = *(const f32x4*)(bn + 2 * C2 + c); b0 = *(const f32x4*)(bn + 3 * C2 + c);
+        m1 = *(const f32x4*)(bn + Cp + c); s1 = *(const f32x4*)(bn + 2 * C2 + Cp + c); b1 = *(const f32x4*)(bn + 3 * C2 + Cp + c);
+    };
+    if (HOIST) params((int)(i_first % c4n) * 4);
+    for (long i = i_first; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
         const long row = i / c4n;                 // b*HW + hw
         const int b = (int)(row / HW);
+        if (!HOIST) params(c);
         f32x4 x0 = sc_load4<XB>(x, row * 2 * Cp + c), x1 = sc_load4<XB>(x, row * 2 * Cp + Cp + c);
         if (bn) {                                 // x is the raw convolution output: relu(bn0(x)) on the fly
-            const int C2 = 2 * Cp;
-            x0 = bn_affine(x0, *(const f32x4*)(bn + c), *(const f32x4*)(bn + 2 * C2 + c), *(const f32x4*)(bn + 3 * C2 + c));
-            x1 = bn_affine(x1, *(const f32x4*)(bn + Cp + c), *(const f32x4*)(bn + 2 * C2 + Cp + c),
-                           *(const f32x4*)(bn + 3 * C2 + Cp + c));
+            x0 = bn_affine(x0, m0, s0, b0);
+            x1 = bn_affine(x1, m1, s1, b1);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { x0[k] = fmaxf(x0[k], 0.f); x1[k] = fmaxf(x1[k], 0.f); }
         }
@@ -327,11 +335,23 @@ extern "C" int scouter_sa_apply_fwd_io(const void* x, const float* a, const floa
             hipLaunchKernelGGL(sa_apply_fwd_bf16x8_kernel<false>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, st, x, a, bn_saved, out, n4 / 2, HW, Cp);
         return sc_check_launch("sa_apply_fwd");
     }
-    switch (io & 3) {
-        case 0: hipLaunchKernelGGL((sa_apply_fwd_kernel<false, false>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
-        case 1: hipLaunchKernelGGL((sa_apply_fwd_kernel<true, false>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
-        case 2: hipLaunchKernelGGL((sa_apply_fwd_kernel<false, true>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
-        default: hipLaunchKernelGGL((sa_apply_fwd_kernel<true, true>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); break;
+    {
+        const int cv = Cp / 4;
+        int hb = 0;
+        if (cv > 0 && 256 % cv == 0) hb = ew_blocks(n4);
+        else if (cv % 256 == 0) { const int m = cv / 256; hb = ew_blocks(n4); if (hb > 1) hb = (hb + m - 1) / m * m; }
+#define SAF(XB_, YB_)                                                                                                 \
+        do {                                                                                                          \
+            if (hb) hipLaunchKernelGGL((sa_apply_fwd_kernel<XB_, YB_, true>), dim3(hb), dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); \
+            else hipLaunchKernelGGL((sa_apply_fwd_kernel<XB_, YB_, false>), grid, dim3(256), 0, st, x, a, bn_saved, out, n4, HW, Cp); \
+        } while (0)
+        switch (io & 3) {
+            case 0: SAF(false, false); break;
+            case 1: SAF(true, false); break;
+            case 2: SAF(false, true); break;
+            default: SAF(true, true); break;
+        }
+#undef SAF
     }
     return sc_check_launch("sa_apply_fwd");
 }
