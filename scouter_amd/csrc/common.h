@@ -156,6 +156,26 @@ __device__ __forceinline__ unsigned long long sc_interleave32(unsigned long long
     return sc_spread32(a) | (sc_spread32(b) << 1);
 }
 
+// eight consecutive elements, storage type as a wave-uniform run-time flag (typed convolution epilogue)
+__device__ __forceinline__ void sc_load8_rt(const void* __restrict__ p, long elem, bool bf, f32x4& lo, f32x4& hi) {
+    if (bf) {
+        const sc_bf16x8 h = *(const sc_bf16x8*)((const __bf16*)p + elem);
+        lo = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        hi = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+    } else {
+        lo = *(const f32x4*)((const float*)p + elem);
+        hi = *(const f32x4*)((const float*)p + elem + 4);
+    }
+}
+__device__ __forceinline__ void sc_store8_rt(void* __restrict__ p, long elem, f32x4 lo, f32x4 hi, bool bf) {
+    if (bf) {
+        sc_store8_bf16(p, elem, lo, hi);
+    } else {
+        *(f32x4*)((float*)p + elem) = lo;
+        *(f32x4*)((float*)p + elem + 4) = hi;
+    }
+}
+
 // run-time flag variants for epilogues (a wave-uniform branch per access)
 __device__ __forceinline__ f32x4 sc_load4_rt(const void* __restrict__ p, long elem, bool bf) {
     return bf ? sc_load4<true>(p, elem) : sc_load4<false>(p, elem);

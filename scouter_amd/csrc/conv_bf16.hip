@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const void* __restri
     // (the fp32 kernels request the fused epilogue's operands at workgroup start; here both that -- 140 instead of 82
     //  registers, fewer resident workgroups: 6.3 -> 7.0 ms per step on BASELINE configs[4] -- and issuing them together
     //  right here in front of the staging -- 4.85 -> 5.03 ms -- were measured to LOSE)
-    igemm_epilogue<BM, BN, WM, WN, DGRAD, false, true>(acc, (float*)ldsh, g, bias, addend, dst, bn_part, relu, m0, n0, grp,
-                                                       mt_id, &fz, nullptr, dst_bf16 != 0);
+    igemm_epilogue_typed<BM, BN, WM, WN, DGRAD>(acc, (float*)ldsh, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz,
+                                                dst_bf16 != 0);
 }
 
 // W (HWIO fp32 [taps][Cin/groups][Cout]) -> bf16 W^T [taps][Cout][Cin/groups]

@@ -170,16 +170,14 @@ __device__ __forceinline__ void igemm_epilogue_prefetch(EpiPre<(WM / (64 / (WN /
 
 // Block epilogue.  acc: this wave's (WM x WN) accumulator tiles in MFMA layout; lds: the block's K-loop LDS (free now,
 // at least 4*WM*(WN+4) floats); rows m0.., columns grp*Ng + n0.. of the [M][N] output.
-// TYPED: the instantiation of the bf16-mode kernels (bf16-input igemm, one-plane plane kernels) -- the storage types of the
-// output / addend / BatchNorm inputs are run-time flags (dst_bf16, fz->io).  The fp32-mode kernels keep TYPED = false: plain
-// fp32 accesses, no flag tests (they cost the parity path 0.5 % of the step when they were unconditional).
-template <int BM, int BN, int WM, int WN, bool BWD = false, bool BWD_PREFETCH = false, bool TYPED = false>
+// (fp32 storage only: the bf16-mode kernels -- bf16-input igemm, one-plane plane kernels -- use igemm_epilogue_typed below;
+// run-time storage flags in THIS function cost the parity path 0.5 % of the step when they were tried)
+template <int BM, int BN, int WM, int WN, bool BWD = false, bool BWD_PREFETCH = false>
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], float* lds, const ConvGeom& g,
                                                const float* __restrict__ bias, const float* __restrict__ addend,
                                                float* __restrict__ dst, double* __restrict__ bn_part, int relu,
                                                long m0, int n0, int grp, int mt_id, const BnBwdFuse* fz = nullptr,
-                                               const EpiPre<(WM / (64 / (WN / 4)) <= 8 ? WM / (64 / (WN / 4)) : 1)>* pre = nullptr,
-                                               bool dst_bf16 = false) {
+                                               const EpiPre<(WM / (64 / (WN / 4)) <= 8 ? WM / (64 / (WN / 4)) : 1)>* pre = nullptr) {
     constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -252,12 +250,9 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
         const long m = m0 + wm * WM + row;
         if (m >= g.M) continue;
         f32x4 v = *(const f32x4*)(Es + row * LDE + qcol) + bv4;
-        const bool add_bf16 = TYPED && BWD && fz != nullptr && (fz->io & 4) != 0;
         if constexpr (PREF) {
             if (pref) v += pre->add[rr];
             else if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
-        } else if constexpr (TYPED) {
-            if (addend) v += sc_load4_rt(addend, m * g.N + ncol, add_bf16);
         } else {
             if (addend) v += *(const f32x4*)(addend + m * g.N + ncol);
         }
@@ -266,16 +261,12 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
                 const long off = m * g.N + ncol;
                 if (fz->mask) relu_mask_apply(v, fz->mask, off >> 2);
                 f32x4 xa;
-                if constexpr (PREF) xa = pre->x1[rr];
-                else if constexpr (TYPED) xa = sc_load4_rt(fz->x1, off, (fz->io & 1) != 0);
-                else xa = *(const f32x4*)(fz->x1 + off);
+                if constexpr (PREF) xa = pre->x1[rr]; else xa = *(const f32x4*)(fz->x1 + off);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { cs[e] += v[e]; cq[e] += (double)v[e] * ((xa[e] - mu1[e]) * rs1[e]); }
                 if (bwd2) {
                     f32x4 xb;
-                    if constexpr (PREF) xb = pre->x2[rr];
-                    else if constexpr (TYPED) xb = sc_load4_rt(fz->x2, off, (fz->io & 2) != 0);
-                    else xb = *(const f32x4*)(fz->x2 + off);
+                    if constexpr (PREF) xb = pre->x2[rr]; else xb = *(const f32x4*)(fz->x2 + off);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) cq2[e] += (double)v[e] * ((xb[e] - mu2[e]) * rs2[e]);
                 }
@@ -289,8 +280,7 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if constexpr (TYPED) sc_store4_rt(dst, m * g.N + ncol, v, dst_bf16 || (fz != nullptr && (fz->io & 8) != 0));
-        else *(f32x4*)(dst + m * g.N + ncol) = v;
+        *(f32x4*)(dst + m * g.N + ncol) = v;
     }
     if (bn_part) {
         // Fused batch statistics of the tile just written: lanes sharing a column quad (stride QPR) are combined by
@@ -337,6 +327,186 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[WM / 32][WN / 32], 
                 if (qrow == 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { Ps[(wave * WN + qcol + e) * 2] = cs[e]; Ps[(wave * WN + qcol + e) * 2 + 1] = cq2[e]; }
+                }
+                __syncthreads();
+                if (tid < BN) {
+                    const int wnn = tid / WN, c = tid % WN;
+                    double a0 = 0, a1 = 0;
+#pragma unroll
+                    for (int w = 0; w < BM / WM; ++w) {
+                        const int wv = w * WAVES_N + wnn;
+                        a0 += Ps[(wv * WN + c) * 2];
+                        a1 += Ps[(wv * WN + c) * 2 + 1];
+                    }
+                    double* o = fz->part2 + ((long)mt_id * g.N + grp * g.Ng + n0 + tid) * 2;
+                    o[0] = a0;
+                    o[1] = a1;
+                }
+            }
+        }
+    }
+}
+
+// The block epilogue of the TYPED kernels (bf16-input igemm, one-plane plane kernels: the bf16 mode), EIGHT columns per lane:
+// a bf16-stored output / addend / BatchNorm input is then one 16-byte access per lane and row (the four-column epilogue
+// above moves 8 bytes per access there: the bf16-output forward launches ran at 2.0-2.4 TB/s against 4.5 of the fp32-output
+// ones).  Storage types are wave-uniform run-time flags: dst_bf16 or fz->io bit 3 (output), fz->io bits 0 / 1 / 2 (x1, x2,
+// addend).  Same arithmetic, same statistics layout (bn_part[mtile][channel][2]) as igemm_epilogue.
+template <int BM, int BN, int WM, int WN, bool BWD>
+__device__ __forceinline__ void igemm_epilogue_typed(f32x16 (&acc)[WM / 32][WN / 32], float* lds, const ConvGeom& g,
+                                                     const float* __restrict__ bias, const float* __restrict__ addend,
+                                                     float* __restrict__ dst, double* __restrict__ bn_part, int relu,
+                                                     long m0, int n0, int grp, int mt_id, const BnBwdFuse* fz,
+                                                     bool dst_bf16) {
+    constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    constexpr int QPR = WN / 8;                               // 8-column groups per tile row
+    constexpr int RPP = 64 / QPR;                             // rows covered per pass by the 64 lanes
+    const int qcol = (lane % QPR) * 8, qrow = lane / QPR;
+    const int ncol = grp * g.Ng + n0 + wn * WN + qcol;
+    __syncthreads();
+    constexpr int LDE = WN + 4;
+    float* Es = lds + wave * (WM * LDE);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Es[(i * 32 + mfma32_row(e, lane)) * LDE + j * 32 + l31] = acc[i][j][e];
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): each wave reads back its own tile only
+    f32x4 bv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (bias) { bv[0] = *(const f32x4*)(bias + ncol); bv[1] = *(const f32x4*)(bias + ncol + 4); }
+    const bool acc_stats = bn_part && !bias && !addend && !(BWD && fz && fz->part1);      // (see igemm_epilogue)
+    double as[NT], aq[NT];
+    if (acc_stats) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            as[j] = 0.0; aq[j] = 0.0;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const double v = (double)acc[i][j][e];
+                    as[j] += v;
+                    aq[j] = fma(v, v, aq[j]);
+                }
+            as[j] += __shfl_xor(as[j], 32, 64);
+            aq[j] += __shfl_xor(aq[j], 32, 64);
+        }
+    }
+    double cs[8], cq[8], cq2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cs[e] = 0.0; cq[e] = 0.0; cq2[e] = 0.0; }
+    bool bwd = false, bwd2 = false;
+    f32x4 mu1[2], rs1[2], mu2[2], rs2[2];
+    const int io = fz != nullptr ? fz->io : 0;
+    const bool out_bf16 = dst_bf16 || (io & 8) != 0;
+    if constexpr (BWD) {
+        bwd = fz != nullptr && fz->part1 != nullptr;
+        if (bwd) {
+            bn_part = fz->part1;
+            bwd2 = fz->part2 != nullptr;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                mu1[q] = *(const f32x4*)(fz->sv1 + ncol + 4 * q);
+                rs1[q] = *(const f32x4*)(fz->sv1 + g.N + ncol + 4 * q);
+                if (bwd2) { mu2[q] = *(const f32x4*)(fz->sv2 + ncol + 4 * q); rs2[q] = *(const f32x4*)(fz->sv2 + g.N + ncol + 4 * q); }
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < WM / RPP; ++rr) {
+        const int row = rr * RPP + qrow;
+        const long m = m0 + wm * WM + row;
+        if (m >= g.M) continue;
+        const long off = m * g.N + ncol;
+        f32x4 v[2];
+        v[0] = *(const f32x4*)(Es + row * LDE + qcol) + bv[0];
+        v[1] = *(const f32x4*)(Es + row * LDE + qcol + 4) + bv[1];
+        if (addend) {
+            f32x4 a0, a1;
+            sc_load8_rt(addend, off, (io & 4) != 0, a0, a1);
+            v[0] += a0; v[1] += a1;
+        }
+        if constexpr (BWD) {
+            if (bwd) {
+                if (fz->mask) { relu_mask_apply(v[0], fz->mask, off >> 2); relu_mask_apply(v[1], fz->mask, (off >> 2) + 1); }
+                f32x4 xa[2];
+                sc_load8_rt(fz->x1, off, (io & 1) != 0, xa[0], xa[1]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        cs[4 * q + e] += v[q][e];
+                        cq[4 * q + e] += (double)v[q][e] * ((xa[q][e] - mu1[q][e]) * rs1[q][e]);
+                    }
+                if (bwd2) {
+                    f32x4 xb[2];
+                    sc_load8_rt(fz->x2, off, (io & 2) != 0, xb[0], xb[1]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cq2[4 * q + e] += (double)v[q][e] * ((xb[q][e] - mu2[q][e]) * rs2[q][e]);
+                }
+            }
+        }
+        if (bn_part && !acc_stats && !bwd) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cs[4 * q + e] += v[q][e]; cq[4 * q + e] += (double)v[q][e] * v[q][e]; }
+        }
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[q][e] = fmaxf(v[q][e], 0.f);
+        }
+        sc_store8_rt(dst, off, v[0], v[1], out_bf16);
+    }
+    if (bn_part) {
+        if (!acc_stats) {
+#pragma unroll
+            for (int o = QPR; o < 64; o <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { cs[e] += __shfl_xor(cs[e], o, 64); cq[e] += __shfl_xor(cq[e], o, 64); }
+        }
+        __syncthreads();
+        double* Ps = (double*)lds;                            // [4 waves][WN][2]
+        if (acc_stats) {
+            if (lane < 32) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { Ps[(wave * WN + j * 32 + l31) * 2] = as[j]; Ps[(wave * WN + j * 32 + l31) * 2 + 1] = aq[j]; }
+            }
+        } else if (qrow == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { Ps[(wave * WN + qcol + e) * 2] = cs[e]; Ps[(wave * WN + qcol + e) * 2 + 1] = cq[e]; }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int wnn = tid / WN, c = tid % WN;
+            double a0 = 0, a1 = 0;
+#pragma unroll
+            for (int w = 0; w < BM / WM; ++w) {
+                const int wv = w * WAVES_N + wnn;
+                a0 += Ps[(wv * WN + c) * 2];
+                a1 += Ps[(wv * WN + c) * 2 + 1];
+            }
+            double* o = bn_part + ((long)mt_id * g.N + grp * g.Ng + n0 + tid) * 2;
+            o[0] = a0;
+            o[1] = a1;
+        }
+        if constexpr (BWD) {
+            if (bwd2) {
+#pragma unroll
+                for (int o = QPR; o < 64; o <<= 1)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cq2[e] += __shfl_xor(cq2[e], o, 64);
+                __syncthreads();
+                if (qrow == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { Ps[(wave * WN + qcol + e) * 2] = cs[e]; Ps[(wave * WN + qcol + e) * 2 + 1] = cq2[e]; }
                 }
                 __syncthreads();
                 if (tid < BN) {

@@ -332,8 +332,11 @@ __global__ __launch_bounds__(NWM * 128, 1) void pconv_kernel(const unsigned shor
     }
     // epilogue shared with the fp32 kernels (LDS-staged 16-byte stores, bias / addend / ReLU, BatchNorm statistics); the
     // one-plane instantiations (bf16 mode) are the TYPED ones: their forward may store bf16 (fz.io bit 3)
-    igemm_epilogue<BM, BN, WM, WN, DGRAD, false, NP == 1>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp,
-                                                          mt_id, &fz);
+    if constexpr (NP == 1)
+        igemm_epilogue_typed<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id,
+                                                    &fz, false);
+    else
+        igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
 }
 
 #include "conv_planes_persist.h"
@@ -618,8 +621,7 @@ __global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __r
     (void)KT;
 #if PHALO_ABLATE & 8
     stamp[2] = __builtin_readcyclecounter();
-    igemm_epilogue<BM, BN, WM, WN, DGRAD, false, NP == 1>(acc, (float*)lds_raw, g, bias, addend, dst, nullptr, relu, m0, n0, grp,
-                                                          mt_id, &fz);
+    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, nullptr, relu, m0, n0, grp, mt_id, &fz);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp[3] = __builtin_readcyclecounter();
     if (tid == 0 && bn_part) {           // dev: [block][4] cycle stamps + the CU-local start order
@@ -627,8 +629,11 @@ __global__ __launch_bounds__(512, 1) void phalo_kernel(const unsigned short* __r
         o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3];
     }
 #else
-    igemm_epilogue<BM, BN, WM, WN, DGRAD, false, NP == 1>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp,
-                                                          mt_id, &fz);
+    if constexpr (NP == 1)
+        igemm_epilogue_typed<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id,
+                                                    &fz, false);
+    else
+        igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
 #endif
 }
 
