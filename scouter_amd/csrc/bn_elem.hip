@@ -64,6 +64,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                     }
             }
         }
+        if (MODE == 1) {                       // four rows' loads in flight (one per round trip left this pass latency-bound)
+            for (; r + 3 * rstep < g.M; r += 4 * rstep) {
+                f32x4 av[4], xv[4], yv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long off = (r + u * rstep) * g.C + c;
+                    av[u] = sc_load4<DB>(p0, off);
+                    xv[u] = sc_load4<XB>(p2, off);
+                    if (!mbits && p1) yv[u] = *(const f32x4*)(p1 + off);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long off = (r + u * rstep) * g.C + c;
+                    f32x4 a = av[u];
+                    if (mbits) {
+                        relu_mask_apply(a, mbits, off >> 2);
+                    } else if (p1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[k] = yv[u][k] > 0.f ? a[k] : 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s[k] += a[k]; t[k] += (double)a[k] * ((xv[u][k] - mu[k]) * rs[k]); }
+                }
+            }
+        }
         for (; r < g.M; r += rstep) {
             const long off = r * g.C + c;
             f32x4 a = sc_load4<(MODE == 1 && DB)>(p0, off);            // (DB: dy of MODE 1 is stored as bf16)
