@@ -79,7 +79,13 @@ def _worker(rank, world, port, q):
             import time
             time.sleep(0.2)                                   # (rank 0 late: a blocking collective would show here)
         ddp(float(rank + 1))
+        # (this step's backward has issued the NEXT prefetch: the buffers are in flight until a forward -- or this wait --
+        #  consumes it; reading or writing them before that races with the collective's own thread, which is what made this
+        #  test fail one run in five when it did)
+        if ddp._buf_work is not None:
+            ddp._buf_work.wait()
         buf_ok = buf_ok and prefetched and float(m.bn.running_mean[0]) == 10.0
+        dist.barrier()                                        # rank 0 must not overwrite its buffer before rank 1 has read
         #    ... unless the buffers were written in between: DDP's "rank 0's buffers as of THIS forward" still holds
         m.bn.running_mean.fill_(float(100 * (rank + 1)))
         ddp(float(rank + 1))
