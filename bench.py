@@ -427,8 +427,11 @@ def main():
         dp_info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                    "ms_per_step_by_rank": [round(v, 3) for v in ms], "ms_per_step_spread": round(max(ms) - min(ms), 3),
                    "allreduce_exposed_ms": round(max(ex), 4), "allreduce_exposed_ms_by_rank": [round(v, 4) for v in ex],
-                   "gradient_bytes_per_step": int(model.grad_arena().numel * 4), "buckets": 5,
-                   "buffer_broadcast": "asynchronous, issued at the end of the previous backward"}
+                   "gradient_bytes_per_step": int(model.grad_arena().numel * 4),
+                   "buckets": int(net.buckets_last_step),
+                   "allreduce_exposed_measured": "hipEvents around the compute stream's wait for the gradient collectives on 5 "
+                                                 "extra EAGER steps after the timed region (also under --graph)",
+                   "buffer_broadcast": "asynchronous in every forward, consumed in front of the first BatchNorm"}
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 

@@ -48,10 +48,13 @@ class GraphedTrainStep:
     # the step exactly as engine.calculation runs it, without the autograd engine in between
     def _eager(self, x, y):
         model = self.model
-        if hasattr(self.net, "_broadcast_buffers") and self.net._active and self.net.broadcast_buffers:
-            self.net._broadcast_buffers()
+        ddp = hasattr(self.net, "_issue_buffer_broadcast") and self.net._active and self.net.broadcast_buffers
+        if ddp:
+            self.net._issue_buffer_broadcast()      # consumed by the backbone in front of its first BatchNorm
         model.grad_arena()
         logp, stats, state = model._forward_impl(x, y, save=True)
+        if ddp:
+            self.net._consume_buffer_broadcast()
         model._backward_impl(state, None, self._one, None, None)
         self.optimizer.step()
         return logp, stats

@@ -337,11 +337,14 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
         wt = torch.empty((kh * kw, Cout, cg), dtype=torch.bfloat16, device=x.device)
         _native.check(L.scouter_conv2d_weight_bf16t(_p(w_hwio), _p(wt), kh, kw, Cin, Cout, groups, st), "weight_bf16t")
 
+    plain = bias is None and addend is None and not relu
+    picking = [AUTOTUNE != "1"]       # the table lookup asks whether the SHAPE admits tile 4; this call's epilogue is checked below
+
     def launch(tile, dry=False, part=None):
         if dry:
             if tile == 4:
                 return not bf16 and _pw_persist_legal(B * H * W, Cin, Cout, kh, kw, stride, pad, groups,
-                                                      bias is None and addend is None and not relu)
+                                                      plain or picking[0])
             return _tile_legal(Cout // groups, tile)
         if bf16:
             _native.check(L.scouter_conv2d_fwd_bf16_io(_p(x), _p(wt), _p(bias), _p(addend), _p(y), _p(part), B, H, W, Cin,
@@ -354,7 +357,11 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
         return True
 
     # (typed storage shares the fp32-storage key: the table is tuned on that; half the bytes move no tile boundary far)
+    # (the cached choice is a function of the layer shape alone -- the key has no epilogue in it, and a first call with
+    #  bias / addend / ReLU must not cache "-1" for the plain calls of the same shape, ADVICE r4 -- legality of tile 4 for
+    #  THIS call's epilogue is decided here, per call)
     tile = _pick_tile(("fwd", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, (0, 1, 2, 3, 4))
+    picking[0] = False
     if tile == 4 and not launch(4, dry=True):        # (the table's entry is for the plain epilogue; this call has bias / addend / ReLU)
         tile = -1
     part, rows = None, 0

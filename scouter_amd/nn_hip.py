@@ -172,7 +172,8 @@ class Conv2d(nn.Module):
             # weight / bias gradients: off the critical path
             with K.side_stream(dev, xt, dy, xp, dyp, enabled=self.use_side_stream):
                 # (the plane kernel's branch-free pixel walk needs maps that are not tiny: 32 // W + 1 < H)
-                if self._dw is not None and xp is not None and dyp is not None and 32 // xshape[2] + 1 < xshape[1]:
+                if (self._dw is not None and xp is not None and dyp is not None and self.planes_wgrad() and
+                        32 // xshape[2] + 1 < xshape[1]):
                     K.conv2d_wgrad_planes(xp, dyp, self._dw, self.padding, self.groups)
                 elif self._dw is not None:
                     if xt is None or dy is None:

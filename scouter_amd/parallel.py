@@ -5,7 +5,8 @@ One process per GPU (torch.distributed, backend 'nccl' == RCCL on ROCm).  Becaus
 path lives in ONE flat fp32 arena, the per-step exchange is a single sum-all-reduce of that buffer (43-98 MiB)
 followed by a scale by 1/world -- no bucketing machinery, no graph walk for unused parameters (`to_q` is excluded
 statically).  Like DDP: parameters and buffers are broadcast from rank 0 at construction, and BatchNorm running
-statistics are re-broadcast from rank 0 before each training forward (`broadcast_buffers=True`)."""
+statistics are re-broadcast from rank 0 in front of EVERY forward (`broadcast_buffers=True`; asynchronously, consumed in
+front of the first BatchNorm)."""
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -25,15 +26,20 @@ class DistributedDataParallel(nn.Module):
         if self._active:
             self._sync_module_states()
         self._pending = []
+        self._buckets = 0
+        self.buckets_last_step = 0
         self._buf_flat = None
-        self._buf_version = -1
-        self._buf_work = None            # the asynchronous buffer broadcast issued at the end of the previous backward
+        self._buf_work = None            # this forward's asynchronous buffer broadcast (consumed in front of the first BatchNorm)
         self.measure_exposed = False     # bench.py: hipEvent pairs around the wait for the gradient collectives
         self.exposed_events = []
         if self._active and broadcast_buffers:
             self._flatten_float_buffers()
         module._grad_ready_hooks.append(self._launch_bucket)
         module._post_backward_hooks.append(self._finish_gradients)
+        # the backbone calls these right before its first BatchNorm touches the running statistics
+        bone = getattr(module, "backbone", None)
+        if bone is not None and hasattr(bone, "_pre_bn_hooks"):
+            bone._pre_bn_hooks.append(self._consume_buffer_broadcast)
 
     def _float_buffers(self):
         return [b for b in self.module.buffers() if b.dtype.is_floating_point]
@@ -84,24 +90,25 @@ class DistributedDataParallel(nn.Module):
     def _buffers_are_flat(self):
         return self._buf_flat is not None and self._buf_first.data_ptr() == self._buf_flat.data_ptr()
 
-    def _broadcast_buffers(self):
-        """DDP's per-forward buffer broadcast from rank 0 (BatchNorm running statistics).  The running statistics only
-        change inside a training forward, so the broadcast for step n + 1 is issued ASYNCHRONOUSLY at the end of step n's
-        backward (`_finish_gradients`: on RCCL's stream, ordered after the forward's finalize kernels, overlapping the
-        optimizer step) and the next forward merely waits for it -- no blocking collective in front of every forward.
-        The first forward, and any forward whose buffers were re-allocated in between, broadcast synchronously."""
+    def _issue_buffer_broadcast(self):
+        """DDP's per-forward buffer broadcast from rank 0 (BatchNorm running statistics; torch DDP does it in front of
+        EVERY forward, training or not).  The same ONE collective on every rank in every forward -- no rank-local decision
+        (round 4 skipped it when the tensor version counter said nothing had written the buffers: a rank-0-only
+        load_state_dict then left rank 0 issuing a collective the other ranks did not) -- but issued
+        ASYNCHRONOUSLY on RCCL's stream: the first kernels of the forward (stem im2col + GEMM) do not touch the running
+        statistics, so the compute stream only waits for it in front of the first BatchNorm (`_consume_buffer_broadcast`,
+        called by the backbone through `_pre_bn_hooks`) and the collective's latency runs under the stem convolution.
+        Nothing is in flight between two forwards: state_dict / load_state_dict / eval never race with the collective."""
+        self._consume_buffer_broadcast()
+        if self._buffers_are_flat():
+            self._buf_work = dist.broadcast(self._buf_flat, src=0, group=self.process_group, async_op=True)
+        else:                                   # buffers were re-allocated (e.g. module.to(...)): gather / scatter
+            self._coalesced_broadcast(self._float_buffers())
+
+    def _consume_buffer_broadcast(self):
         work, self._buf_work = self._buf_work, None
         if work is not None:
             work.wait()                         # compute stream waits for the collective (no host sync on NCCL)
-            # DDP's contract is "rank 0's buffers as they are AT this forward": if anything wrote the buffers through
-            # torch since the prefetch was issued (load_state_dict, a manual edit -- the tensor version counter tells;
-            # the HIP kernels only write them inside a training forward), broadcast again now
-            if self._buffers_are_flat() and self._buf_flat._version == self._buf_version:
-                return
-        if self._buffers_are_flat():
-            dist.broadcast(self._buf_flat, src=0, group=self.process_group)
-        else:                                   # buffers were re-allocated (e.g. module.to(...)): gather / scatter
-            self._coalesced_broadcast(self._float_buffers())
 
     def _launch_bucket(self, arena, lo, hi):
         """arena.flat[lo:hi] is final: start its sum-all-reduce now (asynchronously on RCCL's stream, ordered after
@@ -110,6 +117,7 @@ class DistributedDataParallel(nn.Module):
             return
         self._pending.append(dist.all_reduce(arena.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.process_group,
                                              async_op=True))
+        self._buckets += 1
 
     def _finish_gradients(self, arena):
         if not self._active:
@@ -123,12 +131,10 @@ class DistributedDataParallel(nn.Module):
         for work in self._pending:
             work.wait()                  # makes the compute stream wait for the collective (no host sync on NCCL)
         self._pending = []
+        self.buckets_last_step, self._buckets = self._buckets, 0     # (gradient collectives this backward issued: bench.py)
         if ev is not None:
             ev[1].record()
             self.exposed_events.append(ev)
-        if self.broadcast_buffers and self.module.training and self._buffers_are_flat():
-            self._buf_work = dist.broadcast(self._buf_flat, src=0, group=self.process_group, async_op=True)
-            self._buf_version = self._buf_flat._version
         if arena.flat.is_cuda:
             K.axpby(arena.flat, None, 1.0 / self.world_size, 0.0, out=arena.flat)
         else:                                                 # gloo/CPU plumbing tests only
@@ -141,6 +147,9 @@ class DistributedDataParallel(nn.Module):
         return sum(a.elapsed_time(b) for a, b in evs) / len(evs) if evs else None
 
     def forward(self, *args, **kwargs):
-        if self._active and self.broadcast_buffers and self.module.training and torch.is_grad_enabled():
-            self._broadcast_buffers()
-        return self.module(*args, **kwargs)
+        if self._active and self.broadcast_buffers:
+            self._issue_buffer_broadcast()
+        try:
+            return self.module(*args, **kwargs)
+        finally:
+            self._consume_buffer_broadcast()   # (no-op when the backbone's first BatchNorm already waited for it)

@@ -120,10 +120,12 @@ class SlotModel(nn.Module):
             raise ValueError("activation storage must be fp32 or bf16, got %r" % storage)
         if storage == "bf16" and self.precision != "bf16":
             raise ValueError("bf16 activation storage is an option of precision 'bf16'")
-        from ..timm.models.resnest import ResNestBottleneck
+        from ..timm.models.resnest import ResNestBottleneck, GRAD_STREAM_BF16_DEFAULT
         blocks = [m for m in self.backbone.modules() if isinstance(m, ResNestBottleneck)]
         for i, blk in enumerate(blocks):
             blk.store_bf16 = storage == "bf16" and i + 1 < len(blocks)
+            # the residual-stream gradient follows the activation storage (SCOUTER_BF16_GRAD_STREAM=0: fp32 under bf16 storage)
+            blk.grad_stream_bf16 = storage == "bf16" and GRAD_STREAM_BF16_DEFAULT
         self.activation_storage = storage if blocks else "fp32"
 
     def set_planes(self, nplanes):

@@ -14,7 +14,7 @@ from .resnet import AvgPool2dSpec, ResNet, BRANCH_FWD, BRANCH_BWD
 # bf16 storage of the masked block-output gradients (the residual-stream gradient) next to the bf16-stored activations;
 # SCOUTER_BF16_GRAD_STREAM=0: fp32.  Unlike Conv2d.grad_storage this one rounds values that fp32 arithmetic reads (the
 # BatchNorm backward, the shortcut addend): the oracle emulates it (oracle.torch_oracle.ACTIVATION_STORAGE).
-GRAD_STREAM_BF16 = os.environ.get("SCOUTER_BF16_GRAD_STREAM", "1") != "0"
+GRAD_STREAM_BF16_DEFAULT = os.environ.get("SCOUTER_BF16_GRAD_STREAM", "1") != "0"
 
 
 class ResNestBottleneck(nn.Module):
@@ -38,6 +38,9 @@ class ResNestBottleneck(nn.Module):
         # bf16 activation storage (SlotModel.set_precision("bf16"); never the network's last block, whose output feeds the
         # fp32 head): conv3 / downsample outputs and the block output -- the 4x-wide tensors -- are stored as bf16
         self.store_bf16 = False
+        # ... and the masked block-INPUT gradient this block's conv1 produces (the previous block's output gradient): a
+        # per-block attribute set together with store_bf16 by SlotModel.set_activation_storage (no module global)
+        self.grad_stream_bf16 = False
 
     def _storage(self, x):
         """Storage type of this block's wide tensors for an input batch x: bf16 where the bf16-input kernels run
@@ -105,7 +108,7 @@ class ResNestBottleneck(nn.Module):
             dxres = self.downsample.bwd_join(dxres, dres.device, hnd)
         # the block-INPUT gradient this produces is the previous block's masked output gradient (post): stored as bf16 where
         # that block stores its activations as bf16 (same rule: ResNestBottleneck._storage of the previous block)
-        gdt = K.BF16 if (post is not None and need_dx and GRAD_STREAM_BF16 and isinstance(k1, torch.Tensor) and
+        gdt = K.BF16 if (post is not None and need_dx and self.grad_stream_bf16 and isinstance(k1, torch.Tensor) and
                          k1.dtype == K.BF16) else None
         return self.conv1.bwd(dc1, k1, need_dx, addend=dxres, post=post if need_dx else None, dx_dtype=gdt)
 

@@ -171,6 +171,9 @@ class ResNet(nn.Module):
         self.act1 = Act()
         self.maxpool = Identity()      # MaxPool2d(3, 2, 1) runs in scouter_maxpool_*_f32
         self._capture = None           # test instrumentation: (dict, key) -> the max-pool window indices go there
+        # called after the first convolution has been queued, right before the first BatchNorm reads / updates its running
+        # statistics (scouter_amd.parallel: the compute stream waits for the asynchronous DDP buffer broadcast HERE)
+        self._pre_bn_hooks = []
         self.fuse_stem_pool = os.environ.get("SCOUTER_FUSE_STEM_POOL", "1") == "1"   # bn1 + act1 + maxpool in one pass
         chans, strides = [64, 128, 256, 512], [1, 2, 2, 2]
         for i in range(4):
@@ -205,6 +208,8 @@ class ResNet(nn.Module):
             s = self.conv1
             # (bf16 mode: the two stem activations are read by bf16-input kernels only -- stored as bf16, same results)
             c, k0 = s[0].fwd(x_nchw, save, bn_stats=s[1].training)
+            for hook in self._pre_bn_hooks:
+                hook()
             h, b0 = s[1].fwd(c, save, relu=True, tracked=tracked, out_dtype=s[3].act_storage(*_map_of(c)))
             c, k1 = s[3].fwd(h, save, bn_stats=s[4].training)
             h, b1 = s[4].fwd(c, save, relu=True, tracked=tracked, out_dtype=s[6].act_storage(*_map_of(c)))
@@ -212,6 +217,8 @@ class ResNet(nn.Module):
             ctx.append((k0, b0, k1, b1, k2))
         else:
             c, k0 = self.conv1.fwd(x_nchw, save, bn_stats=self.bn1.training)
+            for hook in self._pre_bn_hooks:
+                hook()
             ctx.append((k0,))
         # bn1 + act1 + maxpool in one pass: only bn1's statistics are finalised, relu(bn1(c)) is evaluated inside the
         # pooling windows (and again, with the same fma, in the backward) -- the 112x112 activation is never stored

@@ -72,24 +72,28 @@ def _worker(rank, world, port, q):
             m.conv.weight.grad.stride() == m.conv.weight.stride()
         # 3. buffers were re-broadcast from rank 0 before the training forward
         buf_ok = float(m.bn.running_mean[0]) == 10.0
-        # 4. the NEXT step's buffer broadcast was issued asynchronously at the end of this backward and
-        #    the next forward consumes it without another collective ...
-        prefetched = ddp._buf_work is not None
+        # 4. nothing is in flight between two forwards (round 4 prefetched the broadcast at the end of the backward
+        #    and an eval forward / state_dict right after it raced with the collective): the forward consumed its own
+        #    asynchronous broadcast -- the Stub has no backbone hook, so the wrapper's `finally` did
+        buf_ok = buf_ok and ddp._buf_work is None
+        # 5. train -> eval: the eval forward broadcasts too (like torch DDP), so every rank evaluates with rank 0's statistics
+        m.bn.running_mean.fill_(float(7 * (rank + 1)))
+        m.eval()
+        with torch.no_grad():
+            ddp(float(rank + 1))
+        buf_ok = buf_ok and ddp._buf_work is None and float(m.bn.running_mean[0]) == 7.0
+        m.train()
+        dist.barrier()
+        # 6. a buffer write on rank 0 ONLY (a rank-0-only load_state_dict): every rank issues the same collectives, nothing
+        #    hangs, and DDP's "rank 0's buffers as of THIS forward" holds
         if rank == 0:
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            sd["bn.running_mean"].fill_(100.0)
+            m.load_state_dict(sd)
             import time
-            time.sleep(0.2)                                   # (rank 0 late: a blocking collective would show here)
+            time.sleep(0.2)                                   # (rank 0 late)
         ddp(float(rank + 1))
-        # (this step's backward has issued the NEXT prefetch: the buffers are in flight until a forward -- or this wait --
-        #  consumes it; reading or writing them before that races with the collective's own thread, which is what made this
-        #  test fail one run in five when it did)
-        if ddp._buf_work is not None:
-            ddp._buf_work.wait()
-        buf_ok = buf_ok and prefetched and float(m.bn.running_mean[0]) == 10.0
-        dist.barrier()                                        # rank 0 must not overwrite its buffer before rank 1 has read
-        #    ... unless the buffers were written in between: DDP's "rank 0's buffers as of THIS forward" still holds
-        m.bn.running_mean.fill_(float(100 * (rank + 1)))
-        ddp(float(rank + 1))
-        buf_ok = buf_ok and float(m.bn.running_mean[0]) == 100.0
+        buf_ok = buf_ok and float(m.bn.running_mean[0]) == 100.0 and float(m.bn.running_mean[-1]) == 100.0
         q.put((rank, same_params, mean_ok, grad_view_ok, buf_ok, bool(torch.equal(w_before, m.conv.weight)) == (rank == 0)))
     finally:
         dist.destroy_process_group()

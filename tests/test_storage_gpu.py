@@ -400,7 +400,8 @@ def test_stem_pool_backward_stores_bf16():
 
 
 def test_residual_stream_gradient_switch(monkeypatch):
-    """SCOUTER_BF16_GRAD_STREAM (resnest.GRAD_STREAM_BF16): with the masked block-output gradient kept in fp32 the step still
+    """SCOUTER_BF16_GRAD_STREAM (resnest.GRAD_STREAM_BF16_DEFAULT -> ResNestBottleneck.grad_stream_bf16, set with the
+    activation storage by SlotModel.set_activation_storage): with the masked block-output gradient kept in fp32 the step still
     runs on the typed kernels, the forward is the same bits, and the parameter gradients differ from the default by a
     bf16-rounding-sized amount only (one rounding per block of a tensor that fp32 arithmetic reads)."""
     import test_model_gpu as T
@@ -408,7 +409,7 @@ def test_residual_stream_gradient_switch(monkeypatch):
     monkeypatch.undo()
     res = []
     for flag in (True, False):
-        monkeypatch.setattr(R, "GRAD_STREAM_BF16", flag)
+        monkeypatch.setattr(R, "GRAD_STREAM_BF16_DEFAULT", flag)
         m, P, images, labels, cfg = T._synthetic_model("resnest26d", 10, 1, 3, 8, 224, 2300)
         m.set_precision("bf16")
         out, (loss, nll, area) = m(images.cuda(), labels.cuda())

@@ -13,7 +13,7 @@ g = np.load(os.path.join(T.GOLD, "model_%s.npz" % case))
 truth = g["f64_log_probs"]
 _, tru_losses, _, _, _ = T.oracle_run(case, torch.float64)
 def hip(storage, grads, stream):
-    nn_hip.GRAD_STORAGE_BF16 = grads; R.GRAD_STREAM_BF16 = stream
+    nn_hip.GRAD_STORAGE_BF16 = grads; R.GRAD_STREAM_BF16_DEFAULT = stream
     mb, _, images, labels = T.build(case)
     mb.set_precision("bf16"); mb.set_activation_storage(storage)
     mb.train()
