@@ -213,10 +213,12 @@ CLASSES = {
         "peak": 157.3, "sustained": 154.0, "what": "fp32 implicit-GEMM convolutions (forward, input gradient incl. the fused BatchNorm-backward "
                                "epilogue, weight gradient), v_mfma_f32_32x32x2_f32"},
     "bf16x3_plane_conv": {
-        "labels": ("pconv_fwd<bf16x3>", "pconv_dgrad<bf16x3>", "pwgrad<bf16x3>"),
+        "labels": ("pconv_fwd<bf16x3>", "pconv_dgrad<bf16x3>", "pwgrad<bf16x3>", "xconv_fwd<bf16x3>", "xconv_dgrad<bf16x3>",
+                   "xconv_dgrad+bn_bwd<bf16x3>"),
         "rocprof": ("void pconv_kernel<", "void phalo_kernel<", "void pwgrad_kernel<", "void ppersist_kernel<",
-                    "void pwgrad_taps_kernel<"),
-        "peak": 2500.0 / 6.0, "sustained": 1886.0 / 6.0, "what": "grouped 3x3 convolutions on exact three-way bf16 operand splits: 6 x "
+                    "void pwgrad_taps_kernel<", "void xgemm_kernel<"),
+        "peak": 2500.0 / 6.0, "sustained": 1886.0 / 6.0, "what": "grouped 3x3 convolutions (pre-split operand planes) and, round 5, the deep 1x1 "
+                                      "convolutions (activation split in registers) on exact three-way bf16 operand splits: 6 x "
                                       "v_mfma_f32_32x32x16_bf16 per fp32-grade product, fp32 accumulate; peak = 2500 / 6 "
                                       "TFLOP/s of algorithmic work"},
     "bf16_mfma_conv": {

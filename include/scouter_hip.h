@@ -355,6 +355,39 @@ int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_planes, flo
                                 int Cout, int kh, int kw, int pad, int groups, int nplanes, int plan_hint,
                                 void* ws, size_t ws_bytes, void* arrival, int arrival_slots, void* stream);
 
+/* ---- POINTWISE convolutions (1x1, stride 1, groups 1) at fp32 accuracy on the bf16 matrix cores with the three-way
+ * operand split done in registers (csrc/conv_x3.hip, round 5): the deep 1x1 layers of the bottlenecks -- conv1 / conv3
+ * (timm/models/resnest.py:111-143) and the downsample convolution (resnet.py:292-306).  The ACTIVATION / GRADIENT is a
+ * plain fp32 NHWC tensor (no producer writes planes); only the WEIGHT arrives as three bf16 planes
+ * (scouter_planes_split_weight_f32 / _weights_multi: forward layout [3][1][Cout][Cin], input-gradient layout
+ * [3][1][Cin][Cout]).  Results are bit-identical to scouter_conv2d_fwd_planes / _dgrad_planes (nplanes = 3) on the split
+ * activation.  Needs 32-multiples (>= 64) of GEMM-K channels and 64-multiples of output columns.
+ * tile_hint: 0 = 256x128 (eight waves), 1 = 128x128, 2 = 128x64, 3 = 64x64, else the library's choice
+ * (scouter_conv2d_x3_tile tells which; every tile gives the same bits).  bn_partial: as scouter_conv2d_fwd_f32, one row
+ * per M tile = scouter_conv2d_x3_partial_rows(M, N, tile_hint).  The input gradient takes the optional fused
+ * BatchNorm-backward epilogue of scouter_conv2d_dgrad_bnbwd_f32 (relu_mask .. part2; part rows as above). */
+int scouter_conv2d_x3_tile(long M, int N, int tile_hint);
+int scouter_conv2d_x3_partial_rows(long M, int N, int tile_hint);
+int scouter_conv2d_fwd_x3(const float* x, const void* w_planes_fwd, const float* bias, const float* addend, float* y,
+                          double* bn_partial, int B, int H, int W, int Cin, int Cout, int relu, int tile_hint,
+                          void* stream);
+int scouter_conv2d_dgrad_x3_bnbwd(const float* dy, const void* w_planes_dgrad, const float* addend, float* dx, int B,
+                                  int H, int W, int Cin, int Cout, int tile_hint, const void* relu_mask,
+                                  const float* x1, const float* saved1, double* part1, const float* x2,
+                                  const float* saved2, double* part2, void* stream);
+
+/* Weight gradient of the same layers, dw[Cin][Cout] = x^T dy over the B*H*W pixels (the HWIO gradient of a 1x1 layer), both
+ * fp32 operands transposed (4x4 register patches) and split three-way on their way into LDS; 128-multiples of Cin and Cout.
+ * Split-K over the pixels into `ws` slabs summed in slab order (deterministic).  plan_hint: -1 / bits 0-1 = workgroup budget
+ * 256 << hint (callers take it from the static table; different plans sum the pixels in another order). */
+size_t scouter_conv2d_wgrad_x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int plan_hint);
+int scouter_conv2d_wgrad_x3(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                            int plan_hint, void* ws, size_t ws_bytes, void* stream);
+
+/* p[i] += v for n 64-bit counters (the num_batches_tracked buffers of a model as views of one flat buffer: one launch per
+ * training forward instead of one ATen launch; torch.nn.BatchNorm2d increments them one by one) */
+int scouter_iadd_i64(long* p, long n, long v, void* stream);
+
 /* ---- optimizer: torch.optim.AdamW defaults (train.py:146).  chunk table = array of {float* param; long offset
  * into the flat grad/moment arenas; int n; int pad} built by the host (scouter_adamw_chunk_bytes() each). */
 int scouter_adamw_chunk_bytes(void);

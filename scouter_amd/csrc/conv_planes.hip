@@ -92,25 +92,49 @@ struct SplitWeightRow {
     int taps, Cg, Cout, groups;
     long first;
 };
+// Round 5: TILED.  The first version ran one thread per element: the input-gradient layout was written coalesced, the
+// forward layout -- its transpose -- as 2-byte stores a whole row apart (22 M scattered stores once the deep 1x1 layers of
+// conv_x3.hip joined the table).  Now a workgroup takes [32 ci][32 co] tiles of one filter tap (every tensor's Cg and
+// Cout are 32-multiples, so `first` / 1024 is the tensor's first tile): coalesced 128-byte reads, the input-gradient planes
+// written straight away (co contiguous), the forward planes through an LDS transpose (ci contiguous, 64-byte segments).
 template <int NP>
 __global__ __launch_bounds__(256) void split_weight_multi_kernel(const SplitWeightRow* __restrict__ rows, int nrows, long total) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    __shared__ unsigned short tile[3][32][34];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 8 rows of 32 lanes
+    const long ntiles = total >> 10;
+    for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         int t = 0;
-        while (t + 1 < nrows && rows[t + 1].first <= i) ++t;
+        while (t + 1 < nrows && (rows[t + 1].first >> 10) <= tl) ++t;
         const SplitWeightRow R = rows[t];
-        const long j = i - R.first, n = (long)R.taps * R.Cg * R.Cout;
+        const long n = (long)R.taps * R.Cg * R.Cout;
         const int Ng = R.Cout / R.groups;
-        const int co = (int)(j % R.Cout);
-        const int ci = (int)((j / R.Cout) % R.Cg);
-        const int tap = (int)(j / ((long)R.Cout * R.Cg));
-        unsigned short s[3];
-        split3(R.w[j], s[0], s[1], s[2]);
-        const int grp = co / Ng;
+        const int cot = R.Cout >> 5, cit = R.Cg >> 5;
+        long j = tl - (R.first >> 10);
+        const int co0 = (int)(j % cot) << 5;
+        j /= cot;
+        const int ci0 = (int)(j % cit) << 5;
+        const int tap = (int)(j / cit);
+        const int co = co0 + tx, grp = co / Ng;
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-            if (R.wf) R.wf[(long)pl * n + ((long)tap * R.Cout + co) * R.Cg + ci] = s[pl];
-            if (R.wd) R.wd[(long)pl * n + ((long)tap * (R.Cg * R.groups) + grp * R.Cg + ci) * Ng + (co - grp * Ng)] = s[pl];
+        for (int r = ty; r < 32; r += 8) {
+            const int ci = ci0 + r;
+            unsigned short s[3];
+            split3(R.w[((long)tap * R.Cg + ci) * R.Cout + co], s[0], s[1], s[2]);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                if (R.wd) R.wd[(long)pl * n + ((long)tap * (R.Cg * R.groups) + grp * R.Cg + ci) * Ng + (co - grp * Ng)] = s[pl];
+                tile[pl][r][tx] = s[pl];
+            }
         }
+        __syncthreads();
+        if (R.wf) {
+#pragma unroll
+            for (int r = ty; r < 32; r += 8)          // row r of the transposed tile: output channel co0 + r, 32 ci contiguous
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    R.wf[(long)pl * n + ((long)tap * R.Cout + co0 + r) * R.Cg + ci0 + tx] = tile[pl][tx][r];
+        }
+        __syncthreads();
     }
 }
 
@@ -677,8 +701,12 @@ extern "C" size_t scouter_planes_split_weights_row_bytes(void) { return sizeof(S
 // (layout of SplitWeightRow: three pointers, four ints, one long = 48 bytes); total = sum of taps * Cin/groups * Cout
 extern "C" int scouter_planes_split_weights_multi(const void* table, int nrows, long total, int nplanes, void* stream) {
     SC_REQUIRE(table && nrows > 0 && total > 0 && (nplanes == 1 || nplanes == 3), "planes_split_weights_multi: bad arguments");
-    long nb = (total + 255) / 256;
+    SC_UNSUPPORTED((total & 1023) == 0, "planes_split_weights_multi: every tensor needs 32-multiples of channels per group "
+                   "and of output channels (total %ld)", total);
+    long nb = total >> 10;                     // one [32 ci][32 co] tile per workgroup and round
     if (nb > 4096) nb = 4096;
+    ScProfScope prof(nplanes == 3 ? "split_weights<bf16x3>" : "split_weights<bf16>", (hipStream_t)stream, 0.0,
+                     (4.0 + 4.0 * nplanes) * (double)total);
     if (nplanes == 3)
         hipLaunchKernelGGL(split_weight_multi_kernel<3>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
                            (const SplitWeightRow*)table, nrows, total);

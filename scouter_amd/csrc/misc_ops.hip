@@ -538,6 +538,8 @@ __global__ __launch_bounds__(256) void slot_loss_fwd_kernel(const float* __restr
         stats[3] = labels ? red[1][0] / B : 0.f;
         stats[4] = area;
         stats[5] = red[2][0];
+        stats[6] = 0.f;                          // (all eight words written: the caller hands over an uninitialised buffer)
+        stats[7] = 0.f;
     }
 }
 // upstream grads (device scalars, NULL = 0): g_loss, g_nll, g_term ; g_logp [B][C] or NULL
@@ -721,4 +723,17 @@ extern "C" int scouter_linear_small_bwd_f32(const float* dy, const float* x, con
     if (dx) hipLaunchKernelGGL(linear_small_dgrad_kernel, dim3(sc_cdiv((long)B * K, 256)), dim3(256), 0, st, dy, w, dx, B, K, C);
     if (dw) hipLaunchKernelGGL(linear_small_wgrad_kernel, dim3(sc_cdiv((long)C * K, 256)), dim3(256), 0, st, dy, x, dw, db, B, K, C);
     return sc_check_launch("linear_small_bwd");
+}
+
+
+// num_batches_tracked += 1 of EVERY train-mode BatchNorm of a forward in one launch (the counters are views of one flat
+// int64 buffer, SlotModel._bump_tracked; reference: torch.nn.BatchNorm2d.forward, nn/modules/batchnorm.py `self.num_batches_tracked.add_(1)`)
+__global__ __launch_bounds__(256) void iadd_i64_kernel(long* __restrict__ p, long n, long v) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] += v;
+}
+extern "C" int scouter_iadd_i64(long* p, long n, long v, void* stream) {
+    SC_REQUIRE(p && n > 0, "iadd_i64: bad arguments");
+    hipLaunchKernelGGL(iadd_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, n, v);
+    return sc_check_launch("iadd_i64");
 }

@@ -134,7 +134,7 @@ def _batch_pos(key):
     """Index of the batch entry in a tuning key: ("fwd", bf16, B, ...), ("dgrad+bn", n, addend, bf16, B, ...),
     ("pdgrad+bn", n, addend, nplanes, B, ...), ("pfwd" | "pdgrad" | "pwgrad", nplanes, B, ...),
     ("wgrad" | "dgrad", bf16, B, ...)."""
-    return 4 if key[0] in ("dgrad+bn", "pdgrad+bn") else 2
+    return 4 if key[0] in ("dgrad+bn", "pdgrad+bn", "xdgrad+bn") else 2
 
 
 def _load_tune_table():
@@ -650,6 +650,127 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
     return dx
 
 
+# ---- pointwise convolutions on the bf16 matrix cores, operand split in registers (csrc/conv_x3.hip)
+# Which 1x1 layers take it is a STATIC function of the layer's channels (never of timing or of the batch): the forward
+# stays a function of the layer shapes, whatever the batch size / process / data-parallel rank.  Measured per layer
+# (tools_dev/x3_bench.py): the layers with Cin * Cout >= 2^16 -- every 1x1 of layer2-4 -- gain, the short-K 56 x 56
+# layers are HBM-co-bound and stay on the persistent fp32 kernel.  SCOUTER_X3=0: every 1x1 on the fp32 MFMA kernels.
+X3_DEFAULT = int(os.environ.get("SCOUTER_X3", "3"))       # bit 0: forward, bit 1: input gradient, bit 2: fused input gradient, bit 3: weight gradient
+X3_MIN_CHANNEL_PRODUCT = 1 << 16
+_X3_TILES = (0, 1, 2, 3)
+
+
+def x3_eligible(cin, cout, kh, kw, stride, pad, groups, has_bias):
+    """Layer shapes the register-split bf16x3 GEMM serves, forward AND input gradient (both GEMM widths 64-multiples)."""
+    return bool(kh == 1 and kw == 1 and stride == 1 and pad == 0 and groups == 1 and not has_bias and
+                cin % 64 == 0 and cout % 64 == 0 and cin * cout >= X3_MIN_CHANNEL_PRODUCT)
+
+
+def _x3_tile_ok(t, n):
+    return n % 128 == 0 if t in (0, 1) else n % 64 == 0
+
+
+def conv2d_fwd_x3(x, wf, addend=None, relu=False, bn_stats=False, tile=None):
+    """x: fp32 NHWC [B, H, W, Cin]; wf: forward weight planes [3, 1, Cout, Cin] (planes_split_weight).  Returns y or
+    (y, (partial, rows)) like conv2d_fwd.  Every tile gives the same bits; the choice comes from the static table."""
+    _chk(x, "x"); _chk(addend, "addend")
+    B, H, W, Cin = x.shape
+    Cout = wf.shape[2]
+    assert wf.dtype == BF16 and wf.shape[0] == 3 and wf.shape[3] == Cin, (tuple(wf.shape), tuple(x.shape))
+    L = _native.lib()
+    y = torch.empty((B, H, W, Cout), dtype=F32, device=x.device)
+    M = B * H * W
+    scratch = [None]
+
+    def launch(t, dry=False, part=None):
+        if dry:
+            return _x3_tile_ok(t, Cout)
+        if bn_stats and part is None:
+            if scratch[0] is None:
+                scratch[0] = torch.empty(((M + 63) // 64, Cout, 2), dtype=torch.float64, device=x.device)
+            part = scratch[0]
+        _native.check(L.scouter_conv2d_fwd_x3(_p(x), _p(wf), None, _p(addend), _p(y), _p(part), B, H, W, Cin, Cout,
+                                              int(relu), t, _stream()), "conv2d_fwd_x3")
+        return True
+    if tile is None:
+        tile = _pick_tile(("xfwd", 3, B, H, W, Cin, Cout), launch, _X3_TILES)
+    tile = L.scouter_conv2d_x3_tile(M, Cout, tile)
+    part, rows = None, 0
+    if bn_stats:
+        rows = L.scouter_conv2d_x3_partial_rows(M, Cout, tile)
+        part = torch.empty((rows, Cout, 2), dtype=torch.float64, device=x.device)
+    launch(tile, part=part)
+    return (y, (part, rows)) if bn_stats else y
+
+
+def conv2d_dgrad_x3(dy, wd, x_shape, addend=None, post=None, tile=None):
+    """dy: fp32 NHWC [B, H, W, Cout]; wd: input-gradient weight planes [3, 1, Cin, Cout].  post (BnBwdFuse): as
+    conv2d_dgrad -- fused when bit 2 of SCOUTER_X3 is set and every BatchNorm input is fp32."""
+    _chk(dy, "dy"); _chk(addend, "addend")
+    B, H, W, Cin = x_shape
+    Cout = dy.shape[-1]
+    assert wd.dtype == BF16 and wd.shape[0] == 3 and wd.shape[2] == Cin and wd.shape[3] == Cout
+    L = _native.lib()
+    dx = torch.empty(x_shape, dtype=F32, device=dy.device)
+    M = B * H * W
+
+    def launch(t, dry=False, fuse=_NO_FUSE):
+        if dry:
+            return _x3_tile_ok(t, Cin)
+        _native.check(L.scouter_conv2d_dgrad_x3_bnbwd(_p(dy), _p(wd), _p(addend), _p(dx), B, H, W, Cin, Cout, t, *fuse,
+                                                      _stream()), "conv2d_dgrad_x3")
+        return True
+    fused = _fuse_wanted(post, 1) and post.x_io() == 0
+    if fused:
+        def launch_fused(t, dry=False):
+            if dry:
+                return launch(t, dry=True)
+            if not post.applied:
+                post.alloc((M + 63) // 64, x_shape)
+            return launch(t, fuse=post.args())
+        if tile is None:
+            tile = _pick_tile(("xdgrad+bn", len(post.entries), addend is not None, 3, B, H, W, Cin, Cout), launch_fused,
+                              _X3_TILES)
+        tile = L.scouter_conv2d_x3_tile(M, Cin, tile)
+        post.alloc(L.scouter_conv2d_x3_partial_rows(M, Cin, tile), x_shape)
+        launch(tile, fuse=post.args())
+    else:
+        if tile is None:
+            tile = _pick_tile(("xdgrad", 3, B, H, W, Cin, Cout), launch, _X3_TILES)
+        launch(L.scouter_conv2d_x3_tile(M, Cin, tile))
+    return dx
+
+
+_X3_WGRAD_PLANS = (-1, 0, 1, 2, 3)
+
+
+def x3_wgrad_ok(cin, cout):
+    return cin % 128 == 0 and cout % 128 == 0
+
+
+def conv2d_wgrad_x3(x, dy, dw_hwio, plan=None):
+    """Weight gradient of a pointwise layer on the register-split bf16x3 GEMM: x [B, H, W, Cin], dy [B, H, W, Cout] fp32 ->
+    dw (HWIO [1, 1, Cin, Cout], written in place).  The split-K plan comes from the static table (plans sum the pixels in
+    different orders; every plan is deterministic)."""
+    _chk(x, "x"); _chk(dy, "dy"); _chk(dw_hwio, "dw")
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    assert tuple(dw_hwio.shape) == (1, 1, Cin, Cout) and tuple(dy.shape[:3]) == (B, H, W)
+    L = _native.lib()
+
+    def launch(pl, dry=False):
+        if dry:
+            return True
+        ws = workspace(L.scouter_conv2d_wgrad_x3_workspace_bytes(B, H, W, Cin, Cout, pl), x.device)
+        _native.check(L.scouter_conv2d_wgrad_x3(_p(x), _p(dy), _p(dw_hwio), B, H, W, Cin, Cout, pl, _p(ws), ws.numel(),
+                                                _stream()), "conv2d_wgrad_x3")
+        return True
+    if plan is None:
+        plan = _pick_tile(("xwgrad", 3, B, H, W, Cin, Cout), launch, _X3_WGRAD_PLANS)
+    launch(plan)
+    return dw_hwio
+
+
 def conv2d_wgrad_planes(xp, dyp, dw_hwio, pad, groups=1):
     """xp [np, B, H, W, Cin], dyp [np, B, H, W, Cout] -> dw (HWIO fp32, written in place).  The (tile, split-K) plan is
     autotuned once per layer shape like the fp32 kernel's (_WGRAD_PLANS)."""
@@ -887,6 +1008,13 @@ def colsum(a, out, b=None, alpha=1.0):
     _native.check(_native.lib().scouter_colsum_f32(_p(a), _p(b), _p(out), M, C, alpha, _p(ws), ws.numel(), _stream()),
                   "colsum")
     return out
+
+
+def iadd_i64(t, v=1):
+    """t (contiguous int64) += v, one launch."""
+    assert t.dtype == torch.int64 and t.is_contiguous() and t.is_cuda
+    _native.check(_native.lib().scouter_iadd_i64(_p(t), t.numel(), int(v), _stream()), "iadd_i64")
+    return t
 
 
 def relu_bwd(dy, y):
@@ -1138,7 +1266,7 @@ def slot_loss_fwd(logits, labels, area_part, area_count, lam, power):
     """Returns (log_probs [B,C], stats [5] = loss, nll, area**power, top-1, area)."""
     B, C = logits.shape
     logp = torch.empty_like(logits)
-    stats = torch.zeros(8, dtype=F32, device=logits.device)
+    stats = torch.empty(8, dtype=F32, device=logits.device)      # (the kernel writes all eight words)
     _chk(labels, "labels", torch.int64)
     _native.check(_native.lib().scouter_slot_loss_fwd_f32(
         _p(logits), _p(labels), _p(area_part), 0 if area_part is None else area_part.numel(), B, C, float(area_count),

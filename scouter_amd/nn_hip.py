@@ -43,11 +43,30 @@ class Conv2d(nn.Module):
         self.use_side_stream = K.SIDE_STREAM_DEFAULT                # weight gradient on the side stream
         self.planes = 0                                             # 3: bf16x3 plane kernels (SlotModel.set_planes)
         self._wsplit = None                                         # (wf, wd) of this step, from the model's one-launch split
+        self.x3 = 0                                                 # bits of kernels.X3_DEFAULT (SlotModel.set_x3): register-split bf16x3 GEMM
         self._capture = None                                        # test instrumentation, see BatchNorm2d
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # timm resnet.py:447-448
         if bias:
             bound = 1.0 / math.sqrt(in_channels // groups * k * k)
             nn.init.uniform_(self.bias, -bound, bound)
+
+    # ---- pointwise layers on the register-split bf16x3 GEMM (csrc/conv_x3.hip): fp32 tensors in, weight planes from the
+    # model's one split launch
+    def x3_static(self):
+        """Shape rule alone (kernels.x3_eligible): 1x1 / stride 1 / no bias / deep enough."""
+        k = self.kernel_size
+        return K.x3_eligible(self.in_channels, self.out_channels, k, k, self.stride, self.padding, self.groups,
+                             self.bias is not None)
+
+    def x3_mode(self):
+        """Bits of `x3` this layer uses now: fp32 precision, no plane operands, and the static shape rule; 0 otherwise."""
+        return self.x3 if (self.x3 and not self.planes and self.precision == "fp32" and self.x3_static()) else 0
+
+    def _x3_weights(self, want_fwd, want_dgrad):
+        ws, self._wsplit = self._wsplit, None
+        if ws is not None and (ws[0] is not None or not want_fwd) and (ws[1] is not None or not want_dgrad):
+            return ws
+        return K.planes_split_weight(K.hwio(self.weight), 1, 3, fwd=want_fwd, dgrad=want_dgrad)
 
     # ---- bf16x3 operand planes (csrc/conv_planes.hip): the producer of this layer's input hands over a K.PlaneTensor
     def _nplanes(self):
@@ -137,6 +156,18 @@ class Conv2d(nn.Module):
                 self._capture[0][self._capture[1]] = y
             return y, ((x.f32 if x.f32 is not None else tuple(x.shape), wd,
                         x.planes if self.planes_wgrad() or x.f32 is None else None) if save else None)
+        xm = self.x3_mode()
+        if (xm & 7) and x.dtype == K.F32 and out_dtype in (None, K.F32):
+            want_wd = bool(save and (xm & 6))
+            wf, wd = self._x3_weights(bool(xm & 1), want_wd) if ((xm & 1) or want_wd) else (None, None)
+            if xm & 1:
+                y = K.conv2d_fwd_x3(x, wf, addend, relu, bn_stats)
+            else:
+                y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
+                                 bn_stats, precision=self.precision)
+            if self._capture is not None and relu:
+                self._capture[0][self._capture[1]] = y
+            return y, ((x, wd, None) if save else None)
         y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
                          bn_stats, precision=self.precision, out_dtype=out_dtype or K.F32)
         if self._capture is not None and relu:
@@ -175,6 +206,9 @@ class Conv2d(nn.Module):
                 if (self._dw is not None and xp is not None and dyp is not None and self.planes_wgrad() and
                         32 // xshape[2] + 1 < xshape[1]):
                     K.conv2d_wgrad_planes(xp, dyp, self._dw, self.padding, self.groups)
+                elif (self._dw is not None and (self.x3_mode() & 8) and xt is not None and dy is not None and
+                      xt.dtype == K.F32 and dy.dtype == K.F32 and K.x3_wgrad_ok(self.in_channels, self.out_channels)):
+                    K.conv2d_wgrad_x3(xt, dy, self._dw)      # (pointwise layer: register-split bf16x3 GEMM, csrc/conv_x3.hip)
                 elif self._dw is not None:
                     if xt is None or dy is None:
                         raise RuntimeError("Conv2d.bwd: the fp32 operands were dropped (planes_only) but the weight "
@@ -184,6 +218,12 @@ class Conv2d(nn.Module):
                     K.colsum(dy, self._db)
         if not need_dx:
             return dx
+        if self.x3_mode() and wd is not None and dyp is None and dy is not None and dy.dtype == K.F32:
+            # pointwise layer on the register-split bf16x3 GEMM (x3_mode): plain input gradient (bit 1), or with the
+            # fused BatchNorm-backward epilogue (bit 2)
+            fused = post is not None and K._fuse_wanted(post, 1) and post.x_io() == 0
+            if (self.x3 & 4) if fused else (self.x3 & 2):
+                return K.conv2d_dgrad_x3(dy, wd, xshape, addend, post=post)
         return K.conv2d_dgrad(dy, K.hwio(self.weight), xshape, addend, self.stride, self.padding, self.groups,
                               precision=self.precision, post=post, out_dtype=dx_dtype or K.F32)
 
@@ -205,6 +245,7 @@ class StemConv2d(Conv2d):
         self.precision = "fp32"
         self.use_side_stream = K.SIDE_STREAM_DEFAULT
         self.planes = 0
+        self.x3 = 0
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
     def fwd(self, x_nchw, save, relu=False, addend=None, bn_stats=False):

@@ -13,13 +13,15 @@ import torch
 import torch.nn as nn
 
 from .. import kernels as K
-from ..nn_hip import Conv2d, GradArena
+from ..nn_hip import Conv2d, GradArena, StemConv2d
 from ..timm.models import create_model
 from .utils.position_encode import build_position_encoding
 from .utils.slot_attention import SlotAttention
 
 # bf16 activation storage under --precision bf16 (SlotModel.set_activation_storage); SCOUTER_BF16_STORAGE=0: fp32 storage
 BF16_STORAGE_DEFAULT = os.environ.get("SCOUTER_BF16_STORAGE", "1") != "0"
+# the per-step weight-plane split on its own stream next to the stem (SlotModel._forward_impl); 0: on the compute stream
+SPLIT_ASYNC = os.environ.get("SCOUTER_SPLIT_ASYNC", "1") != "0"
 
 
 class Identical(nn.Module):
@@ -79,8 +81,11 @@ class SlotModel(nn.Module):
         self.backbone = load_backbone(args)
         self.set_precision(self.precision)
         self.set_planes(int(os.environ.get("SCOUTER_PLANES", "3")))
+        self.set_x3(K.X3_DEFAULT)
         self._arena = None
         self._anchor = None
+        self._split_device = None
+        self._nbt_flat, self._nbt_key = None, None
         self._post_backward_hooks = []       # called with the GradArena after every backward (data-parallel reduce)
         self._grad_ready_hooks = []          # called (arena, lo, hi) as soon as arena.flat[lo:hi] is final
         self.last_stats = None               # device tensor [loss, nll, area**power, top1, area] of the last forward
@@ -143,6 +148,18 @@ class SlotModel(nn.Module):
                 mod.conv.planes = nplanes
         self._plane_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and m.planes]
         self._wsplitter = K.PlaneWeightSplitter()
+
+    def set_x3(self, bits):
+        """Deep pointwise (1x1) convolutions of the backbone on the register-split bf16x3 GEMM (csrc/conv_x3.hip: fp32
+        tensors in and out, fp32-grade products on the bf16 matrix cores): bit 0 forward, bit 1 plain input gradient, bit 2
+        input gradient with the fused BatchNorm-backward epilogue, bit 3 weight gradient; 0: the exact-fp32 MFMA kernels.  Which layers qualify
+        is a static function of their channels (kernels.x3_eligible), so the forward does not depend on batch or timing."""
+        if bits & ~15:
+            raise ValueError("x3 bits must be within 0..15")
+        for mod in self.backbone.modules():
+            if isinstance(mod, Conv2d) and not isinstance(mod, StemConv2d):
+                mod.x3 = int(bits)
+        self._x3_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and m.x3 and m.x3_static()]
 
     def set_side_stream(self, enabled):
         """Weight gradients on the side stream (default) or serially on the compute stream (per-kernel timing)."""
@@ -225,16 +242,42 @@ class SlotModel(nn.Module):
             x = x.float()
         tracked = []
         convs = [c for c in getattr(self, "_plane_convs", ()) if c._nplanes()]
-        if convs:      # this step's weight planes of every plane convolution: one launch into persistent buffers
-            outs = self._wsplitter.run([(K.hwio(c.weight), c.groups, True, bool(save and c.planes_dy())) for c in convs],
-                                       convs[0]._nplanes())
-            for c, o in zip(convs, outs):
+        items = [(K.hwio(c.weight), c.groups, True, bool(save and c.planes_dy())) for c in convs]
+        # (the pointwise layers on the register-split GEMM take three WEIGHT planes too -- same launch; fp32 mode only)
+        xconvs = [c for c in getattr(self, "_x3_convs", ()) if c.x3_mode()] if (not convs or convs[0]._nplanes() == 3) else []
+        xconvs = [c for c in xconvs if (c.x3 & 1) or (save and (c.x3 & 6))]
+        items += [(K.hwio(c.weight), 1, bool(c.x3 & 1), bool(save and (c.x3 & 6))) for c in xconvs]
+        if items:      # this step's weight planes of every plane convolution: one launch into persistent buffers ...
+            # ... on its own stream NEXT TO the stem's kernels (the stem reads no planes; MFMA-bound next to a byte-moving
+            # pass): the backbone joins it after the max-pool (`_post_stem_hooks`).  SCOUTER_SPLIT_ASYNC=0: on the compute stream
+            hooks = getattr(self.backbone, "_post_stem_hooks", None)
+            use_async = SPLIT_ASYNC and hooks is not None
+            if use_async and not hooks:
+                hooks.append(lambda: K.join_side_stream(self._split_device, "wsplit") if self._split_device is not None else None)
+            self._split_device = x.device if use_async else None
+            with K.side_stream(x.device, enabled=use_async, which="wsplit"):
+                outs = self._wsplitter.run(items, convs[0]._nplanes() if convs else 3)
+            for c, o in zip(convs + xconvs, outs):
                 c._wsplit = o
         feat, bctx = self.backbone.features_fwd(x, save, tracked)             # NHWC [B, h, w, channel]
         logp, stats, hstate = self._head_forward(feat, target, save)
         if tracked:
-            torch._foreach_add_(tracked, 1)                                   # BatchNorm num_batches_tracked
+            self._bump_tracked(tracked)                                       # BatchNorm num_batches_tracked
         return logp, stats, ((bctx, hstate) if save else None)
+
+    def _bump_tracked(self, tracked):
+        """num_batches_tracked += 1 for the train-mode BatchNorms of this forward: the counters are views of ONE flat int64
+        buffer (same buffer names / shapes in the state_dict), so it is one launch of the library instead of an ATen
+        multi-tensor kernel.  Re-flattened when the buffers were re-allocated (module.to(...)) or another set trains."""
+        key = tuple(t.data_ptr() for t in tracked)
+        if self._nbt_key != key:
+            from ..nn_hip import BatchNorm2d
+            by_ptr = {m.num_batches_tracked.data_ptr(): m for m in self.modules() if isinstance(m, BatchNorm2d)}
+            flat = torch.stack([t.detach().reshape(()) for t in tracked]).contiguous()
+            for i, t in enumerate(tracked):
+                by_ptr[t.data_ptr()]._buffers["num_batches_tracked"] = flat[i]
+            self._nbt_flat, self._nbt_key = flat, tuple(flat[i].data_ptr() for i in range(flat.numel()))
+        K.iadd_i64(self._nbt_flat, 1)
 
     def _backward_impl(self, state, g_logp, g_loss, g_nll, g_term):
         bctx, hstate = state

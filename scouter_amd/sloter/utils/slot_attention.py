@@ -95,12 +95,20 @@ class SlotAttention(nn.Module):
             if "weight_ih_l0" in g._g:
                 K.matmul_tn(dgi, U, g._g["weight_ih_l0"])
             if "weight_hh_l0" in g._g:
-                # hidden state entering GRU step t: s_0 (initial slots, same for every image) then the saved states
-                sprev = torch.empty((T - 1, B, S, d), dtype=torch.float32, device=X.device)
-                K.axpby(self.initial_slots.expand(B, S, d).contiguous(), None, 1.0, 0.0, out=sprev[0])
-                for t in range(1, T - 1):
-                    K.axpby(saved["states"][t - 1], None, 1.0, 0.0, out=sprev[t])
-                K.matmul_tn(dgh, sprev.view(M, d), g._g["weight_hh_l0"])
+                # dW_hh = sum_t dgh_t^T h_t with the hidden state entering GRU step t: h_0 = the initial slots -- the SAME
+                # [S, d] rows for every image, so its term is (sum over the batch of dgh_0)^T s_0: a column sum over B and an
+                # S-row product instead of B copies of s_0 (round 4 materialised `sprev` with an expand().contiguous() and one
+                # copy per iteration: 60 MB per step at BASELINE configs[4]) -- then the saved states, read where they lie
+                gW = g._g["weight_hh_l0"]
+                dgh0 = torch.empty((S, 3 * d), dtype=torch.float32, device=X.device)
+                K.colsum(r["dgh"][0].view(B, S * 3 * d), dgh0.view(-1))
+                if T > 2:
+                    K.matmul_tn(dgh[B * S:], saved["states"][:T - 2].view((T - 2) * B * S, d), gW)
+                    first = torch.empty_like(gW)
+                    K.matmul_tn(dgh0, self.initial_slots[0], first)
+                    K.axpby(first, gW, 1.0, 1.0, out=gW)
+                else:
+                    K.matmul_tn(dgh0, self.initial_slots[0], gW)
             if "bias_ih_l0" in g._g:
                 K.colsum(dgi, g._g["bias_ih_l0"])
             if "bias_hh_l0" in g._g:

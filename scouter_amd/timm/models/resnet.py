@@ -174,6 +174,9 @@ class ResNet(nn.Module):
         # called after the first convolution has been queued, right before the first BatchNorm reads / updates its running
         # statistics (scouter_amd.parallel: the compute stream waits for the asynchronous DDP buffer broadcast HERE)
         self._pre_bn_hooks = []
+        # called after the stem (max-pool queued), before layer1: SlotModel joins the stream that split this step's weight
+        # planes next to the stem's kernels
+        self._post_stem_hooks = []
         self.fuse_stem_pool = os.environ.get("SCOUTER_FUSE_STEM_POOL", "1") == "1"   # bn1 + act1 + maxpool in one pass
         chans, strides = [64, 128, 256, 512], [1, 2, 2, 2]
         for i in range(4):
@@ -236,6 +239,8 @@ class ResNet(nn.Module):
         if self._capture is not None and arg is not None:
             self._capture[0][self._capture[1]] = arg
         x = p
+        for hook in self._post_stem_hooks:
+            hook()
         for li in range(1, 5):
             for blk in getattr(self, "layer%d" % li):
                 x, c_blk = blk.fwd(x, save, tracked)

@@ -1,0 +1,184 @@
+"""Pointwise convolutions on the register-split bf16x3 GEMM (scouter_amd/csrc/conv_x3.hip): fp32 tensors in and out, the
+three-way bf16 split of the activation done in registers, weight planes by LDS-DMA.  The kernel keeps pconv_kernel's K
+order, product order and accumulator sets, so it must equal -- BIT FOR BIT -- the plane kernels on the pre-split
+activation, for every block tile, incl. ragged last tiles, the fused BatchNorm statistics, addend / ReLU and the fused
+BatchNorm-backward epilogue; against an fp64 convolution it is at least as close as the exact-fp32 MFMA kernel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def K():
+    from scouter_amd import kernels
+    return kernels
+
+
+CASES = [  # B, H, W, Cin, Cout
+    (2, 14, 14, 256, 1024), (3, 7, 7, 512, 2048), (5, 7, 7, 2048, 512), (1, 28, 28, 128, 512), (2, 28, 27, 512, 128),
+    (1, 9, 9, 64, 64), (7, 14, 14, 1024, 256), (1, 1, 37, 64, 128), (33, 28, 27, 256, 512), (1, 3, 5, 96, 192)]
+
+
+def _tiles(kk, n):
+    return [t for t in (0, 1, 2, 3) if kk._x3_tile_ok(t, n)]
+
+
+@pytest.mark.parametrize("cfg", CASES)
+def test_forward_equals_the_plane_kernels_bit_for_bit(cfg):
+    B, H, W, Cin, Cout = cfg
+    kk = K()
+    rng = np.random.default_rng(sum(cfg))
+    x = torch.from_numpy((rng.standard_normal((B, H, W, Cin)) + 0.2).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((1, 1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)).cuda()
+    add = torch.from_numpy(rng.standard_normal((B, H, W, Cout)).astype(np.float32)).cuda()
+    wf, wd = kk.planes_split_weight(w, 1, 3)
+    xp = kk.planes_split(x, 3)
+    ptile = kk._plane_tiles(Cout)[0]
+    y_ref, (pr, rr) = kk.conv2d_fwd_planes(xp, wf, 1, 1, 1, 0, 1, bn_stats=True, tile=ptile)
+    y_add = kk.conv2d_fwd_planes(xp, wf, 1, 1, 1, 0, 1, addend=add, relu=True, tile=ptile)
+    ref64 = (x.double().reshape(-1, Cin) @ w.double().reshape(Cin, Cout)).reshape(B, H, W, Cout)
+    y32 = kk.conv2d_fwd(x, w, None, None, 1, 0, 1)
+    e32 = float((y32.double() - ref64).abs().max())
+    for t in _tiles(kk, Cout):
+        y, (part, rows) = kk.conv2d_fwd_x3(x, wf, bn_stats=True, tile=t)
+        assert torch.equal(y, y_ref), (cfg, t, float((y - y_ref).abs().max()))
+        # statistics: per-tile fp64 partials, grouped by this kernel's M tiles -- equal after the sum to fp64 rounding
+        assert part.shape[0] == rows
+        st, st_ref = part.sum(0), pr.sum(0)
+        assert torch.allclose(st, st_ref, rtol=1e-12, atol=1e-9), (cfg, t)
+        ya = kk.conv2d_fwd_x3(x, wf, addend=add, relu=True, tile=t)
+        assert torch.equal(ya, y_add), (cfg, t)
+    # fp32-grade: no worse than the exact-fp32 MFMA kernel against fp64 (in fact about a third of its error)
+    ex = float((y_ref.double() - ref64).abs().max())
+    assert ex <= max(e32, 1e-6) * 1.05, (ex, e32)
+    # default tile (library heuristic / static table) gives the same bits
+    assert torch.equal(kk.conv2d_fwd_x3(x, wf), y_ref)
+
+
+@pytest.mark.parametrize("cfg", [c for c in CASES if c[3] % 64 == 0])      # (the plane reference needs 64-multiples of Cin)
+def test_input_gradient_equals_the_plane_kernels_bit_for_bit(cfg):
+    B, H, W, Cin, Cout = cfg
+    kk = K()
+    rng = np.random.default_rng(sum(cfg) + 1)
+    dy = torch.from_numpy(rng.standard_normal((B, H, W, Cout)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((1, 1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)).cuda()
+    add = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).cuda()
+    wf, wd = kk.planes_split_weight(w, 1, 3)
+    dyp = kk.planes_split(dy, 3)
+    ptile = kk._plane_tiles(Cin)[0]
+    xs = (B, H, W, Cin)
+    dx_ref = kk.conv2d_dgrad_planes(dyp, wd, xs, 1, 1, 1, 0, 1, tile=ptile)
+    dx_add = kk.conv2d_dgrad_planes(dyp, wd, xs, 1, 1, 1, 0, 1, addend=add, tile=ptile)
+    ref64 = (dy.double().reshape(-1, Cout) @ w.double().reshape(Cin, Cout).t()).reshape(xs)
+    d32 = kk.conv2d_dgrad(dy, w, xs, None, 1, 0, 1)
+    e32 = float((d32.double() - ref64).abs().max())
+    for t in _tiles(kk, Cin):
+        dx = kk.conv2d_dgrad_x3(dy, wd, xs, tile=t)
+        assert torch.equal(dx, dx_ref), (cfg, t, float((dx - dx_ref).abs().max()))
+        assert torch.equal(kk.conv2d_dgrad_x3(dy, wd, xs, addend=add, tile=t), dx_add), (cfg, t)
+    ex = float((dx_ref.double() - ref64).abs().max())
+    assert ex <= max(e32, 1e-6) * 1.05, (ex, e32)
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_fused_batchnorm_backward_epilogue(two):
+    """The input gradient that produces a block-output gradient masks it with the ReLU sign bits and reduces the
+    BatchNorm-backward sums of one or two BatchNorms in its epilogue: same masked gradient bits as the plane kernel's
+    fused launch, the same sums (fp64 partials, other tile grouping) -- and both agree with the fp32 kernel's fused launch
+    to fp32 rounding."""
+    kk = K()
+    B, H, W, Cin, Cout = 3, 14, 13, 512, 128
+    rng = np.random.default_rng(77 + two)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+    dy, w, add = f(B, H, W, Cout), f(1, 1, Cin, Cout) / np.sqrt(Cin), f(B, H, W, Cin)
+    xs = (B, H, W, Cin)
+    # a real BatchNorm forward provides the saved block and the ReLU mask
+    def bn(xin):
+        g_, b_ = torch.ones(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+        rm, rv = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda")
+        return kk.bn_fwd(xin, g_, b_, rm, rv, True, True, want_mask=True)
+    x1, x2 = f(*xs), f(*xs)
+    out1 = bn(x1)
+    saved1, mask = out1[1], out1[2]
+    saved2 = bn(x2)[1]
+    entries = [(x1, saved1)] + ([(x2, saved2)] if two else [])
+    wf, wd = kk.planes_split_weight(w, 1, 3)
+    dyp = kk.planes_split(dy, 3)
+    res = {}
+    for name in ("fp32", "planes", "x3"):
+        post = kk.BnBwdFuse(mask, entries)
+        if name == "fp32":
+            dx = kk.conv2d_dgrad(dy, w, xs, add, 1, 0, 1, post=post)
+        elif name == "planes":
+            dx = kk.conv2d_dgrad_planes(dyp, wd, xs, 1, 1, 1, 0, 1, addend=add, post=post, tile=kk._plane_tiles(Cin)[0])
+        else:
+            dx = kk.conv2d_dgrad_x3(dy, wd, xs, addend=add, post=post)
+        assert post.applied
+        res[name] = (dx, [p[:post.rows].sum(0) for p in post.parts])
+    assert torch.equal(res["x3"][0], res["planes"][0])
+    for a, b in zip(res["x3"][1], res["planes"][1]):
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-9)
+    scale = float(res["fp32"][0].abs().max())
+    assert float((res["x3"][0] - res["fp32"][0]).abs().max()) <= 2e-6 * scale
+    for a, b in zip(res["x3"][1], res["fp32"][1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * float(b.abs().max()))
+
+
+def test_model_routes_the_deep_pointwise_layers_and_the_switch_turns_them_off():
+    """SlotModel.set_x3: the 14 deep 1x1 convolutions of resnest26d (Cin * Cout >= 2^16) run on the register-split
+    GEMM -- a static rule of the layer shapes -- and with the switch off every one is back on the fp32 MFMA kernels;
+    the two forwards agree to fp32 rounding (both are fp32-grade products), neither depends on the batch."""
+    import test_model_gpu as T
+    from scouter_amd import _native
+    res = {}
+    for bits in (3, 0):
+        m, P, images, labels, cfg = T._synthetic_model("resnest26d", 10, 1, 3, 4, 96, 2500)
+        m.set_x3(bits)
+        assert len(m._x3_convs) == (14 if bits else 0)
+        L = _native.lib()
+        L.scouter_prof_enable(1)
+        out, (loss, nll, area) = m(images.cuda(), labels.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        L.scouter_prof_enable(0)
+        import ctypes
+        buf = ctypes.create_string_buffer(1 << 16)
+        L.scouter_prof_collect(buf, len(buf))
+        names = buf.value.decode()
+        assert ("xconv_fwd<bf16x3>" in names) == bool(bits) and ("xconv_dgrad<bf16x3>" in names) == bool(bits)
+        res[bits] = (out.detach().clone(), m.grad_arena().flat.clone())
+    assert float((res[3][0] - res[0][0]).abs().max()) < 5e-4
+    rel = float((res[3][1] - res[0][1]).norm() / res[0][1].norm())
+    assert rel < 5e-2, rel          # (random-init net: ReLU sign flips on ~0 pre-activations move gradients, see test_model_gpu)
+
+
+WCASES = [  # B, H, W, Cin, Cout
+    (70, 7, 7, 512, 2048), (8, 14, 14, 1024, 256), (3, 28, 28, 128, 512), (2, 9, 9, 256, 128), (1, 5, 5, 128, 128), (5, 17, 17, 256, 1024)]
+
+
+@pytest.mark.parametrize("cfg", WCASES)
+def test_weight_gradient_matches_fp64_at_least_as_well_as_the_fp32_kernel(cfg):
+    """dW = X^T dY over the pixels with both operands transposed and split three-way in registers: against an fp64 product it
+    is at least as close as the exact-fp32 MFMA weight gradient, for every split-K plan (incl. pixel counts that are no
+    multiple of the 32-pixel chunk and splits whose last chunk is ragged), and bit-reproducible launch to launch on a
+    poisoned workspace."""
+    B, H, W, Cin, Cout = cfg
+    kk = K()
+    rng = np.random.default_rng(sum(cfg) + 5)
+    x = torch.from_numpy((rng.standard_normal((B, H, W, Cin)) + 0.1).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((B, H, W, Cout)).astype(np.float32)).cuda()
+    ref = x.double().reshape(-1, Cin).t() @ dy.double().reshape(-1, Cout)
+    dw32 = torch.empty(1, 1, Cin, Cout, device="cuda")
+    kk.conv2d_wgrad(x, dy, dw32, 1, 0, 1)
+    e32 = float((dw32.double().view(Cin, Cout) - ref).abs().max())
+    for plan in kk._X3_WGRAD_PLANS:
+        dw = torch.full((1, 1, Cin, Cout), float("nan"), device="cuda")
+        kk.conv2d_wgrad_x3(x, dy, dw, plan=plan)
+        ex = float((dw.double().view(Cin, Cout) - ref).abs().max())
+        assert ex <= max(e32, 1e-6) * 1.05, (cfg, plan, ex, e32)
+        ws = kk.workspace(1, x.device)
+        ws.fill_(0xFF)                                   # NaN patterns: nothing may be read before it is written
+        dw2 = torch.full((1, 1, Cin, Cout), float("nan"), device="cuda")
+        kk.conv2d_wgrad_x3(x, dy, dw2, plan=plan)
+        assert torch.equal(dw, dw2), (cfg, plan)
