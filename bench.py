@@ -200,8 +200,10 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
 # profiles/r04_clocks.txt): the fp32 MFMA holds 2.40 GHz (154 TFLOP/s = 0.98 of nominal), the bf16 MFMA is power-managed down
 # to 1.88 GHz with real data (1 886 TFLOP/s = 0.754 of the 2 500 nominal; 2.39 GHz / 2 497 only with constant operands), and
 # the plane kernels themselves run at 1.62-1.88 GHz (cycle stamps inside pwgrad_taps_kernel, tools_dev/pwt_stamps.py).
-PMC_TRAFFIC_FILE = "r04_pmc_hbm_traffic.json"
-PMC_MFMA_FILE = "r04_pmc_mfma_util.json"
+# committed PMC passes (tools_dev/refresh_profiles.sh) per BASELINE config at its own batch / image size / precision
+PMC_FILES = {2: ("r05_pmc_hbm_traffic.json", "r05_pmc_mfma_util.json"),
+             5: ("r05_pmc_hbm_traffic_config5.json", "r05_pmc_mfma_util_config5.json")}
+HBM_PEAK_TBS, HBM_ACHIEVABLE_TBS = 8.0, 6.3          # MI355X_MICROARCH.md: HBM3E nominal / what a streaming kernel reaches
 # Kernel classes of the roofline object: bench label prefixes (the library's hipEvent scopes) and the rocprofv3 kernel-name
 # prefixes of the SAME kernels.  Names are matched by exact prefix ("void wgrad_kernel<" does not match
 # "void pwgrad_kernel<": round 2's substring match mixed the two).
@@ -214,9 +216,10 @@ CLASSES = {
                                "epilogue, weight gradient), v_mfma_f32_32x32x2_f32"},
     "bf16x3_plane_conv": {
         "labels": ("pconv_fwd<bf16x3>", "pconv_dgrad<bf16x3>", "pwgrad<bf16x3>", "xconv_fwd<bf16x3>", "xconv_dgrad<bf16x3>",
-                   "xconv_dgrad+bn_bwd<bf16x3>"),
+                   "xconv_dgrad+bn_bwd<bf16x3>", "xwgrad<bf16x3>", "xconv3_fwd<bf16x3>", "xconv3_dgrad<bf16x3>",
+                   "xconv3_dgrad+bn_bwd<bf16x3>"),
         "rocprof": ("void pconv_kernel<", "void phalo_kernel<", "void pwgrad_kernel<", "void ppersist_kernel<",
-                    "void pwgrad_taps_kernel<", "void xgemm_kernel<"),
+                    "void pwgrad_taps_kernel<", "void xgemm_kernel<", "void xwgrad_kernel<"),
         "peak": 2500.0 / 6.0, "sustained": 1886.0 / 6.0, "what": "grouped 3x3 convolutions (pre-split operand planes) and, round 5, the deep 1x1 "
                                       "convolutions (activation split in registers) on exact three-way bf16 operand splits: 6 x "
                                       "v_mfma_f32_32x32x16_bf16 per fp32-grade product, fp32 accumulate; peak = 2500 / 6 "
@@ -246,29 +249,43 @@ def _profile_json(fname):
     return doc
 
 
-def pmc_class(prefixes):
+def pmc_class(prefixes, files):
     """(HBM-side bytes per launch, MFMA-busy fraction, sources) of the kernels whose rocprofv3 names start with one of
-    `prefixes`, from the committed PMC passes over THIS command (profiles/r04_pmc_*.json, made by tools_dev/pmc_traffic.py
+    `prefixes`, from the committed PMC passes over THIS command (profiles/r05_pmc_*.json, made by tools_dev/pmc_traffic.py
     -- 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md -- and tools_dev/pmc_mfma.py); PMC
     counters cannot be collected from inside the timed process.  The static tile table makes the instances of those
     runs the instances of this one.  None where a file is missing."""
     traffic = busy = None
     src = []
-    t = _profile_json(PMC_TRAFFIC_FILE)
+    t = _profile_json(files[0])
     if t:
         rows = [r for n, r in t["kernels"].items() if n.startswith(prefixes)]
         nl = sum(r["launches"] for r in rows)
         if nl:
             traffic = round(sum((r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] for r in rows) / nl)
-            src.append("profiles/" + PMC_TRAFFIC_FILE)
-    m = _profile_json(PMC_MFMA_FILE)
+            src.append("profiles/" + files[0])
+    m = _profile_json(files[1])
     if m:
         rows = [r for n, r in m["kernels"].items() if n.startswith(prefixes)]
         tot = sum(r["avg_us"] * r["launches"] for r in rows)
         if tot:
             busy = round(sum(r["mfma_busy"] * r["avg_us"] * r["launches"] for r in rows) / tot, 4)
-            src.append("profiles/" + PMC_MFMA_FILE)
+            src.append("profiles/" + files[1])
     return traffic, busy, src
+
+
+def hbm_step_roofline(files, ms_per_step):
+    """HBM-roofline fraction of the WHOLE step: counter bytes of every kernel of a step (the committed FETCH_SIZE / WRITE_SIZE
+    passes of this command) over the step time measured here, against the nominal 8 TB/s and the 6.3 TB/s a streaming kernel
+    reaches -- the figure that matters for BASELINE configs[4], whose step is bound by its elementwise passes."""
+    t = _profile_json(files[0])
+    if not t or not t.get("hbm_bytes_per_step"):
+        return None
+    tbs = t["hbm_bytes_per_step"] / (ms_per_step * 1e-3) / 1e12
+    return {"bound": "hbm", "bytes_per_step": round(t["hbm_bytes_per_step"]), "achieved": round(tbs, 3), "unit": "TB/s",
+            "peak": HBM_PEAK_TBS, "frac": round(tbs / HBM_PEAK_TBS, 4), "achievable": HBM_ACHIEVABLE_TBS,
+            "frac_of_achievable": round(tbs / HBM_ACHIEVABLE_TBS, 4), "source": "profiles/" + files[0],
+            "note": "HBM-side counter bytes of all kernels of one step / this run's ms_per_step (kernels overlap on streams)"}
 
 
 def spawn_ranks(n, argv):
@@ -450,6 +467,9 @@ def main():
         # ---- roofline: stable kernel CLASSES (not an argmax over near-tied instances): each with its algorithmic FLOPs,
         # time, fraction of ITS matrix peak and -- from the committed PMC passes of this command -- MFMA-busy and HBM-side
         # traffic per launch against the algorithmic bytes.  `roofline` itself = the class with the most time per step.
+        # (the committed PMC passes exist for configs 2 and 5 at their own batch / image size / precision)
+        pmc_files = PMC_FILES.get(a.config) if (cfg["img_size"] == 224 and cfg["batch"] == CONFIGS[a.config]["batch"] and
+                                                cfg["precision"] == CONFIGS[a.config].get("precision", "fp32")) else None
         classes = {}
         for cname, c in CLASSES.items():
             rows = [k for k in kern if k.startswith(c["labels"]) and kern[k]["tflops"]]
@@ -459,8 +479,7 @@ def main():
             fl = sum(kern[k]["tflops"] * kern[k]["ms_per_step"] for k in rows)            # GFLOP per step
             nl = sum(kern[k]["launches_per_step"] for k in rows)
             by = sum((kern[k]["gbps_algorithmic"] or 0.0) * kern[k]["ms_per_step"] * 1e6 for k in rows)   # bytes per step
-            traffic, busy, src = pmc_class(c["rocprof"]) if a.config == 2 and cfg["img_size"] == 224 and \
-                cfg["batch"] == CONFIGS[2]["batch"] and not bf16 else (None, None, [])
+            traffic, busy, src = pmc_class(c["rocprof"], pmc_files) if pmc_files else (None, None, [])
             classes[cname] = {"kernels": c["what"], "instances": sorted(rows), "gflop_per_step": round(fl, 1),
                               "ms_per_step": round(ms, 4), "launches_per_step": nl, "avg_launch_us": round(1e3 * ms / nl, 2),
                               "achieved": round(fl / ms, 2), "peak": round(c["peak"], 1), "unit": "TFLOP/s",
@@ -511,6 +530,10 @@ def main():
                            "launch": "hipGraph replay (one captured graph per step)" if graphed is not None else "eager",
                            "final_loss": round(loss_val, 5)},
                 "roofline": roofline, "kernels": kern}
+        if pmc_files and world == 1:
+            hb = hbm_step_roofline(pmc_files, 1e3 * dt / a.steps)
+            if hb is not None:
+                line["hbm_roofline_step"] = hb
         if dp_info is not None:
             line["data_parallel"] = dp_info
         if world == 1 and not a.no_prof:

@@ -355,26 +355,27 @@ int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_planes, flo
                                 int Cout, int kh, int kw, int pad, int groups, int nplanes, int plan_hint,
                                 void* ws, size_t ws_bytes, void* arrival, int arrival_slots, void* stream);
 
-/* ---- POINTWISE convolutions (1x1, stride 1, groups 1) at fp32 accuracy on the bf16 matrix cores with the three-way
- * operand split done in registers (csrc/conv_x3.hip, round 5): the deep 1x1 layers of the bottlenecks -- conv1 / conv3
- * (timm/models/resnest.py:111-143) and the downsample convolution (resnet.py:292-306).  The ACTIVATION / GRADIENT is a
- * plain fp32 NHWC tensor (no producer writes planes); only the WEIGHT arrives as three bf16 planes
- * (scouter_planes_split_weight_f32 / _weights_multi: forward layout [3][1][Cout][Cin], input-gradient layout
- * [3][1][Cin][Cout]).  Results are bit-identical to scouter_conv2d_fwd_planes / _dgrad_planes (nplanes = 3) on the split
- * activation.  Needs 32-multiples (>= 64) of GEMM-K channels and 64-multiples of output columns.
- * tile_hint: 0 = 256x128 (eight waves), 1 = 128x128, 2 = 128x64, 3 = 64x64, else the library's choice
- * (scouter_conv2d_x3_tile tells which; every tile gives the same bits).  bn_partial: as scouter_conv2d_fwd_f32, one row
- * per M tile = scouter_conv2d_x3_partial_rows(M, N, tile_hint).  The input gradient takes the optional fused
- * BatchNorm-backward epilogue of scouter_conv2d_dgrad_bnbwd_f32 (relu_mask .. part2; part rows as above). */
+/* ---- Convolutions at fp32 accuracy on the bf16 matrix cores with the three-way operand split done in registers
+ * (csrc/conv_x3.hip, round 5): the deep 1x1 layers of the bottlenecks -- conv1 / conv3 (timm/models/resnest.py:111-143),
+ * the downsample convolution (resnet.py:292-306) -- and the stride-1 3x3 layers with 32 channels per group (the deep stem,
+ * resnet.py:471-489, and the first radix convolution, layers/split_attn.py:54-60).  The ACTIVATION / GRADIENT is a plain fp32
+ * NHWC tensor (no producer writes planes); only the WEIGHT arrives as three bf16 planes (scouter_planes_split_weight_f32 /
+ * _weights_multi: forward layout [3][taps][Cout][Cin/groups], input-gradient layout [3][taps][Cin][Cout/groups]).  Results are
+ * bit-identical to scouter_conv2d_fwd_planes / _dgrad_planes (nplanes = 3) on the split activation.  kh x kw: 1x1 (pad 0) or
+ * an odd same-size filter (2 * pad == kh - 1), stride 1; 32-multiples of channels per group, at least two 32-channel K-tiles.
+ * tile_hint: 0 = 256x128 (eight waves), 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64 (eight waves), 5 = 256x32, 6 = 128x32 (two waves), else the
+ * library's choice (scouter_conv2d_x3_tile tells which for N = output columns per group; every tile gives the same bits).
+ * bn_partial: as scouter_conv2d_fwd_f32, one row per M tile = scouter_conv2d_x3_partial_rows(M, N, tile_hint).  The input
+ * gradient takes the optional fused BatchNorm-backward epilogue of scouter_conv2d_dgrad_bnbwd_f32 (relu_mask .. part2). */
 int scouter_conv2d_x3_tile(long M, int N, int tile_hint);
 int scouter_conv2d_x3_partial_rows(long M, int N, int tile_hint);
 int scouter_conv2d_fwd_x3(const float* x, const void* w_planes_fwd, const float* bias, const float* addend, float* y,
-                          double* bn_partial, int B, int H, int W, int Cin, int Cout, int relu, int tile_hint,
-                          void* stream);
+                          double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad, int groups,
+                          int relu, int tile_hint, void* stream);
 int scouter_conv2d_dgrad_x3_bnbwd(const float* dy, const void* w_planes_dgrad, const float* addend, float* dx, int B,
-                                  int H, int W, int Cin, int Cout, int tile_hint, const void* relu_mask,
-                                  const float* x1, const float* saved1, double* part1, const float* x2,
-                                  const float* saved2, double* part2, void* stream);
+                                  int H, int W, int Cin, int Cout, int kh, int kw, int pad, int groups, int tile_hint,
+                                  const void* relu_mask, const float* x1, const float* saved1, double* part1,
+                                  const float* x2, const float* saved2, double* part2, void* stream);
 
 /* Weight gradient of the same layers, dw[Cin][Cout] = x^T dy over the B*H*W pixels (the HWIO gradient of a 1x1 layer), both
  * fp32 operands transposed (4x4 register patches) and split three-way on their way into LDS; 128-multiples of Cin and Cout.

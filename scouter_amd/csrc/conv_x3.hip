@@ -26,6 +26,7 @@
 // so a global load has one whole K-tile of MFMAs (>= 1.5 k cycles) to land, and the split's VALU sits between MFMAs.
 #include "conv_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
@@ -42,84 +43,136 @@ __device__ __forceinline__ f32x16 x3_mfma(xbf16x8 a, xbf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int BM, int BN, int NWM, int MINB, bool DGRAD>
-__global__ __launch_bounds__(NWM * 128, MINB) void xgemm_kernel(const float* __restrict__ a_f32,
-                                                                 const unsigned short* __restrict__ w_planes, long w_plane_elems,
-                                                                 const float* __restrict__ bias, const float* __restrict__ addend,
-                                                                 float* __restrict__ dst, double* __restrict__ bn_part, ConvGeom g,
-                                                                 int relu, int mtiles, int ntiles, BnBwdFuse fz) {
-    constexpr int BK = 32, NW = 2 * NWM, WM = BM / NWM, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+// CONV = false: pointwise GEMM (groups == 1; A rows bounded by the descriptor).  CONV = true: stride-1 convolution with
+// R x S taps, padding and groups -- implicit GEMM with the row state of conv_igemm.hip (block-relative offsets, separable
+// tap masks, out-of-image taps read zeros through an out-of-range offset); K order as pconv_kernel's (forward: tap outer,
+// 32-channel chunk inner; input gradient: chunk outer, tap inner), so results stay bit-identical to the plane kernels.
+// NWM x NWN waves; wave tile (BM / NWM) x (BN / NWN).
+template <int BM, int BN, int NWM, int NWN, int MINB, bool DGRAD, bool CONV>
+__global__ __launch_bounds__(NWM * NWN * 64, MINB) void xgemm_kernel(const float* __restrict__ a_f32,
+                                                                       const unsigned short* __restrict__ w_planes, long w_plane_elems,
+                                                                       const float* __restrict__ bias, const float* __restrict__ addend,
+                                                                       float* __restrict__ dst, double* __restrict__ bn_part, ConvGeom g,
+                                                                       int relu, int mtiles, int ntiles, BnBwdFuse fz) {
+    constexpr int BK = 32, NW = NWM * NWN, WM = BM / NWM, WN = BN / NWN, MT = WM / 32, NT = WN / 32;
     constexpr int A_BYTES = 3 * BM * 64, B_BYTES = 3 * BN * 64, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int ARG = BM / 16 / NW, BRG = BN / 16 / NW;      // 16-row groups per wave and operand
+    constexpr int ARG = BM / 16 / NW;                          // 16-row groups of A per wave
+    constexpr int BRT = BN / 16, BRG = (BRT + NW - 1) / NW;    // 16-row groups of B: in all / per wave (the first BRT waves-slots)
+    constexpr int GF = (ARG + 1) / 2, GB = ARG - GF;           // row groups split in section F / in section B (staggered)
     constexpr int NA = 2 * ARG;                                // global loads of A per thread and K-tile
-    constexpr int NB = 3 * BRG;                                // LDS-DMA instructions of B per wave and K-tile
-    static_assert(BM % 64 == 0 && BN % 64 == 0 && ARG >= 1 && BRG >= 1, "tile");
+    static_assert(BM % (16 * NW) == 0 && WM % 32 == 0 && WN % 32 == 0 && ARG >= 1, "tile");
     extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations are wave-uniform (M0)
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nblk = mtiles * ntiles;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int nblk = mtiles * ntiles * g.groups;
     const int bid = xcd_remap(blockIdx.x, nblk);
-    const int nt_id = bid % ntiles;
-    const int mt_id = bid / ntiles;
+    const int grp = bid % g.groups;
+    const int nt_id = (bid / g.groups) % ntiles;
+    const int mt_id = bid / (g.groups * ntiles);
     const long m0 = (long)mt_id * BM;
     const int n0 = nt_id * BN;
-    const int Kdim = g.Cg;                     // GEMM K = row length of A (groups == 1: Cg == C)
-    const int KT = Kdim / BK;
+    const int cpt = g.Cg / BK;                 // K chunks per filter tap
+    const int ntaps = g.R * g.S;
+    const int KT = ntaps * cpt;
 
     // ---- addressing.  Lane = (row-in-group = lane >> 2, LDS slot = lane & 3); it handles the 16-byte chunk (8 k-values)
     // that the swizzle maps to its slot: chunk c of row r lives at slot c ^ ((r >> 2) & 3), so a wave's 16 rows x 4 slots
     // are lane-linear in LDS (what the DMA needs for B, and conflict-free 16-byte stores for A).
+    constexpr unsigned OOB = 0x80000000u;
     const int slot = lane & 3, rin = lane >> 2;
     const int chunk = slot ^ ((lane >> 4) & 3);
     const int rows_valid = (int)(g.M - m0 < BM ? g.M - m0 : BM);
-    // A: block-relative byte offsets; the descriptor ends with the block's last valid row, rows beyond read zeros
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a_f32 + m0 * Kdim), 0, (unsigned)rows_valid * (unsigned)Kdim * 4u, 0x00020000);
-    unsigned a_voff[ARG];
+    unsigned a_voff[ARG], a_mask[CONV ? ARG : 1];
+    __amdgpu_buffer_rsrc_t rs_a;
+    long shift = 0;
+    if constexpr (CONV) {
+        const int hw = g.Ho * g.Wo;
+        const int blk_b = (int)(((double)(unsigned)m0 + 0.5) * g.inv_hw);
+        const int blk_rem = (int)((unsigned)m0 - (unsigned)blk_b * (unsigned)hw);
+        const int blk_y = fast_div(blk_rem, g.inv_wo), blk_x = blk_rem - blk_y * g.Wo;
 #pragma unroll
-    for (int t = 0; t < ARG; ++t) a_voff[t] = ((unsigned)(16 * (wave + NW * t) + rin) * (unsigned)Kdim + chunk * 8u) * 4u;
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)w_planes, 0, 0x7fffffff, 0x00020000);
+        for (int t = 0; t < ARG; ++t) {
+            const int rowoff = 16 * (wave + NW * t) + rin;
+            const bool okm = rowoff < rows_valid;
+            const int tx = blk_x + rowoff, qx = fast_div(tx, g.inv_wo), x = tx - qx * g.Wo;
+            const int ty = blk_y + qx, qy = fast_div(ty, g.inv_ho), y = ty - qy * g.Ho;
+            const int ay = DGRAD ? y + g.pad : y - g.pad, ax = DGRAD ? x + g.pad : x - g.pad;
+            unsigned colbits = 0, mask = 0;
+            for (int q = 0; q < g.S; ++q) colbits |= ((unsigned)(DGRAD ? ax - q : ax + q) < (unsigned)g.W ? 1u : 0u) << q;
+            for (int r = 0; r < g.R; ++r) mask |= ((unsigned)(DGRAD ? ay - r : ay + r) < (unsigned)g.H ? colbits : 0u) << (r * g.S);
+            a_mask[t] = okm ? mask : 0u;
+            const int rel = okm ? qy * g.H * g.W : 0;
+            const int e = DGRAD ? (rel + ay * g.W + ax) * g.C : (rel + (ay + g.pad) * g.W + (ax + g.pad)) * g.C;
+            a_voff[t] = (unsigned)(e + grp * g.Cg + chunk * 8) * 4u;
+        }
+        const long img_elems = (long)g.H * g.W * g.C;
+        shift = DGRAD ? ((long)(g.R - 1) * g.W + (g.S - 1)) * g.C : ((long)g.pad * g.W + g.pad) * g.C;
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a_f32 + (long)blk_b * img_elems - shift), 0, 0x7fffffff, 0x00020000);
+    } else {
+        // block-relative byte offsets; the descriptor ends with the block's last valid row, rows beyond read zeros
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a_f32 + m0 * g.Cg), 0, (unsigned)rows_valid * (unsigned)g.Cg * 4u, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < ARG; ++t) a_voff[t] = ((unsigned)(16 * (wave + NW * t) + rin) * (unsigned)g.Cg + chunk * 8u) * 4u;
+    }
+    // B rows: n = n0 + row; weight planes [tap][N_total][Cg(k)] with this group's rows at grp * Ng
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(w_planes + (long)grp * g.Ng * g.Cg), 0, 0x7fffffff, 0x00020000);
     unsigned b_voff[BRG];
 #pragma unroll
-    for (int t = 0; t < BRG; ++t) b_voff[t] = (unsigned)((n0 + 16 * (wave + NW * t) + rin) * Kdim + chunk * 8) * 2u;
+    for (int t = 0; t < BRG; ++t) b_voff[t] = (unsigned)((n0 + 16 * (wave + NW * t) + rin) * g.Cg + chunk * 8) * 2u;
     const long w_plane_bytes = w_plane_elems * 2;
+    const long wtap_bytes = (long)g.N * g.Cg * 2;
 
-    f32x4 ra[ARG][2];                                               // A(kt) of this thread: fp32, waiting for the split
-    auto load_a = [&](int kt) {
-        const int soff = kt * (BK * 4);
-#pragma unroll
-        for (int t = 0; t < ARG; ++t) {
-            ra[t][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[t], soff, 0));
-            ra[t][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[t] + 16u, soff, 0));
+    // K-tile state, advanced incrementally (no divisions in the loop): filter tap (r, q) and first channel of the chunk
+    struct XK { int tap, r, q, c0; };
+    auto k_next = [&](XK k) -> XK {
+        if constexpr (!CONV) {
+            k.c0 += BK;
+        } else if constexpr (DGRAD) {               // chunk outer, tap inner
+            ++k.tap; ++k.q;
+            if (k.q == g.S) { k.q = 0; ++k.r; }
+            if (k.tap == ntaps) { k.tap = 0; k.r = 0; k.q = 0; k.c0 += BK; }
+        } else {                                    // tap outer, chunk inner
+            k.c0 += BK;
+            if (k.c0 == g.Cg) { k.c0 = 0; ++k.tap; ++k.q; if (k.q == g.S) { k.q = 0; ++k.r; } }
         }
+        return k;
     };
-    auto store_a = [&](int stage) {                                 // exact split x = hi + mid + lo, one 16-byte chunk per plane
-        char* st = lds_raw + stage * STAGE_BYTES + lane * 16;
-#pragma unroll
-        for (int t = 0; t < ARG; ++t) {
-            xu16x8 ph, pm, pl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                unsigned short a, b, c;
-                split3_bf16(ra[t][e >> 2][e & 3], a, b, c);
-                ph[e] = a; pm[e] = b; pl[e] = c;
-            }
-            char* d = st + (wave + NW * t) * 1024;
-            *(xu16x8*)(d) = ph;
-            *(xu16x8*)(d + BM * 64) = pm;
-            *(xu16x8*)(d + 2 * BM * 64) = pl;
+    f32x4 ra[ARG][2];                                               // A of this thread: fp32, waiting for the split
+    auto load_a_group = [&](const XK& k, int t) {
+        unsigned vo = a_voff[t];
+        int soff = k.c0 * 4;
+        if constexpr (CONV) {
+            const long toff = (DGRAD ? -((long)k.r * g.W + k.q) : ((long)k.r * g.W + k.q)) * g.C + k.c0;
+            soff = (int)((DGRAD ? shift + toff : toff) * 4);
+            vo = ((a_mask[t] >> k.tap) & 1u) ? vo : OOB;
         }
+        ra[t][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, vo, soff, 0));
+        ra[t][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, vo + 16u, soff, 0));
     };
-    auto dma_b = [&](int kt, int stage) {
+    auto store_a_group = [&](int stage, int t) {                    // exact split x = hi + mid + lo, one 16-byte chunk per plane
+        xu16x8 ph, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            unsigned short a, b, c;
+            split3_bf16(ra[t][e >> 2][e & 3], a, b, c);
+            ph[e] = a; pm[e] = b; pl[e] = c;
+        }
+        char* d = lds_raw + stage * STAGE_BYTES + lane * 16 + (wave + NW * t) * 1024;
+        *(xu16x8*)(d) = ph;
+        *(xu16x8*)(d + BM * 64) = pm;
+        *(xu16x8*)(d + 2 * BM * 64) = pl;
+    };
+    auto dma_b = [&](const XK& k, int stage) {
         char* st = lds_raw + stage * STAGE_BYTES + A_BYTES;
-        const long sb = (long)kt * (BK * 2);
+        const long sb = k.tap * wtap_bytes + (long)k.c0 * 2;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int t = 0; t < BRG; ++t)
-                x3_dma16(rs_b, st + pl * (BN * 64) + (wave + NW * t) * 1024, b_voff[t], (int)(sb + pl * w_plane_bytes));
+                if (BRT % NW == 0 || wave + NW * t < BRT)           // (narrow tiles: fewer 16-row groups than waves)
+                    x3_dma16(rs_b, st + pl * (BN * 64) + (wave + NW * t) * 1024, b_voff[t], (int)(sb + pl * w_plane_bytes));
     };
 
     // Two accumulator sets (conv_planes.hip): hi*hi in `acc`, the five correction products in `accl`, added once at the end.
@@ -164,21 +217,38 @@ __global__ __launch_bounds__(NWM * 128, MINB) void xgemm_kernel(const float* __r
 #define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
     constexpr int NMMA = MT * NT * 6;                     // MFMAs per half K-tile
     constexpr int NFR = (MT + NT) * 3;                    // fragment reads per half K-tile
-    constexpr int VPS = (ARG * 52 + NMMA - 1) / NMMA;     // VALU instructions of the split per MFMA slot (~52 per row group)
-    auto WQ = [](int t) constexpr { const int q = ((t + 1) * 52 + VPS - 1) / VPS; return q < NMMA - 4 ? q : NMMA - 4; };
-    auto clampk = [&](int kt) { return kt < KT ? kt : KT - 1; };
+    constexpr int VGRP = CONV ? 58 : 52;                  // VALU instructions of one row group's split (+ its masked addresses)
 
-    // ---- prologue: tiles 0 and 1 into the two stages, A(2) on its way into the registers
-    load_a(0);
-    dma_b(0, 0);
-    dma_b(clampk(1), 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");       // A(0) has landed
-    store_a(0);
-    load_a(clampk(1));
+    // ---- STAGGERED row groups.  Row groups [0, GF) of A(kt+2) are split in section F(kt), groups [GF, ARG) in section
+    // B(kt+1) (same target stage: it is free from barrier D(kt) to barrier D(kt+1)); each group's registers are re-loaded
+    // right behind its split, so every load has a whole iteration (two sections) to come back from HBM -- with ARG * 8
+    // staging registers -- and the split's VALU is spread over both sections.
+    //   B(kt):  frag reads (kt, step 1) | split groups [GF, ARG) of A(kt+1) -> stage(kt+1) | reload them from A(kt+2) | MFMAs step 0
+    //   C/D:    lgkmcnt(0); the DMA of B(kt+1) has landed (NA younger loads may be in flight: counted wait, the DMA is
+    //           kept in front of them by a scheduling fence); barrier
+    //   E:      DMA B(kt+2) -> stage(kt)
+    //   F(kt):  frag reads (kt+1, step 0) | split groups [0, GF) of A(kt+2) -> stage(kt) | reload them from A(kt+3) | MFMAs step 1
+    // Program order inside a section = the order LDS accesses must keep (the compiler cannot tell the two stages apart):
+    // fragment READS first, then the split's stores, then the global loads.
+    const XK k0{0, 0, 0, 0};
+    const XK k1 = KT > 1 ? k_next(k0) : k0;                        // (past the end: the last tile again, never used)
+    XK k2 = KT > 2 ? k_next(k1) : k1;
+    XK k3 = KT > 3 ? k_next(k2) : k2;
+#pragma unroll
+    for (int t = 0; t < ARG; ++t) load_a_group(k0, t);
+    dma_b(k0, 0);
+    dma_b(k1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_a(1);
-    load_a(clampk(2));
-    __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): this wave's LDS stores
+#pragma unroll
+    for (int t = 0; t < ARG; ++t) store_a_group(0, t);
+#pragma unroll
+    for (int t = 0; t < ARG; ++t) load_a_group(k1, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < GF; ++t) store_a_group(1, t);              // (groups [GF, ARG) of A(1) stay in registers for B(0))
+#pragma unroll
+    for (int t = 0; t < GF; ++t) load_a_group(k2, t);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): this wave's LDS stores
     __builtin_amdgcn_s_barrier();
     load_frags(0, 0, 0);
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -186,41 +256,53 @@ __global__ __launch_bounds__(NWM * 128, MINB) void xgemm_kernel(const float* __r
         const int stage = kt & 1, nstage = stage ^ 1;
         SBAR();
         load_frags(1, stage, 1);                                  // A
-        mma(0);                                                   // B
 #pragma unroll
-        for (int q = 0; q < NMMA; ++q) { SG(0x008, 1); if (q < NFR) { SG(0x100, 1); SG(0x006, 2); } }
+        for (int t = GF; t < ARG; ++t) { store_a_group(nstage, t); load_a_group(k2, t); }
+        mma(0);                                                   // B
+        {
+            constexpr int VPS = GB ? (GB * VGRP + NMMA - 1) / NMMA + 1 : 2;
+#pragma unroll
+            for (int q = 0; q < NMMA; ++q) {
+                SG(0x008, 1);
+                if (q < NFR) SG(0x100, 1);
+                SG(GB ? 0x002 : 0x006, VPS);
+#pragma unroll
+                for (int t = 0; t < GB; ++t) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int wq = ((t + 1) * VGRP + VPS - 1) / VPS < NMMA - 2 ? ((t + 1) * VGRP + VPS - 1) / VPS : NMMA - 2;
+                    if (q == wq) { SG(0x200, 3); SG(0x020, 2); }
+                }
+            }
+        }
         SBAR();
-        __builtin_amdgcn_s_waitcnt(0xc07f);                       // C: this wave is done with stage(kt), its split stores
-                                                                  //    of tile kt+1 (issued last iteration) are in LDS
-        // the DMA of B(kt+1) and the loads of A(kt+2) were issued one iteration ago (a whole K-tile of MFMAs).  Both are
-        // waited for HERE: the compiler is free to interleave the global loads with the DMA instructions (they do not
-        // alias), so a counted wait for "the DMA but not the loads behind it" raced on the 64x64 tile.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // C
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");  // the DMA of B(kt+1) has landed; A loads may fly on
         __builtin_amdgcn_s_barrier();                             // D: tile kt+1 complete in LDS, stage(kt) free
         SBAR();
-        // (program order = the order the LDS / memory instructions must keep among themselves -- the compiler cannot tell
-        //  the two stages apart: fragment READS of stage(kt+1) first, then the split's stores into stage(kt), the DMA, the
-        //  global loads; with the reads behind the stores every VALU of the split had to precede the first read, i.e. ran
-        //  with the matrix pipe idle)
+        dma_b(k2, stage);                                         // E (fenced: stays in front of the loads of section F)
+        SBAR();
         load_frags(0, nstage, 0);
-        store_a(stage);                                           // E: split -> LDS (VALU in the MFMAs' shadow)
-        dma_b(clampk(kt + 2), stage);
-        load_a(clampk(kt + 3));
+#pragma unroll
+        for (int t = 0; t < GF; ++t) { store_a_group(stage, t); load_a_group(k3, t); }
         mma(1);                                                   // F
+        {
+            constexpr int VPS = (GF * VGRP + NMMA - 1) / NMMA + 1;
 #pragma unroll
-        for (int q = 0; q < NMMA; ++q) {
-            // per MFMA slot: VPS VALU of the split; the DMA of B early (no dependence); row group t's three LDS stores
-            // once its ~52 VALU are through; the global loads of A(kt+3) behind the last group (they overwrite `ra`)
-            SG(0x008, 1);
-            if (q < NFR) SG(0x100, 1);                            // fragment reads of (kt+1, step 0)
-            SG(0x002, VPS);
+            for (int q = 0; q < NMMA; ++q) {
+                SG(0x008, 1);
+                if (q < NFR) SG(0x100, 1);
+                SG(0x002, VPS);
 #pragma unroll
-            for (int t = 0; t < ARG; ++t)
-                if (q >= WQ(t) && q < WQ(t) + 3) SG(0x200, 1);
-            if (q >= WQ(ARG - 1) + 1) SG(0x020, (NB + NA + NMMA - WQ(ARG - 1) - 2) / (NMMA - WQ(ARG - 1) - 1));
+                for (int t = 0; t < GF; ++t) {
+                    const int wq = ((t + 1) * VGRP + VPS - 1) / VPS < NMMA - 2 ? ((t + 1) * VGRP + VPS - 1) / VPS : NMMA - 2;
+                    if (q == wq) { SG(0x200, 3); SG(0x020, 2); }
+                }
+            }
         }
         SBAR();
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        k2 = k3;
+        if (kt + 4 < KT) k3 = k_next(k3);
     }
 #undef SBAR
 #undef SG
@@ -230,44 +312,59 @@ __global__ __launch_bounds__(NWM * 128, MINB) void xgemm_kernel(const float* __r
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] += accl[i][j];
-    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, 0, mt_id, &fz);
+    igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
 }
 
-template <int BM, int BN, int NWM, int MINB, bool DGRAD>
+template <int BM, int BN, int NWM, int NWN, int MINB, bool DGRAD, bool CONV>
 static void launch_x3(const float* a, const void* w, long w_pe, const float* bias, const float* addend, float* dst,
                       double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz) {
     const int mtiles = sc_cdiv(g.M, BM), ntiles = g.Ng / BN;
+    ConvGeom gg = g;
+    gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
+    gg.inv_wo = 1.0f / (float)g.Wo;
+    gg.inv_ho = 1.0f / (float)g.Ho;
     constexpr int STAGE_BYTES = 3 * (BM + BN) * 64;
-    constexpr int EPI_BYTES = 2 * NWM * (BM / NWM) * (BN / 2 + 4) * 4;
+    constexpr int EPI_BYTES = NWM * NWN * (BM / NWM) * (BN / NWN + 4) * 4;
     const size_t lds = (size_t)(2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES);
-    auto kern = xgemm_kernel<BM, BN, NWM, MINB, DGRAD>;
+    auto kern = xgemm_kernel<BM, BN, NWM, NWN, MINB, DGRAD, CONV>;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(NWM * 128), lds, st, a, (const unsigned short*)w, w_pe, bias, addend,
-                       dst, bn_part, g, relu, mtiles, ntiles, fz);
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles * g.groups), dim3(NWM * NWN * 64), lds, st, a, (const unsigned short*)w, w_pe,
+                       bias, addend, dst, bn_part, gg, relu, mtiles, ntiles, fz);
 }
 
-static int x3_tile_rows(int tile) { return tile == 0 ? 256 : (tile == 3 ? 64 : 128); }
-static bool x3_tile_ok(int tile, int N) {       // 0: 256x128 (8 waves)  1: 128x128  2: 128x64  3: 64x64
-    return (tile == 0 || tile == 1) ? N % 128 == 0 : ((tile == 2 || tile == 3) && N % 64 == 0);
+// block tiles: 0 = 256x128 (eight waves), 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64 (eight waves), 5 = 256x32 (four
+// waves along M), 6 = 128x32 (two waves, two workgroups per CU: the 32-channel layers with a heavy epilogue)
+static int x3_tile_rows(int tile) { return (tile == 0 || tile == 4 || tile == 5) ? 256 : (tile == 3 ? 64 : 128); }
+static bool x3_tile_ok(int tile, int N) {
+    switch (tile) {
+        case 0: case 1: return N % 128 == 0;
+        case 2: case 3: case 4: return N % 64 == 0;
+        case 5: case 6: return N % 32 == 0;
+        default: return false;
+    }
 }
 static int x3_tile(long M, int N, int hint) {
-    if (hint >= 0 && hint <= 3 && x3_tile_ok(hint, N)) return hint;
+    if (hint >= 0 && hint <= 6 && x3_tile_ok(hint, N)) return hint;
+    if (N % 64 != 0) return 6;
     // enough 256 x 128 tiles for two rounds of the chip, else the 128-row tiles (two workgroups per CU)
     if (N % 128 == 0 && (long)sc_cdiv(M, 256) * (N / 128) >= 448) return 0;
     return 2;
 }
-template <bool DGRAD>
+template <bool DGRAD, bool CONV>
 static int dispatch_x3(const float* a, const void* w, long w_pe, const float* bias, const float* addend, float* dst,
                        double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st, const BnBwdFuse& fz) {
     switch (tile) {
-        case 0: launch_x3<256, 128, 4, 1, DGRAD>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
-        case 1: launch_x3<128, 128, 2, 1, DGRAD>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
-        case 2: launch_x3<128, 64, 2, 2, DGRAD>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
-        default: launch_x3<64, 64, 2, 3, DGRAD>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 0: launch_x3<256, 128, 4, 2, 1, DGRAD, CONV>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 1: launch_x3<128, 128, 2, 2, 1, DGRAD, CONV>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 2: launch_x3<128, 64, 2, 2, 2, DGRAD, CONV>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 3: launch_x3<64, 64, 2, 2, 3, DGRAD, CONV>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 4: launch_x3<256, 64, 4, 2, 1, DGRAD, CONV>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        case 5: launch_x3<256, 32, 4, 1, 1, DGRAD, CONV>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
+        default: launch_x3<128, 32, 2, 1, 2, DGRAD, CONV>(a, w, w_pe, bias, addend, dst, bn_part, g, relu, st, fz); break;
     }
     return sc_check_launch(DGRAD ? "conv2d_dgrad_x3" : "conv2d_fwd_x3");
 }
@@ -277,41 +374,54 @@ extern "C" int scouter_conv2d_x3_partial_rows(long M, int N, int tile_hint) {
     return sc_cdiv(M, x3_tile_rows(x3_tile(M, N, tile_hint)));
 }
 
+// kh x kw: 1x1 (pad 0) or an odd "same" filter (pad = (k - 1) / 2), stride 1; groups with 32-multiples of channels per group
 extern "C" int scouter_conv2d_fwd_x3(const float* x, const void* w_planes_fwd, const float* bias, const float* addend, float* y,
-                                     double* bn_partial, int B, int H, int W, int Cin, int Cout, int relu, int tile_hint,
-                                     void* stream) {
+                                     double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad,
+                                     int groups, int relu, int tile_hint, void* stream) {
     SC_REQUIRE(x && w_planes_fwd && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_x3: null pointer or empty shape");
     SC_REQUIRE(!(bn_partial && relu), "conv2d_fwd_x3: fused BatchNorm statistics are taken before any activation");
-    SC_UNSUPPORTED(Cin % 32 == 0 && Cin >= 64 && Cout % 64 == 0, "conv2d_fwd_x3: needs Cin %% 32 == 0, Cin >= 64, Cout %% 64 == 0");
-    ConvGeom g{B, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1, Cin, Cout, 0, Cout, Cin * Cout};
+    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_fwd_x3: channels not divisible by groups");
+    const int Cg = Cin / groups, Ng = Cout / groups;
+    SC_UNSUPPORTED(kh == kw && (kh & 1) && 2 * pad == kh - 1 && kh <= 5, "conv2d_fwd_x3: 1x1 or odd same-size filters only");
+    SC_UNSUPPORTED(Cg % 32 == 0 && Ng % 32 == 0 && kh * kw * (Cg / 32) >= 2, "conv2d_fwd_x3: needs 32-multiples of channels per group and two K-tiles");
+    ConvGeom g{B, H, W, Cin, H, W, Cout, kh, kw, 1, pad, groups, Cg, Ng, 0, Cout, Cg * Cout};
     g.M = (long)B * H * W;
-    SC_UNSUPPORTED(g.M < (1L << 31) && (long)Cin * Cout * 2 * 3 < (1L << 31) && 256L * Cin * 4 < (1L << 31),
-                   "conv2d_fwd_x3: tensor too large for 32-bit offsets");
-    const int tile = x3_tile(g.M, Cout, tile_hint);
-    ScProfScope prof("xconv_fwd<bf16x3>", (hipStream_t)stream, 2.0 * g.M * Cout * Cin, 4.0 * g.M * Cin + 4.0 * g.M * Cout);
-    return dispatch_x3<false>(x, w_planes_fwd, (long)Cin * Cout, bias, addend, y, bn_partial, g, relu, tile,
-                              (hipStream_t)stream, BnBwdFuse{});
+    SC_UNSUPPORTED(g.M < (1L << 31) && (long)kh * kw * Cg * Cout * 2 * 3 < (1L << 31) && (long)H * W * Cin < (1L << 28) &&
+                   256L * Cin * 4 < (1L << 31), "conv2d_fwd_x3: tensor too large for 32-bit offsets");
+    const int tile = x3_tile(g.M, Ng, tile_hint);
+    const bool conv = kh > 1 || groups > 1;
+    ScProfScope prof(conv ? "xconv3_fwd<bf16x3>" : "xconv_fwd<bf16x3>", (hipStream_t)stream, 2.0 * g.M * Cout * Cg * kh * kw,
+                     4.0 * g.M * Cin + 4.0 * g.M * Cout);
+    const long w_pe = (long)kh * kw * Cg * Cout;
+    if (conv) return dispatch_x3<false, true>(x, w_planes_fwd, w_pe, bias, addend, y, bn_partial, g, relu, tile, (hipStream_t)stream, BnBwdFuse{});
+    return dispatch_x3<false, false>(x, w_planes_fwd, w_pe, bias, addend, y, bn_partial, g, relu, tile, (hipStream_t)stream, BnBwdFuse{});
 }
 
-// dx[M][Cin] = dy[M][Cout] * W^T (+ addend), optionally with the BatchNorm-backward epilogue of conv_common.h
+// dx = dy (*) W^T (+ addend), optionally with the BatchNorm-backward epilogue of conv_common.h
 extern "C" int scouter_conv2d_dgrad_x3_bnbwd(const float* dy, const void* w_planes_dgrad, const float* addend, float* dx, int B,
-                                             int H, int W, int Cin, int Cout, int tile_hint, const void* relu_mask,
-                                             const float* x1, const float* saved1, double* part1, const float* x2,
-                                             const float* saved2, double* part2, void* stream) {
+                                             int H, int W, int Cin, int Cout, int kh, int kw, int pad, int groups, int tile_hint,
+                                             const void* relu_mask, const float* x1, const float* saved1, double* part1,
+                                             const float* x2, const float* saved2, double* part2, void* stream) {
     SC_REQUIRE(dy && w_planes_dgrad && dx && B > 0 && H > 0 && W > 0, "conv2d_dgrad_x3: null pointer or empty shape");
     SC_REQUIRE(!part1 || (x1 && saved1), "conv2d_dgrad_x3: fused BatchNorm backward needs x1 and saved1");
     SC_REQUIRE(!part2 || (part1 && x2 && saved2), "conv2d_dgrad_x3: second fused BatchNorm needs the first, x2 and saved2");
-    SC_UNSUPPORTED(Cout % 32 == 0 && Cout >= 64 && Cin % 64 == 0, "conv2d_dgrad_x3: needs Cout %% 32 == 0, Cout >= 64, Cin %% 64 == 0");
-    ConvGeom g{B, H, W, Cout, H, W, Cin, 1, 1, 1, 0, 1, Cout, Cin, 0, Cout, Cin * Cout};
+    SC_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_dgrad_x3: channels not divisible by groups");
+    const int Cig = Cin / groups, Cog = Cout / groups;
+    SC_UNSUPPORTED(kh == kw && (kh & 1) && 2 * pad == kh - 1 && kh <= 5, "conv2d_dgrad_x3: 1x1 or odd same-size filters only");
+    SC_UNSUPPORTED(Cog % 32 == 0 && Cig % 32 == 0 && kh * kw * (Cog / 32) >= 2, "conv2d_dgrad_x3: needs 32-multiples of channels per group and two K-tiles");
+    ConvGeom g{B, H, W, Cout, H, W, Cin, kh, kw, 1, pad, groups, Cog, Cig, 0, Cout, Cig * Cout};
     g.M = (long)B * H * W;
-    SC_UNSUPPORTED(g.M < (1L << 31) && (long)Cin * Cout * 2 * 3 < (1L << 31) && 256L * Cout * 4 < (1L << 31),
-                   "conv2d_dgrad_x3: tensor too large for 32-bit offsets");
-    const int tile = x3_tile(g.M, Cin, tile_hint);
-    ScProfScope prof(part1 ? "xconv_dgrad+bn_bwd<bf16x3>" : "xconv_dgrad<bf16x3>", (hipStream_t)stream, 2.0 * g.M * Cin * Cout,
-                     4.0 * g.M * Cout + 4.0 * g.M * Cin);
+    SC_UNSUPPORTED(g.M < (1L << 31) && (long)kh * kw * Cig * Cout * 2 * 3 < (1L << 31) && (long)H * W * Cout < (1L << 28) &&
+                   256L * Cout * 4 < (1L << 31), "conv2d_dgrad_x3: tensor too large for 32-bit offsets");
+    const int tile = x3_tile(g.M, Cig, tile_hint);
+    const bool conv = kh > 1 || groups > 1;
+    ScProfScope prof(part1 ? (conv ? "xconv3_dgrad+bn_bwd<bf16x3>" : "xconv_dgrad+bn_bwd<bf16x3>")
+                           : (conv ? "xconv3_dgrad<bf16x3>" : "xconv_dgrad<bf16x3>"),
+                     (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw, 4.0 * g.M * Cout + 4.0 * g.M * Cin);
     const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, x1, saved1, part1, x2, saved2, part2, 0};
-    return dispatch_x3<true>(dy, w_planes_dgrad, (long)Cin * Cout, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream,
-                             fz);
+    const long w_pe = (long)kh * kw * Cig * Cout;
+    if (conv) return dispatch_x3<true, true>(dy, w_planes_dgrad, w_pe, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream, fz);
+    return dispatch_x3<true, false>(dy, w_planes_dgrad, w_pe, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream, fz);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -103,19 +103,26 @@ class GraphedTrainStep:
             self._restore(snap)
         return 0 if snap is not None else self.warmup
 
+    def _named_state(self):
+        named = dict(self.model.named_parameters())
+        named.update(dict(self.model.named_buffers()))
+        return named
+
     def _snapshot(self):
-        tensors = [t for t in list(self.model.parameters()) + list(self.model.buffers())]
         opt = {}
         for key, st in self.optimizer.state.items():
             if isinstance(key, str) and key.startswith("_flat_"):
                 opt[key] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
-        return [t.detach().clone() for t in tensors], tensors, opt
+        return {k: t.detach().clone() for k, t in self._named_state().items()}, opt
 
     def _restore(self, snap):
-        copies, tensors, opt = snap
+        copies, opt = snap
+        # by NAME, into the tensors the model holds NOW: the first training forward re-points the BatchNorm step counters
+        # at views of one flat buffer (SlotModel._bump_tracked), so the tensor objects of the snapshot may be stale
+        live = self._named_state()
         with torch.no_grad():
-            for t, c in zip(tensors, copies):
-                t.copy_(c)                                   # in place: the graph holds these addresses
+            for k, c in copies.items():
+                live[k].copy_(c)                             # in place: the graph holds these addresses
             for gi, group in enumerate(self.optimizer.param_groups):
                 key = "_flat_%d" % gi
                 st = self.optimizer.state.get(key)

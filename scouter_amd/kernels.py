@@ -650,77 +650,94 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
     return dx
 
 
-# ---- pointwise convolutions on the bf16 matrix cores, operand split in registers (csrc/conv_x3.hip)
-# Which 1x1 layers take it is a STATIC function of the layer's channels (never of timing or of the batch): the forward
-# stays a function of the layer shapes, whatever the batch size / process / data-parallel rank.  Measured per layer
-# (tools_dev/x3_bench.py): the layers with Cin * Cout >= 2^16 -- every 1x1 of layer2-4 -- gain, the short-K 56 x 56
-# layers are HBM-co-bound and stay on the persistent fp32 kernel.  SCOUTER_X3=0: every 1x1 on the fp32 MFMA kernels.
-X3_DEFAULT = int(os.environ.get("SCOUTER_X3", "3"))       # bit 0: forward, bit 1: input gradient, bit 2: fused input gradient, bit 3: weight gradient
+# ---- convolutions on the bf16 matrix cores, operand split in registers (csrc/conv_x3.hip)
+# Which layers take it is a STATIC function of the layer's shape (never of timing or of the batch): the forward stays a
+# function of the layer shapes, whatever the batch size / process / data-parallel rank.  Measured per layer
+# (tools_dev/x3_bench.py): the 1x1 layers with Cin * Cout >= 2^16 -- every 1x1 of layer2-4 -- gain, the short-K 56 x 56
+# layers are HBM-co-bound and stay on the persistent fp32 kernel; of the 3x3 layers those with 32 channels per group (the
+# deep stem, the first radix convolution) -- the plane kernels need 64 -- ran on the fp32 MFMA kernels until round 5.
+# SCOUTER_X3 bits: 0 forward, 1 plain input gradient, 2 fused input gradient (1x1 layers; measured slower on the 28 x 28
+# layers, off), 3 weight gradient (1x1), 4 the forward of the 3x3 layers of x3_conv_eligible; 0: everything on the fp32
+# MFMA kernels.
+X3_DEFAULT = int(os.environ.get("SCOUTER_X3", "27"))
 X3_MIN_CHANNEL_PRODUCT = 1 << 16
-_X3_TILES = (0, 1, 2, 3)
+_X3_TILES = (0, 1, 2, 3, 4, 5, 6)
 
 
 def x3_eligible(cin, cout, kh, kw, stride, pad, groups, has_bias):
-    """Layer shapes the register-split bf16x3 GEMM serves, forward AND input gradient (both GEMM widths 64-multiples)."""
+    """Pointwise layers the register-split bf16x3 GEMM serves, forward AND input gradient (both GEMM widths 64-multiples)."""
     return bool(kh == 1 and kw == 1 and stride == 1 and pad == 0 and groups == 1 and not has_bias and
                 cin % 64 == 0 and cout % 64 == 0 and cin * cout >= X3_MIN_CHANNEL_PRODUCT)
 
 
+def x3_conv_eligible(cin, cout, kh, kw, stride, pad, groups, has_bias):
+    """3x3 / stride 1 / pad 1 layers with 32 input channels per group and 64-multiples of output channels per group: the
+    FORWARD runs on the register-split kernel (the stem's 32 -> 64 convolution: 308 -> 233 us at batch 70).  Measured and
+    left on the fp32 MFMA kernels (tools_dev/tune_x3.py): everything with 32 OUTPUT columns per group -- the 32 -> 32 stem
+    convolution and every input gradient of these layers -- where one split (6.5 VALU per element) feeds a single 32-column
+    MFMA block: 8 VALU per MFMA, 0.64-0.77x the fp32 kernel."""
+    return bool(kh == 3 and kw == 3 and stride == 1 and pad == 1 and not has_bias and cin % groups == 0 and
+                cout % groups == 0 and cin // groups == 32 and (cout // groups) % 64 == 0)
+
+
 def _x3_tile_ok(t, n):
-    return n % 128 == 0 if t in (0, 1) else n % 64 == 0
+    return n % 128 == 0 if t in (0, 1) else (n % 64 == 0 if t in (2, 3, 4) else (n % 32 == 0 and t in (5, 6)))
 
 
-def conv2d_fwd_x3(x, wf, addend=None, relu=False, bn_stats=False, tile=None):
-    """x: fp32 NHWC [B, H, W, Cin]; wf: forward weight planes [3, 1, Cout, Cin] (planes_split_weight).  Returns y or
-    (y, (partial, rows)) like conv2d_fwd.  Every tile gives the same bits; the choice comes from the static table."""
+def conv2d_fwd_x3(x, wf, addend=None, relu=False, bn_stats=False, tile=None, kh=1, pad=0, groups=1):
+    """x: fp32 NHWC [B, H, W, Cin]; wf: forward weight planes [3, kh*kh, Cout, Cin/groups] (planes_split_weight).  Returns
+    y or (y, (partial, rows)) like conv2d_fwd.  Every tile gives the same bits; the choice comes from the static table."""
     _chk(x, "x"); _chk(addend, "addend")
     B, H, W, Cin = x.shape
     Cout = wf.shape[2]
-    assert wf.dtype == BF16 and wf.shape[0] == 3 and wf.shape[3] == Cin, (tuple(wf.shape), tuple(x.shape))
+    assert wf.dtype == BF16 and wf.shape[0] == 3 and wf.shape[1] == kh * kh and wf.shape[3] * groups == Cin, \
+        (tuple(wf.shape), tuple(x.shape))
     L = _native.lib()
     y = torch.empty((B, H, W, Cout), dtype=F32, device=x.device)
-    M = B * H * W
+    M, Ng = B * H * W, Cout // groups
     scratch = [None]
 
     def launch(t, dry=False, part=None):
         if dry:
-            return _x3_tile_ok(t, Cout)
+            return _x3_tile_ok(t, Ng)
         if bn_stats and part is None:
             if scratch[0] is None:
                 scratch[0] = torch.empty(((M + 63) // 64, Cout, 2), dtype=torch.float64, device=x.device)
             part = scratch[0]
-        _native.check(L.scouter_conv2d_fwd_x3(_p(x), _p(wf), None, _p(addend), _p(y), _p(part), B, H, W, Cin, Cout,
-                                              int(relu), t, _stream()), "conv2d_fwd_x3")
+        _native.check(L.scouter_conv2d_fwd_x3(_p(x), _p(wf), None, _p(addend), _p(y), _p(part), B, H, W, Cin, Cout, kh, kh,
+                                              pad, groups, int(relu), t, _stream()), "conv2d_fwd_x3")
         return True
     if tile is None:
-        tile = _pick_tile(("xfwd", 3, B, H, W, Cin, Cout), launch, _X3_TILES)
-    tile = L.scouter_conv2d_x3_tile(M, Cout, tile)
+        key = ("xfwd", 3, B, H, W, Cin, Cout) if kh == 1 and groups == 1 else ("xfwd", 3, B, H, W, Cin, Cout, kh, groups)
+        tile = _pick_tile(key, launch, _X3_TILES)
+    tile = L.scouter_conv2d_x3_tile(M, Ng, tile)
     part, rows = None, 0
     if bn_stats:
-        rows = L.scouter_conv2d_x3_partial_rows(M, Cout, tile)
+        rows = L.scouter_conv2d_x3_partial_rows(M, Ng, tile)
         part = torch.empty((rows, Cout, 2), dtype=torch.float64, device=x.device)
     launch(tile, part=part)
     return (y, (part, rows)) if bn_stats else y
 
 
-def conv2d_dgrad_x3(dy, wd, x_shape, addend=None, post=None, tile=None):
-    """dy: fp32 NHWC [B, H, W, Cout]; wd: input-gradient weight planes [3, 1, Cin, Cout].  post (BnBwdFuse): as
-    conv2d_dgrad -- fused when bit 2 of SCOUTER_X3 is set and every BatchNorm input is fp32."""
+def conv2d_dgrad_x3(dy, wd, x_shape, addend=None, post=None, tile=None, kh=1, pad=0, groups=1):
+    """dy: fp32 NHWC [B, H, W, Cout]; wd: input-gradient weight planes [3, kh*kh, Cin, Cout/groups].  post (BnBwdFuse): as
+    conv2d_dgrad -- fused when SCOUTER_BN_FUSE wants it and every BatchNorm input is fp32."""
     _chk(dy, "dy"); _chk(addend, "addend")
     B, H, W, Cin = x_shape
     Cout = dy.shape[-1]
-    assert wd.dtype == BF16 and wd.shape[0] == 3 and wd.shape[2] == Cin and wd.shape[3] == Cout
+    assert wd.dtype == BF16 and wd.shape[0] == 3 and wd.shape[1] == kh * kh and wd.shape[2] == Cin and wd.shape[3] * groups == Cout
     L = _native.lib()
     dx = torch.empty(x_shape, dtype=F32, device=dy.device)
-    M = B * H * W
+    M, Ng = B * H * W, Cin // groups
+    shape_key = (B, H, W, Cin, Cout) if kh == 1 and groups == 1 else (B, H, W, Cin, Cout, kh, groups)
 
     def launch(t, dry=False, fuse=_NO_FUSE):
         if dry:
-            return _x3_tile_ok(t, Cin)
-        _native.check(L.scouter_conv2d_dgrad_x3_bnbwd(_p(dy), _p(wd), _p(addend), _p(dx), B, H, W, Cin, Cout, t, *fuse,
-                                                      _stream()), "conv2d_dgrad_x3")
+            return _x3_tile_ok(t, Ng)
+        _native.check(L.scouter_conv2d_dgrad_x3_bnbwd(_p(dy), _p(wd), _p(addend), _p(dx), B, H, W, Cin, Cout, kh, kh, pad,
+                                                      groups, t, *fuse, _stream()), "conv2d_dgrad_x3")
         return True
-    fused = _fuse_wanted(post, 1) and post.x_io() == 0
+    fused = _fuse_wanted(post, kh) and post.x_io() == 0
     if fused:
         def launch_fused(t, dry=False):
             if dry:
@@ -729,15 +746,14 @@ def conv2d_dgrad_x3(dy, wd, x_shape, addend=None, post=None, tile=None):
                 post.alloc((M + 63) // 64, x_shape)
             return launch(t, fuse=post.args())
         if tile is None:
-            tile = _pick_tile(("xdgrad+bn", len(post.entries), addend is not None, 3, B, H, W, Cin, Cout), launch_fused,
-                              _X3_TILES)
-        tile = L.scouter_conv2d_x3_tile(M, Cin, tile)
-        post.alloc(L.scouter_conv2d_x3_partial_rows(M, Cin, tile), x_shape)
+            tile = _pick_tile(("xdgrad+bn", len(post.entries), addend is not None, 3) + shape_key, launch_fused, _X3_TILES)
+        tile = L.scouter_conv2d_x3_tile(M, Ng, tile)
+        post.alloc(L.scouter_conv2d_x3_partial_rows(M, Ng, tile), x_shape)
         launch(tile, fuse=post.args())
     else:
         if tile is None:
-            tile = _pick_tile(("xdgrad", 3, B, H, W, Cin, Cout), launch, _X3_TILES)
-        launch(L.scouter_conv2d_x3_tile(M, Cin, tile))
+            tile = _pick_tile(("xdgrad", 3) + shape_key, launch, _X3_TILES)
+        launch(L.scouter_conv2d_x3_tile(M, Ng, tile))
     return dx
 
 

@@ -58,15 +58,29 @@ class Conv2d(nn.Module):
         return K.x3_eligible(self.in_channels, self.out_channels, k, k, self.stride, self.padding, self.groups,
                              self.bias is not None)
 
+    def x3_conv_static(self):
+        """Shape rule alone (kernels.x3_conv_eligible): 3x3 / stride 1 / pad 1 with 32 channels per group."""
+        k = self.kernel_size
+        return K.x3_conv_eligible(self.in_channels, self.out_channels, k, k, self.stride, self.padding, self.groups,
+                                  self.bias is not None)
+
     def x3_mode(self):
-        """Bits of `x3` this layer uses now: fp32 precision, no plane operands, and the static shape rule; 0 otherwise."""
-        return self.x3 if (self.x3 and not self.planes and self.precision == "fp32" and self.x3_static()) else 0
+        """Bits of `x3` this layer uses now (fp32 precision only): bits 0-3 for a pointwise layer under the static shape
+        rule (and no plane operands), 16 for a 3x3 layer with 32-channel groups and no plane operands (forward only:
+        kernels.x3_conv_eligible); 0 otherwise."""
+        if not self.x3 or self.precision != "fp32":
+            return 0
+        if not self.planes and self.x3_static():
+            return self.x3 & 15
+        if (self.x3 & 16) and not self.planes and self.x3_conv_static():
+            return 16
+        return 0
 
     def _x3_weights(self, want_fwd, want_dgrad):
         ws, self._wsplit = self._wsplit, None
         if ws is not None and (ws[0] is not None or not want_fwd) and (ws[1] is not None or not want_dgrad):
             return ws
-        return K.planes_split_weight(K.hwio(self.weight), 1, 3, fwd=want_fwd, dgrad=want_dgrad)
+        return K.planes_split_weight(K.hwio(self.weight), self.groups, 3, fwd=want_fwd, dgrad=want_dgrad)
 
     # ---- bf16x3 operand planes (csrc/conv_planes.hip): the producer of this layer's input hands over a K.PlaneTensor
     def _nplanes(self):
@@ -157,11 +171,12 @@ class Conv2d(nn.Module):
             return y, ((x.f32 if x.f32 is not None else tuple(x.shape), wd,
                         x.planes if self.planes_wgrad() or x.f32 is None else None) if save else None)
         xm = self.x3_mode()
-        if (xm & 7) and x.dtype == K.F32 and out_dtype in (None, K.F32):
+        if (xm & 23) and x.dtype == K.F32 and out_dtype in (None, K.F32):
             want_wd = bool(save and (xm & 6))
-            wf, wd = self._x3_weights(bool(xm & 1), want_wd) if ((xm & 1) or want_wd) else (None, None)
-            if xm & 1:
-                y = K.conv2d_fwd_x3(x, wf, addend, relu, bn_stats)
+            wf, wd = self._x3_weights(bool(xm & 17), want_wd) if ((xm & 17) or want_wd) else (None, None)
+            if xm & 17:
+                k = self.kernel_size
+                y = K.conv2d_fwd_x3(x, wf, addend, relu, bn_stats, kh=k, pad=self.padding, groups=self.groups)
             else:
                 y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
                                  bn_stats, precision=self.precision)
@@ -221,9 +236,10 @@ class Conv2d(nn.Module):
         if self.x3_mode() and wd is not None and dyp is None and dy is not None and dy.dtype == K.F32:
             # pointwise layer on the register-split bf16x3 GEMM (x3_mode): plain input gradient (bit 1), or with the
             # fused BatchNorm-backward epilogue (bit 2)
-            fused = post is not None and K._fuse_wanted(post, 1) and post.x_io() == 0
-            if (self.x3 & 4) if fused else (self.x3 & 2):
-                return K.conv2d_dgrad_x3(dy, wd, xshape, addend, post=post)
+            xm, k = self.x3_mode(), self.kernel_size
+            fused = post is not None and K._fuse_wanted(post, k) and post.x_io() == 0
+            if (xm & 4) if fused else (xm & 2):
+                return K.conv2d_dgrad_x3(dy, wd, xshape, addend, post=post, kh=k, pad=self.padding, groups=self.groups)
         return K.conv2d_dgrad(dy, K.hwio(self.weight), xshape, addend, self.stride, self.padding, self.groups,
                               precision=self.precision, post=post, out_dtype=dx_dtype or K.F32)
 

@@ -148,18 +148,24 @@ class SlotModel(nn.Module):
                 mod.conv.planes = nplanes
         self._plane_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and m.planes]
         self._wsplitter = K.PlaneWeightSplitter()
+        self._refresh_x3()
 
     def set_x3(self, bits):
         """Deep pointwise (1x1) convolutions of the backbone on the register-split bf16x3 GEMM (csrc/conv_x3.hip: fp32
         tensors in and out, fp32-grade products on the bf16 matrix cores): bit 0 forward, bit 1 plain input gradient, bit 2
-        input gradient with the fused BatchNorm-backward epilogue, bit 3 weight gradient; 0: the exact-fp32 MFMA kernels.  Which layers qualify
+        input gradient with the fused BatchNorm-backward epilogue, bit 3 weight gradient, bit 4 the forward of the 3x3
+        layers with 32 input channels per group (kernels.x3_conv_eligible: the stem's 32 -> 64 convolution); 0: the exact-fp32 MFMA kernels.  Which layers qualify
         is a static function of their channels (kernels.x3_eligible), so the forward does not depend on batch or timing."""
-        if bits & ~15:
-            raise ValueError("x3 bits must be within 0..15")
+        if bits & ~31:
+            raise ValueError("x3 bits must be within 0..31")
         for mod in self.backbone.modules():
             if isinstance(mod, Conv2d) and not isinstance(mod, StemConv2d):
                 mod.x3 = int(bits)
-        self._x3_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and m.x3 and m.x3_static()]
+        self._refresh_x3()
+
+    def _refresh_x3(self):
+        self._x3_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and getattr(m, "x3", 0) and
+                          not m.planes and (m.x3_static() or m.x3_conv_static())]
 
     def set_side_stream(self, enabled):
         """Weight gradients on the side stream (default) or serially on the compute stream (per-kernel timing)."""
@@ -245,8 +251,8 @@ class SlotModel(nn.Module):
         items = [(K.hwio(c.weight), c.groups, True, bool(save and c.planes_dy())) for c in convs]
         # (the pointwise layers on the register-split GEMM take three WEIGHT planes too -- same launch; fp32 mode only)
         xconvs = [c for c in getattr(self, "_x3_convs", ()) if c.x3_mode()] if (not convs or convs[0]._nplanes() == 3) else []
-        xconvs = [c for c in xconvs if (c.x3 & 1) or (save and (c.x3 & 6))]
-        items += [(K.hwio(c.weight), 1, bool(c.x3 & 1), bool(save and (c.x3 & 6))) for c in xconvs]
+        xconvs = [c for c in xconvs if (c.x3_mode() & 17) or (save and (c.x3_mode() & 6))]
+        items += [(K.hwio(c.weight), c.groups, bool(c.x3_mode() & 17), bool(save and (c.x3_mode() & 6))) for c in xconvs]
         if items:      # this step's weight planes of every plane convolution: one launch into persistent buffers ...
             # ... on its own stream NEXT TO the stem's kernels (the stem reads no planes; MFMA-bound next to a byte-moving
             # pass): the backbone joins it after the max-pool (`_post_stem_hooks`).  SCOUTER_SPLIT_ASYNC=0: on the compute stream

@@ -62,11 +62,11 @@ def _one_step(net, model, images, labels, lr=1e-3):
     return out.detach().cpu(), float(losses[0]), grads.cpu(), params
 
 
-def _worker(rank, port, outdir):
+def _worker(rank, port, outdir, backend="gloo"):
     import torch.distributed as dist
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)          # RCCL: one rank per device; gloo: both on cuda:0
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=WORLD)
     try:
         from oracle import torch_oracle as O
         from scouter_amd.parallel import DistributedDataParallel
@@ -78,7 +78,7 @@ def _worker(rank, port, outdir):
                 for b in model.buffers():
                     if b.dtype.is_floating_point:
                         b.add_(0.25)
-        net = DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
+        net = DistributedDataParallel(model, device_ids=[torch.cuda.current_device()], find_unused_parameters=True)
         after_ctor = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
         if rank != 0:                      # diverge the running statistics again: re-broadcast before each forward
             with torch.no_grad():
@@ -162,6 +162,47 @@ def test_world2_real_backward_matches_single_process_and_oracle(tmp_path):
         assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
         checked += 1
     assert checked >= 60
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices: RCCL refuses two ranks on one device")
+def test_world2_over_rccl_on_two_devices(tmp_path):
+    """The same world-2 step over the PRODUCTION backend (torch.distributed 'nccl' == RCCL over xGMI), one rank per device
+    (the single-GPU lease skips it): both ranks end with bit-identical reduced gradients and parameters,
+    the rank-mean gradient equals one process's full-batch gradient, and `bench.py --gpus 2` launches its own two ranks and
+    reports the group size RCCL ran with.  Reference: train.py:139-141 (DDP over the launcher's ranks)."""
+    import json
+    import subprocess
+    import sys
+    import torch.multiprocessing as mp
+    from oracle import torch_oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, port, str(tmp_path), "nccl")) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, "rank process failed (exit code %s)" % p.exitcode
+    r0, r1 = (torch.load(tmp_path / ("rank%d.pt" % r), weights_only=False) for r in range(WORLD))
+    assert torch.equal(r0["grads"], r1["grads"])
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+    model, P = _build()
+    images, labels = O.synth_batch(BATCH, 1, IMG, 10, 310)
+    out, loss, grads, params = _one_step(model, model, images.cuda(), labels.cuda())
+    np.testing.assert_allclose(0.5 * (r0["loss"] + r1["loss"]), loss, rtol=2e-6)
+    for name, p, off, n in model.grad_arena().entries:
+        a, b = r0["grads"][off:off + n], grads[off:off + n]
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (name, float((a - b).abs().max()), scale)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "1", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-prof"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["data_parallel"]["rccl_ranks"] == 2 and line["data_parallel"]["backend"] == "nccl"
+    assert line["data_parallel"]["buckets"] == 5 and line["scaling"] == "weak"
 
 
 def test_world2_buckets_are_launched_per_stage_during_backward():

@@ -21,7 +21,7 @@ CASES = [  # B, H, W, Cin, Cout
 
 
 def _tiles(kk, n):
-    return [t for t in (0, 1, 2, 3) if kk._x3_tile_ok(t, n)]
+    return [t for t in kk._X3_TILES if kk._x3_tile_ok(t, n)]
 
 
 @pytest.mark.parametrize("cfg", CASES)
@@ -132,10 +132,10 @@ def test_model_routes_the_deep_pointwise_layers_and_the_switch_turns_them_off():
     import test_model_gpu as T
     from scouter_amd import _native
     res = {}
-    for bits in (3, 0):
+    for bits in (27, 0):
         m, P, images, labels, cfg = T._synthetic_model("resnest26d", 10, 1, 3, 4, 96, 2500)
         m.set_x3(bits)
-        assert len(m._x3_convs) == (14 if bits else 0)
+        assert len(m._x3_convs) == ((15 if bits & 16 else 14) if bits else 0)       # 14 deep 1x1 layers + the stem's 32 -> 64 3x3
         L = _native.lib()
         L.scouter_prof_enable(1)
         out, (loss, nll, area) = m(images.cuda(), labels.cuda())
@@ -147,9 +147,10 @@ def test_model_routes_the_deep_pointwise_layers_and_the_switch_turns_them_off():
         L.scouter_prof_collect(buf, len(buf))
         names = buf.value.decode()
         assert ("xconv_fwd<bf16x3>" in names) == bool(bits) and ("xconv_dgrad<bf16x3>" in names) == bool(bits)
+        assert ("xwgrad<bf16x3>" in names) == bool(bits)
         res[bits] = (out.detach().clone(), m.grad_arena().flat.clone())
-    assert float((res[3][0] - res[0][0]).abs().max()) < 5e-4
-    rel = float((res[3][1] - res[0][1]).norm() / res[0][1].norm())
+    assert float((res[27][0] - res[0][0]).abs().max()) < 5e-4
+    rel = float((res[27][1] - res[0][1]).norm() / res[0][1].norm())
     assert rel < 5e-2, rel          # (random-init net: ReLU sign flips on ~0 pre-activations move gradients, see test_model_gpu)
 
 
@@ -182,3 +183,66 @@ def test_weight_gradient_matches_fp64_at_least_as_well_as_the_fp32_kernel(cfg):
         dw2 = torch.full((1, 1, Cin, Cout), float("nan"), device="cuda")
         kk.conv2d_wgrad_x3(x, dy, dw2, plan=plan)
         assert torch.equal(dw, dw2), (cfg, plan)
+
+
+CCASES = [  # B, H, W, Cin, Cout, groups   (3x3 / stride 1 / pad 1)
+    (2, 20, 20, 32, 64, 1), (3, 12, 9, 64, 128, 2), (1, 33, 31, 32, 32, 1), (2, 7, 7, 64, 64, 2), (5, 16, 16, 32, 64, 1),
+    (1, 56, 56, 64, 128, 2), (2, 9, 12, 128, 256, 2)]
+
+
+@pytest.mark.parametrize("cfg", CCASES)
+def test_3x3_layers_forward_and_input_gradient(cfg):
+    """The same kernel as an implicit GEMM over filter taps (padding rows read zeros through out-of-range offsets, groups,
+    32-column tiles): the forward equals the plane kernels bit for bit where those support the shape (64-multiples of output
+    channels per group); forward and input gradient are at least as close to an fp64 convolution as the exact-fp32 kernel;
+    every tile gives the same bits; the fused BatchNorm-backward epilogue agrees with the fp32 kernel's."""
+    import torch.nn.functional as F
+    B, H, W, Cin, Cout, G = cfg
+    kk = K()
+    rng = np.random.default_rng(sum(cfg) + 9)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+    x, dy = f(B, H, W, Cin) + 0.2, f(B, H, W, Cout)
+    w = f(3, 3, Cin // G, Cout) / np.sqrt(9 * Cin // G)                      # HWIO
+    wf, wd = kk.planes_split_weight(w, G, 3)
+    w_oihw = w.permute(3, 2, 0, 1).double().cpu()
+    xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, w_oihw, None, 1, 1, 1, G)
+    yr.backward(dy.permute(0, 3, 1, 2).double().cpu())
+    y_ref, dx_ref = yr.detach().permute(0, 2, 3, 1).cuda(), xr.grad.permute(0, 2, 3, 1).cuda()
+    y32 = kk.conv2d_fwd(x, w, None, None, 1, 1, G)
+    d32 = kk.conv2d_dgrad(dy, w, tuple(x.shape), None, 1, 1, G)
+    e32y, e32d = float((y32.double() - y_ref).abs().max()), float((d32.double() - dx_ref).abs().max())
+    ys, ds = [], []
+    for t in _tiles(kk, Cout // G):
+        yt, (part, rows) = kk.conv2d_fwd_x3(x, wf, bn_stats=True, tile=t, kh=3, pad=1, groups=G)
+        ys.append(yt)
+        st = part[:rows].sum(0)
+        assert torch.allclose(st[:, 0], yt.double().reshape(-1, Cout).sum(0), rtol=1e-9, atol=1e-6)
+    for t in _tiles(kk, Cin // G):
+        ds.append(kk.conv2d_dgrad_x3(dy, wd, tuple(x.shape), tile=t, kh=3, pad=1, groups=G))
+    for yt in ys[1:]:
+        assert torch.equal(yt, ys[0])
+    for dt in ds[1:]:
+        assert torch.equal(dt, ds[0])
+    assert float((ys[0].double() - y_ref).abs().max()) <= max(e32y, 1e-6) * 1.05
+    assert float((ds[0].double() - dx_ref).abs().max()) <= max(e32d, 1e-6) * 1.05
+    if (Cout // G) % 64 == 0:
+        xp = kk.planes_split(x, 3)
+        yp = kk.conv2d_fwd_planes(xp, wf, 3, 3, 1, 1, G, tile=kk._plane_tiles(Cout // G)[0])
+        assert torch.equal(ys[0], yp)
+    # fused BatchNorm-backward epilogue against the fp32 kernel's
+    C = Cin
+    g_, b_ = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    _, saved, mask = kk.bn_fwd(x, g_, b_, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), True, True, want_mask=True)
+    res = []
+    for name in ("fp32", "x3"):
+        post = kk.BnBwdFuse(mask, [(x, saved)])
+        if name == "fp32":
+            dxf = kk.conv2d_dgrad(dy, w, tuple(x.shape), None, 1, 1, G, post=post)
+        else:
+            dxf = kk.conv2d_dgrad_x3(dy, wd, tuple(x.shape), post=post, kh=3, pad=1, groups=G)
+        assert post.applied
+        res.append((dxf, post.parts[0][:post.rows].sum(0)))
+    scale = float(res[0][0].abs().max())
+    assert float((res[1][0] - res[0][0]).abs().max()) <= 3e-6 * scale
+    assert torch.allclose(res[1][1], res[0][1], rtol=1e-4, atol=1e-3 * float(res[0][1].abs().max()))

@@ -1,5 +1,5 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over the timed steps of bench.py.
-usage: python tools_dev/pmc_traffic.py <fetch.db> <write.db> [kernel_substring:K]   (see rocpd_summary.py)
+usage: python tools_dev/pmc_traffic.py <fetch.db> <write.db> [kernel_substring:K] [out.json] [steps]   (see rocpd_summary.py)
 FETCH_SIZE / WRITE_SIZE are kilobytes; on gfx950 FETCH_SIZE reports half of the bytes of wide streaming reads
 (MI355X_MICROARCH.md, HBM section), so it is doubled."""
 import json
@@ -41,7 +41,11 @@ print("%-70s %7s %14s %14s %14s" % ("kernel", "calls", "read MB/launch", "write 
 out = {}
 for tot, name, n, rd, wr in rows[:60]:
     print("%-70s %7d %14.2f %14.2f %14.2f" % (name[:70], n, rd / 1e6, wr / 1e6, tot / 1e6))
+for tot, name, n, rd, wr in rows:
     out[name] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr}
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+all_bytes = sum(tot * n for tot, name, n, rd, wr in rows)
+print("all kernels: %.1f MB per step (%d profiled steps)" % (all_bytes / steps / 1e6, steps))
 import hashlib, os
 def _table_sha16():
     p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scouter_amd", "tuning", "gfx950.json")
@@ -49,5 +53,5 @@ def _table_sha16():
 json.dump({"command": "SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE} -- python bench.py "
                       "--steps 3 --warmup 2 --no-cpu-baseline --no-prof (dispatches after the warm-up only)",
            "correction": "read = 2 x FETCH_SIZE KB (gfx950), write = WRITE_SIZE KB", "tuning_sha16": _table_sha16(),
-           "kernels": out},
-          open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+           "steps": steps, "hbm_bytes_per_step": all_bytes / steps, "kernels": out},
+          open(sys.argv[4] if len(sys.argv) > 4 else "gpurun_out/pmc_traffic.json", "w"), indent=1)

@@ -18,12 +18,20 @@ rocprofv3 --kernel-trace --stats -d "$O/xs81" -- python tools_dev/xslot_bench.py
 python tools_dev/rocpd_summary.py "$(db $O/xs81)" > "$O/sum_xs81.txt"
 SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/fetch" -- $B3 > "$O/fetch.log" 2>&1
 SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/write" -- $B3 > "$O/write.log" 2>&1
-python tools_dev/pmc_traffic.py "$(db $O/fetch)" "$(db $O/write)" adamw_kernel:3 > "$O/pmc_traffic.txt" 2> "$O/pmc_traffic.err"
-cp pmc_traffic.json "$O/" 2>/dev/null; cp gpurun_out/pmc_traffic.json "$O/" 2>/dev/null
+python tools_dev/pmc_traffic.py "$(db $O/fetch)" "$(db $O/write)" adamw_kernel:3 "$O/pmc_traffic.json" 3 > "$O/pmc_traffic.txt" 2> "$O/pmc_traffic.err"
 SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d "$O/mfma" -- $B3 > "$O/mfma.log" 2>&1
 python tools_dev/pmc_mfma.py "$(db $O/mfma)" adamw_kernel:3 "$O/pmc_mfma_util.json" > "$O/mfma_bench.txt"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d "$O/mfma_xs" -- python tools_dev/xslot_bench.py 256 300 3 49 3 3 > "$O/mfma_xs.log" 2>&1
 python tools_dev/pmc_mfma.py "$(db $O/mfma_xs)" > "$O/mfma_xs.txt"
+# BASELINE configs[4] (resnest50d, 100 x 3 slots, batch 256, bf16): kernel trace + the same counter passes
+B5="python bench.py --config 5 --steps 3 --warmup 2 --no-cpu-baseline --no-prof"
+SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d "$O/off5" -- python bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline --no-prof > "$O/off5.log" 2>&1
+python tools_dev/rocpd_summary.py "$(db $O/off5)" adamw_kernel:3 > "$O/sum_off_config5.txt"
+SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/fetch5" -- $B5 > "$O/fetch5.log" 2>&1
+SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/write5" -- $B5 > "$O/write5.log" 2>&1
+python tools_dev/pmc_traffic.py "$(db $O/fetch5)" "$(db $O/write5)" adamw_kernel:3 "$O/pmc_traffic_config5.json" 3 > "$O/pmc_traffic_config5.txt" 2> "$O/pmc_traffic_config5.err"
+SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d "$O/mfma5" -- $B5 > "$O/mfma5.log" 2>&1
+python tools_dev/pmc_mfma.py "$(db $O/mfma5)" adamw_kernel:3 "$O/pmc_mfma_util_config5.json" > "$O/mfma_bench_config5.txt"
 grep -h '"metric"' "$O/off.log" "$O/on.log" | tail -2 > "$O/bench_lines.json"
 find "$O" -name "*.db" -delete; find "$O" -name "*.csv" -size +1M -delete
 ls -la "$O"

@@ -9,12 +9,15 @@ if [ "${2:-}" = "tune" ]; then
   python tools_dev/tune_table.py "$O/gfx950.json" > "$O/tune.log" 2>&1
   cp "$O/gfx950.json" scouter_amd/tuning/gfx950.json
 fi
-timeout 1500 python -m pytest tests -m gpu -x -q > "$O/pytest.log" 2>&1; grep -n "passed\|failed" "$O/pytest.log" | tail -2
+timeout 2400 python -m pytest tests -m gpu -x -q > "$O/pytest.log" 2>&1; grep -n "passed\|failed" "$O/pytest.log" | tail -2
 bash tools_dev/refresh_profiles.sh "$O/prof" > "$O/refresh.log" 2>&1
 # the PMC json files must be in place BEFORE the bench lines are taken (bench.py copies traffic / MFMA-busy from them)
 mkdir -p profiles
-cp "$O/prof/pmc_traffic.json" profiles/r04_pmc_hbm_traffic.json 2>/dev/null
-cp "$O/prof/pmc_mfma_util.json" profiles/r04_pmc_mfma_util.json 2>/dev/null
+R=${ROUND:-r05}
+cp "$O/prof/pmc_traffic.json" profiles/${R}_pmc_hbm_traffic.json 2>/dev/null
+cp "$O/prof/pmc_mfma_util.json" profiles/${R}_pmc_mfma_util.json 2>/dev/null
+cp "$O/prof/pmc_traffic_config5.json" profiles/${R}_pmc_hbm_traffic_config5.json 2>/dev/null
+cp "$O/prof/pmc_mfma_util_config5.json" profiles/${R}_pmc_mfma_util_config5.json 2>/dev/null
 python bench.py --steps 40 2>/dev/null | tail -1 > "$O/bench_line_1gpu.json"
 python bench.py --no-cpu-baseline --steps 40 --img-size 260 2>/dev/null | tail -1 > "$O/bench_config2_260.json"
 for c in 1 3 4 5; do python bench.py --config $c --steps 20 2>/dev/null | tail -1 > "$O/bench_config$c.json"; done

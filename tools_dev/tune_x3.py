@@ -67,3 +67,55 @@ doc["choices"] = dict(sorted(ch.items()))
 with open(out, "w") as f:
     json.dump(doc, f, indent=0)
 print("wrote", out)
+
+# ---- the 3x3 layers with 32-channel groups (kernels.x3_conv_eligible): forward and the (fused) input gradient
+tot32 = totx = 0.0
+for ks in sorted(k for k in list(ch) if k.startswith(("fwd|0|", "dgrad+bn|"))):
+    p = ks.split("|")
+    mode = p[0]
+    if mode == "fwd":
+        B, H, W, Cin, Cout, kh, kw, stride, pad, g = [int(v) for v in p[2:]]
+        nent, has_add = 0, False
+    else:
+        nent, has_add = int(p[1]), p[2] == "1"
+        if p[3] != "0":
+            continue
+        B, H, W, Cin, Cout, kh, kw, stride, pad, g = [int(v) for v in p[4:]]
+    if not K.x3_conv_eligible(Cin, Cout, kh, kw, stride, pad, g, False):
+        continue
+    x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(3, 3, Cin // g, Cout, device="cuda") * 0.05
+    dy = torch.randn(B, H, W, Cout, device="cuda")
+    add = torch.randn(B, H, W, Cin, device="cuda") if has_add else None
+    wf, wd = K.planes_split_weight(w, g, 3)
+    xs = (B, H, W, Cin)
+    res = {}
+    if mode == "fwd":
+        N = Cout // g
+        for t in K._X3_TILES:
+            if K._x3_tile_ok(t, N):
+                res[t] = timeit(lambda: K.conv2d_fwd_x3(x, wf, bn_stats=True, tile=t, kh=3, pad=1, groups=g))
+        t32 = timeit(lambda: K.conv2d_fwd(x, w, None, None, 1, 1, g, bn_stats=True))
+        key = "|".join(["xfwd", "3"] + [str(v) for v in (B, H, W, Cin, Cout, 3, g)])
+    else:
+        N = Cin // g
+        ones, zeros = torch.ones(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+        outs = [K.bn_fwd(torch.randn(*xs, device="cuda"), ones, zeros, zeros.clone(), ones.clone(), True, True, want_mask=True)
+                for _ in range(nent)]
+        xin = [torch.randn(*xs, device="cuda") for _ in range(nent)]
+        def fz():
+            return K.BnBwdFuse(outs[0][2], [(xin[i], outs[i][1]) for i in range(nent)])
+        for t in K._X3_TILES:
+            if K._x3_tile_ok(t, N):
+                res[t] = timeit(lambda: K.conv2d_dgrad_x3(dy, wd, xs, addend=add, post=fz(), tile=t, kh=3, pad=1, groups=g))
+        t32 = timeit(lambda: K.conv2d_dgrad(dy, w, xs, add, 1, 1, g, post=fz()))
+        key = "|".join(["xdgrad+bn", str(nent), str(int(has_add)), "3"] + [str(v) for v in (B, H, W, Cin, Cout, 3, g)])
+    best = min(res, key=res.get)
+    ch[key] = best
+    tot32 += t32; totx += res[best]
+    print("%-52s fp32 %7.1f us | x3 %s -> tile %d %7.1f us (%.2fx)" % (
+        ks, t32, " ".join("%d:%6.1f" % kv for kv in sorted(res.items())), best, res[best], t32 / res[best]), flush=True)
+print("3x3 layers, sum over the table's shapes: fp32 %.0f us, x3 %.0f us" % (tot32, totx))
+doc["choices"] = dict(sorted(ch.items()))
+with open(out, "w") as f:
+    json.dump(doc, f, indent=0)
+print("wrote", out)
