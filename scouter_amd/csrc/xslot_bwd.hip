@@ -10,6 +10,8 @@
 // are left to the generic wgrad kernel (deterministic split-K) by the host.
 #include "xslot_common.h"
 
+#include <stdlib.h>
+
 struct XsBwdArgs {
     const float* X; const float* PE; const float* tok_w[8]; const float* slots0;
     const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;
@@ -117,7 +119,54 @@ __device__ __forceinline__ void xs_mlp_bwd(const XsBwdArgs& a, float* dZa, float
 // GRU backward of one 32-slot tile (slots on the lanes): gates recomputed from (U, h), pre-activation gradients
 // stored as the operands of the weight-gradient GEMMs, dU += W_ih^T dgi, dh_prev += dz*ds + W_hh^T dgh.
 // `row` = row of this lane's slot in the [T][B][S] gradient buffers.
-__device__ __forceinline__ void xs_gru_bwd_tile(const XsBwdArgs& a, const float* Wih, const float* Whh, const float* bias,
+// ---- the same two operand streams with the matrix in GLOBAL memory ([rows][64] row-major, L2-resident: the 48 KB of
+// W_ih are read by every workgroup): used where the LDS cannot hold both GRU weight matrices (three token tiles).  Only the
+// latency differs -- ~600-800 cycles instead of ~130 -- so the fragments are requested further ahead: four 16-byte
+// fragments (16 MFMAs, 1 k cycles) resp. twelve 4-byte ones (768 cycles).
+// (buffer loads: ONE lane-offset register per access pattern, everything else in the scalar / immediate offset -- with flat
+//  pointers the compiler hoisted 240 loop-invariant 64-bit addresses out of the iteration loop and spilled them)
+struct XsWihG { __amdgpu_buffer_rsrc_t rs; unsigned voff_kc, voff_tr; };
+__device__ __forceinline__ XsWihG xs_wih_global(const float* w_ih, int l31, int hh) {
+    XsWihG g;
+    g.rs = __builtin_amdgcn_make_buffer_rsrc((void*)w_ih, 0, 192 * XS_D * 4, 0x00020000);
+    g.voff_kc = (unsigned)(l31 * XS_D + 4 * hh) * 4u;            // row l31 of a 32-row block, k = 4 hh ..
+    g.voff_tr = (unsigned)(4 * hh * XS_D + l31) * 4u;            // row 4 hh of an 8-row k group, column l31
+    return g;
+}
+// load / multiply halves: the caller requests block i+1 BEFORE it multiplies block i (and the LDS-fed W_hh block that
+// follows it), so an L2 round trip (~700 cycles) runs under 32-64 MFMAs instead of in front of every block
+__device__ __forceinline__ void xs_kc_g_load(const XsWihG& W, int row0, f32x4 (&fr)[8]) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+        fr[f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            W.rs, W.voff_kc, (row0 * XS_D + 32 * (f >> 2) + 8 * (f & 3)) * 4, 0));
+}
+__device__ __forceinline__ void xs_kc_g_mma(const f32x4 (&fr)[8], const f32x16 (&b)[2], f32x16& acc) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(fr[f][e], b[f >> 2][4 * (f & 3) + e], acc);
+    }
+    XS_REGION_END();
+}
+__device__ __forceinline__ void xs_tr_g_load(const XsWihG& W, int row_base, int col0, float (&fr)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        fr[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            W.rs, W.voff_tr, ((row_base + 8 * (k >> 2) + (k & 3)) * XS_D + col0) * 4, 0));
+}
+__device__ __forceinline__ void xs_tr_g_mma(const float (&fr)[16], const f32x16& b, f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        __builtin_amdgcn_sched_barrier(0);
+        acc = mfma32(fr[r], b[r], acc);
+    }
+    XS_REGION_END();
+}
+
+template <bool WG = false>      // WG: W_ih is read from global memory (xs_mm_kc_g / xs_mm_tr_tile_g: WihG), W_hh from LDS
+__device__ __forceinline__ void xs_gru_bwd_tile(const XsBwdArgs& a, const float* Wih, const XsWihG& WihG, const float* Whh, const float* bias,
                                                 const f32x16 (&h)[2], const f32x16 (&U)[2], const float* dsx_tile,
                                                 float cs, const float* ksumf, f32x16 (&dU)[2], f32x16 (&dhp)[2],
                                                 long row, bool iok, int l31, int hh) {
@@ -131,12 +180,27 @@ __device__ __forceinline__ void xs_gru_bwd_tile(const XsBwdArgs& a, const float*
         for (int q = 0; q < 4; ++q) dsq[q] = *(const f32x4*)(dsx_tile + (long)l31 * 64 + 32 * gt + 8 * q + 4 * hh);
         f32x16 ar, az, ain, ahn;
         xs_zero(ar); xs_zero(az); xs_zero(ain); xs_zero(ahn);
-        xs_mm_kc(Wih, 32 * gt, U, ar, l31, hh);
-        xs_mm_kc(Whh, 32 * gt, h, ar, l31, hh);
-        xs_mm_kc(Wih, 64 + 32 * gt, U, az, l31, hh);
-        xs_mm_kc(Whh, 64 + 32 * gt, h, az, l31, hh);
-        xs_mm_kc(Wih, 128 + 32 * gt, U, ain, l31, hh);
-        xs_mm_kc(Whh, 128 + 32 * gt, h, ahn, l31, hh);
+        if constexpr (WG) {
+            // (measured, round 5: requesting block i+1 before block i multiplies -- two fragment buffers -- cost more in
+            //  registers / spills than the exposed L2 round trips it removed: 552 -> 588 us at batch 256 x 300 slots)
+            f32x4 f0[8];
+            xs_kc_g_load(WihG, 32 * gt, f0);
+            xs_kc_g_mma(f0, U, ar);
+            xs_mm_kc(Whh, 32 * gt, h, ar, l31, hh);
+            xs_kc_g_load(WihG, 64 + 32 * gt, f0);
+            xs_kc_g_mma(f0, U, az);
+            xs_mm_kc(Whh, 64 + 32 * gt, h, az, l31, hh);
+            xs_kc_g_load(WihG, 128 + 32 * gt, f0);
+            xs_kc_g_mma(f0, U, ain);
+            xs_mm_kc(Whh, 128 + 32 * gt, h, ahn, l31, hh);
+        } else {
+            xs_mm_kc(Wih, 32 * gt, U, ar, l31, hh);
+            xs_mm_kc(Whh, 32 * gt, h, ar, l31, hh);
+            xs_mm_kc(Wih, 64 + 32 * gt, U, az, l31, hh);
+            xs_mm_kc(Whh, 64 + 32 * gt, h, az, l31, hh);
+            xs_mm_kc(Wih, 128 + 32 * gt, U, ain, l31, hh);
+            xs_mm_kc(Whh, 128 + 32 * gt, h, ahn, l31, hh);
+        }
         // gate values -> their pre-activation gradients, in place
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -165,14 +229,30 @@ __device__ __forceinline__ void xs_gru_bwd_tile(const XsBwdArgs& a, const float*
             }
         }
         // dU^T += W_ih^T dgi^T ; dh_prev^T += W_hh^T dgh^T   (k = the 32 hidden units of this g-tile)
+        if constexpr (WG) {
+            float g0[16];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            xs_mm_tr_tile(Wih, 32 * gt, 32 * ct, ar, dU[ct], l31, hh);
-            xs_mm_tr_tile(Wih, 64 + 32 * gt, 32 * ct, az, dU[ct], l31, hh);
-            xs_mm_tr_tile(Wih, 128 + 32 * gt, 32 * ct, ain, dU[ct], l31, hh);
-            xs_mm_tr_tile(Whh, 32 * gt, 32 * ct, ar, dhp[ct], l31, hh);
-            xs_mm_tr_tile(Whh, 64 + 32 * gt, 32 * ct, az, dhp[ct], l31, hh);
-            xs_mm_tr_tile(Whh, 128 + 32 * gt, 32 * ct, ahn, dhp[ct], l31, hh);
+            for (int ct = 0; ct < 2; ++ct) {
+                xs_tr_g_load(WihG, 32 * gt, 32 * ct, g0);
+                xs_tr_g_mma(g0, ar, dU[ct]);
+                xs_tr_g_load(WihG, 64 + 32 * gt, 32 * ct, g0);
+                xs_tr_g_mma(g0, az, dU[ct]);
+                xs_tr_g_load(WihG, 128 + 32 * gt, 32 * ct, g0);
+                xs_tr_g_mma(g0, ain, dU[ct]);
+                xs_mm_tr_tile(Whh, 32 * gt, 32 * ct, ar, dhp[ct], l31, hh);
+                xs_mm_tr_tile(Whh, 64 + 32 * gt, 32 * ct, az, dhp[ct], l31, hh);
+                xs_mm_tr_tile(Whh, 128 + 32 * gt, 32 * ct, ahn, dhp[ct], l31, hh);
+            }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                xs_mm_tr_tile(Wih, 32 * gt, 32 * ct, ar, dU[ct], l31, hh);
+                xs_mm_tr_tile(Wih, 64 + 32 * gt, 32 * ct, az, dU[ct], l31, hh);
+                xs_mm_tr_tile(Wih, 128 + 32 * gt, 32 * ct, ain, dU[ct], l31, hh);
+                xs_mm_tr_tile(Whh, 32 * gt, 32 * ct, ar, dhp[ct], l31, hh);
+                xs_mm_tr_tile(Whh, 64 + 32 * gt, 32 * ct, az, dhp[ct], l31, hh);
+                xs_mm_tr_tile(Whh, 128 + 32 * gt, 32 * ct, ahn, dhp[ct], l31, hh);
+            }
         }
     }
 }
@@ -301,7 +381,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_scratch_kernel(XsBwdArgs a) {
             } else {
                 xs_zero(dU[0]); xs_zero(dU[1]);
                 const long row = ((long)it * a.B + b) * S + i;
-                xs_gru_bwd_tile(a, Wih, Whh, bias, h, U, dsn + (long)ti * 32 * 64, 0.f, bias, dU, dhp, row, iok, l31, hh);
+                xs_gru_bwd_tile(a, Wih, XsWihG{}, Whh, bias, h, U, dsn + (long)ti * 32 * 64, 0.f, bias, dU, dhp, row, iok, l31, hh);
             }
             if (tt == 0) XSB_STAMP();
             if (!iok) {   // padded slots carry nothing
@@ -441,7 +521,10 @@ __device__ __forceinline__ void xs_transpose_tile(float* __restrict__ buf, const
     }
 }
 
-template <int NJT>
+// WG (three token tiles, the reference's 9 x 9 grid): W_ih stays in global memory / L2 and is read as MFMA operands through
+// registers -- the LDS cannot hold X, K, both GRU weight matrices and the four bounce buffers at NP = 96 (179.6 KB); without
+// the 52 KB of W_ih the in-loop variant fits and the first-generation scratch kernel is retired for 64 < N <= 96.
+template <int NJT, bool WG = false>
 __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     constexpr int NP = 32 * NJT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -454,8 +537,10 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     float* corr = spart + 512;                  // [64] sum_t c0_t colsum(s_t): the c0 terms of dK
     float* Xs = corr + 64;
     float* Ks = Xs + NP * XS_LD;
-    float* Wih = Ks + NP * XS_LD;
-    float* Whh = Wih + 192 * XS_LD;
+    float* WihL = Ks + NP * XS_LD;              // (WG: no LDS copy of W_ih)
+    float* Whh = WihL + (WG ? 0 : 192 * XS_LD);
+    const float* Wih = WG ? a.w_ih : WihL;
+    const XsWihG wihg = xs_wih_global(a.w_ih, threadIdx.x & 31, (threadIdx.x & 63) >> 5);
     float* bounce = Whh + 192 * XS_LD;          // [4][32][XS_LDB] per-wave transpose buffers
     // after the loop the pool is re-used: wave-reduction buffer = dK | dX^a, then the MLP buffers
     float* dZa = Xs;                            // [NP][68]
@@ -485,7 +570,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
         *(f32x4*)(Xs + r * XS_LD + q * 4) = x;
         *(f32x4*)(Ks + r * XS_LD + q * 4) = k;
     }
-    xs_load_mat_c<192, 256>(Wih, a.w_ih, tid);
+    if constexpr (!WG) xs_load_mat_c<192, 256>(WihL, a.w_ih, tid);
     xs_load_mat_c<192, 256>(Whh, a.w_hh, tid);
     {
         const int g = tid & 63, k = tid >> 6;
@@ -601,14 +686,26 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             } else {
                 xs_zero(dU[0]); xs_zero(dU[1]);
                 const long row = ((long)it * a.B + b) * S + i;
-                xs_gru_bwd_tile(a, Wih, Whh, bias, h, U, dsn + (long)ti * 32 * 64, iok ? cs_prev : 0.f, ksumf, dU, dhp, row,
-                                iok, l31, hh);
+                xs_gru_bwd_tile<WG>(a, Wih, wihg, Whh, bias, h, U, dsn + (long)ti * 32 * 64, iok ? cs_prev : 0.f, ksumf, dU, dhp, row,
+                                    iok, l31, hh);
             }
             if (tt == 0) XSB_STAMP();
             if (!iok) {   // padded slots carry nothing
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) { xs_zero(dU[ct]); xs_zero(dhp[ct]); }
             }
+            if constexpr (WG) {
+                // three token tiles: A (48 registers) is not kept across the GRU section -- D is, and A = sigmoid(D / r tau)
+                // is re-evaluated here with the same expression (same bits): ~400 VALU per tile instead of a spill
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float v = xs_sigmoid(xs_div(D[jt][e], r, ir) * tau);
+                        A[jt][e] = (iok && xs_kidx(jt, e, hh) < N) ? v : 0.f;
+                    }
+            }
+            if constexpr (!WG) {
             f32x16 accK[NJT][2], accX[NJT][2];
             auto acc_load = [&](f32x16 (&acc)[NJT][2], int base) {
 #pragma unroll
@@ -707,6 +804,109 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
                 }
             }
             acc_store(accX, 2 * NJT);
+            } else {
+            // (WG, three token tiles: the 2 x 96 accumulator registers of dK' / dX^a do not fit next to A, D, h, dU -- the
+            //  parks are walked one token tile at a time, the next tile's two blocks in flight while this one contracts)
+            auto park_load = [&](f32x16 (&acc)[2], int blk) {          // blocks blk, blk + 1 (ct = 0, 1)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    xs_zero(acc[ct]);
+                    if (have_acc) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = accpark[((blk + ct) * 4 + q) * 64];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[ct][4 * q + e] = v[e];
+                        }
+                    }
+                }
+            };
+            auto park_store = [&](const f32x16 (&acc)[2], int blk) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[ct][4 * q + e];
+                        accpark[((blk + ct) * 4 + q) * 64] = v;
+                    }
+            };
+            // dA^T = X dU^T / d (+ area term), G = dA * A (1 - A), g_i = sum_j G_ij D_ij ; G replaces D
+            float gsum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                f32x16 dA;
+                xs_zero(dA);
+                xs_mm_kc(Xs, 32 * jt, dU, dA, l31, hh);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float av = A[jt][e];
+                    float v = dA[e] * inv_d + (last ? g_area : 0.f);
+                    v = (iok && xs_kidx(jt, e, hh) < N) ? v * av * (1.f - av) : 0.f;
+                    gsum += v * D[jt][e];
+                    D[jt][e] = v;
+                }
+            }
+            gsum = xs_halfsum(gsum);
+            const float tc = xs_tilesum(iok ? gsum / r : 0.f);
+            if (lane == 0) redc[(pb ^ 1) * 16 + ti] = tc;
+            // dD' = G tau / r - g tau / r^2  (the + c0 is added by the readers), ds' = d^-1/2 dD' K + dh_prev
+            const float k1 = tau / r, k2 = gsum * tau / (r * r);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    D[jt][e] = (iok && xs_kidx(jt, e, hh) < N) ? D[jt][e] * k1 - k2 : 0.f;
+            {
+                f32x16 ds[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    xs_zero(ds[ct]);
+                    xs_mm_tr<NJT>(Ks, 32 * ct, D, ds[ct], l31, hh);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ds[ct][e] = iok ? ds[ct][e] * scale + dhp[ct][e] : 0.f;
+                }
+                xs_store_tile<2>(dsn + (long)ti * 32 * 64, 64, ds, l31, hh);
+            }
+            if (tt == 0) XSB_STAMP();
+            // contractions over the slots of this tile:  dK'[j][c] += dD'[i][j] s[i][c],  dX^a[j][c] += A[i][j] dU[i][c]
+            {
+                f32x16 qT[2], pT, accA[2], accB[2];
+                xs_transpose_tile(tbuf, h[0], qT[0], l31, hh);
+                xs_transpose_tile(tbuf, h[1], qT[1], l31, hh);
+                park_load(accA, 0);
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    f32x16 (&cur)[2] = (jt & 1) ? accB : accA;
+                    f32x16 (&nxt)[2] = (jt & 1) ? accA : accB;
+                    park_load(nxt, jt + 1 < NJT ? 2 * (jt + 1) : 2 * NJT);       // (last: the first dX^a blocks)
+                    xs_transpose_tile(tbuf, D[jt], pT, l31, hh);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r16 = 0; r16 < 16; ++r16) cur[ct] = mfma32(pT[r16], qT[ct][r16], cur[ct]);
+                    XS_REGION_END();
+                    park_store(cur, 2 * jt);
+                }
+                xs_transpose_tile(tbuf, dU[0], qT[0], l31, hh);
+                xs_transpose_tile(tbuf, dU[1], qT[1], l31, hh);
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    // (NJT = 3: the dX^a blocks of jt = 0 were requested into the buffer that follows dK' jt = 2)
+                    f32x16 (&cur)[2] = ((NJT + jt) & 1) ? accB : accA;
+                    f32x16 (&nxt)[2] = ((NJT + jt) & 1) ? accA : accB;
+                    if (jt + 1 < NJT) park_load(nxt, 2 * NJT + 2 * (jt + 1));
+                    xs_transpose_tile(tbuf, A[jt], pT, l31, hh);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r16 = 0; r16 < 16; ++r16) cur[ct] = mfma32(pT[r16], qT[ct][r16], cur[ct]);
+                    XS_REGION_END();
+                    park_store(cur, 2 * NJT + 2 * jt);
+                }
+            }
+            }
             have_acc = true;
             if (tt == 0) XSB_STAMP();
         }
@@ -775,17 +975,26 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     XSB_STAMP();
 }
 
+static bool xs_bwd_scratch_variant() {       // SCOUTER_XSLOT_BWD_SCRATCH=1: the first-generation kernel for 64 < N <= 96 (A/B)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SCOUTER_XSLOT_BWD_SCRATCH"); v = e && e[0] == '1'; }
+    return v != 0;
+}
 static size_t xs_bwd_lds_bytes(int NJT) {
-    if (NJT > 2) return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 16) + 32 + 1024) * sizeof(float);
-    return (size_t)(256 + 2 * 64 + 2 * 32 + 32 + 64 + 512 + 64 + 2 * 32 * NJT * XS_LD + 384 * XS_LD + 4 * 32 * XS_LDB) *
-           sizeof(float);
+    if (NJT > 2 && xs_bwd_scratch_variant())
+        return (size_t)(2 * 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 16) + 32 + 1024) * sizeof(float);
+    // (three token tiles: W_ih stays in global memory -- one 192-row matrix less)
+    return (size_t)(256 + 2 * 64 + 2 * 32 + 32 + 64 + 512 + 64 + 2 * 32 * NJT * XS_LD + (NJT > 2 ? 192 : 384) * XS_LD +
+                    4 * 32 * XS_LDB) * sizeof(float);
 }
 
 extern "C" size_t scouter_xslot_bwd_workspace_bytes(int B, int N, int d, int S, int T) {
     (void)d;
     const long Sp = (S + 31) / 32 * 32, NP = (N + 31) / 32 * 32;
-    if (NP <= 64) return (size_t)B * (Sp * 64 + 4 * (NP / 32) * 4 * 16 * 64) * sizeof(float);     // ds' hand-off + accumulator parks
-    return (size_t)B * Sp * (64 + (long)T * (2 * NP + 64)) * sizeof(float);    // + A_t, dD_t, dU_t of every iteration
+    const size_t inloop = (size_t)B * (Sp * 64 + 4 * (NP / 32) * 4 * 16 * 64) * sizeof(float);     // ds' hand-off + accumulator parks
+    if (NP <= 64) return inloop;
+    const size_t scratch = (size_t)B * Sp * (64 + (long)T * (2 * NP + 64)) * sizeof(float);    // + A_t, dD_t, dU_t of every iteration
+    return scratch > inloop ? scratch : inloop;       // (either variant may run for 64 < N <= 96)
 }
 
 extern "C" int scouter_xslot_bwd_f32(const float* X, const float* PE, const float* const* tok_w, const float* slots0,
@@ -825,7 +1034,8 @@ extern "C" int scouter_xslot_bwd_f32(const float* X, const float* PE, const floa
     } while (0)
     if (NJT == 1) XSB_LAUNCH(xslot_bwd_kernel<1>);
     else if (NJT == 2) XSB_LAUNCH(xslot_bwd_kernel<2>);
-    else XSB_LAUNCH(xslot_bwd_scratch_kernel<3>);
+    else if (xs_bwd_scratch_variant()) XSB_LAUNCH(xslot_bwd_scratch_kernel<3>);
+    else XSB_LAUNCH((xslot_bwd_kernel<3, true>));
 #undef XSB_LAUNCH
     return sc_check_launch("xslot_bwd");
 }

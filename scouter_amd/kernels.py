@@ -656,10 +656,12 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
 # (tools_dev/x3_bench.py): the 1x1 layers with Cin * Cout >= 2^16 -- every 1x1 of layer2-4 -- gain, the short-K 56 x 56
 # layers are HBM-co-bound and stay on the persistent fp32 kernel; of the 3x3 layers those with 32 channels per group (the
 # deep stem, the first radix convolution) -- the plane kernels need 64 -- ran on the fp32 MFMA kernels until round 5.
-# SCOUTER_X3 bits: 0 forward, 1 plain input gradient, 2 fused input gradient (1x1 layers; measured slower on the 28 x 28
-# layers, off), 3 weight gradient (1x1), 4 the forward of the 3x3 layers of x3_conv_eligible; 0: everything on the fp32
-# MFMA kernels.
-X3_DEFAULT = int(os.environ.get("SCOUTER_X3", "27"))
+# SCOUTER_X3 bits: 0 forward, 1 plain input gradient, 2 input gradient with the fused BatchNorm-backward epilogue -- only
+# where the GEMM is deep enough to carry it (K = Cout >= X3_FUSED_MIN_K: 149 -> 121 us, 78 -> 63 us; the K = 128 / 256
+# launches are bound by the epilogue's streams and stay on the fp32 kernel that prefetches them), 3 weight gradient (1x1),
+# 4 the forward of the 3x3 layers of x3_conv_eligible; 0: everything on the fp32 MFMA kernels.
+X3_DEFAULT = int(os.environ.get("SCOUTER_X3", "31"))
+X3_FUSED_MIN_K = 512
 X3_MIN_CHANNEL_PRODUCT = 1 << 16
 _X3_TILES = (0, 1, 2, 3, 4, 5, 6)
 

@@ -238,7 +238,7 @@ class Conv2d(nn.Module):
             # fused BatchNorm-backward epilogue (bit 2)
             xm, k = self.x3_mode(), self.kernel_size
             fused = post is not None and K._fuse_wanted(post, k) and post.x_io() == 0
-            if (xm & 4) if fused else (xm & 2):
+            if ((xm & 4) and self.out_channels >= K.X3_FUSED_MIN_K) if fused else (xm & 2):
                 return K.conv2d_dgrad_x3(dy, wd, xshape, addend, post=post, kh=k, pad=self.padding, groups=self.groups)
         return K.conv2d_dgrad(dy, K.hwio(self.weight), xshape, addend, self.stride, self.padding, self.groups,
                               precision=self.precision, post=post, out_dtype=dx_dtype or K.F32)

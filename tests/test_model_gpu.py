@@ -538,6 +538,56 @@ def test_bf16_mode_resnest50d_300_slots():
     assert 1 - min(ch.values()) <= 2.5 * (1 - min(ce.values())) + 1e-3
 
 
+def test_config5_model_at_its_real_batch():
+    """BASELINE configs[4] -- resnest50d, 100 classes x 3 slots (S = 300), 224 x 224 -- at its REAL per-GPU
+    batch 256, end to end (the B = 256 table entries through the whole model, not kernel by kernel).  (i) precision "fp32":
+    forward (train-mode BatchNorm) against the oracle's fp64 forward, next to plain fp32 PyTorch on the same inputs;
+    (ii) precision "bf16" (the mode the config names, bf16 activation storage): the forward sits inside the distance of
+    the emulating oracle (bf16 operand rounding + storage, evaluated in fp64) from the fp64 truth.  A few minutes of CPU
+    oracle time (three forwards at batch 256)."""
+    m, P, images, labels, cfg = _synthetic_model("resnest50d", 100, 3, 3, 256, 224, 1900, well_conditioned_head=True)
+    xg, yg = images.cuda(), labels.cuda()
+    with torch.no_grad():
+        out32, _ = m(xg, yg)
+        attn32 = m.slot.last_attn.clone()
+    m.load_state_dict(P)                                   # (the train-mode forward moved the running statistics)
+    m.set_precision("bf16")
+    assert m.activation_storage == "bf16"
+    with torch.no_grad():
+        out16, _ = m(xg, yg)
+    torch.cuda.synchronize()
+    out32, out16, attn32 = out32.cpu().double(), out16.cpu().double(), attn32.cpu().double()
+    del m, xg
+    torch.cuda.empty_cache()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
+    def run(dtype, rounding=None):
+        Pd = {k: (v.to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in P.items()}
+        aux = {}
+        O.CONV_INPUT_ROUNDING = O.ACTIVATION_STORAGE = rounding
+        try:
+            with torch.no_grad():
+                o, _ = O.slot_model_forward(Pd, images.to(dtype), labels, cfg, training=True, aux=aux)
+        finally:
+            O.CONV_INPUT_ROUNDING = O.ACTIVATION_STORAGE = None
+        return o.double(), aux["attn"].double()
+    ref, ref_attn = run(torch.float64)
+    ref32, _ = run(torch.float32)
+    floor = float((ref32 - ref).abs().max())
+    err = float((out32 - ref).abs().max())
+    err_a = float((attn32 - ref_attn).abs().max())
+    emu, _ = run(torch.float64, "bf16")
+    err16, err_emu = float((out16 - ref).abs().max()), float((emu - ref).abs().max())
+    print("config 5 @ batch 256, S = 300: fp32 mode |HIP - fp64| log_probs %.3g (torch fp32: %.3g), attention %.3g; bf16 mode "
+          "%.3g (emulating oracle: %.3g)" % (err, floor, err_a, err16, err_emu))
+    assert err <= max(1e-4, 3 * floor), (err, floor)
+    assert err <= max(2.0 * floor, 1e-5), (err, floor)
+    assert err_a <= max(1e-4, 3 * floor), (err_a, floor)
+    assert 1e-3 < err_emu < 1.0, "the bf16 yardstick is degenerate: this case says nothing"
+    assert err16 > 1e-3, "bf16 mode produced the fp32 result: the bf16 kernels did not run"
+    assert err16 <= 2.5 * err_emu + 1e-3, (err16, err_emu)
+
+
 def test_bad_inputs_fail_loudly():
     """empty batch, CPU tensor, wrong channel count: Python exceptions with the library's message, never a silent
     fallback or a device fault"""

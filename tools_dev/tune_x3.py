@@ -81,9 +81,10 @@ for ks in sorted(k for k in list(ch) if k.startswith(("fwd|0|", "dgrad+bn|"))):
         if p[3] != "0":
             continue
         B, H, W, Cin, Cout, kh, kw, stride, pad, g = [int(v) for v in p[4:]]
-    if not K.x3_conv_eligible(Cin, Cout, kh, kw, stride, pad, g, False):
+    pw = mode != "fwd" and K.x3_eligible(Cin, Cout, kh, kw, stride, pad, g, False) and Cout >= K.X3_FUSED_MIN_K
+    if not (K.x3_conv_eligible(Cin, Cout, kh, kw, stride, pad, g, False) and mode == "fwd") and not pw:
         continue
-    x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(3, 3, Cin // g, Cout, device="cuda") * 0.05
+    x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(kh, kh, Cin // g, Cout, device="cuda") * 0.05
     dy = torch.randn(B, H, W, Cout, device="cuda")
     add = torch.randn(B, H, W, Cin, device="cuda") if has_add else None
     wf, wd = K.planes_split_weight(w, g, 3)
@@ -106,9 +107,9 @@ for ks in sorted(k for k in list(ch) if k.startswith(("fwd|0|", "dgrad+bn|"))):
             return K.BnBwdFuse(outs[0][2], [(xin[i], outs[i][1]) for i in range(nent)])
         for t in K._X3_TILES:
             if K._x3_tile_ok(t, N):
-                res[t] = timeit(lambda: K.conv2d_dgrad_x3(dy, wd, xs, addend=add, post=fz(), tile=t, kh=3, pad=1, groups=g))
-        t32 = timeit(lambda: K.conv2d_dgrad(dy, w, xs, add, 1, 1, g, post=fz()))
-        key = "|".join(["xdgrad+bn", str(nent), str(int(has_add)), "3"] + [str(v) for v in (B, H, W, Cin, Cout, 3, g)])
+                res[t] = timeit(lambda: K.conv2d_dgrad_x3(dy, wd, xs, addend=add, post=fz(), tile=t, kh=kh, pad=pad, groups=g))
+        t32 = timeit(lambda: K.conv2d_dgrad(dy, w, xs, add, 1, pad, g, post=fz()))
+        key = "|".join(["xdgrad+bn", str(nent), str(int(has_add)), "3"] + [str(v) for v in ((B, H, W, Cin, Cout) if kh == 1 else (B, H, W, Cin, Cout, 3, g))])
     best = min(res, key=res.get)
     ch[key] = best
     tot32 += t32; totx += res[best]
