@@ -660,7 +660,12 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
 # where the GEMM is deep enough to carry it (K = Cout >= X3_FUSED_MIN_K: 149 -> 121 us, 78 -> 63 us; the K = 128 / 256
 # launches are bound by the epilogue's streams and stay on the fp32 kernel that prefetches them), 3 weight gradient (1x1),
 # 4 the forward of the 3x3 layers of x3_conv_eligible; 0: everything on the fp32 MFMA kernels.
-X3_DEFAULT = int(os.environ.get("SCOUTER_X3", "31"))
+# Default 15: bit 4 (+1 % images/sec: 4 455 vs 4 412) is OFF -- the stem's forward feeds every layer, and with it the head
+# gradients of the full-size parity fixture deviate from the fp64 reference by 2.5 x plain fp32 PyTorch's own deviation (bound
+# 2 x; tests/test_model_gpu.py::test_full_size_resnest26d_224_against_reference_fp64_digests) -- one draw of rounding noise
+# (the kernel itself is bit-identical to the plane kernels, a third of the fp32 kernel's error), but over the yardstick the
+# tests hold the path to, like plane tile 5 in the forward (SCOUTER_HALO).
+X3_DEFAULT = int(os.environ.get("SCOUTER_X3", "15"))
 X3_FUSED_MIN_K = 512
 X3_MIN_CHANNEL_PRODUCT = 1 << 16
 _X3_TILES = (0, 1, 2, 3, 4, 5, 6)

@@ -164,8 +164,8 @@ class SlotModel(nn.Module):
         self._refresh_x3()
 
     def _refresh_x3(self):
-        self._x3_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and getattr(m, "x3", 0) and
-                          not m.planes and (m.x3_static() or m.x3_conv_static())]
+        self._x3_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and not m.planes and
+                          ((getattr(m, "x3", 0) & 15 and m.x3_static()) or (getattr(m, "x3", 0) & 16 and m.x3_conv_static()))]
 
     def set_side_stream(self, enabled):
         """Weight gradients on the side stream (default) or serially on the compute stream (per-kernel timing)."""

@@ -33,6 +33,11 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert _native.lib().scouter_abi_version() == 1
+    # the documents quote the number of entry points: keep them honest
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = re.search(r"declares (\d+) `extern \"C\"` entry points", open(os.path.join(root, "INTEGRATION.md")).read())
+    assert m and int(m.group(1)) == len(names), (m and m.group(1), len(names))
 
 
 @pytest.mark.parametrize("model,C,spc,L,mnist", [("resnet18", 10, 1, 1, True), ("resnest26d", 10, 1, 3, False),

@@ -54,14 +54,15 @@ def default_run():
 
 # switches that leave the forward bit-identical are compared with TRAIN-mode BatchNorm (their backward kernels -- fused
 # BatchNorm-backward epilogues, statistics passes, stem fusion -- only run there); the others with eval-mode BatchNorm
-FORWARD_CHANGING = ("SCOUTER_PLANES", "SCOUTER_HALO")
+FORWARD_CHANGING = ("SCOUTER_PLANES", "SCOUTER_HALO", "SCOUTER_X3")
 
 
 @pytest.mark.parametrize("setting", [
     {"SCOUTER_PLANES": "0"}, {"SCOUTER_AUTOTUNE": "0"}, {"SCOUTER_AUTOTUNE": "1"}, {"SCOUTER_AUTOTUNE": "1", "SCOUTER_WGRAD_TUNE": "0"},
     {"SCOUTER_HALO": "0"}, {"SCOUTER_HALO": "3"}, {"SCOUTER_BN_FUSE": "0"}, {"SCOUTER_BN_FUSE": "6"},
     {"SCOUTER_FUSE_STEM_POOL": "0"}, {"SCOUTER_SA_SUMS": "0"}, {"SCOUTER_SIDE_STREAM": "0"},
-    {"SCOUTER_SIDE_FWD": "0", "SCOUTER_SIDE_BWD": "0"}], ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()))
+    {"SCOUTER_SIDE_FWD": "0", "SCOUTER_SIDE_BWD": "0"}, {"SCOUTER_X3": "0"}, {"SCOUTER_X3": "3"}, {"SCOUTER_X3": "31"}, {"SCOUTER_X3": "15", "SCOUTER_AUTOTUNE": "1"},
+    {"SCOUTER_SPLIT_ASYNC": "0"}], ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()))
 def test_switch_setting_computes_the_same_step(setting, default_run):
     mode = "eval" if any(k in FORWARD_CHANGING for k in setting) else "train"
     got = run(setting, mode)
