@@ -387,7 +387,7 @@ def main():
             return [stats[0]]
         opt.zero_grad()
         out, losses = net(x, y)
-        losses[0].backward()
+        losses[0].backward(model.loss_seed(losses[0]))      # (as engine.calculation: cached ones instead of autograd's fill)
         opt.step()
         return losses
 

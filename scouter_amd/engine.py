@@ -113,7 +113,8 @@ def calculation(model, mode, data_loader, device, record, epoch, optimizer=None)
             optimizer.zero_grad()
         logits, losses = model(images, labels)
         if training:
-            losses[0].backward()
+            seed = getattr(_unwrap(model), "loss_seed", None)     # (cached ones: no `ones_like` launch per step)
+            losses[0].backward(seed(losses[0])) if seed is not None else losses[0].backward()
             optimizer.step()
         stats = getattr(_unwrap(model), "last_stats", None)
         if stats is not None:

@@ -271,6 +271,14 @@ class SlotModel(nn.Module):
             self._bump_tracked(tracked)                                       # BatchNorm num_batches_tracked
         return logp, stats, ((bctx, hstate) if save else None)
 
+    def loss_seed(self, loss):
+        """A cached tensor of ones shaped like the scalar loss: `loss.backward(model.loss_seed(loss))` spares autograd the
+        `ones_like` fill it launches for a bare `loss.backward()` (the last ATen kernel of the step; engine.py, bench.py)."""
+        seed = getattr(self, "_loss_seed", None)
+        if seed is None or seed.device != loss.device or seed.shape != loss.shape or seed.dtype != loss.dtype:
+            seed = self._loss_seed = torch.ones_like(loss)
+        return seed
+
     def _bump_tracked(self, tracked):
         """num_batches_tracked += 1 for the train-mode BatchNorms of this forward: the counters are views of ONE flat int64
         buffer (same buffer names / shapes in the state_dict), so it is one launch of the library instead of an ATen

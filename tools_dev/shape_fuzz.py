@@ -17,7 +17,7 @@ def run(arch, B, H, planes, seed=7):
                               to_k_layer=L, lambda_value="1")
     P = O.synth_state(O.state_dict_spec(arch, C, spc, L), seed)
     images, labels = O.synth_batch(B, 3, H, C, seed + 1)
-    m = SlotModel(args); m.load_state_dict(P); m.set_planes(planes); m = m.cuda().train()
+    m = SlotModel(args); m.load_state_dict(P); m.set_planes(planes); m.set_x3(31 if planes else 0); m = m.cuda().train()
     out, losses = m(images.cuda(), labels.cuda())
     losses[0].backward()
     torch.cuda.synchronize()
