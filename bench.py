@@ -525,6 +525,7 @@ def main():
                                           "bf16, statistics / sums / master weights / head fp32" if bf16 else ""),
                            "baseline_config": a.config, "precision": cfg["precision"],
                            "activation_storage": getattr(model, "activation_storage", "fp32"),
+                           "register_split_bf16x3_layers": len([c for c in getattr(model, "_x3_convs", ()) if c.x3_mode()]),
                            "global_batch": world * cfg["batch"], "parallelism": "dp%d" % world,
                            "step": "zero_grad+fwd+loss+bwd(+allreduce)+adamw",
                            "launch": "hipGraph replay (one captured graph per step)" if graphed is not None else "eager",
