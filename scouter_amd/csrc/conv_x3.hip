@@ -34,6 +34,13 @@ typedef unsigned short xu16x8 __attribute__((ext_vector_type(8)));
 
 #define X3_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// Development builds only (tools_dev/x3_ablate.sh): X3_ABLATE bits remove one ingredient of xgemm_kernel's K loop each --
+// 1 the split's arithmetic (the planes get the raw upper halves), 2 the global loads of A, 4 the LDS-DMA of B, 8 the fragment
+// reads, 16 the barrier, 32 the MFMAs, 64 the epilogue.  Results are WRONG; only the timing means something.
+#ifndef X3_ABLATE
+#define X3_ABLATE 0
+#endif
+
 // (a NON-template helper on purpose -- see conv_planes.hip: the builtin inside a kernel template makes hipcc's host pass drop
 //  the kernel's launch stub)
 __device__ __forceinline__ void x3_dma16(__amdgpu_buffer_rsrc_t rs, char* lds, unsigned voff, int soff) {
@@ -156,7 +163,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void xgemm_kernel(const float
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             unsigned short a, b, c;
-            split3_bf16(ra[t][e >> 2][e & 3], a, b, c);
+            if (X3_ABLATE & 1) { a = b = c = (unsigned short)(__float_as_uint(ra[t][e >> 2][e & 3]) >> 16); }
+            else split3_bf16(ra[t][e >> 2][e & 3], a, b, c);
             ph[e] = a; pm[e] = b; pl[e] = c;
         }
         char* d = lds_raw + stage * STAGE_BYTES + lane * 16 + (wave + NW * t) * 1024;
@@ -255,10 +263,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void xgemm_kernel(const float
     for (int kt = 0; kt < KT; ++kt) {
         const int stage = kt & 1, nstage = stage ^ 1;
         SBAR();
-        load_frags(1, stage, 1);                                  // A
+        if (!(X3_ABLATE & 8)) load_frags(1, stage, 1);           // A
 #pragma unroll
-        for (int t = GF; t < ARG; ++t) { store_a_group(nstage, t); load_a_group(k2, t); }
-        mma(0);                                                   // B
+        for (int t = GF; t < ARG; ++t) { store_a_group(nstage, t); if (!(X3_ABLATE & 2)) load_a_group(k2, t); }
+        if (!(X3_ABLATE & 32)) mma(0);                            // B
         {
             constexpr int VPS = GB ? (GB * VGRP + NMMA - 1) / NMMA + 1 : 2;
 #pragma unroll
@@ -277,14 +285,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void xgemm_kernel(const float
         SBAR();
         __builtin_amdgcn_s_waitcnt(0xc07f);                       // C
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");  // the DMA of B(kt+1) has landed; A loads may fly on
-        __builtin_amdgcn_s_barrier();                             // D: tile kt+1 complete in LDS, stage(kt) free
+        if (!(X3_ABLATE & 16)) __builtin_amdgcn_s_barrier();      // D: tile kt+1 complete in LDS, stage(kt) free
         SBAR();
-        dma_b(k2, stage);                                         // E (fenced: stays in front of the loads of section F)
+        if (!(X3_ABLATE & 4)) dma_b(k2, stage);                   // E (fenced: stays in front of the loads of section F)
         SBAR();
-        load_frags(0, nstage, 0);
+        if (!(X3_ABLATE & 8)) load_frags(0, nstage, 0);
 #pragma unroll
-        for (int t = 0; t < GF; ++t) { store_a_group(stage, t); load_a_group(k3, t); }
-        mma(1);                                                   // F
+        for (int t = 0; t < GF; ++t) { store_a_group(stage, t); if (!(X3_ABLATE & 2)) load_a_group(k3, t); }
+        if (!(X3_ABLATE & 32)) mma(1);                            // F
         {
             constexpr int VPS = (GF * VGRP + NMMA - 1) / NMMA + 1;
 #pragma unroll
@@ -312,6 +320,17 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void xgemm_kernel(const float
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] += accl[i][j];
+    if (X3_ABLATE & 64) {                       // (every accumulator stays live: nothing of the K loop may be eliminated)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+        if (sum == 12345.678f) dst[tid] = sum;
+        return;
+    }
     igemm_epilogue<BM, BN, WM, WN, DGRAD>(acc, (float*)lds_raw, g, bias, addend, dst, bn_part, relu, m0, n0, grp, mt_id, &fz);
 }
 
