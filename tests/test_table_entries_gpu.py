@@ -349,3 +349,53 @@ def test_fused_plane_input_gradient_entries(ks, monkeypatch):
     if addend is not None:
         ref = ref + addend[idx].double()
     _check(ks + " (plain)", plain[idx], ref, mag + (addend[idx].abs().double() if addend is not None else 0))
+
+
+# ---- the register-split bf16x3 kernels (csrc/conv_x3.hip, round 5): their table keys carry (nplanes = 3, B, H, W, Cin, Cout
+# [, k, groups]); fp32 operands in, fp32-grade products -- same sampled fp64 check, fp32 tolerance
+def _x_entries(mode):
+    out = []
+    for ks in sorted(TABLE):
+        p = ks.split("|")
+        if p[0] == mode and p[4 if mode == "xdgrad+bn" else 2] in BATCHES:
+            out.append(ks)
+    return out
+
+
+@pytest.mark.parametrize("ks", _x_entries("xfwd"))
+def test_register_split_forward_entries(ks):
+    v = _parse(ks, 2)
+    B, H, W, Cin, Cout = v[:5]
+    kh, groups = (v[5], v[6]) if len(v) > 5 else (1, 1)
+    pad = kh // 2
+    kk = K()
+    if not (kk.x3_eligible(Cin, Cout, kh, kh, 1, pad, groups, False) or kk.x3_conv_eligible(Cin, Cout, kh, kh, 1, pad, groups, False)):
+        pytest.skip("shape no longer routed to the register-split kernel (kept in the table by an earlier tuning pass)")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(zlib.crc32(ks.encode()))
+    x = _rnd(gen, B, H, W, Cin)
+    w = _rnd(gen, kh, kh, Cin // groups, Cout, scale=1.0 / np.sqrt(Cin // groups * kh * kh))
+    wf, _ = kk.planes_split_weight(w, groups, 3, fwd=True, dgrad=False)
+    y, (part, rows) = kk.conv2d_fwd_x3(x, wf, bn_stats=True, kh=kh, pad=pad, groups=groups)
+    key = ("xfwd", 3, B, H, W, Cin, Cout) if kh == 1 and groups == 1 else ("xfwd", 3, B, H, W, Cin, Cout, kh, groups)
+    _chosen(kk, key, ks)
+    idx, ref, mag = _sample_fwd(x, w, 1, pad, groups, gen, False)
+    _check(ks, y[idx], ref, mag)
+    yd = y.double().view(-1, Cout)
+    s = part[:rows].sum(0)
+    torch.testing.assert_close(s[:, 0], yd.sum(0), rtol=1e-9, atol=1e-7)
+    torch.testing.assert_close(s[:, 1], (yd * yd).sum(0), rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.parametrize("ks", _x_entries("xdgrad"))
+def test_register_split_input_gradient_entries(ks):
+    B, H, W, Cin, Cout = _parse(ks, 2)[:5]
+    kk = K()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(zlib.crc32(ks.encode()))
+    dy = _rnd(gen, B, H, W, Cout)
+    w = _rnd(gen, 1, 1, Cin, Cout, scale=1.0 / np.sqrt(Cout))
+    add = _rnd(gen, B, H, W, Cin)
+    _, wd = kk.planes_split_weight(w, 1, 3, fwd=False, dgrad=True)
+    dx = kk.conv2d_dgrad_x3(dy, wd, (B, H, W, Cin), addend=add)
+    _chosen(kk, ("xdgrad", 3, B, H, W, Cin, Cout), ks)
+    idx, ref, mag = _sample_dgrad(dy, w, (B, H, W, Cin), 1, 0, 1, gen, False)
+    _check(ks, dx[idx] - add[idx], ref, mag + add[idx].abs().double())
