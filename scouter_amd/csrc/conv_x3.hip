@@ -462,6 +462,11 @@ extern "C" int scouter_conv2d_dgrad_x3_bnbwd(const float* dy, const void* w_plan
 //     ~1.6 k cycles, before they are needed: the loop is unrolled by two, set = chunk parity);
 //   * the split + transposed stores of chunk c+1 are issued between the MFMAs of chunk c (program order: fragment reads,
 //     then the stores -- the compiler cannot tell the two stages apart and keeps LDS accesses in order).
+// development builds (tools_dev/x3_ablate.sh xw): XW_ABLATE bits 1 no split arithmetic, 2 no global loads in the loop, 8 no
+// fragment reads, 16 no barrier, 32 no MFMAs, 128 no LDS stores.  Results are WRONG; only the timing means something.
+#ifndef XW_ABLATE
+#define XW_ABLATE 0
+#endif
 template <int DUMMY>
 __global__ __launch_bounds__(256, 1) void xwgrad_kernel(const float* __restrict__ act, const float* __restrict__ dy,
                                                         float* __restrict__ out, ConvGeom g, int ci_tiles, int co_tiles,
@@ -510,10 +515,12 @@ __global__ __launch_bounds__(256, 1) void xwgrad_kernel(const float* __restrict_
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 unsigned short a, b, c;
-                split3_bf16(v[rr][e], a, b, c);
+                if (XW_ABLATE & 1) { a = b = c = (unsigned short)(__float_as_uint(v[rr][e]) >> 16); }
+                else split3_bf16(v[rr][e], a, b, c);
                 oh[rr] = a; om[rr] = b; ol[rr] = c;
             }
             __bf16* d = T + (4 * cq + e) * LDP + 4 * pq;
+            if (XW_ABLATE & 128) { if (oh[0] == 0x7fc1 && om[1] == 0x7fc1 && ol[2] == 0x7fc1) *(xu16x4*)(d) = oh; continue; }
             *(xu16x4*)(d) = oh;
             *(xu16x4*)(d + plane_elems) = om;
             *(xu16x4*)(d + 2 * plane_elems) = ol;
@@ -570,12 +577,15 @@ __global__ __launch_bounds__(256, 1) void xwgrad_kernel(const float* __restrict_
     //        24 MFMAs of step 1 | between them: split + stores of chunk kt+2's X patch (ra[cur], requested a chunk ago)
     //        into stage cur
     // Program order inside a section = the order LDS accesses must keep (reads of one stage, then stores into the other).
+    // (round 5: the build without the loop's global loads is 16 us of 102 faster, but requesting the patches FOUR chunks ahead
+    //  (four register sets, loop unrolled by four) changed nothing, 106 vs 103 us, and neither did spreading the eight loads
+    //  over both sections (one per six MFMAs, 107 us): neither latency nor issue pressure.  Two sets, one burst stay.)
     auto chunk = [&](int kt, auto CUR) {
         constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
         SBAR();
-        load_frags(1, cur, 1);                                                  // A
+        if (!(XW_ABLATE & 8)) load_frags(1, cur, 1);                            // A
         store_t3(ldsx + nxt * STAGE_H + 3 * PL_A, PL_B, rb[nxt]);               // (chunk kt+1's dY patch)
-        mma(0);                                                                 // B
+        if (!(XW_ABLATE & 32)) mma(0);                                          // B
 #pragma unroll
         for (int q = 0; q < NMMA; ++q) {
             SG(0x008, 1);
@@ -585,12 +595,12 @@ __global__ __launch_bounds__(256, 1) void xwgrad_kernel(const float* __restrict_
         }
         SBAR();
         __builtin_amdgcn_s_waitcnt(0xc07f);                                     // C
-        __builtin_amdgcn_s_barrier();                                           // D
+        if (!(XW_ABLATE & 16)) __builtin_amdgcn_s_barrier();                    // D
         SBAR();
-        load_ab(kt + 3, std::integral_constant<int, nxt>{});                    // E (beyond the split: zeros, never used)
-        load_frags(0, nxt, 0);
+        if (!(XW_ABLATE & 2)) load_ab(kt + 3, std::integral_constant<int, nxt>{});    // E (beyond the split: zeros, never used)
+        if (!(XW_ABLATE & 8)) load_frags(0, nxt, 0);
         store_t3(ldsx + cur * STAGE_H, PL_A, ra[cur]);                          // (chunk kt+2's X patch)
-        mma(1);                                                                 // F
+        if (!(XW_ABLATE & 32)) mma(1);                                          // F
 #pragma unroll
         for (int q = 0; q < NMMA; ++q) {
             SG(0x008, 1);
