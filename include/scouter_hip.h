@@ -124,6 +124,14 @@ int scouter_conv2d_dgrad_bnbwd_bf16_io(const void* dy, const float* w, const voi
                                        int tile_hint, const void* relu_mask, const void* x1, const float* saved1,
                                        double* part1, const void* x2, const float* saved2, double* part2, int io,
                                        void* stream);
+/* tile_hint 4 of the typed input gradient (round 5): the PERSISTENT pointwise kernel (csrc/conv_pw_persist_bf16.h) -- 1x1 /
+ * stride 1 / groups 1, Cout of 64 / 128 / 256 / 512, 128-multiples of Cin, the fused BatchNorm-backward epilogue present
+ * (part1 != NULL) and EVERY tensor stored as bf16 (io = DY | DX | X1 [| X2] [| ADDEND]); anything else named with tile 4 is
+ * SC_ERR_UNSUPPORTED, never re-routed.  It writes ONE partial row per workgroup row: rows =
+ * scouter_conv2d_dgrad_bn_partial_rows_bf16(..., 4, part2 != NULL) (tile_hint 0-3: the rows of the bf16-input tiles, as
+ * scouter_conv2d_dgrad_bn_partial_rows). */
+int scouter_conv2d_dgrad_bn_partial_rows_bf16(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                              int groups, int tile_hint, int two_batchnorms);
 int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
                               int kw, int stride, int pad, int groups, int plan_hint, void* ws, size_t ws_bytes,
                               void* arrival, int arrival_slots, void* stream);

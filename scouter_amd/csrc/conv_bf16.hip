@@ -15,6 +15,7 @@
 // 2.1 MFLOP (32 FLOP per L2 byte), so these kernels run at the operand-delivery rate.  Same scalar addressing
 // (buffer descriptors), block epilogue and BatchNorm-statistics fusion as conv_igemm.hip (conv_common.h).
 #include "conv_common.h"
+#include "conv_pw_persist_bf16.h"
 
 #include <type_traits>
 
@@ -299,6 +300,49 @@ static int bf16_tile(const ConvGeom& g, int hint) {       // 0: 128x128  1: 128x
 }
 static int conv_out_b(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
+// ---- tile 4: the persistent pointwise input gradient with the fused BatchNorm-backward epilogue, all tensors bf16-stored
+// (conv_pw_persist_bf16.h)
+struct PwbPlan { int ks, wg_per_col; };
+static bool pwb_geom_ok(const ConvGeom& g, bool has_addend, const BnBwdFuse& fz, int io) {
+    const bool pointwise = g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
+    const bool k_ok = g.Cg == 64 || g.Cg == 128 || g.Cg == 256 || g.Cg == 512;
+    const bool stored_bf16 = (io & SC_IO_X_BF16) && (io & SC_IO_Y_BF16) && (fz.io & 1) && (!fz.part2 || (fz.io & 2)) &&
+                             (!has_addend || (fz.io & 4));
+    return pointwise && k_ok && g.Ng % 128 == 0 && fz.part1 != nullptr && stored_bf16 && (g.M + 128) * g.Ng < (1L << 31) &&
+           g.M * g.Cg < (1L << 30);
+}
+static PwbPlan pwb_plan(const ConvGeom& g, bool two) {
+    PwbPlan p;
+    p.ks = g.Cg / 64;
+    const int resident = p.ks <= 2 && !two ? PWB_RESIDENT : 1;          // workgroups per CU (registers; LDS: 48 / 64 KB for K = 64 / 128)
+    const int colgroups = g.Ng / 128;
+    int w = ((256 * resident) / colgroups) & ~7;
+    p.wg_per_col = w < 8 ? 8 : w;
+    return p;
+}
+static void launch_pwb_fused(const void* src, const float* w, const void* addend, void* dst, const ConvGeom& g, hipStream_t st,
+                             const BnBwdFuse& fz) {
+    const PwbPlan p = pwb_plan(g, fz.part2 != nullptr);
+    const int mtiles = sc_cdiv(g.M, 64), grid = p.wg_per_col * (g.Ng / 128);
+    const size_t lds = (size_t)128 * g.Cg * 2 + 4 * 8192;
+    const long mask_words = ((g.M * g.Ng / 4 + 63) / 64) * 4;
+#define PWB(KS_, TWO_)                                                                                             \
+    do {                                                                                                           \
+        auto kern = pwb_fused_kernel<KS_, TWO_>;                                                                   \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 64 * KS_ * 2 + 4 * 8192); attr_set = true; } \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, src, w, addend, dst, g.M, g.Ng, mtiles, p.wg_per_col, fz, \
+                           mask_words);                                                                            \
+    } while (0)
+#define PWB2(KS_) do { if (fz.part2) PWB(KS_, true); else PWB(KS_, false); } while (0)
+    if (p.ks == 1) PWB2(1);
+    else if (p.ks == 2) PWB2(2);
+    else if (p.ks == 4) PWB2(4);
+    else PWB2(8);
+#undef PWB2
+#undef PWB
+}
+
 extern "C" int scouter_conv2d_weight_bf16t(const float* w, void* wt, int kh, int kw, int Cin, int Cout, int groups,
                                            void* stream) {
     SC_REQUIRE(w && wt && groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_weight_bf16t: bad arguments");
@@ -356,14 +400,36 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_bf16_io(const void* dy, const float* w
     const int Ho = conv_out_b(H, kh, stride, pad), Wo = conv_out_b(W, kw, stride, pad);
     ConvGeom g{B, Ho, Wo, Cout, H, W, Cin, kh, kw, stride, pad, groups, Cog, Cig, 0, Cout, Cig * Cout};
     g.M = (long)B * H * W;
-    static const char* names[4] = {"igemm_dgrad_bf16<128x128>", "igemm_dgrad_bf16<128x64>", "igemm_dgrad_bf16<64x64>", "igemm_dgrad_bf16<128x32>"};
-    const int tile = bf16_tile(g, tile_hint);
-    ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw,
-                     ((io & 8) ? 2.0 : 4.0) * B * Ho * Wo * Cout + ((io & 16) ? 2.0 : 4.0) * g.M * Cin);
+    static const char* names[5] = {"igemm_dgrad_bf16<128x128>", "igemm_dgrad_bf16<128x64>", "igemm_dgrad_bf16<64x64>", "igemm_dgrad_bf16<128x32>",
+                                   "igemm_dgrad_bf16<persistent>"};
     const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, (const float*)x1, saved1, part1,
                        (const float*)x2, saved2, part2, io & 7};
+    const int io_xy = ((io & 8) ? SC_IO_X_BF16 : 0) | ((io & 16) ? SC_IO_Y_BF16 : 0);
+    // (the caller named the persistent kernel: its partial-row layout differs, so an unsupported request is an error, never a
+    // silent re-route)
+    SC_UNSUPPORTED(tile_hint != 4 || pwb_geom_ok(g, addend != nullptr, fz, io_xy),
+                   "conv2d_dgrad_bf16: tile 4 (persistent) covers 1x1 / stride 1 / groups 1 input gradients with the fused "
+                   "BatchNorm-backward epilogue, Cout of 64 / 128 / 256 / 512, 128-multiples of Cin, every tensor stored as bf16");
+    const int tile = tile_hint == 4 ? 4 : bf16_tile(g, tile_hint);
+    ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw,
+                     ((io & 8) ? 2.0 : 4.0) * B * Ho * Wo * Cout + ((io & 16) ? 2.0 : 4.0) * g.M * Cin);
+    if (tile == 4) {
+        launch_pwb_fused(dy, w, addend, dx, g, (hipStream_t)stream, fz);
+        return sc_check_launch("conv2d_dgrad_bf16(persistent)");
+    }
     return dispatch_bf16<true>(dy, w, nullptr, (const float*)addend, (float*)dx, nullptr, g, 0, tile, (hipStream_t)stream,
-                               fz, ((io & 8) ? SC_IO_X_BF16 : 0) | ((io & 16) ? SC_IO_Y_BF16 : 0));
+                               fz, io_xy);
+}
+// partial rows ([rows][Cin][2] fp64) the fused launch writes: tiles 0-3 one per M tile, tile 4 one per workgroup row
+extern "C" int scouter_conv2d_dgrad_bn_partial_rows_bf16(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                                                         int pad, int groups, int tile_hint, int two_batchnorms) {
+    if (!(groups > 0 && Cin % groups == 0 && Cout % groups == 0) || stride != 1) return 0;
+    const int Cig = Cin / groups, Cog = Cout / groups;
+    const int Ho = conv_out_b(H, kh, stride, pad), Wo = conv_out_b(W, kw, stride, pad);
+    ConvGeom g{B, Ho, Wo, Cout, H, W, Cin, kh, kw, stride, pad, groups, Cog, Cig, 0, Cout, Cig * Cout};
+    g.M = (long)B * H * W;
+    if (tile_hint == 4) return pwb_plan(g, two_batchnorms != 0).wg_per_col;
+    return sc_cdiv(g.M, bf16_tile(g, tile_hint) == 2 ? 64 : 128);
 }
 extern "C" int scouter_conv2d_dgrad_bnbwd_bf16(const float* dy, const float* w, const float* addend, float* dx, int B,
                                                int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,

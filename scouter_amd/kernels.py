@@ -403,8 +403,14 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
 
     def launch(tile, dry=False, fuse=_NO_FUSE):
         if dry:
+            if tile == 4 and bf16:
+                # the persistent typed kernel (csrc/conv_pw_persist_bf16.h): fused launches with every tensor stored as bf16
+                return bool(will_fuse and kh == 1 and kw == 1 and pad == 0 and groups == 1 and Cout in (64, 128, 256, 512) and
+                            Cin % 128 == 0 and (B * H * W + 128) * Cin < (1 << 31) and B * H * W * Cout < (1 << 30) and
+                            (io & DGRAD_IO_DY) and (io & DGRAD_IO_DX) and (addend is None or io & DGRAD_IO_ADDEND) and
+                            post.x_io() == (1 << len(post.entries)) - 1)
             if tile == 4:        # (GEMM-K of the input gradient = Cout)
-                return not bf16 and _pw_persist_legal(B * H * W, Cout, Cin, kh, kw, stride, pad, groups, True)
+                return _pw_persist_legal(B * H * W, Cout, Cin, kh, kw, stride, pad, groups, True)
             return _tile_legal(Cin // groups, tile)
         if bf16:
             _native.check(L.scouter_conv2d_dgrad_bnbwd_bf16_io(
@@ -416,6 +422,7 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
                 "conv2d_dgrad")
         return True
 
+    will_fuse = fuse
     if fuse:
         # the fused launch is tuned as what it is (its epilogue reads one or two more tensors: on the short-K layers a
         # different tile wins than for the plain input gradient); partials sized for the most rows while timing
@@ -429,7 +436,11 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
                            pad, groups), launch_fused, (0, 1, 2, 3, 4))
         if tile < 0:                              # autotuning disabled: name a tile, the partial rows depend on it
             tile = 2 if (Cin // groups) % 64 == 0 else 3
-        rows = L.scouter_conv2d_dgrad_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
+        if bf16:
+            rows = L.scouter_conv2d_dgrad_bn_partial_rows_bf16(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile,
+                                                               int(len(post.entries) > 1))
+        else:
+            rows = L.scouter_conv2d_dgrad_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
         post.alloc(rows, x_shape)
         launch(tile, fuse=post.args())
     else:

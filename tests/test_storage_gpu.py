@@ -255,6 +255,61 @@ def test_gradient_storage_changes_no_bit_of_the_model(monkeypatch):
     assert float(res[0][1].abs().max()) > 0
 
 
+@pytest.mark.parametrize("case", [(3, 20, 19, 256, 64, True, True), (5, 14, 14, 512, 128, False, True), (2, 28, 28, 256, 128, True, False),
+                                  (2, 14, 13, 1024, 256, False, True), (3, 7, 7, 2048, 512, True, True), (9, 31, 29, 128, 64, False, False),
+                                  (40, 56, 56, 256, 64, False, True)])
+def test_persistent_typed_fused_input_gradient_against_the_tile_kernel(case, monkeypatch):
+    """Tile 4 of the typed input gradient (csrc/conv_pw_persist_bf16.h: persistent, v_mfma_f32_16x16x32_bf16 with permuted
+    columns, register epilogue) against tile 1 (igemm_bf16_kernel): the same products summed over K in another order inside
+    the matrix unit -- g equal to an fp32 ulp before its RNE to bf16, i.e. to ONE bf16 ulp on a few elements; the fp64 sums
+    (one partial row per workgroup instead of one per M tile) equal to that.  Ragged M, one / two BatchNorms, with / without
+    the shortcut gradient, more tiles than workgroups (last case)."""
+    B, H, W, Cin, Cout, two, with_add = case
+    kk = K()
+    monkeypatch.setattr(kk, "BN_BWD_FUSE", 15)
+    rng = np.random.default_rng(sum(case[:5]) + 11)
+    shape = (B, H, W, Cin)
+    dy = _rand(rng, B, H, W, Cout).to(BF16)
+    w = _rand(rng, 1, 1, Cin, Cout, scale=0.1)
+    add = _rand(rng, *shape).to(BF16) if with_add else None
+    gamma, beta = _rand(rng, Cin).abs() + 0.5, _rand(rng, Cin)
+    xs = [_rand(rng, *shape).to(BF16) for _ in range(2 if two else 1)]
+    saved = []
+    for i, xh in enumerate(xs):
+        rm, rv = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda")
+        if i == 0:
+            _, sv, mask = kk.bn_fwd(xh, gamma, beta, rm, rv, True, True, stats=_stats_of(xh.float()), want_mask=True)
+        else:
+            sv = kk.bn_stats(xh, gamma, beta, rm, rv, True, stats=_stats_of(xh.float()))
+        saved.append(sv)
+    key = ("dgrad+bn", len(xs), with_add, True, B, H, W, Cin, Cout, 1, 1, 1, 0, 1)
+    out = {}
+    for tile in (1, 4):
+        monkeypatch.setitem(kk._tile_cache, key, tile)
+        post = kk.BnBwdFuse(mask, list(zip(xs, saved)))
+        g = kk.conv2d_dgrad(dy, w, shape, add, 1, 0, 1, precision="bf16", post=post, out_dtype=BF16)
+        assert post.applied and g.dtype == BF16
+        out[tile] = (g.float(), [p_[:post.rows].sum(0) for p_ in post.parts], post.rows)
+    L = kk._native.lib()
+    assert out[4][2] == L.scouter_conv2d_dgrad_bn_partial_rows_bf16(B, H, W, Cin, Cout, 1, 1, 1, 0, 1, 4, int(two))
+    assert out[4][2] != out[1][2]
+    g1, g4 = out[1][0], out[4][0]
+    assert float(g1.abs().max()) > 0
+    d = (g1 - g4).abs()
+    # (2e-6: where the product and the shortcut gradient cancel, an fp32 ulp of the product is not small against g)
+    assert bool((d <= g1.abs() * 2.0 ** -7 + 2e-6).all()), "more than one bf16 ulp"
+    assert float((d > 0).float().mean()) < 0.02, "an fp32 ulp before the rounding flips a bf16 ulp on a few elements only"
+    scale = g1.abs().double().sum((0, 1, 2))
+    for a, b in zip(out[1][1], out[4][1]):
+        assert bool(((a[:, 0] - b[:, 0]).abs() <= 2.0 ** -8 * 0.02 * scale + 1e-9).all())
+        assert float((a - b).abs().max()) <= 1e-3 * float(a.abs().max())
+    # anything the persistent kernel does not cover, named with tile 4, is an error -- never a silent re-route
+    post = kk.BnBwdFuse(mask, [(xs[0].float(), saved[0])])
+    rc = L.scouter_conv2d_dgrad_bnbwd_bf16_io(kk._p(dy), kk._p(w), None, kk._p(torch.empty(shape, dtype=BF16, device="cuda")), B, H, W,
+                                              Cin, Cout, 1, 1, 1, 0, 1, 4, *kk._NO_FUSE, kk.DGRAD_IO_DY | kk.DGRAD_IO_DX, None)
+    assert rc != 0 and "tile 4" in L.scouter_last_error().decode()
+
+
 @pytest.mark.parametrize("case", [(3, 20, 19, 256, 64, True, True), (5, 14, 14, 512, 128, False, True), (2, 28, 28, 256, 128, True, False)])
 def test_masked_block_gradient_stored_as_bf16(case, monkeypatch):
     """The residual-stream gradient: conv1's fused input-gradient epilogue stores the masked gradient g as bf16 (= RNE of the

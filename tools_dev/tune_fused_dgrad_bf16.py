@@ -1,5 +1,6 @@
 """Block tiles of the fused 1x1 input gradient (conv1 + the previous block's BatchNorm-backward sums) of BASELINE configs[4]
-under bf16 STORAGE (dy, dx, addend, BatchNorm inputs all bf16): times tiles 0-3 per shape, prints the table lines."""
+under bf16 STORAGE (dy, dx, addend, BatchNorm inputs all bf16): times tiles 0-3 and the persistent kernel (4) per shape,
+prints the table lines."""
 import sys, torch
 sys.path.insert(0, '.')
 from scouter_amd import kernels as K
@@ -31,8 +32,8 @@ for H, cin, cout, nbn, n in [(56, 256, 64, 2, 1), (56, 256, 64, 1, 1), (56, 256,
     key = ("dgrad+bn", nbn, True, True, B, H, H, cin, cout, 1, 1, 1, 0, 1)
     old = K._table_choice(key, lambda t, dry=False: True)
     res = {}
-    for t in (0, 1, 2, 3):
-        if not K._tile_legal(cin, t): continue
+    for t in (0, 1, 2, 3, 4):
+        if not (K._tile_legal(cin, t) if t < 4 else (cin % 128 == 0 and cout in (64, 128, 256, 512))): continue
         K._tile_cache[key] = t
         def run():
             post = K.BnBwdFuse(mask, list(zip(xs, saved)))
