@@ -14,6 +14,7 @@
 #include "conv_wgrad_bf16.h"
 #include "conv_wgrad_taps.h"
 #include "conv_pw_persist.h"
+#include "conv_pw_persist_x3.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -751,13 +752,53 @@ static void launch_pwp_fused(const float* src, const float* w, const float* adde
 #undef PWF
 }
 
+// ---- tile 5: the persistent pointwise input gradient with the fused BatchNorm-backward epilogue on the bf16 matrix cores
+// (three-way operand split in registers / in LDS; conv_pw_persist_x3.h)
+struct XpwPlan { int ks, wg_per_col; };
+static bool xpw_geom_ok(const ConvGeom& g) {                 // (g as for the GEMM: Cg = K, Ng = N)
+    return g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.H == g.Ho && g.W == g.Wo && g.groups == 1 &&
+           (g.Cg == 64 || g.Cg == 128 || g.Cg == 256) && g.Ng % 64 == 0 && g.M * g.Cg < (1L << 29) &&
+           (g.M + 128) * g.Ng < (1L << 30);
+}
+static XpwPlan xpw_plan(const ConvGeom& g) {
+    XpwPlan p;
+    p.ks = g.Cg / 64;
+    const int resident = p.ks <= 2 ? 2 : 1;                  // workgroups per CU (LDS: 56 / 80 / 128 KB for K = 64 / 128 / 256)
+    const int colgroups = g.Ng / 64;
+    int w = ((256 * resident) / colgroups) & ~7;
+    p.wg_per_col = w < 8 ? 8 : w;
+    return p;
+}
+static void launch_xpw_fused(const float* src, const float* w, const float* addend, float* dst, const ConvGeom& g,
+                             hipStream_t st, const BnBwdFuse& fz) {
+    const XpwPlan p = xpw_plan(g);
+    const int mtiles = sc_cdiv(g.M, 64), grid = p.wg_per_col * (g.Ng / 64);
+    const size_t lds = (size_t)3 * 64 * g.Cg * 2 + 4 * 8192;
+    const long mask_words = ((g.M * g.Ng / 4 + 63) / 64) * 4;
+#define XPW(KS_, TWO_)                                                                                             \
+    do {                                                                                                           \
+        auto kern = xpw_fused_kernel<KS_, TWO_>;                                                                   \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 64 * KS_ * 2 + 4 * 8192); attr_set = true; } \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, src, w, addend, dst, g.M, g.Ng, mtiles, p.wg_per_col, fz, \
+                           mask_words);                                                                            \
+    } while (0)
+#define XPW2(KS_) do { if (fz.part2) XPW(KS_, true); else XPW(KS_, false); } while (0)
+    if (p.ks == 1) XPW2(1);
+    else if (p.ks == 2) XPW2(2);
+    else XPW2(4);
+#undef XPW2
+#undef XPW
+}
+
 // tile choice: largest tile that still fills the chip (>= ~1.5 rounds of 256 CUs x 2 blocks); Ng is a multiple of 32
 static bool igemm_tile_ok(const ConvGeom& g, int t) {
     return (t == 0 && g.Ng % 128 == 0) || ((t == 1 || t == 2) && g.Ng % 64 == 0) || t == 3;
 }
 // hint >= 0: the caller's (autotuned) choice if legal for this shape; otherwise the static heuristic
 static int igemm_tile(const ConvGeom& g, int hint = -1) {     // 0: 128x128  1: 128x64  2: 64x64  3: 128x32  4: persistent
-    if (hint == 4 && pwp_geom_ok(g)) return 4;
+    if (hint == 4 && pwp_geom_ok(g)) return 4;                //                                  5: persistent bf16x3 (fused dgrad)
+    if (hint == 5 && xpw_geom_ok(g)) return 5;
     if (hint >= 0 && hint <= 3 && igemm_tile_ok(g, hint)) return hint;
     auto blocks = [&](int bm, int bn) { return (long)sc_cdiv(g.M, bm) * (g.Ng / bn) * g.groups; };
     const long want = 768;
@@ -782,6 +823,13 @@ static int dispatch_igemm(const float* src, const float* w, const float* bias, c
         if (DGRAD && fz.part1) launch_pwp_fused(src, w, addend, dst, g, st, fz);
         else launch_pwp<DGRAD>(src, w, addend, dst, bn_part, g, st);
         return sc_check_launch(DGRAD ? "conv2d_dgrad(persistent)" : "conv2d_fwd(persistent)");
+    }
+    if (tile == 5) {
+        SC_UNSUPPORTED(DGRAD && fz.part1 && xpw_geom_ok(g) && !bias && !relu,
+                       "conv2d: tile 5 (persistent bf16x3 kernel) covers 1x1 / stride 1 / groups 1 input gradients with the fused "
+                       "BatchNorm-backward epilogue, Cout of 64 / 128 / 256, 64-multiples of Cin");
+        if constexpr (DGRAD) launch_xpw_fused(src, w, addend, dst, g, st, fz);
+        return sc_check_launch("conv2d_dgrad(persistent bf16x3)");
     }
     switch (tile) {
         case 0: launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
@@ -829,6 +877,7 @@ extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const floa
     }
     static const char* names[5] = {"igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>",
                                    "igemm_fwd<persistent>"};
+    SC_UNSUPPORTED(tile_hint != 5, "conv2d_fwd: tile 5 is an input-gradient kernel");
     const int tile = igemm_tile(g, tile_hint);
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
                      4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
@@ -851,6 +900,7 @@ extern "C" int scouter_conv2d_dgrad_bn_partial_rows(int B, int H, int W, int Cin
     const ConvGeom g = dgrad_geom(B, H, W, Cin, Cout, kh, kw, stride, pad, groups);
     const int t = igemm_tile(g, tile_hint);
     if (t == 4) { const PwpPlan p = pwp_fused_plan(g); return p.wg_per_col * p.waves_m; }   // one row per (workgroup, wave row)
+    if (t == 5) return xpw_plan(g).wg_per_col;                                              // one row per workgroup row
     return sc_cdiv(g.M, t == 2 ? 64 : 128);
 }
 
@@ -871,8 +921,12 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, c
                                    "igemm_dgrad<128x32>", "igemm_dgrad<persistent>"};
     // with the BatchNorm-backward reductions in the epilogue the kernel is a different piece of work (it also reads the
     // BatchNorm input(s), the addend and the ReLU bits -- co-bound by HBM on the short-K layers): its own profile row
-    static const char* names_bn[5] = {"igemm_dgrad+bn_bwd<128x128>", "igemm_dgrad+bn_bwd<128x64>",
-                                      "igemm_dgrad+bn_bwd<64x64>", "igemm_dgrad+bn_bwd<128x32>", "igemm_dgrad+bn_bwd<persistent>"};
+    static const char* names_bn[6] = {"igemm_dgrad+bn_bwd<128x128>", "igemm_dgrad+bn_bwd<128x64>",
+                                      "igemm_dgrad+bn_bwd<64x64>", "igemm_dgrad+bn_bwd<128x32>", "igemm_dgrad+bn_bwd<persistent>",
+                                      "xpw_dgrad+bn_bwd<bf16x3>"};
+    SC_UNSUPPORTED(tile_hint != 5 || (part1 && xpw_geom_ok(g)),
+                   "conv2d_dgrad: tile 5 (persistent bf16x3 kernel) covers 1x1 / stride 1 / groups 1 input gradients with the fused "
+                   "BatchNorm-backward epilogue, Cout of 64 / 128 / 256, 64-multiples of Cin");
     const int tile = igemm_tile(g, tile_hint);
     const double out_elems = (double)g.M * Cin;
     ScProfScope prof(part1 ? names_bn[tile] : names[tile], (hipStream_t)stream,

@@ -411,6 +411,11 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
                             post.x_io() == (1 << len(post.entries)) - 1)
             if tile == 4:        # (GEMM-K of the input gradient = Cout)
                 return _pw_persist_legal(B * H * W, Cout, Cin, kh, kw, stride, pad, groups, True)
+            if tile == 5:
+                # the persistent bf16x3 kernel (csrc/conv_pw_persist_x3.h): fused fp32 launches of the short-K 1x1 layers
+                return bool(will_fuse and not bf16 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and groups == 1 and
+                            Cout in (64, 128, 256) and Cin % 64 == 0 and (B * H * W + 128) * Cin < (1 << 30) and
+                            B * H * W * Cout < (1 << 29))
             return _tile_legal(Cin // groups, tile)
         if bf16:
             _native.check(L.scouter_conv2d_dgrad_bnbwd_bf16_io(
@@ -433,7 +438,7 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
                 post.alloc(max(-(-B * H * W // 64), 512), x_shape)   # (the most rows any tile writes; tile 4: <= 512)
             return launch(tile, fuse=post.args())
         tile = _pick_tile(("dgrad+bn", len(post.entries), addend is not None, bf16, B, H, W, Cin, Cout, kh, kw, stride,
-                           pad, groups), launch_fused, (0, 1, 2, 3, 4))
+                           pad, groups), launch_fused, (0, 1, 2, 3, 4, 5))
         if tile < 0:                              # autotuning disabled: name a tile, the partial rows depend on it
             tile = 2 if (Cin // groups) % 64 == 0 else 3
         if bf16:

@@ -125,6 +125,62 @@ def test_fused_batchnorm_backward_epilogue(two):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * float(b.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(3, 20, 19, 256, 64, True, True), (5, 14, 14, 512, 128, False, True), (2, 28, 28, 256, 128, True, False),
+                                  (2, 14, 13, 1024, 256, False, True), (9, 31, 29, 64, 64, True, False), (40, 56, 56, 256, 64, False, True),
+                                  (36, 28, 28, 512, 256, True, True)])
+def test_persistent_fused_input_gradient_on_the_bf16_matrix_cores(case, monkeypatch):
+    """Tile 5 of the fp32 fused input gradient (csrc/conv_pw_persist_x3.h: persistent, dY split three-way in registers, W^T
+    planes resident in LDS, v_mfma_f32_16x16x32_bf16 with permuted columns, register epilogue) against the exact-fp32 MFMA
+    kernel (tile 2) and an fp64 product: at least as close to fp64 as the fp32 kernel, the same ReLU masking (exact zeros in
+    the same places), the same fp64 sums to the rounding of the masked gradient; ragged M, one / two BatchNorms, with /
+    without the shortcut gradient, more tiles than workgroups with two workgroups per CU (the last two cases)."""
+    B, H, W, Cin, Cout, two, with_add = case
+    kk = K()
+    monkeypatch.setattr(kk, "BN_BWD_FUSE", 15)
+    rng = np.random.default_rng(sum(case[:5]) + 13)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+    shape = (B, H, W, Cin)
+    dy, w = f(B, H, W, Cout), f(1, 1, Cin, Cout) / np.sqrt(Cout)
+    add = f(*shape) if with_add else None
+    g_, b_ = torch.ones(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+    xs = [f(*shape) for _ in range(2 if two else 1)]
+    saved, mask = [], None
+    for i, xh in enumerate(xs):
+        rm, rv = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda")
+        o = kk.bn_fwd(xh, g_, b_, rm, rv, True, True, want_mask=True)
+        saved.append(o[1])
+        mask = o[2] if i == 0 else mask
+    key = ("dgrad+bn", len(xs), with_add, False, B, H, W, Cin, Cout, 1, 1, 1, 0, 1)
+    out = {}
+    for tile in (2, 5):
+        monkeypatch.setitem(kk._tile_cache, key, tile)
+        post = kk.BnBwdFuse(mask, list(zip(xs, saved)))
+        g = kk.conv2d_dgrad(dy, w, shape, add, 1, 0, 1, post=post)
+        assert post.applied
+        out[tile] = (g, [p_[:post.rows].sum(0) for p_ in post.parts], post.rows)
+    L = kk._native.lib()
+    assert out[5][2] == L.scouter_conv2d_dgrad_bn_partial_rows(B, H, W, Cin, Cout, 1, 1, 1, 0, 1, 5) != out[2][2]
+    g2, g5 = out[2][0], out[5][0]
+    # (an unmasked element may cancel to an exact zero in one of the two roundings: a handful in ten million)
+    assert int(((g2 == 0) != (g5 == 0)).sum()) <= 1 + g2.numel() // 1000000 and 0.2 < float((g2 == 0).float().mean()) < 0.8
+    ref = dy.double().reshape(-1, Cout) @ w.double().reshape(Cin, Cout).t()
+    if with_add:
+        ref = ref + add.double().reshape(-1, Cin)
+    ref = torch.where((g2.reshape(-1, Cin) == 0) | (g5.reshape(-1, Cin) == 0), torch.zeros_like(ref), ref)
+    live = (ref != 0).double()
+    e2, e5 = float(((g2.reshape(-1, Cin).double() - ref) * live).abs().max()), float(((g5.reshape(-1, Cin).double() - ref) * live).abs().max())
+    assert e5 <= e2 + 1e-7, (e5, e2)
+    assert float(((g5.reshape(-1, Cin).double() - ref) * live).pow(2).mean()) <= float(((g2.reshape(-1, Cin).double() - ref) * live).pow(2).mean()) * 1.01
+    scale = ref.abs().sum(0)
+    for a, b in zip(out[2][1], out[5][1]):
+        assert bool(((a[:, 0] - b[:, 0]).abs() <= 1e-6 * scale + 1e-9).all())
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    # named where it does not apply: an error, not a re-route
+    rc = L.scouter_conv2d_dgrad_bnbwd_f32(kk._p(dy), kk._p(w), None, kk._p(torch.empty(shape, device="cuda")), B, H, W, Cin, Cout, 1, 1,
+                                          1, 0, 1, 5, *kk._NO_FUSE, None)
+    assert rc != 0 and "tile 5" in L.scouter_last_error().decode()
+
+
 def test_model_routes_the_deep_pointwise_layers_and_the_switch_turns_them_off():
     """SlotModel.set_x3: the 14 deep 1x1 convolutions of resnest26d (Cin * Cout >= 2^16) run on the register-split
     GEMM -- a static rule of the layer shapes -- and with the switch off every one is back on the fp32 MFMA kernels;
