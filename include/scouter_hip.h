@@ -73,7 +73,12 @@ int scouter_conv2d_dgrad_f32(const float* dy, const float* w, const float* adden
  * [B][H][W][Cin]; saved1 / saved2: their [4][Cin] blocks {mean, rstd, scale, shift}.  rows =
  * scouter_conv2d_dgrad_bn_partial_rows(...) (fp32 / bf16-input kernels: ceil(B*H*W / 64) for tile 2, / 128 otherwise;
  * plane kernels: / 128, 128, 128, 64, 256, 256 for tile 0..5, 4 * ceil(B*H*W / 256) for tile 6).  scouter_bn_bwd_f32(ext_partial = part, ext_rows = rows) then
- * runs without its own reduction pass.  part1 == NULL: exactly scouter_conv2d_dgrad_f32. */
+ * runs without its own reduction pass.  part1 == NULL: exactly scouter_conv2d_dgrad_f32.
+ * tile_hint 5 (round 5; csrc/conv_pw_persist_x3.h): the PERSISTENT kernel on the bf16 matrix cores (three-way operand split:
+ * fp32-grade products, another summation order) -- 1x1 / stride 1 / groups 1 with GEMM-K of 64 / 128 / 256 and 64-multiples of
+ * output columns: the input gradient WITH the fused epilogue (one partial row per workgroup row:
+ * scouter_conv2d_dgrad_bn_partial_rows(..., 5)), and the forward without bias / addend / ReLU
+ * (scouter_conv2d_fwd_bn_partial_rows(..., 5)); named where it does not apply: SC_ERR_UNSUPPORTED, never re-routed. */
 int scouter_conv2d_dgrad_bn_partial_rows(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
                                          int groups, int tile_hint);
 int scouter_conv2d_dgrad_bnbwd_f32(const float* dy, const float* w, const float* addend, float* dx, int B, int H, int W,

@@ -791,6 +791,25 @@ static void launch_xpw_fused(const float* src, const float* w, const float* adde
 #undef XPW
 }
 
+static void launch_xpw_fwd(const float* src, const float* w, float* dst, double* bn_part, const ConvGeom& g, hipStream_t st) {
+    const XpwPlan p = xpw_plan(g);
+    const int mtiles = sc_cdiv(g.M, 64), grid = p.wg_per_col * (g.Ng / 64);
+    const size_t lds = (size_t)3 * 64 * g.Cg * 2 + 4 * 8192;
+#define XPF(KS_, ST_)                                                                                              \
+    do {                                                                                                           \
+        auto kern = xpw_fwd_kernel<KS_, ST_>;                                                                      \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 64 * KS_ * 2 + 4 * 8192); attr_set = true; } \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, src, w, dst, bn_part, g.M, g.Ng, mtiles, p.wg_per_col); \
+    } while (0)
+#define XPF2(KS_) do { if (bn_part) XPF(KS_, true); else XPF(KS_, false); } while (0)
+    if (p.ks == 1) XPF2(1);
+    else if (p.ks == 2) XPF2(2);
+    else XPF2(4);
+#undef XPF2
+#undef XPF
+}
+
 // tile choice: largest tile that still fills the chip (>= ~1.5 rounds of 256 CUs x 2 blocks); Ng is a multiple of 32
 static bool igemm_tile_ok(const ConvGeom& g, int t) {
     return (t == 0 && g.Ng % 128 == 0) || ((t == 1 || t == 2) && g.Ng % 64 == 0) || t == 3;
@@ -825,11 +844,13 @@ static int dispatch_igemm(const float* src, const float* w, const float* bias, c
         return sc_check_launch(DGRAD ? "conv2d_dgrad(persistent)" : "conv2d_fwd(persistent)");
     }
     if (tile == 5) {
-        SC_UNSUPPORTED(DGRAD && fz.part1 && xpw_geom_ok(g) && !bias && !relu,
-                       "conv2d: tile 5 (persistent bf16x3 kernel) covers 1x1 / stride 1 / groups 1 input gradients with the fused "
-                       "BatchNorm-backward epilogue, Cout of 64 / 128 / 256, 64-multiples of Cin");
+        SC_UNSUPPORTED(xpw_geom_ok(g) && !bias && !relu && (DGRAD ? fz.part1 != nullptr : (!addend && !fz.part1)),
+                       "conv2d: tile 5 (persistent bf16x3 kernel) covers 1x1 / stride 1 / groups 1 layers with GEMM-K of 64 / 128 / "
+                       "256 and 64-multiples of output columns: the forward without bias / addend / ReLU, the input gradient with "
+                       "the fused BatchNorm-backward epilogue");
         if constexpr (DGRAD) launch_xpw_fused(src, w, addend, dst, g, st, fz);
-        return sc_check_launch("conv2d_dgrad(persistent bf16x3)");
+        else launch_xpw_fwd(src, w, dst, bn_part, g, st);
+        return sc_check_launch(DGRAD ? "conv2d_dgrad(persistent bf16x3)" : "conv2d_fwd(persistent bf16x3)");
     }
     switch (tile) {
         case 0: launch_igemm<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz); break;
@@ -860,6 +881,7 @@ extern "C" int scouter_conv2d_fwd_bn_partial_rows(int B, int H, int W, int Cin, 
     if (conv_fwd_geom(g, B, H, W, Cin, Cout, kh, kw, stride, pad, groups) != SC_OK) return 0;
     const int t = igemm_tile(g, tile_hint);
     if (t == 4) { const PwpPlan p = pwp_plan(g); return p.wg_per_col * p.waves_m; }    // one row per (workgroup, wave row)
+    if (t == 5) return xpw_plan(g).wg_per_col;                                         // one row per workgroup row
     return sc_cdiv(g.M, t == 2 ? 64 : 128);
 }
 
@@ -875,9 +897,10 @@ extern "C" int scouter_conv2d_fwd_f32(const float* x, const float* w, const floa
         sc_set_error("conv2d_fwd: per-group channels must be multiples of 32 (got %d -> %d)", Cin / groups, Cout / groups);
         return rc;
     }
-    static const char* names[5] = {"igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>",
-                                   "igemm_fwd<persistent>"};
-    SC_UNSUPPORTED(tile_hint != 5, "conv2d_fwd: tile 5 is an input-gradient kernel");
+    static const char* names[6] = {"igemm_fwd<128x128>", "igemm_fwd<128x64>", "igemm_fwd<64x64>", "igemm_fwd<128x32>",
+                                   "igemm_fwd<persistent>", "xpw_fwd<bf16x3>"};
+    SC_UNSUPPORTED(tile_hint != 5 || xpw_geom_ok(g), "conv2d_fwd: tile 5 (persistent bf16x3 kernel) covers 1x1 / stride 1 / groups 1 "
+                   "layers with 64 / 128 / 256 input channels and 64-multiples of output channels");
     const int tile = igemm_tile(g, tile_hint);
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
                      4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));

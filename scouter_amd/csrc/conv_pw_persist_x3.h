@@ -246,3 +246,165 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 2 : 1)) void xpw_fused_kernel(
         if (TWO) { fz.part2[o] = tg; fz.part2[o + 1] = t2; }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same skeleton for the FORWARD of the short-K pointwise layers (K = Cin = 64 / 128 / 256: conv1 / conv3 / downsample of
+// layer1 and layer2, /root/reference/timm/models/resnest.py:111-143, resnet.py:292-306) with the fused BatchNorm statistics:
+// y = x W, per column sum y and sum y^2 in fp64.  These are output streams (64 -> 256 at 56 x 56, batch 70: 225 MB written,
+// 56 MB read, 7.2 GFLOP) that pwp_kernel (exact-fp32 MFMA, one workgroup per CU, 4-byte stores per lane) runs at 2.75 TB/s.
+// W (HWIO [k][n]) is transposed and split three-way into the resident [n][k] planes once per workgroup; no epilogue operands,
+// so two workgroups per CU fit for every K.  part: [wg_per_col][N][2] fp64.
+template <int KS, bool STATS>
+__global__ __launch_bounds__(256, (KS <= 2 ? 2 : 1)) void xpw_fwd_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
+                                                                         float* __restrict__ dst, double* __restrict__ part, long M,
+                                                                         int N, int mtiles, int wg_per_col) {
+    constexpr int K = 64 * KS, BN = 64, RB = 2 * K;
+    constexpr int PLANE = BN * RB, WBYTES = 3 * PLANE, SLOT = 64 * 128, NST = 2 * KS;
+    constexpr int CHM = (K / 8 < 16 ? K / 8 : 16) - 1;
+    extern __shared__ __attribute__((aligned(1024))) char xpw_lds[];
+    char* Wl = xpw_lds;
+    char* ring = xpw_lds + WBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int colgroups = N / BN;
+    const int L = blockIdx.x;
+    const int cg = (L >> 3) % colgroups, p = (L & 7) + 8 * ((L >> 3) / colgroups);
+    const int n0 = cg * BN;
+    const int n_my = p < mtiles ? (mtiles - p + wg_per_col - 1) / wg_per_col : 0;
+    const int nstage4 = (n_my * NST + 3) / 4;
+
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)(M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (unsigned)(M * N * 4), 0x00020000);
+    unsigned a_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * (wave + 4 * j) + (lane >> 3), c = (lane & 7) ^ (r & 7);
+        a_voff[j] = (unsigned)((r * K + c * 4) * 4);
+    }
+    auto issue = [&](int G, int slot) __attribute__((always_inline)) {
+        const int ti = G / NST, kc = G % NST;
+        const long m0 = (long)__builtin_amdgcn_readfirstlane(p + ti * wg_per_col) * 64;
+        const long off = (m0 * K + kc * 32) * 4;
+        const int soff = off > 0x7fffffffL ? 0x7fffffff : (int)off;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xpw_dma16(rs_a, ring + slot * SLOT + (wave + 4 * j) * 1024, a_voff[j], soff);
+    };
+    issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);
+    // ---- W[k][n0 .. n0 + 63] -> planes [n][k]: a thread gathers eight k-values of one column (lanes = consecutive columns)
+    for (int e = tid; e < BN * (K / 8); e += 256) {
+        const int n = e % BN, c = e / BN;
+        xpw_u16x8 ph, pm, pl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned short a, b, cc;
+            split3_bf16(wgt[(long)(8 * c + i) * N + n0 + n], a, b, cc);
+            ph[i] = a; pm[i] = b; pl[i] = cc;
+        }
+        char* d = Wl + n * RB + ((c ^ ((n >> 2) & CHM)) << 4);
+        *(xpw_u16x8*)(d) = ph;
+        *(xpw_u16x8*)(d + PLANE) = pm;
+        *(xpw_u16x8*)(d + 2 * PLANE) = pl;
+    }
+
+    const int arow = 16 * wave + l15;
+    const char* a_base = ring + arow * 128;
+    const int a_sw = arow & 7;
+    const char* b_base = Wl + 4 * l15 * RB;
+    const int b_t = q ^ (l15 & CHM);
+    const int col0 = n0 + 4 * l15;
+    const int row_in = 16 * wave + 4 * q;
+    const unsigned o_voff = (unsigned)(((long)row_in * N + col0) * 4);
+
+    f32x4 acc[4], accl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    auto epilogue = [&](int ti) __attribute__((always_inline)) {
+        const long m0 = (long)__builtin_amdgcn_readfirstlane(p + ti * wg_per_col) * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4 out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = acc[k][e] + accl[k][e];
+                out[k] = v;
+                if (STATS) {                                     // (rows beyond M: their A rows read zeros, v = 0)
+                    const double d = (double)v;
+                    s1[k] += d;
+                    s2[k] = __builtin_fma(d, d, s2[k]);
+                }
+                acc[k][e] = 0.f;
+                accl[k][e] = 0.f;
+            }
+            // (row offset in the per-lane offset, scalar offset an immediate 0: see the input-gradient kernel above)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xpw_u32x4, out), rs_o,
+                                                   o_voff + (unsigned)((m0 + e) * (long)N * 4), 0, 0);
+        }
+    };
+    auto stage_body = [&](int G, int slot, int kc) __attribute__((always_inline)) {
+        const bool last = kc == NST - 1 && G / NST < n_my;
+        const char* As = a_base + slot * SLOT;
+        const f32x4 a0 = *(const f32x4*)(As + (((2 * q) ^ a_sw) << 4)), a1 = *(const f32x4*)(As + (((2 * q + 1) ^ a_sw) << 4));
+        xpw_bf16x8 fb[3][4];
+        const char* bp = b_base + (((kc * 4) ^ b_t) << 4);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[pl][j] = *(const xpw_bf16x8*)(bp + pl * PLANE + j * RB);
+        xpw_u16x8 h, m, l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned short a, b, c;
+            split3_bf16(i < 4 ? a0[i & 3] : a1[i & 3], a, b, c);
+            h[i] = a; m[i] = b; l[i] = c;
+        }
+        const xpw_bf16x8 fa[3] = {__builtin_bit_cast(xpw_bf16x8, h), __builtin_bit_cast(xpw_bf16x8, m), __builtin_bit_cast(xpw_bf16x8, l)};
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (pr < 5) accl[j] = xpw_mfma(fa[PA[pr]], fb[PB[pr]][j], accl[j]);
+                else acc[j] = xpw_mfma(fa[PA[pr]], fb[PB[pr]][j], acc[j]);
+            }
+        SB();
+        // the next stage's DMA has landed: two younger stages (4 instructions) -- and, behind an epilogue, its four stores, which
+        // are younger than all three -- may stay in flight
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (last) epilogue(G / NST);
+        __builtin_amdgcn_s_barrier();
+        SB();
+        issue(G + 4, slot);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int base = 0; base < nstage4; ++base) {
+#pragma unroll
+        for (int S = 0; S < 4; ++S) stage_body(4 * base + S, S, NST <= 4 ? S % NST : (4 * base + S) % NST);
+    }
+#undef SB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STATS) {
+        __syncthreads();
+        double* Ps = (double*)xpw_lds;                           // [4 waves][64 columns][2]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double t1 = s1[k], t2 = s2[k];
+            t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+            t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+            if (q == 0) { double* o = Ps + ((wave * BN) + 4 * l15 + k) * 2; o[0] = t1; o[1] = t2; }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { t1 += Ps[(w * BN + tid) * 2]; t2 += Ps[(w * BN + tid) * 2 + 1]; }
+            const long o = ((long)p * N + n0 + tid) * 2;
+            part[o] = t1;
+            part[o + 1] = t2;
+        }
+    }
+}

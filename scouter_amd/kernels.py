@@ -311,10 +311,19 @@ def _pw_persist_legal(M, K_, N_, kh, kw, stride, pad, groups, plain):
                 N_ % 64 == 0 and 4 * M * max(K_, N_) < (1 << 31))
 
 
+def xpw_fwd_eligible(cin, cout, kh, kw, stride, pad, groups, has_bias):
+    """Short-K pointwise layers whose FORWARD runs on the persistent bf16x3 kernel (csrc/conv_pw_persist_x3.h, tile 5 of the
+    fp32 forward): 64 / 128 / 256 input channels, 64-multiples of output channels, no bias.  A STATIC rule (the forward
+    is a function of the layer shapes alone, whatever the batch); SCOUTER_X3 bit 5."""
+    return bool(kh == 1 and kw == 1 and stride == 1 and pad == 0 and groups == 1 and not has_bias and
+                cin in (64, 128, 256) and cout % 64 == 0)
+
+
 def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, relu=False, bn_stats=False,
-               precision="fp32", out_dtype=F32):
+               precision="fp32", out_dtype=F32, tile=None):
     """bn_stats=True: the epilogue also produces the per-tile fp64 channel sums BatchNorm needs; returns
     (y, (partial, rows)) and `bn_fwd(..., stats=(partial, rows))` then skips its own statistics pass.
+    tile=5: the persistent bf16x3 kernel (xpw_fwd_eligible layers, plain epilogue; other calls fall back to the table).
     Activation storage (precision "bf16" only, layers the bf16 kernel runs): x may be a bfloat16 tensor -- the values the
     kernel rounds an fp32 input to, so the product is the same bits -- and out_dtype=torch.bfloat16 stores y rounded (the
     statistics still come from the fp32 accumulators)."""
@@ -360,10 +369,14 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     # (the cached choice is a function of the layer shape alone -- the key has no epilogue in it, and a first call with
     #  bias / addend / ReLU must not cache "-1" for the plain calls of the same shape, ADVICE r4 -- legality of tile 4 for
     #  THIS call's epilogue is decided here, per call)
-    tile = _pick_tile(("fwd", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, (0, 1, 2, 3, 4))
-    picking[0] = False
-    if tile == 4 and not launch(4, dry=True):        # (the table's entry is for the plain epilogue; this call has bias / addend / ReLU)
-        tile = -1
+    if tile == 5 and not (plain and not bf16 and xpw_fwd_eligible(Cin, Cout, kh, kw, stride, pad, groups, False) and
+                          (B * H * W + 128) * Cout < (1 << 30) and B * H * W * Cin < (1 << 29)):
+        tile = None
+    if tile is None:
+        tile = _pick_tile(("fwd", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, (0, 1, 2, 3, 4))
+        picking[0] = False
+        if tile == 4 and not launch(4, dry=True):    # (the table's entry is for the plain epilogue; this call has bias / addend / ReLU)
+            tile = -1
     part, rows = None, 0
     if bn_stats:
         rows = L.scouter_conv2d_fwd_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
@@ -681,6 +694,13 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
 # 2 x; tests/test_model_gpu.py::test_full_size_resnest26d_224_against_reference_fp64_digests) -- one draw of rounding noise
 # (the kernel itself is bit-identical to the plane kernels, a third of the fp32 kernel's error), but over the yardstick the
 # tests hold the path to, like plane tile 5 in the forward (SCOUTER_HALO).
+# Bit 5 (round 5, late; OFF by default like bit 4): the forward of the short-K pointwise layers (64 / 128 input channels; 256
+# where the register-split GEMM does not serve the layer) on the PERSISTENT bf16x3 kernel (csrc/conv_pw_persist_x3.h, tile 5 of
+# the fp32 forward) -- output streams the fp32 kernels run at 2.7 TB/s: 64 -> 256 at 56 x 56 109 -> 76 us, 128 -> 512 at 28 x 28
+# 82 -> 53 us (tools_dev/xpw_fwd_bench.py), +1.1 % images/sec (4 387 / 4 392 vs 4 340 / 4 338 interleaved on one box); a third
+# of the fp32 kernel's rounding error per layer -- and yet on the full-size parity fixture the log-probabilities land 8.5e-5 from
+# the fp64 reference = 2.1 x plain fp32 PyTorch's own 4.0e-5 (default: 5.1e-5 = 1.27 x; bound 1.5 x): another draw of the
+# head's amplified rounding noise, under north_star's 1e-4, over the yardstick the tests hold the default path to.
 X3_DEFAULT = int(os.environ.get("SCOUTER_X3", "15"))
 X3_FUSED_MIN_K = 512
 X3_MIN_CHANNEL_PRODUCT = 1 << 16

@@ -64,6 +64,18 @@ class Conv2d(nn.Module):
         return K.x3_conv_eligible(self.in_channels, self.out_channels, k, k, self.stride, self.padding, self.groups,
                                   self.bias is not None)
 
+    def xpw_static(self):
+        """Shape rule alone: the FORWARD of this pointwise layer runs on the persistent bf16x3 kernel (kernels.xpw_fwd_eligible;
+        csrc/conv_pw_persist_x3.h) -- 64 / 128 input channels always, 256 where the register-split GEMM does not serve the
+        layer (it wins from 512 output channels on: tools_dev/xpw_fwd_bench.py)."""
+        k = self.kernel_size
+        return (K.xpw_fwd_eligible(self.in_channels, self.out_channels, k, k, self.stride, self.padding, self.groups,
+                                   self.bias is not None) and (self.in_channels <= 128 or not self.x3_static()))
+
+    def fwd_on_xpw(self):
+        """x3 bit 5, fp32 precision, no plane operands, the shape rule."""
+        return bool(self.x3 & 32) and self.precision == "fp32" and not self.planes and self.xpw_static()
+
     def x3_mode(self):
         """Bits of `x3` this layer uses now (fp32 precision only): bits 0-3 for a pointwise layer under the static shape
         rule (and no plane operands), 16 for a 3x3 layer with 32-channel groups and no plane operands (forward only:
@@ -171,10 +183,15 @@ class Conv2d(nn.Module):
             return y, ((x.f32 if x.f32 is not None else tuple(x.shape), wd,
                         x.planes if self.planes_wgrad() or x.f32 is None else None) if save else None)
         xm = self.x3_mode()
+        # (the persistent bf16x3 forward has the plain epilogue only; a call with an addend / ReLU takes the other kernels)
+        xpw = 5 if (self.fwd_on_xpw() and addend is None and not relu and x.dtype == K.F32 and out_dtype in (None, K.F32)) else None
         if (xm & 23) and x.dtype == K.F32 and out_dtype in (None, K.F32):
             want_wd = bool(save and (xm & 6))
-            wf, wd = self._x3_weights(bool(xm & 17), want_wd) if ((xm & 17) or want_wd) else (None, None)
-            if xm & 17:
+            want_wf = bool(xm & 17) and xpw is None
+            wf, wd = self._x3_weights(want_wf, want_wd) if (want_wf or want_wd) else (None, None)
+            if xpw is not None:
+                y = K.conv2d_fwd(x, K.hwio(self.weight), None, None, 1, 0, 1, False, bn_stats, tile=5)
+            elif xm & 17:
                 k = self.kernel_size
                 y = K.conv2d_fwd_x3(x, wf, addend, relu, bn_stats, kh=k, pad=self.padding, groups=self.groups)
             else:
@@ -184,7 +201,7 @@ class Conv2d(nn.Module):
                 self._capture[0][self._capture[1]] = y
             return y, ((x, wd, None) if save else None)
         y = K.conv2d_fwd(x, K.hwio(self.weight), self.bias, addend, self.stride, self.padding, self.groups, relu,
-                         bn_stats, precision=self.precision, out_dtype=out_dtype or K.F32)
+                         bn_stats, precision=self.precision, out_dtype=out_dtype or K.F32, tile=xpw)
         if self._capture is not None and relu:
             self._capture[0][self._capture[1]] = y
         return y, (x if save else None)

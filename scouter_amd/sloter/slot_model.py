@@ -154,10 +154,12 @@ class SlotModel(nn.Module):
         """Deep pointwise (1x1) convolutions of the backbone on the register-split bf16x3 GEMM (csrc/conv_x3.hip: fp32
         tensors in and out, fp32-grade products on the bf16 matrix cores): bit 0 forward, bit 1 plain input gradient, bit 2
         input gradient with the fused BatchNorm-backward epilogue, bit 3 weight gradient, bit 4 the forward of the 3x3
-        layers with 32 input channels per group (kernels.x3_conv_eligible: the stem's 32 -> 64 convolution); 0: the exact-fp32 MFMA kernels.  Which layers qualify
-        is a static function of their channels (kernels.x3_eligible), so the forward does not depend on batch or timing."""
-        if bits & ~31:
-            raise ValueError("x3 bits must be within 0..31")
+        layers with 32 input channels per group (kernels.x3_conv_eligible: the stem's 32 -> 64 convolution), bit 5 the forward of
+        the short-K pointwise layers on the persistent bf16x3 kernel (nn_hip.Conv2d.xpw_static, csrc/conv_pw_persist_x3.h); 0:
+        the exact-fp32 MFMA kernels.  Which layers qualify is a static function of their channels (kernels.x3_eligible,
+        kernels.xpw_fwd_eligible), so the forward does not depend on batch or timing."""
+        if bits & ~63:
+            raise ValueError("x3 bits must be within 0..63")
         for mod in self.backbone.modules():
             if isinstance(mod, Conv2d) and not isinstance(mod, StemConv2d):
                 mod.x3 = int(bits)
@@ -251,8 +253,11 @@ class SlotModel(nn.Module):
         items = [(K.hwio(c.weight), c.groups, True, bool(save and c.planes_dy())) for c in convs]
         # (the pointwise layers on the register-split GEMM take three WEIGHT planes too -- same launch; fp32 mode only)
         xconvs = [c for c in getattr(self, "_x3_convs", ()) if c.x3_mode()] if (not convs or convs[0]._nplanes() == 3) else []
-        xconvs = [c for c in xconvs if (c.x3_mode() & 17) or (save and (c.x3_mode() & 6))]
-        items += [(K.hwio(c.weight), c.groups, bool(c.x3_mode() & 17), bool(save and (c.x3_mode() & 6))) for c in xconvs]
+        # (forward planes only where the forward runs on the register-split GEMM: the persistent bf16x3 forward -- bit 5 -- splits
+        #  its weight tile itself)
+        xitems = [(c, bool(c.x3_mode() & 17) and not c.fwd_on_xpw(), bool(save and (c.x3_mode() & 6))) for c in xconvs]
+        xconvs = [c for c, f, d in xitems if f or d]
+        items += [(K.hwio(c.weight), c.groups, f, d) for c, f, d in xitems if f or d]
         if items:      # this step's weight planes of every plane convolution: one launch into persistent buffers ...
             # ... on its own stream NEXT TO the stem's kernels (the stem reads no planes; MFMA-bound next to a byte-moving
             # pass): the backbone joins it after the max-pool (`_post_stem_hooks`).  SCOUTER_SPLIT_ASYNC=0: on the compute stream

@@ -61,7 +61,7 @@ FORWARD_CHANGING = ("SCOUTER_PLANES", "SCOUTER_HALO", "SCOUTER_X3")
     {"SCOUTER_PLANES": "0"}, {"SCOUTER_AUTOTUNE": "0"}, {"SCOUTER_AUTOTUNE": "1"}, {"SCOUTER_AUTOTUNE": "1", "SCOUTER_WGRAD_TUNE": "0"},
     {"SCOUTER_HALO": "0"}, {"SCOUTER_HALO": "3"}, {"SCOUTER_BN_FUSE": "0"}, {"SCOUTER_BN_FUSE": "6"},
     {"SCOUTER_FUSE_STEM_POOL": "0"}, {"SCOUTER_SA_SUMS": "0"}, {"SCOUTER_SIDE_STREAM": "0"},
-    {"SCOUTER_SIDE_FWD": "0", "SCOUTER_SIDE_BWD": "0"}, {"SCOUTER_X3": "0"}, {"SCOUTER_X3": "3"}, {"SCOUTER_X3": "31"}, {"SCOUTER_X3": "15", "SCOUTER_AUTOTUNE": "1"},
+    {"SCOUTER_SIDE_FWD": "0", "SCOUTER_SIDE_BWD": "0"}, {"SCOUTER_X3": "0"}, {"SCOUTER_X3": "3"}, {"SCOUTER_X3": "63"}, {"SCOUTER_X3": "15", "SCOUTER_AUTOTUNE": "1"},
     {"SCOUTER_SPLIT_ASYNC": "0"}], ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()))
 def test_switch_setting_computes_the_same_step(setting, default_run):
     mode = "eval" if any(k in FORWARD_CHANGING for k in setting) else "train"

@@ -188,10 +188,12 @@ def test_model_routes_the_deep_pointwise_layers_and_the_switch_turns_them_off():
     import test_model_gpu as T
     from scouter_amd import _native
     res = {}
-    for bits in (31, 15, 0):
+    for bits in (63, 31, 15, 0):
         m, P, images, labels, cfg = T._synthetic_model("resnest26d", 10, 1, 3, 4, 96, 2500)
         m.set_x3(bits)
         assert len(m._x3_convs) == ((15 if bits & 16 else 14) if bits else 0)       # 14 deep 1x1 layers + the stem's 32 -> 64 3x3
+        # bit 5: the forward of the eight short-K pointwise layers (layer1's five, layer2's 256 -> 128 and its two 128 -> 512)
+        assert sum(c.fwd_on_xpw() for c in m.backbone.modules() if hasattr(c, "fwd_on_xpw")) == (8 if bits & 32 else 0)
         L = _native.lib()
         L.scouter_prof_enable(1)
         out, (loss, nll, area) = m(images.cuda(), labels.cuda())
@@ -204,8 +206,10 @@ def test_model_routes_the_deep_pointwise_layers_and_the_switch_turns_them_off():
         names = buf.value.decode()
         assert ("xconv_fwd<bf16x3>" in names) == bool(bits) and ("xconv_dgrad<bf16x3>" in names) == bool(bits)
         assert ("xwgrad<bf16x3>" in names) == bool(bits)
+        assert ("xpw_fwd<bf16x3>" in names) == bool(bits & 32)
         res[bits] = (out.detach().clone(), m.grad_arena().flat.clone())
     assert float((res[31][0] - res[0][0]).abs().max()) < 5e-4 and float((res[15][0] - res[0][0]).abs().max()) < 5e-4
+    assert float((res[63][0] - res[0][0]).abs().max()) < 5e-4
     rel = float((res[31][1] - res[0][1]).norm() / res[0][1].norm())
     assert rel < 5e-2, rel          # (random-init net: ReLU sign flips on ~0 pre-activations move gradients, see test_model_gpu)
 
