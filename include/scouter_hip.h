@@ -129,6 +129,12 @@ int scouter_conv2d_dgrad_bnbwd_bf16_io(const void* dy, const float* w, const voi
                                        int tile_hint, const void* relu_mask, const void* x1, const float* saved1,
                                        double* part1, const void* x2, const float* saved2, double* part2, int io,
                                        void* stream);
+/* tile_hint 4 of the typed FORWARD (round 5): the persistent pointwise kernel (csrc/conv_pw_persist_bf16.h pwb_fwd_kernel) --
+ * 1x1 / stride 1 / groups 1, 64 / 128 / 256 / 512 input channels STORED as bf16 (SCOUTER_IO_X_BF16), 128-multiples of output
+ * channels, no bias / addend / ReLU; y bf16 or fp32; bn_partial rows = scouter_conv2d_fwd_bn_partial_rows_bf16(..., 4)
+ * (tile_hint 0-3: as scouter_conv2d_fwd_bn_partial_rows).  Named where it does not apply: SC_ERR_UNSUPPORTED. */
+int scouter_conv2d_fwd_bn_partial_rows_bf16(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                                            int groups, int tile_hint);
 /* tile_hint 4 of the typed input gradient (round 5): the PERSISTENT pointwise kernel (csrc/conv_pw_persist_bf16.h) -- 1x1 /
  * stride 1 / groups 1, Cout of 64 / 128 / 256 / 512, 128-multiples of Cin, the fused BatchNorm-backward epilogue present
  * (part1 != NULL) and EVERY tensor stored as bf16 (io = DY | DX | X1 [| X2] [| ADDEND]); anything else named with tile 4 is

@@ -343,6 +343,43 @@ static void launch_pwb_fused(const void* src, const float* w, const void* addend
 #undef PWB
 }
 
+// ---- tile 4 of the typed forward: persistent pointwise kernel, input stored as bf16 (conv_pw_persist_bf16.h pwb_fwd_kernel)
+static bool pwb_fwd_geom_ok(const ConvGeom& g, bool plain, int io) {
+    const bool pointwise = g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
+    const bool k_ok = g.Cg == 64 || g.Cg == 128 || g.Cg == 256 || g.Cg == 512;
+    return pointwise && k_ok && g.Ng % 128 == 0 && plain && (io & SC_IO_X_BF16) &&
+           (g.M + 128) * g.Ng * ((io & SC_IO_Y_BF16) ? 2 : 4) < (1L << 32) && g.M * g.Cg < (1L << 30);
+}
+static int pwb_fwd_wg_per_col(const ConvGeom& g) {
+    const int ks = g.Cg / 64, resident = ks == 1 ? 3 : (ks == 2 ? 2 : 1);     // LDS: 48 / 64 / 96 / 160 KB
+    int w = ((256 * resident) / (g.Ng / 128)) & ~7;
+    return w < 8 ? 8 : w;
+}
+static void launch_pwb_fwd(const void* src, const void* wt, void* dst, double* bn_part, const ConvGeom& g, hipStream_t st, int io) {
+    const int wg = pwb_fwd_wg_per_col(g), mtiles = sc_cdiv(g.M, 64), grid = wg * (g.Ng / 128);
+    const size_t lds = (size_t)128 * g.Cg * 2 + 4 * 8192;
+#define PWF(KS_, YB_, ST_)                                                                                         \
+    do {                                                                                                           \
+        auto kern = pwb_fwd_kernel<KS_, YB_, ST_>;                                                                 \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 64 * KS_ * 2 + 4 * 8192); attr_set = true; } \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, src, wt, dst, bn_part, g.M, g.Ng, mtiles, wg);    \
+    } while (0)
+#define PWF3(KS_)                                                                                                  \
+    do {                                                                                                           \
+        if (io & SC_IO_Y_BF16) { if (bn_part) PWF(KS_, true, true); else PWF(KS_, true, false); }                  \
+        else { if (bn_part) PWF(KS_, false, true); else PWF(KS_, false, false); }                                  \
+    } while (0)
+    switch (g.Cg / 64) {
+        case 1: PWF3(1); break;
+        case 2: PWF3(2); break;
+        case 4: PWF3(4); break;
+        default: PWF3(8); break;
+    }
+#undef PWF3
+#undef PWF
+}
+
 extern "C" int scouter_conv2d_weight_bf16t(const float* w, void* wt, int kh, int kw, int Cin, int Cout, int groups,
                                            void* stream) {
     SC_REQUIRE(w && wt && groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv2d_weight_bf16t: bad arguments");
@@ -368,12 +405,31 @@ extern "C" int scouter_conv2d_fwd_bf16_io(const void* x, const void* wt_bf16, co
     ConvGeom g{B, H, W, Cin, conv_out_b(H, kh, stride, pad), conv_out_b(W, kw, stride, pad), Cout, kh, kw, stride, pad,
                groups, Cg, Ng, 0, Cout, Cg * Cout};
     g.M = (long)B * g.Ho * g.Wo;
-    static const char* names[4] = {"igemm_fwd_bf16<128x128>", "igemm_fwd_bf16<128x64>", "igemm_fwd_bf16<64x64>", "igemm_fwd_bf16<128x32>"};
-    const int tile = bf16_tile(g, tile_hint);
+    static const char* names[5] = {"igemm_fwd_bf16<128x128>", "igemm_fwd_bf16<128x64>", "igemm_fwd_bf16<64x64>", "igemm_fwd_bf16<128x32>",
+                                   "igemm_fwd_bf16<persistent>"};
+    SC_UNSUPPORTED(tile_hint != 4 || pwb_fwd_geom_ok(g, !bias && !addend && !relu, io),
+                   "conv2d_fwd_bf16: tile 4 (persistent) covers 1x1 / stride 1 / groups 1 layers with 64 / 128 / 256 / 512 input "
+                   "channels stored as bf16, 128-multiples of output channels, no bias / addend / ReLU");
+    const int tile = tile_hint == 4 ? 4 : bf16_tile(g, tile_hint);
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
                      ((io & SC_IO_X_BF16) ? 2.0 : 4.0) * B * H * W * Cin + ((io & SC_IO_Y_BF16) ? 2.0 : 4.0) * g.M * Cout);
+    if (tile == 4) {
+        launch_pwb_fwd(x, wt_bf16, y, bn_partial, g, (hipStream_t)stream, io);
+        return sc_check_launch("conv2d_fwd_bf16(persistent)");
+    }
     return dispatch_bf16<false>(x, wt_bf16, bias, addend, (float*)y, bn_partial, g, relu, tile, (hipStream_t)stream,
                                 BnBwdFuse{}, io);
+}
+// rows of bn_partial the typed forward writes: tiles 0-3 one per M tile, tile 4 one per workgroup row
+extern "C" int scouter_conv2d_fwd_bn_partial_rows_bf16(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                                                       int pad, int groups, int tile_hint) {
+    if (!(groups > 0 && Cin % groups == 0 && Cout % groups == 0)) return 0;
+    const int Cg = Cin / groups, Ng = Cout / groups;
+    ConvGeom g{B, H, W, Cin, conv_out_b(H, kh, stride, pad), conv_out_b(W, kw, stride, pad), Cout, kh, kw, stride, pad,
+               groups, Cg, Ng, 0, Cout, Cg * Cout};
+    g.M = (long)B * g.Ho * g.Wo;
+    if (tile_hint == 4) return pwb_fwd_wg_per_col(g);
+    return sc_cdiv(g.M, bf16_tile(g, tile_hint) == 2 ? 64 : 128);
 }
 extern "C" int scouter_conv2d_fwd_bf16(const float* x, const void* wt_bf16, const float* bias, const float* addend,
                                        float* y, double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh,

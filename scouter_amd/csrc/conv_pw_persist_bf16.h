@@ -247,3 +247,158 @@ __global__ __launch_bounds__(256, (KS <= 2 && !TWO ? PWB_RESIDENT : 1)) void pwb
         if (TWO) { fz.part2[o] = tg; fz.part2[o + 1] = t2; }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same skeleton for the FORWARD of the pointwise layers whose input is stored as bf16 (tile 4 of
+// scouter_conv2d_fwd_bf16_io): y = x W with the fused BatchNorm statistics (fp64 column sums of the fp32 accumulators), y
+// stored as bf16 (Y_BF16: conv3 / downsample outputs) or fp32 (conv1 outputs).  Call sites: conv1 / downsample of the ResNeSt
+// bottlenecks (/root/reference/timm/models/resnest.py:111-118, resnet.py:292-306) under BASELINE configs[4].  igemm_bf16_kernel
+// runs these output streams at 2.5 TB/s of algorithmic bytes.  W^T arrives as bf16 [N][K] (scouter_conv2d_weight_bf16t) and is
+// copied once into LDS; K = Cin <= 512.  part: [wg_per_col][N][2] fp64.
+template <int KS, bool Y_BF16, bool STATS>
+__global__ __launch_bounds__(256, (KS == 1 ? 3 : (KS == 2 ? 2 : 1))) void pwb_fwd_kernel(
+    const void* __restrict__ src, const void* __restrict__ wt, void* __restrict__ dst, double* __restrict__ part, long M, int N,
+    int mtiles, int wg_per_col) {
+    constexpr int K = 64 * KS, BN = 128, RB = 2 * K;
+    constexpr int WBYTES = BN * RB, SLOT = 64 * 128;
+    constexpr int CHM = (K / 8 < 16 ? K / 8 : 16) - 1;
+    constexpr int OB = Y_BF16 ? 2 : 4;                          // bytes per output element
+    extern __shared__ __attribute__((aligned(1024))) char pwb_lds[];
+    char* Wl = pwb_lds;
+    char* ring = pwb_lds + WBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int colgroups = N / BN;
+    const int L = blockIdx.x;
+    const int cg = (L >> 3) % colgroups, p = (L & 7) + 8 * ((L >> 3) / colgroups);
+    const int n0 = cg * BN;
+    const int n_my = p < mtiles ? (mtiles - p + wg_per_col - 1) / wg_per_col : 0;
+    const int nstage4 = (n_my * KS + 3) / 4;
+
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)(M * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (unsigned)(M * N * OB), 0x00020000);
+    unsigned a_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * (wave + 4 * j) + (lane >> 3), c = (lane & 7) ^ (r & 7);
+        a_voff[j] = (unsigned)((r * K + c * 8) * 2);
+    }
+    auto issue = [&](int G, int slot) __attribute__((always_inline)) {
+        const int ti = G / KS, kc = G % KS;
+        const long m0 = (long)__builtin_amdgcn_readfirstlane(p + ti * wg_per_col) * 64;
+        const long off = (m0 * K + kc * 64) * 2;
+        const int soff = off > 0x7fffffffL ? 0x7fffffff : (int)off;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pwb_dma16(rs_a, ring + slot * SLOT + (wave + 4 * j) * 1024, a_voff[j], soff);
+    };
+    issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);
+    for (int e = tid; e < BN * (K / 8); e += 256) {              // W^T rows n0 .. n0 + 127, 16-byte chunks
+        const int n = e / (K / 8), c = e % (K / 8);
+        const pwb_u32x4 v = *(const pwb_u32x4*)((const __bf16*)wt + (long)(n0 + n) * K + 8 * c);
+        *(pwb_u32x4*)(Wl + n * RB + ((c ^ ((n >> 3) & CHM)) << 4)) = v;
+    }
+
+    const int arow = 16 * wave + l15;
+    const char* a_base = ring + arow * 128;
+    const int a_sw = arow & 7;
+    const char* b_base = Wl + 8 * l15 * RB;
+    const int b_t = q ^ (l15 & CHM);
+    const int col0 = n0 + 8 * l15;
+    const int row_in = 16 * wave + 4 * q;
+    const unsigned o_voff = (unsigned)(((long)row_in * N + col0) * OB);
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    double s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    auto epilogue = [&](int ti) __attribute__((always_inline)) {
+        const long m0 = (long)__builtin_amdgcn_readfirstlane(p + ti * wg_per_col) * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // (row offset in the per-lane offset, scalar offset an immediate 0: see the input-gradient kernel above)
+            const unsigned off = o_voff + (unsigned)((m0 + e) * (long)N * OB);
+            pwb_u32x4 ob;
+            f32x4 of[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = acc[k][e];
+                if (STATS) {                                     // (rows beyond M: their A rows read zeros, v = 0)
+                    const double d = (double)v;
+                    s1[k] += d;
+                    s2[k] = __builtin_fma(d, d, s2[k]);
+                }
+                if (Y_BF16) {
+                    const unsigned short hb = __builtin_bit_cast(unsigned short, (__bf16)v);
+                    if (k & 1) ob[k >> 1] |= (unsigned)hb << 16; else ob[k >> 1] = hb;
+                } else {
+                    of[k >> 2][k & 3] = v;
+                }
+                acc[k][e] = 0.f;
+            }
+            if (Y_BF16) {
+                __builtin_amdgcn_raw_buffer_store_b128(ob, rs_o, off, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pwb_u32x4, of[0]), rs_o, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pwb_u32x4, of[1]), rs_o, off + 16u, 0, 0);
+            }
+        }
+    };
+    auto stage_body = [&](int G, int slot, int kc) __attribute__((always_inline)) {
+        const bool last = kc == KS - 1 && G / KS < n_my;
+        const char* As = a_base + slot * SLOT;
+        pwb_bf16x8 fa[2], fb[2][8];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            fa[s] = *(const pwb_bf16x8*)(As + (((4 * s + q) ^ a_sw) << 4));
+            const char* bp = b_base + ((((kc * 8 + 4 * s) ^ b_t)) << 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fb[s][j] = *(const pwb_bf16x8*)(bp + j * RB);
+        }
+        SB();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = pwb_mfma(fa[s], fb[s][j], acc[j]);
+        SB();
+        // the next stage's DMA has landed: at most the two younger stages (4 instructions) stay in flight -- stores of an
+        // epilogue in between are younger than the stage waited for and only make the wait stricter
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (last) epilogue(G / KS);
+        __builtin_amdgcn_s_barrier();
+        SB();
+        issue(G + 4, slot);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int base = 0; base < nstage4; ++base) {
+#pragma unroll
+        for (int S = 0; S < 4; ++S) stage_body(4 * base + S, S, KS <= 4 ? S % KS : (4 * base + S) % KS);
+    }
+#undef SB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STATS) {
+        __syncthreads();
+        double* Ps = (double*)pwb_lds;                           // [4 waves][128 columns][2]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double t1 = s1[k], t2 = s2[k];
+            t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+            t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+            if (q == 0) { double* o = Ps + ((wave * BN) + 8 * l15 + k) * 2; o[0] = t1; o[1] = t2; }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { t1 += Ps[(w * BN + tid) * 2]; t2 += Ps[(w * BN + tid) * 2 + 1]; }
+            const long o = ((long)p * N + n0 + tid) * 2;
+            part[o] = t1;
+            part[o + 1] = t2;
+        }
+    }
+}

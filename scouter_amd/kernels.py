@@ -311,6 +311,9 @@ def _pw_persist_legal(M, K_, N_, kh, kw, stride, pad, groups, plain):
                 N_ % 64 == 0 and 4 * M * max(K_, N_) < (1 << 31))
 
 
+PWB_FWD = os.environ.get("SCOUTER_PWB_FWD", "1") != "0"
+
+
 def xpw_fwd_eligible(cin, cout, kh, kw, stride, pad, groups, has_bias):
     """Short-K pointwise layers whose FORWARD runs on the persistent bf16x3 kernel (csrc/conv_pw_persist_x3.h, tile 5 of the
     fp32 forward): 64 / 128 / 256 input channels, 64-multiples of output channels, no bias.  A STATIC rule (the forward
@@ -372,6 +375,13 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     if tile == 5 and not (plain and not bf16 and xpw_fwd_eligible(Cin, Cout, kh, kw, stride, pad, groups, False) and
                           (B * H * W + 128) * Cout < (1 << 30) and B * H * W * Cin < (1 << 29)):
         tile = None
+    # bf16 mode, input STORED as bf16: the pointwise layers with up to 512 input channels run on the persistent typed kernel
+    # (csrc/conv_pw_persist_bf16.h pwb_fwd_kernel; tile 4 of the typed forward) -- a static rule of shape and storage, never of
+    # timing.  SCOUTER_PWB_FWD=0: the tile kernels.
+    if (tile is None and bf16 and PWB_FWD and plain and x.dtype == BF16 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and
+            groups == 1 and Cin in (64, 128, 256, 512) and Cout % 128 == 0 and B * H * W * Cin < (1 << 30) and
+            (B * H * W + 128) * Cout * (2 if out_dtype == BF16 else 4) < (1 << 32)):
+        tile = 4
     if tile is None:
         tile = _pick_tile(("fwd", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, (0, 1, 2, 3, 4))
         picking[0] = False
@@ -379,7 +389,8 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
             tile = -1
     part, rows = None, 0
     if bn_stats:
-        rows = L.scouter_conv2d_fwd_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
+        rows_fn = L.scouter_conv2d_fwd_bn_partial_rows_bf16 if bf16 else L.scouter_conv2d_fwd_bn_partial_rows
+        rows = rows_fn(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
         part = torch.empty((rows, Cout, 2), dtype=torch.float64, device=x.device)
     launch(tile, part=part)
     return (y, (part, rows)) if bn_stats else y

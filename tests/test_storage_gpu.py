@@ -34,9 +34,10 @@ def _rand(rng, *shape, scale=1.0):
     (2, 28, 28, 128, 512, 1, 0, 1),
     (4, 23, 9, 96, 64, 1, 0, 1),        # K = 96: the 32-channel K tile
     (2, 24, 24, 64, 128, 3, 1, 2)])     # a 3x3 layer through the same kernel
-def test_conv_forward_typed_storage(case):
+def test_conv_forward_typed_storage(case, monkeypatch):
     B, H, W, Cin, Cout, k, pad, groups = case
     kk = K()
+    monkeypatch.setattr(kk, "PWB_FWD", False)          # (the tile kernels; the persistent typed forward has its own test below)
     rng = np.random.default_rng(sum(case))
     xh = _rand(rng, B, H, W, Cin).to(BF16)
     w = _rand(rng, k, k, Cin // groups, Cout, scale=0.1)
@@ -55,6 +56,44 @@ def test_conv_forward_typed_storage(case):
     del kk._tile_cache[key]
     with pytest.raises(RuntimeError, match="bf16-stored activations"):
         kk.conv2d_fwd(xh, w, None, None, 1, pad, groups, precision="fp32")
+
+
+@pytest.mark.parametrize("case", [(5, 17, 17, 64, 256), (2, 28, 28, 128, 512), (3, 20, 19, 256, 128), (2, 14, 13, 512, 256),
+                                  (40, 56, 56, 64, 256), (36, 28, 28, 256, 512), (9, 28, 27, 128, 128)])
+def test_persistent_typed_forward_against_the_tile_kernel(case, monkeypatch):
+    """Tile 4 of the typed forward (csrc/conv_pw_persist_bf16.h pwb_fwd_kernel: persistent, v_mfma_f32_16x16x32_bf16 with
+    permuted columns, register epilogue) -- the static choice for pointwise layers whose input is stored as bf16 -- against
+    the tile kernel: the same bf16 products summed in another order inside the matrix unit: fp32 outputs equal to fp32
+    rounding, bf16-stored outputs to one bf16 ulp on a few elements, the fp64 statistics of the fp32 accumulators to that;
+    ragged M, more tiles than workgroups with two / three workgroups per CU."""
+    B, H, W, Cin, Cout = case
+    kk = K()
+    rng = np.random.default_rng(sum(case) + 5)
+    xh = _rand(rng, B, H, W, Cin).to(BF16)
+    w = _rand(rng, 1, 1, Cin, Cout, scale=0.1)
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(kk, "PWB_FWD", on)
+        y32, (p32, r32) = kk.conv2d_fwd(xh, w, bn_stats=True, precision="bf16")
+        y16, (p16, r16) = kk.conv2d_fwd(xh, w, bn_stats=True, precision="bf16", out_dtype=BF16)
+        yn = kk.conv2d_fwd(xh, w, precision="bf16", out_dtype=BF16)
+        assert torch.equal(yn, y16) and r16 == r32 and torch.equal(p16, p32)
+        res[on] = (y32, y16.float(), p32[:r32].sum(0), r32)
+    L = kk._native.lib()
+    assert res[True][3] == L.scouter_conv2d_fwd_bn_partial_rows_bf16(B, H, W, Cin, Cout, 1, 1, 1, 0, 1, 4) != res[False][3]
+    a, b = res[False][0], res[True][0]
+    scale = float(a.abs().max())
+    assert scale > 0 and float((a - b).abs().max()) <= 2e-6 * scale
+    d = (res[False][1] - res[True][1]).abs()
+    assert bool((d <= res[False][1].abs() * 2.0 ** -7 + 1e-30).all()) and float((d > 0).float().mean()) < 0.02
+    assert torch.equal(res[True][1], b.to(BF16).float()), "the bf16-stored output is the RNE of the fp32 one"
+    sa, sb = res[False][2], res[True][2]
+    assert float((sa - sb).abs().max()) <= 1e-6 * float(sa.abs().max())
+    # named where it does not apply (fp32-stored input): an error, not a re-route
+    y = torch.empty(B, H, W, Cout, device="cuda")
+    wt = torch.empty(1, Cout, Cin, dtype=BF16, device="cuda")
+    rc = L.scouter_conv2d_fwd_bf16_io(kk._p(xh.float()), kk._p(wt), None, None, kk._p(y), None, B, H, W, Cin, Cout, 1, 1, 1, 0, 1, 0, 4, 0, None)
+    assert rc != 0 and "tile 4" in L.scouter_last_error().decode()
 
 
 def _stats_of(x):
