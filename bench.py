@@ -234,6 +234,19 @@ CLASSES = {
 }
 
 
+# The PERSISTENT pointwise kernels (weights resident in LDS, the activation streamed through an LDS ring, register epilogue) serve
+# the short-K 1x1 layers: 6-18 bytes per output element against 2 K FLOP -- streams with a small GEMM attached, bound by HBM
+# whatever matrix instruction multiplies.  They are a class of their own, priced against the HBM roofline (algorithmic bytes /
+# time vs 8 TB/s nominal, 6.3 TB/s a streaming kernel reaches), and are NOT counted in the matrix classes above.
+HBM_CLASS = {
+    "labels": ("igemm_fwd<persistent>", "igemm_dgrad<persistent>", "igemm_dgrad+bn_bwd<persistent>", "xpw_dgrad+bn_bwd<bf16x3>",
+               "xpw_fwd<bf16x3>", "igemm_fwd_bf16<persistent>", "igemm_dgrad_bf16<persistent>"),
+    "rocprof": ("void pwp_kernel<", "void pwp_fused_kernel<", "void xpw_fused_kernel<", "void xpw_fwd_kernel<",
+                "void pwb_fused_kernel<", "void pwb_fwd_kernel<"),
+    "what": "persistent pointwise kernels of the short-K 1x1 layers (forward with fused statistics, input gradient with the fused "
+            "BatchNorm-backward epilogue): HBM streams with a small GEMM attached (fp32 MFMA / bf16x3 / bf16 MFMA)"}
+
+
 def _profile_json(fname):
     path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path):
@@ -473,7 +486,7 @@ def main():
                                                 cfg["precision"] == CONFIGS[a.config].get("precision", "fp32")) else None
         classes = {}
         for cname, c in CLASSES.items():
-            rows = [k for k in kern if k.startswith(c["labels"]) and kern[k]["tflops"]]
+            rows = [k for k in kern if k.startswith(c["labels"]) and not k.startswith(HBM_CLASS["labels"]) and kern[k]["tflops"]]
             if not rows:
                 continue
             ms = sum(kern[k]["ms_per_step"] for k in rows)
@@ -490,9 +503,27 @@ def main():
                               "algorithmic_bytes_per_launch": round(by / nl), "traffic": traffic,
                               "traffic_over_algorithmic": round(traffic / (by / nl), 2) if traffic and by else None,
                               "pmc_source": src or None}
+        # the HBM-bound stream class (see HBM_CLASS): algorithmic bytes / time against the HBM roofline
+        rows = [k for k in kern if k.startswith(HBM_CLASS["labels"]) and kern[k]["gbps_algorithmic"]]
+        if rows and classes:
+            ms = sum(kern[k]["ms_per_step"] for k in rows)
+            fl = sum((kern[k]["tflops"] or 0.0) * kern[k]["ms_per_step"] for k in rows)
+            nl = sum(kern[k]["launches_per_step"] for k in rows)
+            by = sum(kern[k]["gbps_algorithmic"] * kern[k]["ms_per_step"] * 1e6 for k in rows)
+            traffic, busy, src = pmc_class(HBM_CLASS["rocprof"], pmc_files) if pmc_files else (None, None, [])
+            tbs = by / (ms * 1e-3) / 1e12
+            classes["hbm_stream_conv"] = {
+                "kernels": HBM_CLASS["what"], "instances": sorted(rows), "bound": "hbm", "gflop_per_step": round(fl, 1),
+                "ms_per_step": round(ms, 4), "launches_per_step": nl, "avg_launch_us": round(1e3 * ms / nl, 2),
+                "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4),
+                "achievable": HBM_ACHIEVABLE_TBS, "frac_of_achievable": round(tbs / HBM_ACHIEVABLE_TBS, 4),
+                "tflops": round(fl / ms, 2), "pmc_mfma_busy": busy, "algorithmic_bytes_per_launch": round(by / nl),
+                "traffic": traffic, "traffic_over_algorithmic": round(traffic / (by / nl), 2) if traffic and by else None,
+                "pmc_source": src or None}
         roofline = None
         if classes:
-            dom = max(classes, key=lambda c: classes[c]["ms_per_step"])
+            # `roofline` = the MATRIX class with the most time per step (the HBM stream class is reported next to them)
+            dom = max((c for c in classes if classes[c].get("bound") != "hbm"), key=lambda c: classes[c]["ms_per_step"])
             d = classes[dom]
             tot_ms = sum(c["ms_per_step"] for c in classes.values())
             tot_fl = sum(c["gflop_per_step"] for c in classes.values())

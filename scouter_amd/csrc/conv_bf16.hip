@@ -467,8 +467,14 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_bf16_io(const void* dy, const float* w
                    "conv2d_dgrad_bf16: tile 4 (persistent) covers 1x1 / stride 1 / groups 1 input gradients with the fused "
                    "BatchNorm-backward epilogue, Cout of 64 / 128 / 256 / 512, 128-multiples of Cin, every tensor stored as bf16");
     const int tile = tile_hint == 4 ? 4 : bf16_tile(g, tile_hint);
+    // algorithmic bytes: dy, dx and -- the fused launch -- the shortcut gradient, the BatchNorm input(s) and the ReLU bits
+    const double out_elems = (double)g.M * Cin;
     ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw,
-                     ((io & 8) ? 2.0 : 4.0) * B * Ho * Wo * Cout + ((io & 16) ? 2.0 : 4.0) * g.M * Cin);
+                     ((io & 8) ? 2.0 : 4.0) * B * Ho * Wo * Cout + ((io & 16) ? 2.0 : 4.0) * out_elems +
+                         (addend ? ((io & 4) ? 2.0 : 4.0) * out_elems : 0.0) +
+                         (part1 ? ((io & 1) ? 2.0 : 4.0) * out_elems + (part2 ? ((io & 2) ? 2.0 : 4.0) * out_elems : 0.0) +
+                                      (relu_mask ? out_elems / 8 : 0.0)
+                                : 0.0));
     if (tile == 4) {
         launch_pwb_fused(dy, w, addend, dx, g, (hipStream_t)stream, fz);
         return sc_check_launch("conv2d_dgrad_bf16(persistent)");

@@ -24,6 +24,6 @@ for cin, cout, H, ybf, cnt in [(64, 256, 56, True, 1), (256, 128, 56, False, 1),
         K.PWB_FWD = on
         t.append(timeit(lambda: K.conv2d_fwd(x, w, bn_stats=True, precision="bf16", out_dtype=od)))
     mb = B * H * H * (cin * 2 + cout * (2 if ybf else 4)) / 1e6
-    print("%-22s %6.0f MB | tile kernel %6.1f us (%.2f TB/s) | persistent %6.1f us (%.2f TB/s)" % (str((cin, cout, H, 'y bf16' if ybf else 'y fp32')), mb, t[0], mb / t[0] / 1e6 * 1e6 / 1e6, t[1], mb / t[1] / 1e6 * 1e6 / 1e6))
+    print("%-22s %6.0f MB | tile kernel %6.1f us (%.2f TB/s) | persistent %6.1f us (%.2f TB/s)" % (str((cin, cout, H, 'y bf16' if ybf else 'y fp32')), mb, t[0], mb / t[0], t[1], mb / t[1]))
     tot[0] += cnt * t[0]; tot[1] += cnt * min(t)
 print("listed launches per step: %.0f -> %.0f us" % tuple(tot))

@@ -41,6 +41,6 @@ for H, cin, cout, nbn, has_add, n in [(56, 64, 64, 1, True, 1), (56, 256, 64, 2,
             pass
     best = min(res, key=res.get)
     mb = B * H * H * (cout + cin * (2 + int(has_add) + nbn)) * 4 / 1e6
-    print('"%s": %d,   # %s  (table had %s; %.0f MB -> %.2f TB/s)' % (K._key_str(key), best, "  ".join("%d: %.0f us" % kv for kv in sorted(res.items())), old, mb, mb / res[best] / 1e6 * 1e6 / 1e6))
+    print('"%s": %d,   # %s  (table had %s; %.0f MB -> %.2f TB/s)' % (K._key_str(key), best, "  ".join("%d: %.0f us" % kv for kv in sorted(res.items())), old, mb, mb / res[best]))
     tot_old += n * res.get(old, res[best]); tot_new += n * res[best]
 print("sum: table %.2f ms -> best %.2f ms" % (tot_old / 1e3, tot_new / 1e3))

@@ -27,7 +27,7 @@ for cin, cout, H, cnt in [(64, 64, 56, 1), (64, 256, 56, 3), (256, 64, 56, 1), (
     e5, e32 = float((y5.reshape(-1, cout).double() - ref).abs().max()), float((y32.reshape(-1, cout).double() - ref).abs().max())
     mb = B * H * H * (cin + cout) * 4 / 1e6
     print("%-16s %6.0f MB | fp32 %6.1f us | persistent bf16x3 %6.1f us (%.2f TB/s) | register-split GEMM %6.1f us | max err vs fp64: %.2e (fp32 kernel %.2e)"
-          % (str((cin, cout, H)), mb, t32, t5, mb / t5 / 1e6, tx, e5, e32))
+          % (str((cin, cout, H)), mb, t32, t5, mb / t5, tx, e5, e32))
     cur = min(t32, tx) if tx == tx else t32
     tot[0] += cnt * cur; tot[1] += cnt * min(cur, t5)
 print("per step: now %.0f us -> with the persistent kernel where it wins %.0f us" % tuple(tot))
