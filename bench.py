@@ -242,7 +242,7 @@ HBM_CLASS = {
     "labels": ("igemm_fwd<persistent>", "igemm_dgrad<persistent>", "igemm_dgrad+bn_bwd<persistent>", "xpw_dgrad+bn_bwd<bf16x3>",
                "xpw_fwd<bf16x3>", "igemm_fwd_bf16<persistent>", "igemm_dgrad_bf16<persistent>"),
     "rocprof": ("void pwp_kernel<", "void pwp_fused_kernel<", "void xpw_fused_kernel<", "void xpw_fwd_kernel<",
-                "void pwb_fused_kernel<", "void pwb_fwd_kernel<"),
+                "void pwb_fused_kernel<", "void pwb_fwd_kernel<", "void pwb_dgrad_kernel<"),
     "what": "persistent pointwise kernels of the short-K 1x1 layers (forward with fused statistics, input gradient with the fused "
             "BatchNorm-backward epilogue): HBM streams with a small GEMM attached (fp32 MFMA / bf16x3 / bf16 MFMA)"}
 

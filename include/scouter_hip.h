@@ -138,7 +138,9 @@ int scouter_conv2d_fwd_bn_partial_rows_bf16(int B, int H, int W, int Cin, int Co
 /* tile_hint 4 of the typed input gradient (round 5): the PERSISTENT pointwise kernel (csrc/conv_pw_persist_bf16.h) -- 1x1 /
  * stride 1 / groups 1, Cout of 64 / 128 / 256 / 512, 128-multiples of Cin, the fused BatchNorm-backward epilogue present
  * (part1 != NULL) and EVERY tensor stored as bf16 (io = DY | DX | X1 [| X2] [| ADDEND]); anything else named with tile 4 is
- * SC_ERR_UNSUPPORTED, never re-routed.  It writes ONE partial row per workgroup row: rows =
+ * SC_ERR_UNSUPPORTED, never re-routed.  WITHOUT the fused epilogue (part1 == NULL) tile 4 is the plain persistent kernel:
+ * Cout of 64 ... 1024, 64-multiples of Cin, dy stored as bf16 (DY), dx fp32, optional addend (fp32 or bf16).
+ * The fused kernel writes ONE partial row per workgroup row: rows =
  * scouter_conv2d_dgrad_bn_partial_rows_bf16(..., 4, part2 != NULL) (tile_hint 0-3: the rows of the bf16-input tiles, as
  * scouter_conv2d_dgrad_bn_partial_rows). */
 int scouter_conv2d_dgrad_bn_partial_rows_bf16(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,

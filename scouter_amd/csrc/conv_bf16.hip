@@ -343,6 +343,39 @@ static void launch_pwb_fused(const void* src, const float* w, const void* addend
 #undef PWB
 }
 
+// ---- tile 4 of the typed input gradient WITHOUT the fused epilogue (conv_pw_persist_bf16.h pwb_dgrad_kernel): dY bf16, dx fp32
+static bool pwb_plain_geom_ok(const ConvGeom& g, int io_xy) {
+    const bool pointwise = g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
+    const bool k_ok = g.Cg == 64 || g.Cg == 128 || g.Cg == 256 || g.Cg == 512 || g.Cg == 1024;
+    return pointwise && k_ok && g.Ng % 64 == 0 && (io_xy & SC_IO_X_BF16) && !(io_xy & SC_IO_Y_BF16) &&
+           (g.M + 128) * g.Ng < (1L << 30) && g.M * g.Cg < (1L << 30);
+}
+static void launch_pwb_dgrad(const void* src, const float* w, const void* addend, float* dst, const ConvGeom& g, hipStream_t st,
+                             int add_bf16) {
+    const int ks = g.Cg / 64, resident = ks <= 1 ? 3 : (ks <= 4 ? 2 : 1);     // LDS: 40 ... 64 / 96 / 160 KB
+    int wg = ((256 * resident) / (g.Ng / 64)) & ~7;
+    if (wg < 8) wg = 8;
+    const int mtiles = sc_cdiv(g.M, 64), grid = wg * (g.Ng / 64);
+    const size_t lds = (size_t)64 * g.Cg * 2 + 4 * 8192;
+#define PWD(KS_, ADD_)                                                                                             \
+    do {                                                                                                           \
+        auto kern = pwb_dgrad_kernel<KS_, ADD_>;                                                                   \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 64 * KS_ * 2 + 4 * 8192); attr_set = true; } \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, src, w, addend, dst, g.M, g.Ng, mtiles, wg, add_bf16); \
+    } while (0)
+#define PWD2(KS_) do { if (addend) PWD(KS_, true); else PWD(KS_, false); } while (0)
+    switch (ks) {
+        case 1: PWD2(1); break;
+        case 2: PWD2(2); break;
+        case 4: PWD2(4); break;
+        case 8: PWD2(8); break;
+        default: PWD2(16); break;
+    }
+#undef PWD2
+#undef PWD
+}
+
 // ---- tile 4 of the typed forward: persistent pointwise kernel, input stored as bf16 (conv_pw_persist_bf16.h pwb_fwd_kernel)
 static bool pwb_fwd_geom_ok(const ConvGeom& g, bool plain, int io) {
     const bool pointwise = g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.groups == 1;
@@ -463,9 +496,10 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_bf16_io(const void* dy, const float* w
     const int io_xy = ((io & 8) ? SC_IO_X_BF16 : 0) | ((io & 16) ? SC_IO_Y_BF16 : 0);
     // (the caller named the persistent kernel: its partial-row layout differs, so an unsupported request is an error, never a
     // silent re-route)
-    SC_UNSUPPORTED(tile_hint != 4 || pwb_geom_ok(g, addend != nullptr, fz, io_xy),
-                   "conv2d_dgrad_bf16: tile 4 (persistent) covers 1x1 / stride 1 / groups 1 input gradients with the fused "
-                   "BatchNorm-backward epilogue, Cout of 64 / 128 / 256 / 512, 128-multiples of Cin, every tensor stored as bf16");
+    SC_UNSUPPORTED(tile_hint != 4 || (part1 ? pwb_geom_ok(g, addend != nullptr, fz, io_xy) : pwb_plain_geom_ok(g, io_xy)),
+                   "conv2d_dgrad_bf16: tile 4 (persistent) covers 1x1 / stride 1 / groups 1 input gradients -- with the fused "
+                   "BatchNorm-backward epilogue: Cout of 64 / 128 / 256 / 512, 128-multiples of Cin, every tensor stored as bf16; "
+                   "without: Cout of 64 ... 1024, 64-multiples of Cin, dy stored as bf16, dx fp32");
     const int tile = tile_hint == 4 ? 4 : bf16_tile(g, tile_hint);
     // algorithmic bytes: dy, dx and -- the fused launch -- the shortcut gradient, the BatchNorm input(s) and the ReLU bits
     const double out_elems = (double)g.M * Cin;
@@ -476,7 +510,8 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_bf16_io(const void* dy, const float* w
                                       (relu_mask ? out_elems / 8 : 0.0)
                                 : 0.0));
     if (tile == 4) {
-        launch_pwb_fused(dy, w, addend, dx, g, (hipStream_t)stream, fz);
+        if (part1) launch_pwb_fused(dy, w, addend, dx, g, (hipStream_t)stream, fz);
+        else launch_pwb_dgrad(dy, w, addend, (float*)dx, g, (hipStream_t)stream, (io & 4) ? 1 : 0);
         return sc_check_launch("conv2d_dgrad_bf16(persistent)");
     }
     return dispatch_bf16<true>(dy, w, nullptr, (const float*)addend, (float*)dx, nullptr, g, 0, tile, (hipStream_t)stream,

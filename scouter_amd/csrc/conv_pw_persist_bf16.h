@@ -402,3 +402,140 @@ __global__ __launch_bounds__(256, (KS == 1 ? 3 : (KS == 2 ? 2 : 1))) void pwb_fw
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The PLAIN input gradient of the pointwise layers whose output gradient is stored as bf16 (tile 4 of
+// scouter_conv2d_dgrad_bnbwd_bf16_io without the fused epilogue): dx = dY W^T (+ addend), dx fp32.  Call sites: conv3 and the
+// downsample convolution of the ResNeSt bottlenecks (/root/reference/timm/models/resnest.py:128-143, resnet.py:292-306) under
+// BASELINE configs[4] -- dY is 4 g wide, dx g wide: input streams (64 <- 256 at 56 x 56, batch 256: 411 MB read, 205 MB
+// written) that igemm_bf16_kernel<64, 64> runs at 1.9 TB/s of algorithmic bytes.  64 output columns per workgroup (wave =
+// 16 rows x 64 columns, a lane's four accumulators of a row are four consecutive fp32 columns: 16-byte stores), W^T [64][K]
+// converted once into LDS, K = Cout up to 1024.
+template <int KS, bool HAS_ADD>
+__global__ __launch_bounds__(256, (KS <= 1 ? 3 : (KS <= 4 ? 2 : 1))) void pwb_dgrad_kernel(
+    const void* __restrict__ src, const float* __restrict__ wgt, const void* __restrict__ addend, float* __restrict__ dst, long M,
+    int N, int mtiles, int wg_per_col, int add_bf16) {
+    constexpr int K = 64 * KS, BN = 64, RB = 2 * K;
+    constexpr int WBYTES = BN * RB, SLOT = 64 * 128;
+    constexpr int CHM = (K / 8 < 16 ? K / 8 : 16) - 1;
+    extern __shared__ __attribute__((aligned(1024))) char pwb_lds[];
+    char* Wl = pwb_lds;
+    char* ring = pwb_lds + WBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int colgroups = N / BN;
+    const int L = blockIdx.x;
+    const int cg = (L >> 3) % colgroups, p = (L & 7) + 8 * ((L >> 3) / colgroups);
+    const int n0 = cg * BN;
+    const int n_my = p < mtiles ? (mtiles - p + wg_per_col - 1) / wg_per_col : 0;
+    const int nstage4 = (n_my * KS + 3) / 4;
+
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)(M * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (unsigned)(M * N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_ADD ? addend : (const void*)dst), 0,
+                                                                          (unsigned)(M * N * (add_bf16 ? 2 : 4)), 0x00020000);
+    unsigned a_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * (wave + 4 * j) + (lane >> 3), c = (lane & 7) ^ (r & 7);
+        a_voff[j] = (unsigned)((r * K + c * 8) * 2);
+    }
+    auto issue = [&](int G, int slot) __attribute__((always_inline)) {
+        const int ti = G / KS, kc = G % KS;
+        const long m0 = (long)__builtin_amdgcn_readfirstlane(p + ti * wg_per_col) * 64;
+        const long off = (m0 * K + kc * 64) * 2;
+        const int soff = off > 0x7fffffffL ? 0x7fffffff : (int)off;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pwb_dma16(rs_a, ring + slot * SLOT + (wave + 4 * j) * 1024, a_voff[j], soff);
+    };
+    issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);
+    for (int e = tid; e < BN * (K / 8); e += 256) {              // W^T rows n0 .. n0 + 63 (n = ci, k = co contiguous) -> bf16
+        const int n = e / (K / 8), c = e % (K / 8);
+        const float* wp = wgt + (long)(n0 + n) * K + 8 * c;
+        const f32x4 lo = *(const f32x4*)wp, hi = *(const f32x4*)(wp + 4);
+        pwb_bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = (__bf16)lo[i]; v[4 + i] = (__bf16)hi[i]; }
+        *(pwb_bf16x8*)(Wl + n * RB + ((c ^ ((n >> 2) & CHM)) << 4)) = v;
+    }
+
+    const int arow = 16 * wave + l15;
+    const char* a_base = ring + arow * 128;
+    const int a_sw = arow & 7;
+    const char* b_base = Wl + 4 * l15 * RB;
+    const int b_t = q ^ (l15 & CHM);
+    const int col0 = n0 + 4 * l15;
+    const int row_in = 16 * wave + 4 * q;
+    const long elem0 = (long)row_in * N + col0;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pa[4];
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    auto prefetch = [&](int ti) __attribute__((always_inline)) {
+        const long m0 = (long)__builtin_amdgcn_readfirstlane(p + ti * wg_per_col) * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long el = elem0 + (m0 + e) * (long)N;
+            if (add_bf16) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 w = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_d, (unsigned)(el * 2), 0, 0));
+                pa[e] = f32x4{pwb_f32(w[0], 0), pwb_f32(w[0], 1), pwb_f32(w[1], 0), pwb_f32(w[1], 1)};
+            } else {
+                pa[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, (unsigned)(el * 4), 0, 0));
+            }
+        }
+    };
+    auto epilogue = [&](int ti) __attribute__((always_inline)) {
+        const long m0 = (long)__builtin_amdgcn_readfirstlane(p + ti * wg_per_col) * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4 out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                out[k] = acc[k][e] + (HAS_ADD ? pa[e][k] : 0.f);
+                acc[k][e] = 0.f;
+            }
+            // (row offset in the per-lane offset, scalar offset an immediate 0: see the fused kernel above)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pwb_u32x4, out), rs_o,
+                                                   (unsigned)((elem0 + (m0 + e) * (long)N) * 4), 0, 0);
+        }
+    };
+    auto stage_body = [&](int G, int slot, int kc) __attribute__((always_inline)) {
+        const bool last = kc == KS - 1 && G / KS < n_my;
+        const char* As = a_base + slot * SLOT;
+        pwb_bf16x8 fa[2], fb[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            fa[s] = *(const pwb_bf16x8*)(As + (((4 * s + q) ^ a_sw) << 4));
+            const char* bp = b_base + ((((kc * 8 + 4 * s) ^ b_t)) << 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[s][j] = *(const pwb_bf16x8*)(bp + j * RB);
+        }
+        if (HAS_ADD && last) prefetch(G / KS);
+        SB();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = pwb_mfma(fa[s], fb[s][j], acc[j]);
+        SB();
+        // the next stage's DMA has landed (at most the two younger stages = 4 instructions stay in flight; with an addend its
+        // loads are younger still and waited for by the compiler where they are used)
+        if (!(HAS_ADD && last)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (last) epilogue(G / KS);
+        __builtin_amdgcn_s_barrier();
+        SB();
+        issue(G + 4, slot);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int base = 0; base < nstage4; ++base) {
+#pragma unroll
+        for (int S = 0; S < 4; ++S) stage_body(4 * base + S, S, KS <= 4 ? S % KS : (4 * base + S) % KS);
+    }
+#undef SB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}

@@ -312,6 +312,7 @@ def _pw_persist_legal(M, K_, N_, kh, kw, stride, pad, groups, plain):
 
 
 PWB_FWD = os.environ.get("SCOUTER_PWB_FWD", "1") != "0"
+PWB_DGRAD = os.environ.get("SCOUTER_PWB_DGRAD", "1") != "0"
 
 
 def xpw_fwd_eligible(cin, cout, kh, kw, stride, pad, groups, has_bias):
@@ -472,6 +473,15 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
             rows = L.scouter_conv2d_dgrad_bn_partial_rows(B, H, W, Cin, Cout, kh, kw, stride, pad, groups, tile)
         post.alloc(rows, x_shape)
         launch(tile, fuse=post.args())
+    elif (bf16 and PWB_DGRAD and kh == 1 and kw == 1 and pad == 0 and groups == 1 and Cout in (64, 128, 256, 512) and
+          Cin % 64 == 0 and (io & DGRAD_IO_DY) and not (io & DGRAD_IO_DX) and (B * H * W + 128) * Cin < (1 << 30) and
+          B * H * W * Cout < (1 << 30)):
+        # bf16 mode, dy STORED as bf16: the plain pointwise input gradients (conv3 / downsample) run on the persistent typed
+        # kernel (csrc/conv_pw_persist_bf16.h pwb_dgrad_kernel) -- a static rule of shape and storage (Cout <= 512: at 1024 the
+        # tile kernel is level, tools_dev/pwb_dgrad_bench.py: 64 <- 256 at 56 x 56 141 -> 115 us, 64 <- 64 87 -> 49, 128 <- 512
+        # at 28 x 28 91 -> 76; +0.15 % on config 5, most of whose plain input gradients read an fp32 dy).  SCOUTER_PWB_DGRAD=0:
+        # the tile kernels
+        launch(4)
     else:
         launch(_pick_tile(("dgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, (0, 1, 2, 3, 4)))
     return dx

@@ -243,11 +243,12 @@ def test_fused_batchnorm_backward_epilogue_reads_typed_storage(case, monkeypatch
 @pytest.mark.parametrize("case", [
     # B, H, W, Cin, Cout, k, pad, groups
     (3, 20, 19, 64, 256, 1, 0, 1), (2, 28, 28, 128, 512, 1, 0, 1), (4, 23, 9, 96, 64, 1, 0, 1), (2, 24, 24, 64, 128, 3, 1, 2)])
-def test_gradients_read_only_by_bf16_kernels_may_be_stored_as_bf16(case):
+def test_gradients_read_only_by_bf16_kernels_may_be_stored_as_bf16(case, monkeypatch):
     """dc = BatchNorm-backward output in front of a convolution whose input- and weight-gradient kernels are the bf16-input
     ones: stored as bf16 it is exactly what those kernels round an fp32 dc to -- dx and dW bit for bit the same."""
     B, H, W, Cin, Cout, k, pad, groups = case
     kk = K()
+    monkeypatch.setattr(kk, "PWB_DGRAD", False)        # (the tile kernels; the persistent plain input gradient has its own test)
     rng = np.random.default_rng(sum(case) + 2)
     C = Cout
     x = _rand(rng, B, H, W, Cin)
@@ -272,6 +273,35 @@ def test_gradients_read_only_by_bf16_kernels_may_be_stored_as_bf16(case):
     assert torch.equal(dw32, dw16)
     with pytest.raises(RuntimeError, match="bf16-stored gradients"):
         kk.conv2d_dgrad(dc16, w, tuple(x.shape), None, 1, pad, groups, precision="fp32")
+
+
+@pytest.mark.parametrize("case", [(3, 20, 19, 64, 256, False), (2, 28, 28, 128, 512, False), (5, 14, 13, 256, 1024, False), (9, 31, 29, 64, 64, True),
+                                  (40, 56, 56, 64, 256, False), (36, 28, 28, 256, 512, True), (2, 14, 14, 512, 1024, False)])
+def test_persistent_plain_typed_input_gradient_against_the_tile_kernel(case, monkeypatch):
+    """Tile 4 of the typed input gradient WITHOUT the fused epilogue (csrc/conv_pw_persist_bf16.h pwb_dgrad_kernel: dy stored
+    as bf16, dx fp32, optional addend) -- the static choice for the plain pointwise input gradients of the bf16 mode -- against
+    the tile kernel: the same bf16 products summed in another order inside the matrix unit: equal to fp32 rounding; ragged M,
+    with / without the addend (fp32 and bf16-stored), K = Cout up to 1024, more tiles than workgroups."""
+    B, H, W, Cin, Cout, with_add = case
+    kk = K()
+    rng = np.random.default_rng(sum(case[:5]) + 17)
+    dy = _rand(rng, B, H, W, Cout).to(BF16)
+    w = _rand(rng, 1, 1, Cin, Cout, scale=0.1)
+    shape = (B, H, W, Cin)
+    adds = [None] if not with_add else [_rand(rng, *shape), _rand(rng, *shape).to(BF16)]
+    for add in adds:
+        res = {}
+        for on in (False, True):
+            monkeypatch.setattr(kk, "PWB_DGRAD", on)
+            res[on] = kk.conv2d_dgrad(dy, w, shape, add, 1, 0, 1, precision="bf16")
+            assert res[on].dtype == torch.float32
+        scale = float(res[False].abs().max())
+        assert scale > 0 and float((res[False] - res[True]).abs().max()) <= 2e-6 * scale
+    # named where it does not apply (fp32-stored dy): an error, not a re-route
+    L = kk._native.lib()
+    rc = L.scouter_conv2d_dgrad_bnbwd_bf16_io(kk._p(dy.float()), kk._p(w), None, kk._p(torch.empty(shape, device="cuda")), B, H, W, Cin,
+                                              Cout, 1, 1, 1, 0, 1, 4, *kk._NO_FUSE, 0, None)
+    assert rc != 0 and "tile 4" in L.scouter_last_error().decode()
 
 
 def test_gradient_storage_changes_no_bit_of_the_model(monkeypatch):
