@@ -372,6 +372,13 @@ def test_persistent_typed_fused_input_gradient_against_the_tile_kernel(case, mon
     for a, b in zip(out[1][1], out[4][1]):
         assert bool(((a[:, 0] - b[:, 0]).abs() <= 2.0 ** -8 * 0.02 * scale + 1e-9).all())
         assert float((a - b).abs().max()) <= 1e-3 * float(a.abs().max())
+    # no ReLU between the BatchNorm and the consumer (mask None): the unmasked gradient
+    nm = {}
+    for tile in (1, 4):
+        monkeypatch.setitem(kk._tile_cache, key, tile)
+        post = kk.BnBwdFuse(None, list(zip(xs, saved)))
+        nm[tile] = kk.conv2d_dgrad(dy, w, shape, add, 1, 0, 1, precision="bf16", post=post, out_dtype=BF16).float()
+    assert bool(((nm[1] - nm[4]).abs() <= nm[1].abs() * 2.0 ** -7 + 2e-6).all()) and float(nm[1].abs().max()) > 0
     # anything the persistent kernel does not cover, named with tile 4, is an error -- never a silent re-route
     post = kk.BnBwdFuse(mask, [(xs[0].float(), saved[0])])
     rc = L.scouter_conv2d_dgrad_bnbwd_bf16_io(kk._p(dy), kk._p(w), None, kk._p(torch.empty(shape, dtype=BF16, device="cuda")), B, H, W,

@@ -175,6 +175,15 @@ def test_persistent_fused_input_gradient_on_the_bf16_matrix_cores(case, monkeypa
     for a, b in zip(out[2][1], out[5][1]):
         assert bool(((a[:, 0] - b[:, 0]).abs() <= 1e-6 * scale + 1e-9).all())
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    # no ReLU between the BatchNorm and the consumer (mask None): the unmasked gradient
+    nm = {}
+    for tile in (2, 5):
+        monkeypatch.setitem(kk._tile_cache, key, tile)
+        post = kk.BnBwdFuse(None, list(zip(xs, saved)))
+        nm[tile] = (kk.conv2d_dgrad(dy, w, shape, add, 1, 0, 1, post=post), [p_[:post.rows].sum(0) for p_ in post.parts])
+    assert float((nm[2][0] - nm[5][0]).abs().max()) <= 4e-6 * float(nm[2][0].abs().max())
+    for a, b in zip(nm[2][1], nm[5][1]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
     # named where it does not apply: an error, not a re-route
     rc = L.scouter_conv2d_dgrad_bnbwd_f32(kk._p(dy), kk._p(w), None, kk._p(torch.empty(shape, device="cuda")), B, H, W, Cin, Cout, 1, 1,
                                           1, 0, 1, 5, *kk._NO_FUSE, None)
