@@ -678,9 +678,20 @@ static PwpPlan pwp_plan(const ConvGeom& g) {
     PwpPlan p;
     p.ks = g.Cg / 64;
     const int cap = 256 / p.ks;                              // columns whose [K][BN] fp32 tile fits 64 KB
-    p.bn = (cap >= 256 && g.Ng % 256 == 0) ? 256 : ((cap >= 128 && g.Ng % 128 == 0) ? 128 : 64);
+    // (128 columns even where 256 fit: 64 -> 256 at 56 x 56, batch 70: 110.6 -> 91.7 us, the same bits -- twice the workgroups
+    //  per M range share the XCD's L2 copy of A; tools_dev/pwp_plan_bench.py.  256 stays reachable through the development override)
+    p.bn = (cap >= 128 && g.Ng % 128 == 0) ? 128 : 64;
+    int resident = 1;
+    // development override (tools_dev/pwp_plan_bench.py): "bn,resident"
+    if (const char* e = getenv("SCOUTER_PWP_PLAN_DEV")) {
+        int bn = 0, r = 0;
+        if (sscanf(e, "%d,%d", &bn, &r) == 2 && (bn == 64 || bn == 128 || bn == 256) && bn * p.ks <= 256 && g.Ng % bn == 0 && r >= 1 && r <= 4) {
+            p.bn = bn;
+            resident = r;
+        }
+    }
     const int colgroups = g.Ng / p.bn;
-    int w = (256 / colgroups) & ~7;
+    int w = ((256 * resident) / colgroups) & ~7;
     p.wg_per_col = w < 8 ? 8 : w;
     p.waves_m = p.bn >= 256 ? 1 : 2;
     return p;
