@@ -422,6 +422,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = step()
+    t_host = time.perf_counter() - t0           # the host has ENQUEUED the K steps (diagnostic: close to dt = launch-bound)
     fence()
     dt = time.perf_counter() - t0
     # Per-kernel timing pass (same process, model, batch): hipEvents around every launch, on its stream.  It runs with
@@ -561,7 +562,10 @@ def main():
                            "global_batch": world * cfg["batch"], "parallelism": "dp%d" % world,
                            "step": "zero_grad+fwd+loss+bwd(+allreduce)+adamw",
                            "launch": "hipGraph replay (one captured graph per step)" if graphed is not None else "eager",
-                           "final_loss": round(loss_val, 5)},
+                           "final_loss": round(loss_val, 5),
+                           # diagnostic: wall time until the host had enqueued the K timed steps, per step -- well under
+                           # ms_per_step: the GPU is the limiter; close to it: the eager launch chain is (slow / shared host)
+                           "host_enqueue_ms_per_step": round(1e3 * t_host / a.steps, 3)},
                 "roofline": roofline, "kernels": kern}
         if pmc_files and world == 1:
             hb = hbm_step_roofline(pmc_files, 1e3 * dt / a.steps)
