@@ -453,7 +453,7 @@ def main():
         fence()
         exposed = net.exposed_allreduce_ms()
         net.measure_exposed = False
-        mine = torch.tensor([dt, exposed if exposed is not None else -1.0], dtype=torch.float64, device=device)
+        mine = torch.tensor([dt, exposed if exposed is not None else -1.0, t_host], dtype=torch.float64, device=device)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         ms = [1e3 * float(t[0]) / a.steps for t in every]
@@ -461,6 +461,9 @@ def main():
         dp_info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                    "ms_per_step_by_rank": [round(v, 3) for v in ms], "ms_per_step_spread": round(max(ms) - min(ms), 3),
                    "allreduce_exposed_ms": round(max(ex), 4), "allreduce_exposed_ms_by_rank": [round(v, 4) for v in ex],
+                   # wall time until each rank's host had ENQUEUED its K timed steps, per step: a rank whose figure is close to
+                   # its ms_per_step is launch-bound (N processes share the host's cores)
+                   "host_enqueue_ms_per_step_by_rank": [round(1e3 * float(t[2]) / a.steps, 3) for t in every],
                    "gradient_bytes_per_step": int(model.grad_arena().numel * 4),
                    "buckets": int(net.buckets_last_step),
                    "allreduce_exposed_measured": "hipEvents around the compute stream's wait for the gradient collectives on 5 "

@@ -308,7 +308,8 @@ static bool pwb_geom_ok(const ConvGeom& g, bool has_addend, const BnBwdFuse& fz,
     const bool k_ok = g.Cg == 64 || g.Cg == 128 || g.Cg == 256 || g.Cg == 512;
     const bool stored_bf16 = (io & SC_IO_X_BF16) && (io & SC_IO_Y_BF16) && (fz.io & 1) && (!fz.part2 || (fz.io & 2)) &&
                              (!has_addend || (fz.io & 4));
-    return pointwise && k_ok && g.Ng % 128 == 0 && fz.part1 != nullptr && stored_bf16 && (g.M + 128) * g.Ng < (1L << 31) &&
+    return pointwise && k_ok && g.Ng % 128 == 0 && fz.part1 != nullptr && stored_bf16 &&
+           (g.M + 128) * g.Ng < (1L << 30) &&      // (every bf16 tensor < 2 GiB: the kernel clamps scalar row offsets at 2^31 - 1)
            g.M * g.Cg < (1L << 30);
 }
 static PwbPlan pwb_plan(const ConvGeom& g, bool two) {

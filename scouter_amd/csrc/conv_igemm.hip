@@ -769,7 +769,7 @@ struct XpwPlan { int ks, wg_per_col; };
 static bool xpw_geom_ok(const ConvGeom& g) {                 // (g as for the GEMM: Cg = K, Ng = N)
     return g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.H == g.Ho && g.W == g.Wo && g.groups == 1 &&
            (g.Cg == 64 || g.Cg == 128 || g.Cg == 256) && g.Ng % 64 == 0 && g.M * g.Cg < (1L << 29) &&
-           (g.M + 128) * g.Ng < (1L << 30);
+           (g.M + 128) * g.Ng < (1L << 29);          // (every streamed tensor < 2 GiB: the kernels clamp scalar row offsets at 2^31 - 1)
 }
 static XpwPlan xpw_plan(const ConvGeom& g) {
     XpwPlan p;

@@ -51,6 +51,8 @@ class GraphedTrainStep:
         ddp = hasattr(self.net, "_issue_buffer_broadcast") and self.net._active and self.net.broadcast_buffers
         if ddp:
             self.net._issue_buffer_broadcast()      # consumed by the backbone in front of its first BatchNorm
+            if not getattr(self.net, "_bn_hooked", False):
+                self.net._consume_buffer_broadcast()    # (no backbone hook: the forward starts behind the collective)
         model.grad_arena()
         logp, stats, state = model._forward_impl(x, y, save=True)
         if ddp:

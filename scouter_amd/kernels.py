@@ -374,7 +374,7 @@ def conv2d_fwd(x, w_hwio, bias=None, addend=None, stride=1, pad=0, groups=1, rel
     #  bias / addend / ReLU must not cache "-1" for the plain calls of the same shape, ADVICE r4 -- legality of tile 4 for
     #  THIS call's epilogue is decided here, per call)
     if tile == 5 and not (plain and not bf16 and xpw_fwd_eligible(Cin, Cout, kh, kw, stride, pad, groups, False) and
-                          (B * H * W + 128) * Cout < (1 << 30) and B * H * W * Cin < (1 << 29)):
+                          (B * H * W + 128) * Cout < (1 << 29) and B * H * W * Cin < (1 << 29)):
         tile = None
     # bf16 mode, input STORED as bf16: the pointwise layers with up to 512 input channels run on the persistent typed kernel
     # (csrc/conv_pw_persist_bf16.h pwb_fwd_kernel; tile 4 of the typed forward) -- a static rule of shape and storage, never of
@@ -431,7 +431,7 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
             if tile == 4 and bf16:
                 # the persistent typed kernel (csrc/conv_pw_persist_bf16.h): fused launches with every tensor stored as bf16
                 return bool(will_fuse and kh == 1 and kw == 1 and pad == 0 and groups == 1 and Cout in (64, 128, 256, 512) and
-                            Cin % 128 == 0 and (B * H * W + 128) * Cin < (1 << 31) and B * H * W * Cout < (1 << 30) and
+                            Cin % 128 == 0 and (B * H * W + 128) * Cin < (1 << 30) and B * H * W * Cout < (1 << 30) and
                             (io & DGRAD_IO_DY) and (io & DGRAD_IO_DX) and (addend is None or io & DGRAD_IO_ADDEND) and
                             post.x_io() == (1 << len(post.entries)) - 1)
             if tile == 4:        # (GEMM-K of the input gradient = Cout)
@@ -439,7 +439,7 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
             if tile == 5:
                 # the persistent bf16x3 kernel (csrc/conv_pw_persist_x3.h): fused fp32 launches of the short-K 1x1 layers
                 return bool(will_fuse and not bf16 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and groups == 1 and
-                            Cout in (64, 128, 256) and Cin % 64 == 0 and (B * H * W + 128) * Cin < (1 << 30) and
+                            Cout in (64, 128, 256) and Cin % 64 == 0 and (B * H * W + 128) * Cin < (1 << 29) and
                             B * H * W * Cout < (1 << 29))
             return _tile_legal(Cin // groups, tile)
         if bf16:
@@ -551,6 +551,11 @@ class PlaneWeightSplitter:
             for w, groups, fwd, dgrad in items:
                 _chk(w, "weight")
                 kh, kw, cg, Cout = w.shape
+                if cg % 32 or Cout % 32 or (Cout // groups) % 32:
+                    # (the tiled kernel walks [32 ci][32 co] tiles and assumes every tensor starts on a 1024-element boundary)
+                    raise RuntimeError("scouter_amd: the one-launch weight split takes 32-multiples of channels per group, got "
+                                       "a %dx%d weight with %d input channels per group, %d output channels, %d groups"
+                                       % (kh, kw, cg, Cout, groups))
                 wf = torch.empty((nplanes, kh * kw, Cout, cg), dtype=BF16, device=dev) if fwd else None
                 wd = torch.empty((nplanes, kh * kw, cg * groups, Cout // groups), dtype=BF16, device=dev) if dgrad else None
                 rows.append(struct.pack("<QQQiiiiq", w.data_ptr(), _p(wf) or 0, _p(wd) or 0, kh * kw, cg, Cout, groups, first))

@@ -38,7 +38,8 @@ class DistributedDataParallel(nn.Module):
         module._post_backward_hooks.append(self._finish_gradients)
         # the backbone calls these right before its first BatchNorm touches the running statistics
         bone = getattr(module, "backbone", None)
-        if bone is not None and hasattr(bone, "_pre_bn_hooks"):
+        self._bn_hooked = bone is not None and hasattr(bone, "_pre_bn_hooks")
+        if self._bn_hooked:
             bone._pre_bn_hooks.append(self._consume_buffer_broadcast)
 
     def _float_buffers(self):
@@ -149,6 +150,10 @@ class DistributedDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         if self._active and self.broadcast_buffers:
             self._issue_buffer_broadcast()
+            if not self._bn_hooked:
+                # no backbone hook in front of the first BatchNorm (a module that is not a ResNet SlotModel): nothing tells us
+                # where the buffers are first touched, so the forward starts behind the collective
+                self._consume_buffer_broadcast()
         try:
             return self.module(*args, **kwargs)
         finally:

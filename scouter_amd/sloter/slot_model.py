@@ -85,7 +85,7 @@ class SlotModel(nn.Module):
         self._arena = None
         self._anchor = None
         self._split_device = None
-        self._nbt_flat, self._nbt_key = None, None
+        self._flatten_tracked()              # BatchNorm counters: views of one flat buffer, from construction on
         self._post_backward_hooks = []       # called with the GradArena after every backward (data-parallel reduce)
         self._grad_ready_hooks = []          # called (arena, lo, hi) as soon as arena.flat[lo:hi] is final
         self.last_stats = None               # device tensor [loss, nll, area**power, top1, area] of the last forward
@@ -284,19 +284,58 @@ class SlotModel(nn.Module):
             seed = self._loss_seed = torch.ones_like(loss)
         return seed
 
+    def _flatten_tracked(self):
+        """Every BatchNorm's `num_batches_tracked` becomes a view of ONE flat int64 buffer (same buffer names / shapes in the
+        state_dict).  Done at construction and after every `_apply` (module.to / .cuda), never during a step: buffer identity is
+        stable from the first forward on, so references taken by EMA copies, external buffer lists or a captured hipGraph
+        keep pointing at the counters that advance."""
+        from ..nn_hip import BatchNorm2d
+        bns = [m for m in self.modules() if isinstance(m, BatchNorm2d)]
+        self._nbt_runs = {}
+        if not bns:
+            self._nbt_flat, self._nbt_index = None, {}
+            return
+        flat = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in bns]).contiguous()
+        for i, m in enumerate(bns):
+            m._buffers["num_batches_tracked"] = flat[i]
+        self._nbt_flat = flat
+        self._nbt_index = {flat[i].data_ptr(): i for i in range(len(bns))}
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        if hasattr(self, "_nbt_flat"):
+            self._flatten_tracked()
+        return out
+
     def _bump_tracked(self, tracked):
-        """num_batches_tracked += 1 for the train-mode BatchNorms of this forward: the counters are views of ONE flat int64
-        buffer (same buffer names / shapes in the state_dict), so it is one launch of the library instead of an ATen
-        multi-tensor kernel.  Re-flattened when the buffers were re-allocated (module.to(...)) or another set trains."""
+        """num_batches_tracked += 1 for the train-mode BatchNorms of this forward (one launch of the library per contiguous run of
+        counters in the flat buffer -- ONE when every BatchNorm trains -- instead of an ATen multi-tensor kernel); a BatchNorm
+        that ran twice in the forward is counted twice."""
         key = tuple(t.data_ptr() for t in tracked)
-        if self._nbt_key != key:
-            from ..nn_hip import BatchNorm2d
-            by_ptr = {m.num_batches_tracked.data_ptr(): m for m in self.modules() if isinstance(m, BatchNorm2d)}
-            flat = torch.stack([t.detach().reshape(()) for t in tracked]).contiguous()
-            for i, t in enumerate(tracked):
-                by_ptr[t.data_ptr()]._buffers["num_batches_tracked"] = flat[i]
-            self._nbt_flat, self._nbt_key = flat, tuple(flat[i].data_ptr() for i in range(flat.numel()))
-        K.iadd_i64(self._nbt_flat, 1)
+        runs = self._nbt_runs.get(key)
+        if runs is None:
+            if any(p not in self._nbt_index for p in key):
+                # a counter was re-assigned behind the model's back (module.num_batches_tracked = ...): flatten again and follow
+                # this forward's tensors to their modules
+                from ..nn_hip import BatchNorm2d
+                by_ptr = {m.num_batches_tracked.data_ptr(): m for m in self.modules() if isinstance(m, BatchNorm2d)}
+                mods = [by_ptr[p] for p in key]
+                self._flatten_tracked()
+                idx = [self._nbt_index[m.num_batches_tracked.data_ptr()] for m in mods]
+            else:
+                idx = [self._nbt_index[p] for p in key]
+            count = {}
+            for i in idx:
+                count[i] = count.get(i, 0) + 1
+            runs, order = [], sorted(count)
+            for i in order:
+                if runs and runs[-1][1] == i and runs[-1][2] == count[i]:
+                    runs[-1][1] = i + 1
+                else:
+                    runs.append([i, i + 1, count[i]])
+            self._nbt_runs[key] = runs
+        for lo, hi, c in runs:
+            K.iadd_i64(self._nbt_flat[lo:hi], c)
 
     def _backward_impl(self, state, g_logp, g_loss, g_nll, g_term):
         bctx, hstate = state

@@ -207,6 +207,15 @@ class ResNet(nn.Module):
     # ---- explicit forward / backward over NHWC tensors
     def features_fwd(self, x_nchw, save, tracked=None):
         ctx = []
+        joined = [False]
+
+        def join_weight_planes():
+            # the stream that splits this step's weight planes is joined ONCE per forward, in front of the first kernel that
+            # reads planes: layer1 by default, a stem convolution when it runs on the register-split kernel (SCOUTER_X3 bit 4)
+            if not joined[0]:
+                joined[0] = True
+                for hook in self._post_stem_hooks:
+                    hook()
         if isinstance(self.conv1, nn.Sequential):
             s = self.conv1
             # (bf16 mode: the two stem activations are read by bf16-input kernels only -- stored as bf16, same results)
@@ -214,8 +223,12 @@ class ResNet(nn.Module):
             for hook in self._pre_bn_hooks:
                 hook()
             h, b0 = s[1].fwd(c, save, relu=True, tracked=tracked, out_dtype=s[3].act_storage(*_map_of(c)))
+            if s[3].x3_mode():
+                join_weight_planes()
             c, k1 = s[3].fwd(h, save, bn_stats=s[4].training)
             h, b1 = s[4].fwd(c, save, relu=True, tracked=tracked, out_dtype=s[6].act_storage(*_map_of(c)))
+            if s[6].x3_mode():
+                join_weight_planes()
             c, k2 = s[6].fwd(h, save, bn_stats=self.bn1.training)
             ctx.append((k0, b0, k1, b1, k2))
         else:
@@ -239,8 +252,7 @@ class ResNet(nn.Module):
         if self._capture is not None and arg is not None:
             self._capture[0][self._capture[1]] = arg
         x = p
-        for hook in self._post_stem_hooks:
-            hook()
+        join_weight_planes()
         for li in range(1, 5):
             for blk in getattr(self, "layer%d" % li):
                 x, c_blk = blk.fwd(x, save, tracked)
