@@ -217,9 +217,11 @@ CLASSES = {
     "bf16x3_plane_conv": {
         "labels": ("pconv_fwd<bf16x3>", "pconv_dgrad<bf16x3>", "pwgrad<bf16x3>", "xconv_fwd<bf16x3>", "xconv_dgrad<bf16x3>",
                    "xconv_dgrad+bn_bwd<bf16x3>", "xwgrad<bf16x3>", "xconv3_fwd<bf16x3>", "xconv3_dgrad<bf16x3>",
-                   "xconv3_dgrad+bn_bwd<bf16x3>", "xpw_dgrad+bn_bwd<bf16x3>", "xpw_fwd<bf16x3>"),
+                   "xconv3_dgrad+bn_bwd<bf16x3>", "xpw_dgrad+bn_bwd<bf16x3>", "xpw_fwd<bf16x3>", "xhalo_fwd<bf16x3>",
+                   "xhalo_dgrad<bf16x3>", "xhalo_dgrad+bn_bwd<bf16x3>"),
         "rocprof": ("void pconv_kernel<", "void phalo_kernel<", "void pwgrad_kernel<", "void ppersist_kernel<",
-                    "void pwgrad_taps_kernel<", "void xgemm_kernel<", "void xwgrad_kernel<", "void xpw_fused_kernel<", "void xpw_fwd_kernel<"),
+                    "void pwgrad_taps_kernel<", "void xgemm_kernel<", "void xwgrad_kernel<", "void xpw_fused_kernel<", "void xpw_fwd_kernel<",
+                    "void xhalo_kernel<"),
         "peak": 2500.0 / 6.0, "sustained": 1886.0 / 6.0, "what": "grouped 3x3 convolutions (pre-split operand planes) and, round 5, the deep 1x1 "
                                       "convolutions (activation split in registers) on exact three-way bf16 operand splits: 6 x "
                                       "v_mfma_f32_32x32x16_bf16 per fp32-grade product, fp32 accumulate; peak = 2500 / 6 "

@@ -387,9 +387,17 @@ int scouter_conv2d_wgrad_planes(const void* x_planes, const void* dy_planes, flo
  * tile_hint: 0 = 256x128 (eight waves), 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64 (eight waves), 5 = 256x32, 6 = 128x32 (two waves), else the
  * library's choice (scouter_conv2d_x3_tile tells which for N = output columns per group; every tile gives the same bits).
  * bn_partial: as scouter_conv2d_fwd_f32, one row per M tile = scouter_conv2d_x3_partial_rows(M, N, tile_hint).  The input
- * gradient takes the optional fused BatchNorm-backward epilogue of scouter_conv2d_dgrad_bnbwd_f32 (relu_mask .. part2). */
+ * gradient takes the optional fused BatchNorm-backward epilogue of scouter_conv2d_dgrad_bnbwd_f32 (relu_mask .. part2).
+ * tile_hint 7 (round 6, csrc/conv_xhalo.hip; only on request, never the library's choice): the 3x3 / pad 1 layers whose GEMM
+ * is 32 columns wide per group -- forward with Cout / groups == 32, input gradient with Cin / groups == 32 (the deep stem's
+ * 32 -> 32 and 32 -> 64 convolutions, resnet.py:471-489; the input gradient of layer1's radix convolution,
+ * layers/split_attn.py:54-60), maps up to 126 pixels wide, no bias / forward addend -- on a PERSISTENT kernel that splits
+ * every input element once and keeps the split rows resident in LDS for all nine taps.  Same error bound as the other
+ * tiles, another summation order (16-channel chunk outer, tap inner): equal to fp32 rounding, not bit for bit.  Its
+ * bn_partial / part1 / part2 have scouter_conv2d_x3_halo_partial_rows(groups) rows (one per workgroup of a group). */
 int scouter_conv2d_x3_tile(long M, int N, int tile_hint);
 int scouter_conv2d_x3_partial_rows(long M, int N, int tile_hint);
+int scouter_conv2d_x3_halo_partial_rows(int groups);
 int scouter_conv2d_fwd_x3(const float* x, const void* w_planes_fwd, const float* bias, const float* addend, float* y,
                           double* bn_partial, int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad, int groups,
                           int relu, int tile_hint, void* stream);

@@ -136,6 +136,13 @@ struct BnBwdFuse {
                                                            // bit 3: the OUTPUT is (plane forward kernels, which have no other flag)
 };
 
+// conv_xhalo.hip: the persistent resident-rows kernel with the operand split in registers (3x3 / stride 1 / pad 1 layers with 32
+// GEMM columns per group); reached through tile 7 of the scouter_conv2d_{fwd,dgrad}_x3 entry points (conv_x3.hip)
+bool sc_xhalo_ok(const ConvGeom& g);
+int sc_xhalo_partial_rows(int groups);
+void sc_launch_xhalo(bool dgrad, const float* a, const void* w_planes, long w_plane_elems, const float* addend, float* dst,
+                     double* bn_part, const ConvGeom& g, int relu, hipStream_t st, const BnBwdFuse& fz);
+
 // Operands of the fused BatchNorm-backward epilogue that do not depend on the GEMM (shortcut gradient, BatchNorm inputs):
 // requested at the START of the workgroup (igemm_epilogue_prefetch), so their latency overlaps the K loop -- these launches
 // are HBM-latency bound (tools_dev/fused_dgrad_tiles.py).  NR = rows per lane of the epilogue's row-major pass (<= 8: the

@@ -393,10 +393,12 @@ static int dispatch_x3(const float* a, const void* w, long w_pe, const float* bi
     return sc_check_launch(DGRAD ? "conv2d_dgrad_x3" : "conv2d_fwd_x3");
 }
 
-extern "C" int scouter_conv2d_x3_tile(long M, int N, int tile_hint) { return x3_tile(M, N, tile_hint); }
+extern "C" int scouter_conv2d_x3_tile(long M, int N, int tile_hint) { return tile_hint == 7 && N == 32 ? 7 : x3_tile(M, N, tile_hint); }
 extern "C" int scouter_conv2d_x3_partial_rows(long M, int N, int tile_hint) {
     return sc_cdiv(M, x3_tile_rows(x3_tile(M, N, tile_hint)));
 }
+// tile 7 (conv_xhalo.hip, persistent): ONE partial row per workgroup of a group, whatever M
+extern "C" int scouter_conv2d_x3_halo_partial_rows(int groups) { return groups > 0 ? sc_xhalo_partial_rows(groups) : 0; }
 
 // kh x kw: 1x1 (pad 0) or an odd "same" filter (pad = (k - 1) / 2), stride 1; groups with 32-multiples of channels per group
 extern "C" int scouter_conv2d_fwd_x3(const float* x, const void* w_planes_fwd, const float* bias, const float* addend, float* y,
@@ -412,11 +414,18 @@ extern "C" int scouter_conv2d_fwd_x3(const float* x, const void* w_planes_fwd, c
     g.M = (long)B * H * W;
     SC_UNSUPPORTED(g.M < (1L << 31) && (long)kh * kw * Cg * Cout * 2 * 3 < (1L << 31) && (long)H * W * Cin < (1L << 28) &&
                    256L * Cin * 4 < (1L << 31), "conv2d_fwd_x3: tensor too large for 32-bit offsets");
+    const long w_pe = (long)kh * kw * Cg * Cout;
+    if (tile_hint == 7) {           // resident rows, split once per element, persistent (conv_xhalo.hip): 32 columns per group
+        SC_UNSUPPORTED(sc_xhalo_ok(g) && !bias && !addend, "conv2d_fwd_x3: tile 7 covers 3x3 / pad 1 layers with 32 output channels per "
+                       "group, 16-multiples of input channels per group, maps up to 126 wide, no bias / addend");
+        ScProfScope prof("xhalo_fwd<bf16x3>", (hipStream_t)stream, 2.0 * g.M * Cout * Cg * kh * kw, 4.0 * g.M * Cin + 4.0 * g.M * Cout);
+        sc_launch_xhalo(false, x, w_planes_fwd, w_pe, nullptr, y, bn_partial, g, relu, (hipStream_t)stream, BnBwdFuse{});
+        return sc_check_launch("conv2d_fwd_x3<halo>");
+    }
     const int tile = x3_tile(g.M, Ng, tile_hint);
     const bool conv = kh > 1 || groups > 1;
     ScProfScope prof(conv ? "xconv3_fwd<bf16x3>" : "xconv_fwd<bf16x3>", (hipStream_t)stream, 2.0 * g.M * Cout * Cg * kh * kw,
                      4.0 * g.M * Cin + 4.0 * g.M * Cout);
-    const long w_pe = (long)kh * kw * Cg * Cout;
     if (conv) return dispatch_x3<false, true>(x, w_planes_fwd, w_pe, bias, addend, y, bn_partial, g, relu, tile, (hipStream_t)stream, BnBwdFuse{});
     return dispatch_x3<false, false>(x, w_planes_fwd, w_pe, bias, addend, y, bn_partial, g, relu, tile, (hipStream_t)stream, BnBwdFuse{});
 }
@@ -437,13 +446,21 @@ extern "C" int scouter_conv2d_dgrad_x3_bnbwd(const float* dy, const void* w_plan
     g.M = (long)B * H * W;
     SC_UNSUPPORTED(g.M < (1L << 31) && (long)kh * kw * Cig * Cout * 2 * 3 < (1L << 31) && (long)H * W * Cout < (1L << 28) &&
                    256L * Cout * 4 < (1L << 31), "conv2d_dgrad_x3: tensor too large for 32-bit offsets");
+    const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, x1, saved1, part1, x2, saved2, part2, 0};
+    const long w_pe = (long)kh * kw * Cig * Cout;
+    if (tile_hint == 7) {           // (conv_xhalo.hip: 32 input channels per group = 32 GEMM columns)
+        SC_UNSUPPORTED(sc_xhalo_ok(g), "conv2d_dgrad_x3: tile 7 covers 3x3 / pad 1 layers with 32 input channels per group, "
+                       "16-multiples of output channels per group, maps up to 126 wide");
+        ScProfScope prof(part1 ? "xhalo_dgrad+bn_bwd<bf16x3>" : "xhalo_dgrad<bf16x3>", (hipStream_t)stream,
+                         2.0 * g.M * Cin * Cog * kh * kw, 4.0 * g.M * Cout + 4.0 * g.M * Cin);
+        sc_launch_xhalo(true, dy, w_planes_dgrad, w_pe, addend, dx, nullptr, g, 0, (hipStream_t)stream, fz);
+        return sc_check_launch("conv2d_dgrad_x3<halo>");
+    }
     const int tile = x3_tile(g.M, Cig, tile_hint);
     const bool conv = kh > 1 || groups > 1;
     ScProfScope prof(part1 ? (conv ? "xconv3_dgrad+bn_bwd<bf16x3>" : "xconv_dgrad+bn_bwd<bf16x3>")
                            : (conv ? "xconv3_dgrad<bf16x3>" : "xconv_dgrad<bf16x3>"),
                      (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw, 4.0 * g.M * Cout + 4.0 * g.M * Cin);
-    const BnBwdFuse fz{part1 ? (const unsigned long long*)relu_mask : nullptr, x1, saved1, part1, x2, saved2, part2, 0};
-    const long w_pe = (long)kh * kw * Cig * Cout;
     if (conv) return dispatch_x3<true, true>(dy, w_planes_dgrad, w_pe, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream, fz);
     return dispatch_x3<true, false>(dy, w_planes_dgrad, w_pe, nullptr, addend, dx, nullptr, g, 0, tile, (hipStream_t)stream, fz);
 }

@@ -72,6 +72,22 @@ class Conv2d(nn.Module):
         return (K.xpw_fwd_eligible(self.in_channels, self.out_channels, k, k, self.stride, self.padding, self.groups,
                                    self.bias is not None) and (self.in_channels <= 128 or not self.x3_static()))
 
+    def x3_halo_static(self):
+        """(forward, input gradient) on the persistent resident-rows kernel -- shape rule alone (kernels.x3_halo_eligible)."""
+        k = self.kernel_size
+        return K.x3_halo_eligible(self.in_channels, self.out_channels, k, k, self.stride, self.padding, self.groups,
+                                  self.bias is not None)
+
+    def halo_fwd(self):
+        """x3 bit 6, fp32 precision, no plane operands: the FORWARD of this 3x3 layer has 32 output channels per group and runs
+        on csrc/conv_xhalo.hip (tile 7 of the register-split entry points)."""
+        return bool(self.x3 & 64) and self.precision == "fp32" and not self.planes and self.x3_halo_static()[0]
+
+    def halo_dgrad(self):
+        """x3 bit 6, fp32 precision: the INPUT GRADIENT of this 3x3 layer has 32 input channels per group and runs on
+        csrc/conv_xhalo.hip from the fp32 output gradient (plane layers included: their gradient planes need 64)."""
+        return bool(self.x3 & 64) and self.precision == "fp32" and self.x3_halo_static()[1]
+
     def fwd_on_xpw(self):
         """x3 bit 5, fp32 precision, no plane operands, the shape rule."""
         return bool(self.x3 & 32) and self.precision == "fp32" and not self.planes and self.xpw_static()
@@ -84,9 +100,12 @@ class Conv2d(nn.Module):
             return 0
         if not self.planes and self.x3_static():
             return self.x3 & 15
+        bits = 0
         if (self.x3 & 16) and not self.planes and self.x3_conv_static():
-            return 16
-        return 0
+            bits |= 16
+        if not self.planes and (self.halo_fwd() or self.halo_dgrad()):
+            bits |= 64                    # (3x3 layers with 32 GEMM columns per group: csrc/conv_xhalo.hip)
+        return bits
 
     def _x3_weights(self, want_fwd, want_dgrad):
         ws, self._wsplit = self._wsplit, None
@@ -170,7 +189,7 @@ class Conv2d(nn.Module):
         out_dtype=torch.bfloat16: the output is STORED as bf16 (activation storage of the bf16 mode, kernels.conv2d_fwd)."""
         if isinstance(x, K.PlaneTensor):
             k = self.kernel_size
-            want_wd = save and self.planes_dy() > 0
+            want_wd = save and (self.planes_dy() > 0 or self.halo_dgrad())
             ws, self._wsplit = self._wsplit, None
             if ws is not None and ws[0] is not None and ws[0].shape[0] == x.planes.shape[0] and (ws[1] is not None or not want_wd):
                 wf, wd = ws[0], (ws[1] if want_wd else None)        # split by SlotModel for the whole model in one launch
@@ -185,12 +204,15 @@ class Conv2d(nn.Module):
         xm = self.x3_mode()
         # (the persistent bf16x3 forward has the plain epilogue only; a call with an addend / ReLU takes the other kernels)
         xpw = 5 if (self.fwd_on_xpw() and addend is None and not relu and x.dtype == K.F32 and out_dtype in (None, K.F32)) else None
-        if (xm & 23) and x.dtype == K.F32 and out_dtype in (None, K.F32):
-            want_wd = bool(save and (xm & 6))
-            want_wf = bool(xm & 17) and xpw is None
+        if (xm & 87) and x.dtype == K.F32 and out_dtype in (None, K.F32):
+            hf = bool(xm & 64) and self.halo_fwd() and addend is None and x.shape[2] <= K.X3_HALO_MAX_W
+            want_wd = bool(save and ((xm & 6) or ((xm & 64) and self.halo_dgrad())))
+            want_wf = (bool(xm & 17) and xpw is None) or hf
             wf, wd = self._x3_weights(want_wf, want_wd) if (want_wf or want_wd) else (None, None)
             if xpw is not None:
                 y = K.conv2d_fwd(x, K.hwio(self.weight), None, None, 1, 0, 1, False, bn_stats, tile=5)
+            elif hf:
+                y = K.conv2d_fwd_x3(x, wf, None, relu, bn_stats, tile=7, kh=3, pad=1, groups=self.groups)
             elif xm & 17:
                 k = self.kernel_size
                 y = K.conv2d_fwd_x3(x, wf, addend, relu, bn_stats, kh=k, pad=self.padding, groups=self.groups)
@@ -225,7 +247,7 @@ class Conv2d(nn.Module):
         if dy is None and dyp is not None and dyp.shape[0] == 1 and wd is None:
             dy, dyp = dyp[0], None        # (likewise the output gradient, Conv2d.dy_plane_only)
         dev = dy.device if dy is not None else dyp.device
-        if need_dx and dyp is not None and wd is not None:
+        if need_dx and dyp is not None and wd is not None and self.planes_dy():
             k = self.kernel_size
             dx = K.conv2d_dgrad_planes(dyp, wd, xshape, k, k, self.stride, self.padding, self.groups, addend, post=post)
             need_dx = False
@@ -250,6 +272,10 @@ class Conv2d(nn.Module):
                     K.colsum(dy, self._db)
         if not need_dx:
             return dx
+        if (self.halo_dgrad() and wd is not None and dy is not None and dy.dtype == K.F32 and xshape[2] <= K.X3_HALO_MAX_W and
+                dx_dtype in (None, K.F32)):
+            # 3x3 layer with 32 input channels per group: resident rows, split once per element (csrc/conv_xhalo.hip)
+            return K.conv2d_dgrad_x3(dy, wd, xshape, addend, post=post, tile=7, kh=3, pad=1, groups=self.groups)
         if self.x3_mode() and wd is not None and dyp is None and dy is not None and dy.dtype == K.F32:
             # pointwise layer on the register-split bf16x3 GEMM (x3_mode): plain input gradient (bit 1), or with the
             # fused BatchNorm-backward epilogue (bit 2)

@@ -155,19 +155,23 @@ class SlotModel(nn.Module):
         tensors in and out, fp32-grade products on the bf16 matrix cores): bit 0 forward, bit 1 plain input gradient, bit 2
         input gradient with the fused BatchNorm-backward epilogue, bit 3 weight gradient, bit 4 the forward of the 3x3
         layers with 32 input channels per group (kernels.x3_conv_eligible: the stem's 32 -> 64 convolution), bit 5 the forward of
-        the short-K pointwise layers on the persistent bf16x3 kernel (nn_hip.Conv2d.xpw_static, csrc/conv_pw_persist_x3.h); 0:
+        the short-K pointwise layers on the persistent bf16x3 kernel (nn_hip.Conv2d.xpw_static, csrc/conv_pw_persist_x3.h), bit 6
+        the 3x3 passes whose GEMM is 32 columns wide per group on the persistent resident-rows kernel (nn_hip.Conv2d.halo_fwd /
+        halo_dgrad, csrc/conv_xhalo.hip; these include the input gradient of the plane layers with 32-channel groups); 0:
         the exact-fp32 MFMA kernels.  Which layers qualify is a static function of their channels (kernels.x3_eligible,
         kernels.xpw_fwd_eligible), so the forward does not depend on batch or timing."""
-        if bits & ~63:
-            raise ValueError("x3 bits must be within 0..63")
+        if bits & ~127:
+            raise ValueError("x3 bits must be within 0..127")
         for mod in self.backbone.modules():
             if isinstance(mod, Conv2d) and not isinstance(mod, StemConv2d):
                 mod.x3 = int(bits)
         self._refresh_x3()
 
     def _refresh_x3(self):
-        self._x3_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and not m.planes and
-                          ((getattr(m, "x3", 0) & 15 and m.x3_static()) or (getattr(m, "x3", 0) & 16 and m.x3_conv_static()))]
+        self._x3_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and not isinstance(m, StemConv2d) and
+                          not m.planes and ((getattr(m, "x3", 0) & 15 and m.x3_static()) or
+                                            (getattr(m, "x3", 0) & 16 and m.x3_conv_static()) or
+                                            (getattr(m, "x3", 0) & 64 and any(m.x3_halo_static())))]
 
     def set_side_stream(self, enabled):
         """Weight gradients on the side stream (default) or serially on the compute stream (per-kernel timing)."""
@@ -250,12 +254,14 @@ class SlotModel(nn.Module):
             x = x.float()
         tracked = []
         convs = [c for c in getattr(self, "_plane_convs", ()) if c._nplanes()]
-        items = [(K.hwio(c.weight), c.groups, True, bool(save and c.planes_dy())) for c in convs]
+        # (input-gradient planes also where that gradient runs on the resident-rows register-split kernel: Conv2d.halo_dgrad)
+        items = [(K.hwio(c.weight), c.groups, True, bool(save and (c.planes_dy() or c.halo_dgrad()))) for c in convs]
         # (the pointwise layers on the register-split GEMM take three WEIGHT planes too -- same launch; fp32 mode only)
         xconvs = [c for c in getattr(self, "_x3_convs", ()) if c.x3_mode()] if (not convs or convs[0]._nplanes() == 3) else []
         # (forward planes only where the forward runs on the register-split GEMM: the persistent bf16x3 forward -- bit 5 -- splits
         #  its weight tile itself)
-        xitems = [(c, bool(c.x3_mode() & 17) and not c.fwd_on_xpw(), bool(save and (c.x3_mode() & 6))) for c in xconvs]
+        xitems = [(c, (bool(c.x3_mode() & 17) and not c.fwd_on_xpw()) or (bool(c.x3_mode() & 64) and c.halo_fwd()),
+                   bool(save and ((c.x3_mode() & 6) or ((c.x3_mode() & 64) and c.halo_dgrad())))) for c in xconvs]
         xconvs = [c for c, f, d in xitems if f or d]
         items += [(K.hwio(c.weight), c.groups, f, d) for c, f, d in xitems if f or d]
         if items:      # this step's weight planes of every plane convolution: one launch into persistent buffers ...

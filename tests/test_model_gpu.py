@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import torch_oracle as O                                        # noqa: E402
-from oracle.gen_golden import MODEL_CASES, LAMBDA, model_inputs, grad_digest   # noqa: E402
+from oracle.gen_golden import MODEL_CASES, LAMBDA, HEAD_PREFIXES, model_inputs, grad_digest   # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -83,7 +83,7 @@ def _oracle_run_inputs(P, images, labels, cfg, dtype):
     return out, losses, aux, leaves, Q
 
 
-def pinned_gradient_check(what, case, signs, named, kf=2.0, ks=1e-3, kf_squeeze=None):
+def pinned_gradient_check(what, case, signs, named, kf=2.0, ks=1e-3, kf_squeeze=None, kf_head=None):
     """Every parameter gradient of the HIP model against the oracle's fp64 autograd evaluated under the SIGN PATTERN the
     HIP forward produced (`signs` from capture_relu_signs: every BatchNorm+ReLU output, conv1x1, the stem max-pool's
     window indices), next to the oracle's fp32 autograd under the same pattern:
@@ -107,7 +107,8 @@ def pinned_gradient_check(what, case, signs, named, kf=2.0, ks=1e-3, kf_squeeze=
         e = float((mine - ref.grad).abs().max())
         e32 = float((lv32[k].grad.double() - ref.grad).abs().max())
         squeeze = ".conv2.bn1." in k or ".conv2.fc1." in k or ".conv2.fc2." in k
-        if e > max((kf_squeeze if squeeze and kf_squeeze else kf) * e32, ks * scale) + 1e-9:
+        f = kf_squeeze if squeeze and kf_squeeze else (kf_head if kf_head and k.startswith(HEAD_PREFIXES) else kf)
+        if e > max(f * e32, ks * scale) + 1e-9:
             bad.append((k, e, e32, scale))
         if scale > 0 and e / scale > worst[0]:
             worst = (e / scale, k)
@@ -135,11 +136,13 @@ def test_model_fwd_bwd_parity(case):
     # 1e-5, a tenth of north_star's 1e-4.  Measured r2: 6.6e-6 vs 2.1e-6 (resnet18), 1.5e-4 vs 1.2e-4 (resnest26d 96^2),
     # 3.9e-4 vs 7.4e-4 (resnest50d S=300).
     assert err <= max(1.5 * floor, 1e-5), (err, floor)
-    np.testing.assert_allclose(m.slot.last_attn.cpu().numpy(), g["f64_attn"], atol=max(1e-4, tol), rtol=0)
-    if "f32_attn" in g.files:
-        floor_a = float(np.abs(g["f32_attn"] - g["f64_attn"]).max())
-        err_a = float(np.abs(m.slot.last_attn.cpu().numpy() - g["f64_attn"]).max())
-        assert err_a <= max(2.0 * floor_a, 2e-5), (err_a, floor_a)
+    # attention maps against the reference's own fp32 deviation ON THE MAPS (the normaliser of slot_attention.py:56 makes it
+    # larger than on the log-probabilities: resnest50d S = 36: 2.3e-3 / 2.5e-3 / 1.6e-3 at 8 / 16 / 32 threads vs 7.4e-4):
+    # north_star's gate max(1e-4, 3 x floor) with the floor of the quantity itself, and the tight 2 x form next to it
+    floor_a = float(np.abs(g["f32_attn"] - g["f64_attn"]).max())
+    err_a = float(np.abs(m.slot.last_attn.cpu().numpy() - g["f64_attn"]).max())
+    assert err_a <= max(1e-4, tol, 3 * floor_a), (err_a, floor_a, tol)
+    assert err_a <= max(2.0 * floor_a, 2e-5), (err_a, floor_a)
     np.testing.assert_allclose([float(loss), float(nll), float(area)],
                                [float(g["f64_loss"]), float(g["f64_nll"]), float(g["f64_area"])], atol=tol, rtol=1e-4)
     # gradients vs the oracle's fp64 autograd (full tensors)
@@ -206,9 +209,18 @@ def test_full_size_resnest26d_224_against_reference_fp64_digests():
     floor = float(np.abs(g["f32_log_probs"] - g["f64_log_probs"]).max())
     tol = max(1e-4, 3 * floor)
     err = float(np.abs(out.detach().cpu().numpy() - g["f64_log_probs"]).max())
-    assert err <= tol
-    # tight: no more than 1.5x the error of the reference's own fp32 arithmetic on these inputs (measured 5.1e-5 vs 4.0e-5)
-    assert err <= max(1.5 * floor, 1e-5), (err, floor)
+    assert err <= tol                                    # north_star's gate on this draw: unchanged
+    # The tight statement is a DISTRIBUTION (round 6): `floor` is ONE draw of PyTorch's own fp32 noise (8
+    # threads: 4.0e-5; the same reference at 16 / 32 threads: 1.06e-4 / 6.9e-5), and the HIP path's error is one draw of the
+    # same kind of noise for every choice of (bit-compatible or not) kernel instance.  This seed is seed 0 of
+    # model_resnest26d_224_seeds.npz: test_rounding_noise_over_five_seeds holds the geometric mean of |HIP - fp64| / |PyTorch
+    # fp32 - fp64| over five seeds to <= 1.5 and every seed to <= 3; here the per-seed cap of that statement, against the
+    # geometric mean of the reference's three thread counts on THIS seed.  (Round 5 held this one draw to 1.5 x the 8-thread
+    # draw: 5.1e-5 vs 4.0e-5 for the default path then, 7.4e-5 / 8.5e-5 for the options that are defaults now.)
+    gs = np.load(os.path.join(GOLD, "model_%s_seeds.npz" % case))
+    assert int(gs["seeds"][0]) == 200 and np.array_equal(gs["f64_log_probs"][0], g["f64_log_probs"])
+    floors = np.abs(gs["f32_log_probs"][0].astype(np.float64) - gs["f64_log_probs"][0][None]).max((1, 2))
+    assert err <= max(3.0 * float(np.exp(np.log(floors).mean())), 1e-5), (err, floors)
     # attention maps: against the reference's own fp32 deviation on the maps (4.4e-4 here -- larger than on the
     # log-probabilities, the normaliser of slot_attention.py:56 is the ill-conditioned step)
     floor_a = float(np.abs(g["f32_attn"] - g["f64_attn"]).max())
@@ -227,36 +239,113 @@ def test_full_size_resnest26d_224_against_reference_fp64_digests():
     # upstream gradient in EITHER implementation); the sharp statement is the per-tensor bound under the HIP path's own
     # sign pattern, here at the full 224 x 224 size too
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    pinned_gradient_check(case, case, signs, named)
+    # backbone tensors: kf = 2 as everywhere.  Head tensors (slot.*, conv1x1.*) see the forward's feature noise coherently
+    # -- on one seed all thirteen sit at the same multiple of PyTorch-fp32's own deviation (seed 200: 1.3-1.6 x for the round-5
+    # default, 2.2-2.6 x with the stem on the register-split kernel, 0.4 x with every option on; other seeds 0.1-1.3 x) -- so
+    # their tight bound is the distribution over five seeds (test_gradient_noise_over_five_seeds: geometric mean <= 1.5, no
+    # seed > 3) and this single seed gets that statement's per-seed cap.
+    pinned_gradient_check(case, case, signs, named, kf_head=3.0)
 
 
-@pytest.mark.parametrize("switches", [{}, {"x3": 47}, {"x3": 31}, {"x3": 63}, {"halo": 3}, {"x3": 63, "halo": 3}])
+def _seed_model(seed):
+    from scouter_amd.sloter.slot_model import SlotModel
+    from oracle.gen_golden import SEED_CASE
+    arch, C, spc, L, ls, power, B, H, in_chans, mnist = MODEL_CASES[SEED_CASE]
+    args = argparse.Namespace(model=arch, pre_trained=False, num_classes=C, dataset="ImageNet", use_slot=True, use_pre=False,
+                              grad=False, channel=O.ARCHS[arch]["channel"], slots_per_class=spc, hidden_dim=64,
+                              freeze_layers=0, vis=False, vis_id=0, loss_status=ls, power=power, to_k_layer=L,
+                              lambda_value=LAMBDA)
+    spec, P, images, labels = model_inputs(SEED_CASE, int(seed))
+    m = SlotModel(args)
+    m.load_state_dict(P)
+    return m.cuda().train(), images, labels
+
+
+# the forward-option sets the distribution tests cover: the defaults (round 6: every option on), round 5's defaults, each option
+# alone on top of those, and the exact-fp32 / plane-free path
+NOISE_SWITCHES = [{}, {"x3": 15, "halo": 2}, {"x3": 31, "halo": 2}, {"x3": 47, "halo": 2}, {"x3": 15, "halo": 3},
+                  {"x3": 0, "halo": 2}]
+
+
+@pytest.mark.parametrize("switches", NOISE_SWITCHES)
+def test_gradient_noise_over_five_seeds(switches, monkeypatch):
+    """The gradient yardstick as a DISTRIBUTION (round 6).  tests/golden/model_resnest26d_224_seeds.npz holds,
+    for the five seeds of the forward test below, the REFERENCE's fp64 gradients of the head tensors (`slot.*`, `conv1x1.*`) and,
+    per tensor, max |fp32 - fp64| of the reference's plain-fp32 backward at 8 / 16 / 32 CPU threads (oracle/gen_golden.py).
+    Head gradients are produced before the backward crosses any backbone ReLU / max-pool, so no sign flip of a ~0 backbone
+    pre-activation can move them: what moves them is the rounding noise of the forward's features, coherently -- on one seed
+    every head tensor sits at about the same multiple of PyTorch-fp32's own deviation, which is why ONE seed held to 2 x
+    (round 5) rejected forward options whose noise is no larger: seed 200 draws 1.3-1.6 x for round 5's default, 2.6 x with the
+    stem's 3x3 on the register-split kernel, 0.4 x with every option on.  Per seed and tensor
+        r = |HIP - fp64| / max(geometric mean over the thread counts of |PyTorch fp32 - fp64|, 5e-4 max|grad|)
+    (the second term = ks / kf of pinned_gradient_check).  TIGHT, on the tensors behind which no ReLU of the head sits either
+    (last to_k layer, GRU, initial slots): worst tensor per seed, geometric mean over the seeds <= 1.5, no seed > 3.  The tensors
+    in front of the head's own ReLUs (conv1x1, the earlier to_k layers) additionally move by ~1 / (B N) of their largest entry
+    when one ~0 pre-activation of conv1x1 / the to_k MLP lands on the other side (seed 4200 does, for several option sets:
+    4.8e-3): they get the per-seed cap with that allowance, and their tight bound is the pinned check of
+    test_full_size_resnest26d_224_against_reference_fp64_digests.  Every seed also keeps north_star's gate on the forward."""
+    from scouter_amd import kernels as K
+    from oracle.gen_golden import SEED_CASE
+    g = np.load(os.path.join(GOLD, "model_%s_seeds.npz" % SEED_CASE))
+    if "halo" in switches:
+        monkeypatch.setattr(K, "HALO_TILE", switches["halo"])
+    keys = [str(k) for k in g["grad_keys"]]
+    head = [str(k) for k in g["head_keys"]]
+    offs = np.concatenate([[0], np.cumsum(g["head_sizes"])])
+    last_to_k = max(int(k.split(".")[2]) for k in head if k.startswith("slot.to_k."))
+    flip_free = [k for k in head if k.startswith(("slot.gru.", "slot.initial_slots", "slot.to_k.%d." % last_to_k))]
+    assert len(flip_free) == 7 and len(head) == 13
+    worst, table = [], []
+    for i, seed in enumerate(g["seeds"]):
+        m, images, labels = _seed_model(seed)
+        if "x3" in switches:
+            m.set_x3(switches["x3"])
+        out, losses = m(images.cuda(), labels.cuda())
+        losses[0].backward()
+        torch.cuda.synchronize()
+        err = float(np.abs(out.detach().cpu().numpy().astype(np.float64) - g["f64_log_probs"][i]).max())
+        floors = np.abs(g["f32_log_probs"][i].astype(np.float64) - g["f64_log_probs"][i][None]).max((1, 2))
+        assert err <= max(1e-4, 3 * float(floors.max())), (int(seed), err, floors)      # north_star's gate, per seed
+        named = dict(m.named_parameters())
+        r = {}
+        for j, k in enumerate(head):
+            ref = g["f64_head_grads"][i][offs[j]:offs[j + 1]].astype(np.float64)
+            mine = named[k].grad.detach().cpu().double().flatten().numpy()
+            e = float(np.abs(mine - ref).max())
+            e32 = g["f32_grad_maxdev"][i][:, keys.index(k)]
+            scale = float(g["f64_grad_absmax"][i][keys.index(k)])
+            r[k] = e / max(float(np.exp(np.log(e32).mean())), 5e-4 * scale)
+            if k not in flip_free:
+                # per-seed cap + one head-ReLU flip among the B x N = 294 rows (measured 4.8e-3 of the largest entry)
+                assert e <= max(3.0 * float(np.exp(np.log(e32).mean())), 1.5e-3 * scale) + 1e-2 * scale, (int(seed), k, e, e32, scale)
+        worst.append(max(r[k] for k in flip_free))
+        table.append(["%.2f" % r[k] for k in head])
+        del m
+    gm = float(np.exp(np.log(worst).mean()))
+    print("gradient noise over five seeds", switches or "(default)", "worst flip-free head tensor per seed",
+          ["%.2f" % w for w in worst], "geometric mean %.2f" % gm, "| all head tensors per seed:", table)
+    assert gm <= 1.5 and max(worst) <= 3.0, (worst, gm)
+
+
+@pytest.mark.parametrize("switches", NOISE_SWITCHES)
 def test_rounding_noise_over_five_seeds(switches, monkeypatch):
     """The yardstick as a DISTRIBUTION (round 5).  tests/golden/model_resnest26d_224_seeds.npz holds, for five parameter / input
     seeds of the BASELINE-size network (224 x 224, batch 6, train-mode BatchNorm), the reference's fp64 log-probabilities and its
     plain-fp32 ones at 8 / 16 / 32 CPU threads: PyTorch's own fp32 lands 4.0e-5 / 1.06e-4 / 6.9e-5 from fp64 on seed 200 just by
     the thread count (another summation order), and 3e-6 ... 2.9e-4 across the seeds -- one draw is no yardstick.  Here: per
     seed r = |HIP - fp64| / geometric mean over the thread counts of |PyTorch fp32 - fp64|; the geometric mean of r over the five
-    seeds stays <= 1.5 and no seed exceeds 3 -- for the default path and for every forward-changing option that one draw (seed
-    200, 8 threads: test_full_size_resnest26d_224_against_reference_fp64_digests) puts over its 1.5 x: SCOUTER_X3 bit 4 (stem's
-    3x3 on the register-split kernel), bit 5 (short-K pointwise forward on the persistent bf16x3 kernel), SCOUTER_HALO=3."""
-    from scouter_amd.sloter.slot_model import SlotModel
+    seeds stays <= 1.5 and no seed exceeds 3 -- for the default path (round 6: SCOUTER_X3 bit 4, the stem's 3x3 on the
+    register-split kernel, bit 5, the short-K pointwise forward on the persistent bf16x3 kernel, and SCOUTER_HALO=3, the
+    resident-rows plane forward, are ON), for round 5's defaults, for each of those options alone and for the exact-fp32 path
+    (NOISE_SWITCHES).  One draw (seed 200 at 8 threads) had put each option over round 5's single-draw 1.5 x."""
     from scouter_amd import kernels as K
     from oracle.gen_golden import SEED_CASE
     g = np.load(os.path.join(GOLD, "model_%s_seeds.npz" % SEED_CASE))
-    arch, C, spc, L, ls, power, B, H, in_chans, mnist = MODEL_CASES[SEED_CASE]
     if "halo" in switches:
         monkeypatch.setattr(K, "HALO_TILE", switches["halo"])
     ratios = []
     for i, seed in enumerate(g["seeds"]):
-        args = argparse.Namespace(model=arch, pre_trained=False, num_classes=C, dataset="ImageNet", use_slot=True, use_pre=False,
-                                  grad=False, channel=O.ARCHS[arch]["channel"], slots_per_class=spc, hidden_dim=64,
-                                  freeze_layers=0, vis=False, vis_id=0, loss_status=ls, power=power, to_k_layer=L,
-                                  lambda_value=LAMBDA)
-        spec, P, images, labels = model_inputs(SEED_CASE, int(seed))
-        m = SlotModel(args)
-        m.load_state_dict(P)
-        m = m.cuda().train()
+        m, images, labels = _seed_model(seed)
         if "x3" in switches:
             m.set_x3(switches["x3"])
         with torch.no_grad():
@@ -360,13 +449,24 @@ def test_other_baseline_shapes_forward_parity(arch, C, spc, B, H):
     # S >= 200: the reference's own fp32 result is only reproducible to ~1e-4
     # yardstick: what plain fp32 PyTorch loses against fp64 on the very same inputs (~1e-4 and more
     # for S >= 200 -- the row-sum division of slot_attention.py:56 is ill-conditioned)
+    # ... measured at three thread counts (the summation order of PyTorch's CPU convolutions depends on it): with S = 300 the
+    # reference's own fp32 log-probabilities move by 0.19 / 0.10 / 0.096 against fp64 on THESE inputs just by the thread count
+    # (other seeds: 0.04 ... 5, tools_dev/head_noise_s300.py) -- one draw is no yardstick for another draw of the same noise
+    # (round 6: with one draw the gate passed or failed with the forward options in either direction, seed by seed).  The gate
+    # stays north_star's max(1e-4, 3 x floor); `floor` is the largest of the reference's three draws.
+    floors = []
+    keep = torch.get_num_threads()
     with torch.no_grad():
-        P32 = {k: v.clone() for k, v in P.items()}
-        ref32 = O.slot_model_forward(P32, images, labels, cfg, training=train)[0]
-    floor = float((ref32.double() - ref).abs().max())
+        for t in (8, 16, 32):
+            torch.set_num_threads(t)
+            ref32 = O.slot_model_forward({k: v.clone() for k, v in P.items()}, images, labels, cfg, training=train)[0]
+            floors.append(float((ref32.double() - ref).abs().max()))
+    torch.set_num_threads(keep)
+    floor = max(floors)
     tol = max(1e-4, 3 * floor)
     err = float((out.detach().cpu().double() - ref).abs().max())
-    print("%s C=%d spc=%d %dx%d: |HIP - fp64| = %.3g, |torch fp32 - fp64| = %.3g" % (arch, C, spc, H, H, err, floor))
+    print("%s C=%d spc=%d %dx%d: |HIP - fp64| = %.3g, |torch fp32 - fp64| at 8 / 16 / 32 threads = %s"
+          % (arch, C, spc, H, H, err, ["%.3g" % f for f in floors]))
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), atol=tol, rtol=0)
     np.testing.assert_allclose(m.slot.last_attn.cpu().numpy(), aux["attn"].numpy(), atol=tol, rtol=0)
     assert torch.isfinite(g1).all()
@@ -428,24 +528,65 @@ def test_bf16_mode_sits_inside_the_bf16_noise_of_the_reference_arithmetic():
     assert 1 - cos_hip[worst] <= 2.5 * (1 - min(cos_emu.values())) + 1e-3
 
 
-def _synthetic_model(arch, C, spc, L, B, H, seed, power=2, well_conditioned_head=False):
+def _synthetic_model(arch, C, spc, L, B, H, seed, power=2, well_conditioned_head=False, mnist=False):
     from scouter_amd.sloter.slot_model import SlotModel
-    args = argparse.Namespace(model=arch, pre_trained=False, num_classes=C, dataset="ImageNet", use_slot=True,
-                              use_pre=False, grad=False, channel=O.ARCHS[arch]["channel"], slots_per_class=spc,
+    args = argparse.Namespace(model=arch, pre_trained=False, num_classes=C, dataset="MNIST" if mnist else "ImageNet",
+                              use_slot=True, use_pre=False, grad=False, channel=O.ARCHS[arch]["channel"], slots_per_class=spc,
                               hidden_dim=64, freeze_layers=0, vis=False, vis_id=0, loss_status=1, power=power,
                               to_k_layer=L, lambda_value="1")
-    P = O.synth_state(O.state_dict_spec(arch, C, spc, L), seed)
+    P = O.synth_state(O.state_dict_spec(arch, C, spc, L, in_chans=1 if mnist else 3, mnist_stem=mnist), seed)
     if well_conditioned_head:
         # small initial slots: the dots rows of slot_attention.py:55-57 stay O(1) after the tau / r_i normalisation, so the
         # S = 300 head neither saturates (attention == 0 / 1, logits independent of the features) nor amplifies a feature
         # perturbation by 1e3 as the random mixed-sign head does; chosen with the CPU oracle alone:
         # bf16-rounded vs exact backbone features move the log-probs by 0.31 (11.8 with the unscaled head)
         P["slot.initial_slots"] = P["slot.initial_slots"] * 0.05
-    images, labels = O.synth_batch(B, 3, H, C, seed + 1)
+    images, labels = O.synth_batch(B, 1 if mnist else 3, H, C, seed + 1)
     m = SlotModel(args)
     m.load_state_dict(P)
     cfg = dict(model=arch, num_classes=C, slots_per_class=spc, loss_status=1, power=power, lambda_value=1.0)
     return m.cuda().train(), P, images, labels, cfg
+
+
+def test_config1_at_its_real_batch_forward_and_backward_parity():
+    """BASELINE configs[0] -- the MNIST-stem resnet18 + xSlot (10 slots, one to_k layer, power 1; reference
+    README.md:94-96) -- at the batch and resolution the bench runs it at (64 x 224 x 224, train-mode BatchNorm): the B = 64
+    instances of the fp32 kernels (7 x 7 ... 112 x 112 maps, 64 ... 512 channels, no plane / register-split layers) through the
+    whole model.  Forward vs the fp64 oracle next to plain fp32 PyTorch on the same inputs, then every parameter gradient under
+    the HIP forward's sign pattern with the fixtures' kf = 2 / ks = 1e-3 bound.  CPU oracle time: seconds per pass."""
+    m, P, images, labels, cfg = _synthetic_model("resnet18", 10, 1, 1, 64, 224, 2100, power=1, mnist=True)
+    signs = capture_relu_signs(m)
+    out, losses = m(images.cuda(), labels.cuda())
+    losses[0].backward()
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    signs = {k: (v if k == "maxpool" else (v > 0)).cpu() for k, v in signs.items()}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        Pd = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in P.items()}
+        aux = {}
+        ref, rl = O.slot_model_forward(Pd, images.double(), labels, cfg, training=True, aux=aux)
+        ref32, rl32 = O.slot_model_forward({k: v.clone() for k, v in P.items()}, images, labels, cfg, training=True)
+        floors = [float((ref32.double() - ref).abs().max())]
+        for t in (8, 16):           # the reference arithmetic at two more thread counts: its noise is a distribution (see above)
+            torch.set_num_threads(t)
+            r32 = O.slot_model_forward({k: v.clone() for k, v in P.items()}, images, labels, cfg, training=True)[0]
+            floors.append(float((r32.double() - ref).abs().max()))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    floor = float(np.exp(np.log(floors).mean()))
+    err = float((out.detach().cpu().double() - ref).abs().max())
+    err_a = float((m.slot.last_attn.cpu().double() - aux["attn"]).abs().max())
+    print("config 1 @ batch 64: |HIP - fp64| log_probs %.3g (torch fp32 at 32 / 8 / 16 threads: %s), attention %.3g, loss %.6f vs "
+          "%.6f" % (err, ["%.3g" % f for f in floors], err_a, float(losses[0]), float(rl[0])))
+    assert err <= max(1e-4, 3 * max(floors))                     # north_star's gate
+    # the per-seed cap of the distribution statements (test_rounding_noise_over_five_seeds): 3 x the geometric mean of the
+    # reference's own draws -- or half of north_star's 1e-4 (measured: 3.7e-5 against a 32-thread draw of 1.0e-5; every
+    # convolution of this model runs on the exact-fp32 MFMA kernels)
+    assert err <= max(3.0 * floor, 5e-5), (err, floors)
+    assert err_a <= max(1e-4, 3 * max(floors))
+    assert abs(float(losses[0]) - float(rl[0])) <= max(2.0 * abs(float(rl32[0]) - float(rl[0])), 2e-5)
+    del Pd, aux, ref, ref32
+    pinned_gradient_check("config 1 @ batch 64", (P, images, labels, cfg), signs, named)
 
 
 def test_config2_at_its_real_batch_forward_parity():
@@ -710,3 +851,49 @@ def test_config2_batch70_backward_is_the_mean_of_its_half_batches():
     for k in order:
         assert rel[k] <= 2e-5, (k, rel[k])
     assert float(np.median(list(rel.values()))) <= 1e-6
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config5_batch256_backward_is_the_mean_of_its_half_batches(precision):
+    """the BACKWARD of BASELINE configs[4] -- resnest50d, 100 classes x 3 slots (S = 300), 224 x 224 -- at its
+    REAL per-GPU batch 256, through the size-independent property of the config-2 test above (BatchNorm in eval mode, power 1:
+    the full-batch gradient is the mean of the two half-batch gradients): the B = 256 entries of the static table -- block tiles,
+    split-K weight-gradient plans, plane tiles, persistent kernels, fused epilogue row counts -- against the B = 128 ones, which
+    `test_config4_at_its_real_batch_...` and tests/test_table_entries_gpu.py hold to the oracle.  No oracle time at all.
+    "fp32": rounding of fp32 sums only.  "bf16" (the precision the config names; bf16-stored activations and residual-stream
+    gradient): the forward of a sample is still the same function in both batch sizes, but gradients that travel as bf16 round
+    each half-batch stream on its own -- the bound is that rounding (2^-9 per stored element, averaged over the pixels)."""
+    from scouter_amd.nn_hip import BatchNorm2d
+    m, P, images, labels, cfg = _synthetic_model("resnest50d", 100, 3, 3, 256, 224, 2300, power=1, well_conditioned_head=True)
+    if precision == "bf16":
+        m.set_precision("bf16")
+        assert m.activation_storage == "bf16"
+    for mod in m.modules():
+        if isinstance(mod, BatchNorm2d):
+            mod.eval()
+    named = dict(m.named_parameters())
+
+    def grads(sl):
+        m.zero_grad(set_to_none=True)
+        _, losses = m(images[sl].cuda(), labels[sl].cuda())
+        losses[0].backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().double().clone() for k, p in named.items() if p.grad is not None}, float(losses[0])
+
+    g_full, l_full = grads(slice(0, 256))
+    g_a, l_a = grads(slice(0, 128))
+    g_b, l_b = grads(slice(128, 256))
+    assert abs(l_full - 0.5 * (l_a + l_b)) <= (2e-6 if precision == "fp32" else 2e-5) * max(1.0, abs(l_full))
+    rel = {}
+    for k, g in g_full.items():
+        ref = 0.5 * (g_a[k] + g_b[k])
+        scale = float(ref.abs().max())
+        rel[k] = float((g - ref).abs().max()) / max(scale, 1e-30)
+    order = sorted(rel, key=rel.get, reverse=True)
+    med = float(np.median(list(rel.values())))
+    print("config 5 (%s) batch 256 vs mean of 2 x 128: relative gradient differences, worst first:" % precision,
+          [(k, "%.1e" % rel[k]) for k in order[:6]], "median %.1e over %d tensors" % (med, len(rel)))
+    worst_ok, med_ok = (2e-5, 1e-6) if precision == "fp32" else (2e-2, 2e-3)
+    for k in order:
+        assert rel[k] <= worst_ok, (k, rel[k])
+    assert med <= med_ok

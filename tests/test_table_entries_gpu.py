@@ -223,14 +223,27 @@ def test_plane_forward_entries(ks):
     x = _rnd(gen, B, H, W, Cin)
     w = _rnd(gen, kh, kw, Cin // groups, Cout, scale=1.0 / np.sqrt(Cin // groups * kh * kw))
     wf, _ = kk.planes_split_weight(w, groups, nplanes, fwd=True, dgrad=False)
-    y, (part, rows) = kk.conv2d_fwd_planes(_planes(kk, x, nplanes), wf, kh, kw, stride, pad, groups, bn_stats=True)
-    _chosen(kk, ("pfwd", nplanes, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), ks)
+    xp = _planes(kk, x, nplanes)
+    key = ("pfwd", nplanes, B, H, W, Cin, Cout, kh, kw, stride, pad, groups)
     idx, ref, mag = _sample_fwd(x, w, stride, pad, groups, gen, nplanes == 1)
-    _check(ks, y[idx], ref, mag)
-    yd = y.double().view(-1, Cout)
-    s = part[:rows].sum(0)
-    torch.testing.assert_close(s[:, 0], yd.sum(0), rtol=1e-9, atol=1e-7)
-    torch.testing.assert_close(s[:, 1], (yd * yd).sum(0), rtol=1e-9, atol=1e-7)
+
+    def check(y, part, rows):
+        _check(ks, y[idx], ref, mag)
+        yd = y.double().view(-1, Cout)
+        s = part[:rows].sum(0)
+        torch.testing.assert_close(s[:, 0], yd.sum(0), rtol=1e-9, atol=1e-7)
+        torch.testing.assert_close(s[:, 1], (yd * yd).sum(0), rtol=1e-9, atol=1e-7)
+    y, (part, rows) = kk.conv2d_fwd_planes(xp, wf, kh, kw, stride, pad, groups, bn_stats=True)
+    check(y, part, rows)
+    if kk._halo_ok(kh, kw, stride, pad, H, W, 1) and H * W >= kk.HALO_FWD_MIN_PIXELS:
+        # the FORWARD of same-size 3x3 layers on maps of at least 14 x 14 pixels runs the resident-rows tile by a STATIC rule
+        # (kernels.HALO_TILE bit 0, default since round 6): no table lookup, the same bits for every batch / process / rank.
+        # The table's entry is what the layer runs with SCOUTER_HALO=2 -- that instance is checked here as well.
+        assert key not in kk._tile_cache, "the static forward rule must not consult the table (%s)" % ks
+        y, (part, rows) = kk.conv2d_fwd_planes(xp, wf, kh, kw, stride, pad, groups, bn_stats=True, tile=TABLE[ks])
+        check(y, part, rows)
+    else:
+        _chosen(kk, key, ks)
 
 
 @pytest.mark.parametrize("ks", _entries("pdgrad"))
