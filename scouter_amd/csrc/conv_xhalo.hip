@@ -119,18 +119,32 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
         if (++ld_c == CPT) { ld_c = 0; ++ld_k; setup_load_tile(ld_k); }
     };
     const int st_off = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);      // row, swizzled half
-    auto store_group = [&](int buf, int v) {                     // exact split x = hi + mid + lo, one 16-byte piece per plane
-        hu16x8 ph, pm, pl;
+    // exact split x = hi + mid + lo of one group's 8 values, two at a time (spread over the filter taps of the MFMA loop: ~13
+    // VALU per tap next to six MFMAs), then one 16-byte piece per plane.  Waves without a second group (AG < 16) store theirs
+    // into a 3-KB landing zone: no branch inside the scheduled region.
+    constexpr bool ALWAYS_G1 = AG >= 2 * NW;
+    constexpr int DUMMY = W_OFF + 2 * WSTAGE;
+    hu16x8 sp[3];
+    auto split_pair = [&](int v, int part) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 2 * part; e < 2 * part + 2; ++e) {
             unsigned short a, b, c;
             split3_bf16(ra[v][e >> 2][e & 3], a, b, c);
-            ph[e] = a; pm[e] = b; pl[e] = c;
+            sp[0][e] = a; sp[1][e] = b; sp[2][e] = c;
         }
-        char* d = lds_raw + buf * ABUF + (wave + NW * v) * 1024 + st_off;
-        *(hu16x8*)(d) = ph;
-        *(hu16x8*)(d + APLANE) = pm;
-        *(hu16x8*)(d + 2 * APLANE) = pl;
+    };
+    auto store_split = [&](int buf, int v) {
+        const bool real = v == 0 || ALWAYS_G1 || g1;
+        char* d = lds_raw + (real ? buf * ABUF + (wave + NW * v) * 1024 : DUMMY) + st_off;
+        const int ps = real ? APLANE : 1024;
+        *(hu16x8*)(d) = sp[0];
+        *(hu16x8*)(d + ps) = sp[1];
+        *(hu16x8*)(d + 2 * ps) = sp[2];
+    };
+    auto store_group = [&](int buf, int v) {                     // (prologue)
+#pragma unroll
+        for (int part = 0; part < 4; ++part) split_pair(v, part);
+        store_split(buf, v);
     };
     // ---- weights of chunk c -> weight stage: piece e = tap * 3 + plane, wave w fetches e = w, w + 8, ...
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(w_planes + (long)grp * 32 * g.Cg), 0, 0x7fffffff, 0x00020000);
@@ -191,7 +205,31 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
             else acc = xh_mfma(F[buf][0][PA[pr]], F[buf][1][PB[pr]], acc);
         }
     };
-    // ---- epilogue of tile round k, straight from the accumulators: lane = column, rows mfma32_row(e, lane)
+    // ---- epilogue of tile round k, straight from the accumulators: lane = column, rows mfma32_row(e, lane).
+    // The operands of the BatchNorm-backward epilogue (BatchNorm input, ReLU sign words) are requested when the tile's LAST chunk
+    // starts and arrive under its MFMAs: read inside the store loop (first version) every row paid its own L2 / HBM round trip
+    // behind the previous row's store -- 12 us per tile, four times the tile's matrix work.
+    float px1[16];
+    unsigned long long pmw[4];
+    // (rows 4h .. 4h + 3 of an 8-row block share ONE 64-bit mask word when a row has at most 64 channels -- every layer this
+    //  kernel serves; wider rows take the in-loop path)
+    const bool mask_shared = g.N <= 64;
+    auto epi_prefetch = [&](int k) {
+        const long m0 = (long)tile_of(k) * BM + wave * 32;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long m = m0 + mfma32_row(e, lane);
+            px1[e] = fz.x1[(m < g.M ? m : 0) * g.N + col];
+        }
+        if (fz.mask && mask_shared) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long m = m0 + 8 * q + 4 * h;
+                const long i4 = ((m < g.M ? m : 0) * g.N + col) >> 2;
+                pmw[q] = fz.mask[(i4 >> 6) * 4 + (col & 3)];
+            }
+        }
+    };
     auto epilogue = [&](int k) {
         const long m0 = (long)tile_of(k) * BM + wave * 32;
 #pragma unroll
@@ -206,9 +244,10 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
                 if (bwd) {
                     if (fz.mask) {
                         const long i4 = off >> 2;
-                        v = ((fz.mask[(i4 >> 6) * 4 + (off & 3)] >> (i4 & 63)) & 1ull) ? v : 0.f;
+                        const unsigned long long word = mask_shared ? pmw[e >> 2] : fz.mask[(i4 >> 6) * 4 + (off & 3)];
+                        v = ((word >> (i4 & 63)) & 1ull) ? v : 0.f;
                     }
-                    const float xh1 = (fz.x1[off] - mu1) * rs1;
+                    const float xh1 = (px1[e] - mu1) * rs1;
                     s0 += v;
                     s1 += (double)v * xh1;
                     if (bwd2) s2 += (double)v * ((fz.x2[off] - mu2) * rs2);
@@ -222,6 +261,7 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
     };
 
 #define SBAR() __builtin_amdgcn_sched_barrier(0)
+#define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
     // ---- prologue: chunk 0 split into image buffer 0, chunk 1 in registers, weights of chunk 0 in stage 0
     setup_load_tile(0);
     load_group(0); load_group(1);
@@ -229,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
     dma_w(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     store_group(0, 0);
-    if (g1) store_group(0, 1);
+    store_group(0, 1);
     load_group(0); load_group(1);                                // chunk 1 (zeros beyond the stream's end)
     advance_load();
     setup_masks(0);
@@ -242,20 +282,37 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
         const int kc_next = kc + 1 == CPT ? 0 : kc + 1;
         SBAR();
         dma_w(kc_next, nxt);                                     // weights of chunk s + 1 (fenced: in front of the reloads below)
+        if constexpr (DGRAD) {
+            if (bwd && kc + 1 == CPT) epi_prefetch(kt);          // (older than the image reloads: covered by the wait below)
+        }
         SBAR();
         load_frags(0, cur, 0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // Nine taps, six MFMAs each.  Under the MFMAs of tap t: the fragment reads of tap t + 1 (one per MFMA slot) and a quarter of
+        // the split of chunk s + 1's rows (requested a whole chunk ago) -- group 0 under taps 0-3, group 1 under taps 4-7; a
+        // finished group goes to the other image buffer and its registers are re-loaded with chunk s + 2 right behind.
+        // Program order inside a tap = the order LDS accesses must keep (the compiler cannot tell the buffers apart):
+        // fragment READS first, then the stores.
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+            SBAR();
             if (tap + 1 < 9) load_frags((tap + 1) & 1, cur, tap + 1);
-            // the rows of chunk s + 1 (requested a whole chunk ago) are split into the other image buffer between the MFMAs;
-            // their registers are re-loaded with chunk s + 2 right behind (program order = LDS order: reads, then stores)
-            if (tap == 1) { store_group(nxt, 0); load_group(0); }
-            if (tap == 5) { if (g1) store_group(nxt, 1); load_group(1); }
+            if (tap < 8) split_pair(tap >> 2, tap & 3);
+            if (tap == 3) { store_split(nxt, 0); load_group(0); }
+            if (tap == 7) { store_split(nxt, 1); load_group(1); }
             mma(tap & 1);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                SG(0x008, 1);
+                if (tap + 1 < 9) SG(0x100, 1);
+                SG(0x006, 4);
+            }
+            if (tap == 3 || tap == 7) { SG(0x200, 3); SG(0x020, 2); }
+            SBAR();
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // fragments of tap t + 1 (and this wave's stores)
         }
         advance_load();
         SBAR();
-        __builtin_amdgcn_s_waitcnt(0xc07f);                      // this wave's LDS reads and stores
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // the weight DMAs have landed (four image loads fly on)
         __builtin_amdgcn_s_barrier();                            // chunk s + 1 complete in LDS; buffers of chunk s free
         SBAR();
@@ -266,6 +323,7 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
         }
     }
 #undef SBAR
+#undef SG
     }
     // ---- partial row of this workgroup: the two lane halves of a column, then the eight waves, in a fixed order
     if (bn_part || bwd) {
@@ -316,7 +374,7 @@ static void launch_xhalo_ag(const float* a, const void* w, long w_pe, const floa
     gg.inv_hw = 1.0 / ((double)g.Ho * g.Wo);
     gg.inv_wo = 1.0f / (float)g.Wo;
     gg.inv_ho = 1.0f / (float)g.Ho;
-    constexpr int LDS = 2 * 3 * (AG + 1) * 1024 + 2 * 27 * 1024;
+    constexpr int LDS = 2 * 3 * (AG + 1) * 1024 + 2 * 27 * 1024 + (AG < 16 ? 3 * 1024 : 0);
     auto kern = xhalo_kernel<AG, DGRAD>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -732,6 +732,14 @@ def conv2d_dgrad_planes(dyp, wd, x_shape, kh, kw, stride=1, pad=0, groups=1, add
 # oracle/gen_golden.py): every option set, this default included, has a geometric-mean ratio of 0.5-0.8 (bound 1.5) and no seed
 # over 3 (tools_dev/seed_noise.py prints the table); north_star's max(1e-4, 3 x floor) gate holds per seed.  SCOUTER_X3=15:
 # round 5's default.
+# Bits 6 / 7 (round 6): the 3x3 passes whose GEMM is 32 columns wide per group on the persistent resident-rows kernel with the
+# split in registers (csrc/conv_xhalo.hip, x3_halo_eligible) -- bit 6 the INPUT GRADIENTS (both deep-stem convolutions, layer1's
+# radix convolutions: 220 -> 138, 366 -> 233, 2 x 187 -> 112 us with the fused BatchNorm-backward epilogue at batch 70; +3 %
+# images/sec), bit 7 the FORWARD of the stem's 32 -> 32 convolution (191 -> 113 us, +0.5 %).  Default 127: bit 7 is OFF.  The
+# kernel is a third of the fp32 kernel's rounding error per element, yet with it in the forward the five-seed distribution reads
+# [3.98, 0.61, 0.90, 0.71, 1.55] (geometric mean 1.19 <= 1.5, but seed 200 is over the per-seed cap of 3: 2.6e-4 from fp64
+# against the reference's own 4.0e-5 ... 1.06e-4) -- the criterion decides, not the kernel's merit: the head at random
+# initialisation amplifies ANY change of summation order chaotically.  Input gradients do not enter the forward at all.
 X3_DEFAULT = int(os.environ.get("SCOUTER_X3", "127"))
 X3_FUSED_MIN_K = 512
 X3_MIN_CHANNEL_PRODUCT = 1 << 16
@@ -756,7 +764,7 @@ def x3_conv_eligible(cin, cout, kh, kw, stride, pad, groups, has_bias):
 
 def x3_halo_eligible(cin, cout, kh, kw, stride, pad, groups, has_bias):
     """(forward, input gradient): which passes of a 3x3 / stride 1 / pad 1 layer run on the PERSISTENT resident-rows kernel with
-    the split in registers (csrc/conv_xhalo.hip; tile 7 of the register-split entry points; SCOUTER_X3 bit 6) -- the passes whose
+    the split in registers (csrc/conv_xhalo.hip; tile 7 of the register-split entry points; SCOUTER_X3 bits 7 / 6) -- the passes whose
     GEMM is 32 columns wide per group: the forward with 32 output channels per group (the stem's 32 -> 32), the input gradient
     with 32 input channels per group (both deep-stem convolutions, layer1's radix convolution).  A static function of the
     layer's channels; the map width (<= 126) is checked per call."""

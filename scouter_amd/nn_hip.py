@@ -79,9 +79,9 @@ class Conv2d(nn.Module):
                                   self.bias is not None)
 
     def halo_fwd(self):
-        """x3 bit 6, fp32 precision, no plane operands: the FORWARD of this 3x3 layer has 32 output channels per group and runs
-        on csrc/conv_xhalo.hip (tile 7 of the register-split entry points)."""
-        return bool(self.x3 & 64) and self.precision == "fp32" and not self.planes and self.x3_halo_static()[0]
+        """x3 bit 7 (opt-in), fp32 precision, no plane operands: the FORWARD of this 3x3 layer has 32 output channels per group
+        and runs on csrc/conv_xhalo.hip (tile 7 of the register-split entry points)."""
+        return bool(self.x3 & 128) and self.precision == "fp32" and not self.planes and self.x3_halo_static()[0]
 
     def halo_dgrad(self):
         """x3 bit 6, fp32 precision: the INPUT GRADIENT of this 3x3 layer has 32 input channels per group and runs on
@@ -104,7 +104,8 @@ class Conv2d(nn.Module):
         if (self.x3 & 16) and not self.planes and self.x3_conv_static():
             bits |= 16
         if not self.planes and (self.halo_fwd() or self.halo_dgrad()):
-            bits |= 64                    # (3x3 layers with 32 GEMM columns per group: csrc/conv_xhalo.hip)
+            bits |= 64                    # (3x3 layers with 32 GEMM columns per group: csrc/conv_xhalo.hip; forward x3 bit 7,
+            #                               input gradient x3 bit 6)
         return bits
 
     def _x3_weights(self, want_fwd, want_dgrad):

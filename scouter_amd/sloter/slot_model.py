@@ -156,12 +156,13 @@ class SlotModel(nn.Module):
         input gradient with the fused BatchNorm-backward epilogue, bit 3 weight gradient, bit 4 the forward of the 3x3
         layers with 32 input channels per group (kernels.x3_conv_eligible: the stem's 32 -> 64 convolution), bit 5 the forward of
         the short-K pointwise layers on the persistent bf16x3 kernel (nn_hip.Conv2d.xpw_static, csrc/conv_pw_persist_x3.h), bit 6
-        the 3x3 passes whose GEMM is 32 columns wide per group on the persistent resident-rows kernel (nn_hip.Conv2d.halo_fwd /
-        halo_dgrad, csrc/conv_xhalo.hip; these include the input gradient of the plane layers with 32-channel groups); 0:
-        the exact-fp32 MFMA kernels.  Which layers qualify is a static function of their channels (kernels.x3_eligible,
+        the INPUT GRADIENT of the 3x3 layers with 32 input channels per group on the persistent resident-rows kernel
+        (nn_hip.Conv2d.halo_dgrad, csrc/conv_xhalo.hip: both deep-stem convolutions and layer1's radix convolutions, plane
+        layers whose gradient planes would need 64), bit 7 (opt-in) the FORWARD of the 3x3 layers with 32 output channels per
+        group on the same kernel (the stem's 32 -> 32); 0: the exact-fp32 MFMA kernels.  Which layers qualify is a static function of their channels (kernels.x3_eligible,
         kernels.xpw_fwd_eligible), so the forward does not depend on batch or timing."""
-        if bits & ~127:
-            raise ValueError("x3 bits must be within 0..127")
+        if bits & ~255:
+            raise ValueError("x3 bits must be within 0..255")
         for mod in self.backbone.modules():
             if isinstance(mod, Conv2d) and not isinstance(mod, StemConv2d):
                 mod.x3 = int(bits)
@@ -171,7 +172,7 @@ class SlotModel(nn.Module):
         self._x3_convs = [m for m in self.backbone.modules() if isinstance(m, Conv2d) and not isinstance(m, StemConv2d) and
                           not m.planes and ((getattr(m, "x3", 0) & 15 and m.x3_static()) or
                                             (getattr(m, "x3", 0) & 16 and m.x3_conv_static()) or
-                                            (getattr(m, "x3", 0) & 64 and any(m.x3_halo_static())))]
+                                            (getattr(m, "x3", 0) & 192 and any(m.x3_halo_static())))]
 
     def set_side_stream(self, enabled):
         """Weight gradients on the side stream (default) or serially on the compute stream (per-kernel timing)."""

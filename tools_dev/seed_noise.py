@@ -71,5 +71,8 @@ if __name__ == "__main__":
     import __graft_entry__ as G
     G.build()
     g = np.load(os.path.join(GOLD, "model_%s_seeds.npz" % SEED_CASE))
-    for sw in ({}, {"x3": 31}, {"x3": 47}, {"x3": 63}, {"halo": 3}, {"x3": 63, "halo": 3}):
+    sets = [{}, {"x3": 31}, {"x3": 47}, {"x3": 63}, {"halo": 3}, {"x3": 63, "halo": 3}]
+    if len(sys.argv) > 1:            # e.g. 127:3 79:2  (x3:halo pairs)
+        sets = [dict(x3=int(a.split(":")[0]), halo=int(a.split(":")[1])) for a in sys.argv[1:]]
+    for sw in sets:
         run(sw, g)

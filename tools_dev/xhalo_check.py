@@ -39,7 +39,7 @@ def check_fwd(B, H, W, Cin, Cout, groups, seed):
     wf, _ = K.planes_split_weight(w, groups, 3, fwd=True, dgrad=False)
     y32, (p32, r32) = K.conv2d_fwd(x, w, None, None, 1, 1, groups, False, True)
     yx, (px, rx) = K.conv2d_fwd_x3(x, wf, None, False, True, tile=7, kh=3, pad=1, groups=groups)
-    big = B * H * W * Cin > 3e7
+    big = B * H * W * Cin > 6e7
     if big:
         sl = slice(0, 2)
         ref = ref_fwd64(x[sl], w, groups)
@@ -78,7 +78,7 @@ def check_dgrad(B, H, W, Cin, Cout, groups, seed, fused, with_add=False):
         mk = lambda: None
     d32 = K.conv2d_dgrad(dy, w, xs, add, 1, 1, groups, post=post32)
     dx = K.conv2d_dgrad_x3(dy, wd, xs, add, post=postx, tile=7, kh=3, pad=1, groups=groups)
-    sl = slice(0, 2) if B * H * W * Cout > 3e7 else slice(0, B)
+    sl = slice(0, 2) if B * H * W * Cout > 6e7 else slice(0, B)
     ref = ref_dgrad64(dy[sl], w, groups)
     if with_add:
         ref = ref + add[sl].double()
@@ -111,6 +111,11 @@ if __name__ == "__main__":
     for i, c in enumerate(smalld):
         check_dgrad(*c, seed=20 + i, fused=False, with_add=(i % 2 == 1))
         check_dgrad(*c, seed=30 + i, fused=True, with_add=(i % 2 == 0))
+    for B in (6, 4):                  # the parity fixtures' batch: 294 tiles on 256 workgroups (two rounds), full comparison
+        check_fwd(B, 112, 112, 32, 32, 1, 50 + B)
+        check_dgrad(B, 112, 112, 32, 32, 1, 51 + B, fused=True)
+        check_dgrad(B, 112, 112, 32, 64, 1, 52 + B, fused=True)
+        check_dgrad(B, 56, 56, 64, 128, 2, 53 + B, fused=True)
     if not quick:
         B = 70
         check_fwd(B, 112, 112, 32, 32, 1, 40)
