@@ -39,6 +39,13 @@ typedef unsigned short hu16x8 __attribute__((ext_vector_type(8)));
 
 #define XH_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// Development builds only (tools_dev/xhalo_ablate.sh): XH_ABLATE bits remove one ingredient of the chunk loop each -- 1 the
+// MFMAs, 2 the image loads, 4 the weight DMAs, 8 the split + its LDS stores, 16 the fragment reads, 32 the barrier and the DMA
+// wait, 64 the epilogue.  Results are WRONG; only the timing means something.
+#ifndef XH_ABLATE
+#define XH_ABLATE 0
+#endif
+
 // (NON-template helpers on purpose -- see conv_planes.hip: the builtin inside a kernel template makes hipcc's host pass drop
 //  the kernel's launch stub)
 __device__ __forceinline__ void xh_dma16(__amdgpu_buffer_rsrc_t rs, char* lds, unsigned voff, int soff) {
@@ -162,9 +169,9 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
     };
 
     // ---- COMPUTE side
-    f32x16 acc, accl;
+    f32x16 acc, accl, accm;                                      // hi * hi | the five correction products in two chains
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc[e] = 0.f; accl[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.f; accl[e] = 0.f; accm[e] = 0.f; }
     unsigned amask = 0;                                          // 9 tap bits of this lane's row (wave * 32 + l31) of the tile
     auto setup_masks = [&](int k) {
         const long m = (long)tile_of(k) * BM + wave * 32 + l31;
@@ -201,62 +208,82 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
         constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first (conv_planes.hip)
 #pragma unroll
         for (int pr = 0; pr < 6; ++pr) {
-            if (pr < 5) accl = xh_mfma(F[buf][0][PA[pr]], F[buf][1][PB[pr]], accl);
-            else acc = xh_mfma(F[buf][0][PA[pr]], F[buf][1][PB[pr]], acc);
+            // (one 32 x 32 block per wave: the correction products alternate between two accumulators so that no MFMA waits
+            //  for the one in front of it)
+            if (pr == 5) acc = xh_mfma(F[buf][0][PA[pr]], F[buf][1][PB[pr]], acc);
+            else if (pr & 1) accm = xh_mfma(F[buf][0][PA[pr]], F[buf][1][PB[pr]], accm);
+            else accl = xh_mfma(F[buf][0][PA[pr]], F[buf][1][PB[pr]], accl);
         }
     };
     // ---- epilogue of tile round k, straight from the accumulators: lane = column, rows mfma32_row(e, lane).
     // The operands of the BatchNorm-backward epilogue (BatchNorm input, ReLU sign words) are requested when the tile's LAST chunk
     // starts and arrive under its MFMAs: read inside the store loop (first version) every row paid its own L2 / HBM round trip
     // behind the previous row's store -- 12 us per tile, four times the tile's matrix work.
+    // Addressing: buffer descriptors over the whole tensors, ONE per-lane offset for the lane's first row of a tile (row
+    // wave * 32 + 4 h, its column), everything else -- tile, row of the accumulator register -- in the scalar offset; rows beyond
+    // M fall outside the descriptor (loads return zeros, stores are dropped): no per-row branch, no 64-bit address arithmetic.
+    const unsigned out_bytes = (unsigned)(g.M * g.N * 4);
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd ? fz.x1 : a_f32), 0, bwd ? out_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd2 ? fz.x2 : a_f32), 0, bwd2 ? out_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend : a_f32), 0, addend ? out_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd && fz.mask ? (const void*)fz.mask : (const void*)a_f32), 0,
+                                                                             bwd && fz.mask ? (unsigned)((g.M * g.N + 255) / 256 * 32) : 0u, 0x00020000);
+    const unsigned lane_elem = (unsigned)((wave * 32 + 4 * h) * g.N + col);       // element index of the lane's first row, tile-relative
+    const unsigned lane_off = lane_elem * 4u;
+    auto row_soff = [&](int k, int e) -> int {                  // scalar byte offset of accumulator register e's row in tile round k
+        return (int)(((unsigned)tile_of(k) * (unsigned)BM + (unsigned)((e & 3) + 8 * (e >> 2))) * (unsigned)g.N * 4u);
+    };
     float px1[16];
     unsigned long long pmw[4];
     // (rows 4h .. 4h + 3 of an 8-row block share ONE 64-bit mask word when a row has at most 64 channels -- every layer this
     //  kernel serves; wider rows take the in-loop path)
     const bool mask_shared = g.N <= 64;
+    auto mask_word = [&](unsigned elem) -> unsigned long long {  // the 64-bit word holding the ReLU bit of flat element `elem`
+        const unsigned idx = ((elem >> 8) << 2) + (elem & 3u);
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 w = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_msk, idx * 8u, 0, 0));
+        return (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+    };
     auto epi_prefetch = [&](int k) {
-        const long m0 = (long)tile_of(k) * BM + wave * 32;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const long m = m0 + mfma32_row(e, lane);
-            px1[e] = fz.x1[(m < g.M ? m : 0) * g.N + col];
-        }
+        for (int e = 0; e < 16; ++e)
+            px1[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x1, lane_off, row_soff(k, e), 0));
         if (fz.mask && mask_shared) {
+            const unsigned base = (unsigned)tile_of(k) * (unsigned)BM * (unsigned)g.N + lane_elem;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long m = m0 + 8 * q + 4 * h;
-                const long i4 = ((m < g.M ? m : 0) * g.N + col) >> 2;
-                pmw[q] = fz.mask[(i4 >> 6) * 4 + (col & 3)];
-            }
+            for (int q = 0; q < 4; ++q) pmw[q] = mask_word(base + (unsigned)(8 * q) * (unsigned)g.N);
         }
     };
     auto epilogue = [&](int k) {
-        const long m0 = (long)tile_of(k) * BM + wave * 32;
+        const unsigned base = (unsigned)tile_of(k) * (unsigned)BM * (unsigned)g.N + lane_elem;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const long m = m0 + mfma32_row(e, lane);
-            float v = acc[e] + accl[e];
-            acc[e] = 0.f; accl[e] = 0.f;
-            if (m >= g.M) continue;
-            const long off = m * g.N + col;
-            if (addend) v += addend[off];
+            const int soff = row_soff(k, e);
+            float v = acc[e] + (accl[e] + accm[e]);
+            acc[e] = 0.f; accl[e] = 0.f; accm[e] = 0.f;
+            if (addend) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, lane_off, soff, 0));
             if constexpr (DGRAD) {
                 if (bwd) {
                     if (fz.mask) {
-                        const long i4 = off >> 2;
-                        const unsigned long long word = mask_shared ? pmw[e >> 2] : fz.mask[(i4 >> 6) * 4 + (off & 3)];
-                        v = ((word >> (i4 & 63)) & 1ull) ? v : 0.f;
+                        const unsigned elem = base + (unsigned)((e & 3) + 8 * (e >> 2)) * (unsigned)g.N;
+                        const unsigned long long word = mask_shared ? pmw[e >> 2] : mask_word(elem);
+                        v = ((word >> ((elem >> 2) & 63u)) & 1ull) ? v : 0.f;
                     }
+                    // (rows beyond M: the accumulator is an exact zero -- their A rows read zeros -- and so are their terms)
                     const float xh1 = (px1[e] - mu1) * rs1;
                     s0 += v;
                     s1 += (double)v * xh1;
-                    if (bwd2) s2 += (double)v * ((fz.x2[off] - mu2) * rs2);
+                    if (bwd2) {
+                        const float x2v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, lane_off, soff, 0));
+                        s2 += (double)v * ((x2v - mu2) * rs2);
+                    }
                 }
             } else {
                 if (bn_part) { const double vd = (double)v; s0 += vd; s1 = fma(vd, vd, s1); }
                 if (relu) v = fmaxf(v, 0.f);
             }
-            dst[off] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dst, lane_off, soff, 0);
         }
     };
 
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
         const int cur = s & 1, nxt = cur ^ 1;
         const int kc_next = kc + 1 == CPT ? 0 : kc + 1;
         SBAR();
-        dma_w(kc_next, nxt);                                     // weights of chunk s + 1 (fenced: in front of the reloads below)
+        if (!(XH_ABLATE & 4)) dma_w(kc_next, nxt);               // weights of chunk s + 1 (fenced: in front of the reloads below)
         if constexpr (DGRAD) {
             if (bwd && kc + 1 == CPT) epi_prefetch(kt);          // (older than the image reloads: covered by the wait below)
         }
@@ -296,15 +323,15 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             SBAR();
-            if (tap + 1 < 9) load_frags((tap + 1) & 1, cur, tap + 1);
-            if (tap < 8) split_pair(tap >> 2, tap & 3);
-            if (tap == 3) { store_split(nxt, 0); load_group(0); }
-            if (tap == 7) { store_split(nxt, 1); load_group(1); }
-            mma(tap & 1);
+            if (tap + 1 < 9 && !(XH_ABLATE & 16)) load_frags((tap + 1) & 1, cur, tap + 1);
+            if (tap < 8 && !(XH_ABLATE & 8)) split_pair(tap >> 2, tap & 3);
+            if (tap == 3) { if (!(XH_ABLATE & 8)) store_split(nxt, 0); if (!(XH_ABLATE & 2)) load_group(0); }
+            if (tap == 7) { if (!(XH_ABLATE & 8)) store_split(nxt, 1); if (!(XH_ABLATE & 2)) load_group(1); }
+            if (!(XH_ABLATE & 1)) mma(tap & 1);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
+            for (int q = 0; q < 6; ++q) {                        // (the six reads go out under the first three MFMAs: landed by the sixth)
                 SG(0x008, 1);
-                if (tap + 1 < 9) SG(0x100, 1);
+                if (tap + 1 < 9 && q < 3) SG(0x100, 2);
                 SG(0x006, 4);
             }
             if (tap == 3 || tap == 7) { SG(0x200, 3); SG(0x020, 2); }
@@ -313,11 +340,13 @@ __global__ __launch_bounds__(512, 1) void xhalo_kernel(const float* __restrict__
         }
         advance_load();
         SBAR();
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // the weight DMAs have landed (four image loads fly on)
-        __builtin_amdgcn_s_barrier();                            // chunk s + 1 complete in LDS; buffers of chunk s free
+        if (!(XH_ABLATE & 32)) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the weight DMAs have landed (four image loads fly on)
+            __builtin_amdgcn_s_barrier();                        // chunk s + 1 complete in LDS; buffers of chunk s free
+        }
         SBAR();
         if (++kc == CPT) {
-            epilogue(kt);
+            if (!(XH_ABLATE & 64)) epilogue(kt);
             kc = 0; ++kt;
             if (kt < n_mine) setup_masks(kt);
         }
