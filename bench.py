@@ -201,8 +201,8 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
 # to 1.88 GHz with real data (1 886 TFLOP/s = 0.754 of the 2 500 nominal; 2.39 GHz / 2 497 only with constant operands), and
 # the plane kernels themselves run at 1.62-1.88 GHz (cycle stamps inside pwgrad_taps_kernel, tools_dev/pwt_stamps.py).
 # committed PMC passes (tools_dev/refresh_profiles.sh) per BASELINE config at its own batch / image size / precision
-PMC_FILES = {2: ("r05_pmc_hbm_traffic.json", "r05_pmc_mfma_util.json"),
-             5: ("r05_pmc_hbm_traffic_config5.json", "r05_pmc_mfma_util_config5.json")}
+PMC_FILES = {2: ("r06_pmc_hbm_traffic.json", "r06_pmc_mfma_util.json"),
+             5: ("r06_pmc_hbm_traffic_config5.json", "r06_pmc_mfma_util_config5.json")}
 HBM_PEAK_TBS, HBM_ACHIEVABLE_TBS = 8.0, 6.3          # MI355X_MICROARCH.md: HBM3E nominal / what a streaming kernel reaches
 # Kernel classes of the roofline object: bench label prefixes (the library's hipEvent scopes) and the rocprofv3 kernel-name
 # prefixes of the SAME kernels.  Names are matched by exact prefix ("void wgrad_kernel<" does not match

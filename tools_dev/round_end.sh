@@ -13,7 +13,7 @@ timeout 2400 python -m pytest tests -m gpu -x -q > "$O/pytest.log" 2>&1; grep -n
 bash tools_dev/refresh_profiles.sh "$O/prof" > "$O/refresh.log" 2>&1
 # the PMC json files must be in place BEFORE the bench lines are taken (bench.py copies traffic / MFMA-busy from them)
 mkdir -p profiles
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 cp "$O/prof/pmc_traffic.json" profiles/${R}_pmc_hbm_traffic.json 2>/dev/null
 cp "$O/prof/pmc_mfma_util.json" profiles/${R}_pmc_mfma_util.json 2>/dev/null
 cp "$O/prof/pmc_traffic_config5.json" profiles/${R}_pmc_hbm_traffic_config5.json 2>/dev/null
