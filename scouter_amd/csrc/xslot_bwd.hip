@@ -975,6 +975,12 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     XSB_STAMP();
 }
 
+#include "xslot_small_bwd.h"
+
+static bool xs_small_bwd_enabled() {       // SCOUTER_XSLOT_SMALL=0: heads with <= 16 slots stay on the 32-slot-tile kernels (A/B, tests)
+    const char* e = getenv("SCOUTER_XSLOT_SMALL");
+    return !(e && e[0] == '0');
+}
 static bool xs_bwd_scratch_variant() {       // SCOUTER_XSLOT_BWD_SCRATCH=1: the first-generation kernel for 64 < N <= 96 (A/B)
     static int v = -1;
     if (v < 0) { const char* e = getenv("SCOUTER_XSLOT_BWD_SCRATCH"); v = e && e[0] == '1'; }
@@ -1026,6 +1032,12 @@ extern "C" int scouter_xslot_bwd_f32(const float* X, const float* PE, const floa
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * (double)B * (2.0 * L * N * d * d + (double)T * 4.0 * S * N * d + (T - 1) * 12.0 * S * d * d);
     ScProfScope prof("xslot_bwd", st, flops, 4.0 * B * (3.0 * N * d + (double)S * d));
+    if (S <= 16 && N <= 64 && xs_small_bwd_enabled()) {        // the metric's own head: xslot_small_bwd.h
+        const int slds = (int)xs_small_bwd_lds_bytes();
+        hipFuncSetAttribute((const void*)xslot_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, slds);
+        hipLaunchKernelGGL(xslot_small_bwd_kernel, dim3(B), dim3(256), slds, st, a);
+        return sc_check_launch("xslot_small_bwd");
+    }
 #define XSB_LAUNCH(KERN)                                                                                   \
     do {                                                                                                   \
         auto kern = KERN;                                                                                  \

@@ -11,6 +11,8 @@
 // and one barrier per iteration (tiles summed in a fixed order -> deterministic).
 #include "xslot_common.h"
 
+#include <stdlib.h>
+
 struct XsFwdArgs {
     const float* X; const float* PE; const float* tok_w[8]; const float* tok_b[8]; const float* slots0;
     const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;
@@ -575,6 +577,14 @@ __global__ __launch_bounds__(64 * XS_FWD_WAVES) void xslot_fwd_kernel(XsFwdArgs 
     XS_STAMP();
 }
 
+#include "xslot_small_fwd.h"
+
+// SCOUTER_XSLOT_SMALL=0 keeps heads with <= 16 slots on the 32-slot-tile kernels (A/B runs, tests of those paths)
+static bool xs_small_enabled() {          // (read at every launch: the tests flip it inside one process)
+    const char* e = getenv("SCOUTER_XSLOT_SMALL");
+    return !(e && e[0] == '0');
+}
+
 static size_t xs_fwd_lds_bytes(int NJT) {
     return (size_t)(XS_XT_FLOATS(32 * NJT) + 32 * NJT * XS_LD + 384 * XS_LD + 256 + 2 * (64 + 128) + 16 + 512 +
                     (NJT <= 2 ? 4096 : 0)) * sizeof(float);
@@ -605,6 +615,11 @@ extern "C" int scouter_xslot_fwd_f32(const float* X, const float* PE, const floa
     hipStream_t st = (hipStream_t)stream;
     const double flops = (double)B * (2.0 * L * N * d * d + (double)T * 4.0 * S * N * d + (T - 1) * 12.0 * S * d * d);
     ScProfScope prof("xslot_fwd", st, flops, 4.0 * B * (2.0 * N * d + (double)S * N));
+    if (S <= 16 && xs_small_enabled()) {          // the metric's own head (10 slots): xslot_small_fwd.h
+        if (N <= 64) hipLaunchKernelGGL(xslot_small_fwd_kernel<1>, dim3(B), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(xslot_small_fwd_kernel<2>, dim3(B), dim3(256), 0, st, a);
+        return sc_check_launch("xslot_small_fwd");
+    }
 #define XS_LAUNCH(NJT_, TPW_, ...)                                                                                  \
     do {                                                                                                            \
         auto kern = xslot_fwd_kernel<NJT_, TPW_, ##__VA_ARGS__>;                                                    \

@@ -1,0 +1,145 @@
+"""The small-S instantiation of the fused xSlot kernels (heads with <= 16 slots per image: the metric's own 10-class head,
+sloter/utils/slot_attention.py:44-96; scouter_amd/csrc/xslot_small_fwd.h / xslot_small_bwd.h) straight through the C ABI:
+ (a) against the fp64 oracle and its autograd on the same seeded inputs (yardstick: what plain fp32 PyTorch loses),
+ (b) against the 32-slot-tile kernels they replace (SCOUTER_XSLOT_SMALL=0), which the golden head cases pinned first,
+ (c) bit-reproducible, batch entries independent, stale output buffers ignored.
+Shapes: the headline head (70 x 10 slots x 49 tokens, three to_k layers), ragged slot / token counts, one token, one
+iteration (no GRU), two token tiles per wave (the reference's 9 x 9 grid), slots_per_class > 1."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_oracle as O                       # noqa: E402
+
+SHAPES = [(70, 10, 49, 3, 3, 1),     # BASELINE configs[1]: bs70, 10 classes, 7x7 grid, T = 3, three to_k layers
+          (5, 16, 64, 3, 2, 1),      # every slot column and token row live
+          (3, 6, 9, 2, 2, 2),        # slots_per_class = 2, one sparse token tile
+          (2, 5, 1, 3, 1, 1),        # a single token (D / r_i == 1)
+          (4, 12, 49, 1, 1, 3),      # one iteration: no GRU, no saved states
+          (3, 10, 81, 3, 1, 1),      # 9 x 9 grid: two token tiles per wave
+          (2, 7, 96, 4, 2, 1),       # N at the kernels' limit (two token tiles per wave), T = 4
+          (3, 1, 17, 3, 2, 1)]       # one slot
+
+
+def _inputs(B, S, N, T, L, spc, seed=0):
+    d = 64
+    g = torch.Generator().manual_seed(1000 * S + N + seed)
+    r = lambda *sh: torch.randn(*sh, generator=g)
+    P = {"slot.initial_slots": (r(1, S, d).abs() * 0.5), "slot.gru.weight_ih_l0": r(3 * d, d) * 0.1,
+         "slot.gru.weight_hh_l0": r(3 * d, d) * 0.1, "slot.gru.bias_ih_l0": r(3 * d) * 0.1,
+         "slot.gru.bias_hh_l0": r(3 * d) * 0.1}
+    for l in range(L):
+        P["slot.to_k.%d.weight" % (2 * l)] = r(d, d) * (0.2 if L > 2 else 0.1)
+        P["slot.to_k.%d.bias" % (2 * l)] = r(d) * 0.1
+    X, PE = r(B, N, d).relu(), r(N, d) * 0.3
+    wl = r(B, S // spc)
+    return P, X, PE, wl, 0.01
+
+
+def _run(P, X, PE, wl, ga, S, T, L, spc, small):
+    from scouter_amd import kernels as Kk
+    os.environ["SCOUTER_XSLOT_SMALL"] = "1" if small else "0"
+    try:
+        dev = torch.device("cuda")
+        cu = lambda t: t.float().contiguous().to(dev)
+        tw = [cu(P["slot.to_k.%d.weight" % (2 * l)]) for l in range(L)]
+        tb = [cu(P["slot.to_k.%d.bias" % (2 * l)]) for l in range(L)]
+        gru = [cu(P["slot.gru." + n]) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+        s0 = cu(P["slot.initial_slots"][0])
+        fwd = Kk.xslot_fwd(cu(X), cu(PE), tw, tb, s0, *gru, spc, T, 1)
+        bwd = Kk.xslot_bwd(cu(X), cu(PE), tw, s0, *gru, fwd, cu(wl), torch.full((1,), ga, device=dev), spc, T, 1)
+        torch.cuda.synchronize()
+        return fwd, bwd
+    finally:
+        os.environ.pop("SCOUTER_XSLOT_SMALL", None)
+
+
+@pytest.mark.parametrize("B,S,N,T,L,spc", SHAPES)
+def test_small_slot_kernels_match_the_oracle_and_the_tile_kernels(B, S, N, T, L, spc):
+    d, C = 64, S // spc
+    P, X, PE, wl, ga = _inputs(B, S, N, T, L, spc)
+
+    def oracle(dtype):
+        Q = {k: v.to(dtype).clone().requires_grad_(True) for k, v in P.items()}
+        x = X.to(dtype).clone().requires_grad_(True)
+        aux = {}
+        lg, _ = O.xslot_forward(Q, x + PE.to(dtype), x, C, spc, 1, 1, iters=T, aux=aux)
+        ((lg * wl.to(dtype)).sum() + ga * aux["attn"].sum()).backward()
+        return lg.detach(), aux["attn"].detach(), x.grad, Q
+
+    lg64, at64, gx64, Q64 = oracle(torch.float64)
+    lg32, at32, gx32, Q32 = oracle(torch.float32)
+    floor = float((lg32.double() - lg64).abs().max())
+    tol = max(1e-4, 3 * floor)
+    fwd, bwd = _run(P, X, PE, wl, ga, S, T, L, spc, True)
+    ref_f, ref_b = _run(P, X, PE, wl, ga, S, T, L, spc, False)
+    # ---- forward: the oracle, then the tile kernels (same arithmetic, different summation order: rounding level)
+    np.testing.assert_allclose(fwd["logits"].cpu().numpy(), lg64.numpy(), atol=tol, rtol=1e-4)
+    np.testing.assert_allclose(fwd["attn"].cpu().numpy(), at64.numpy(), atol=max(tol, 1e-4), rtol=0)
+    err_small = float((fwd["logits"].cpu().double() - lg64).abs().max())
+    err_tiles = float((ref_f["logits"].cpu().double() - lg64).abs().max())
+    # (over ten seeds the two kernels draw from one error distribution, 2e-6 ... 1.6e-5 at |logits| ~ 15 -- a few ulp --,
+    #  plain fp32 PyTorch 1.6e-6 ... 8.4e-6: tools_dev/xslot_small_noise.py)
+    assert err_small <= max(4 * max(err_tiles, floor), 2e-5), (err_small, err_tiles, floor)
+    np.testing.assert_allclose(fwd["area_part"].cpu().double().numpy(), at64.sum((1, 2)).numpy(), rtol=1e-5)
+    for k in ("K", "H"):
+        np.testing.assert_allclose(fwd[k].cpu().numpy(), ref_f[k].cpu().numpy(), atol=2e-5, rtol=1e-5, err_msg=k)
+    if T > 1:
+        np.testing.assert_allclose(fwd["states"].cpu().numpy(), ref_f["states"].cpu().numpy(), atol=5e-5, rtol=1e-4)
+
+    # ---- backward against fp64 autograd
+    def close(mine, ref, ref32, name):
+        sc = float(ref.abs().max())
+        noise = float((ref32.double() - ref).abs().max())                      # fp32 autograd's own deviation
+        assert float((mine.cpu().double() - ref).abs().max()) <= 3e-3 * sc + 3 * noise + 1e-6, name
+
+    close(bwd["dX"], gx64, gx32, "dX")
+    close(bwd["ds0"].sum(0), Q64["slot.initial_slots"].grad[0], Q32["slot.initial_slots"].grad[0], "d initial_slots")
+    if T > 1:
+        dgi, U = bwd["dgi"].double().cpu().reshape(-1, 3 * d), bwd["U"].double().cpu().reshape(-1, d)
+        close(dgi.t() @ U, Q64["slot.gru.weight_ih_l0"].grad, Q32["slot.gru.weight_ih_l0"].grad, "dW_ih")
+        s0 = P["slot.initial_slots"][0].float().cuda().expand(B, S, d)
+        hprev = torch.cat([(s0 if t == 0 else fwd["states"][t - 1]).reshape(-1, d) for t in range(T - 1)]).double().cpu()
+        dgh = bwd["dgh"].double().cpu().reshape(-1, 3 * d)
+        close(dgh.t() @ hprev, Q64["slot.gru.weight_hh_l0"].grad, Q32["slot.gru.weight_hh_l0"].grad, "dW_hh")
+        close(dgh.sum(0), Q64["slot.gru.bias_hh_l0"].grad, Q32["slot.gru.bias_hh_l0"].grad, "db_hh")
+        close(dgi.sum(0), Q64["slot.gru.bias_ih_l0"].grad, Q32["slot.gru.bias_ih_l0"].grad, "db_ih")
+    Hin = (X + PE).double().reshape(-1, d)
+    for l in range(L):
+        dz = bwd["dZ"][l].double().cpu().reshape(-1, d)
+        hin = Hin if l == 0 else fwd["H"][l].double().cpu().reshape(-1, d)
+        close(dz.t() @ hin, Q64["slot.to_k.%d.weight" % (2 * l)].grad, Q32["slot.to_k.%d.weight" % (2 * l)].grad,
+              "dW_to_k%d" % l)
+        close(dz.sum(0), Q64["slot.to_k.%d.bias" % (2 * l)].grad, Q32["slot.to_k.%d.bias" % (2 * l)].grad, "db_to_k%d" % l)
+    # ---- and against the tile kernels' backward (both hand-derived from oracle/xslot_manual.py)
+    for k in ("dX", "ds0", "dZ") + (("dgi", "dgh", "U") if T > 1 else ()):
+        a, r = bwd[k].cpu().double(), ref_b[k].cpu().double()
+        assert float((a - r).abs().max()) <= 5e-3 * float(r.abs().max()) + 1e-6, k
+
+
+@pytest.mark.parametrize("B,S,N,T,L,spc", [SHAPES[0], SHAPES[5], SHAPES[2]])
+def test_small_slot_kernels_are_reproducible_and_batch_independent(B, S, N, T, L, spc):
+    from scouter_amd import kernels as Kk
+    P, X, PE, wl, ga = _inputs(B, S, N, T, L, spc, seed=3)
+    dev = torch.device("cuda")
+    outs = []
+    for fill in (0.0, float("nan"), 7.0):
+        Kk.workspace(1, dev).view(torch.float32).fill_(fill)
+        junk = torch.empty(8 << 20, device=dev).fill_(fill)                 # what torch.empty hands out next
+        del junk
+        f, bw = _run(P, X, PE, wl, ga, S, T, L, spc, True)
+        outs.append({**{"f_" + k: v.clone() for k, v in f.items() if T > 1 or k != "states"},
+                     **{"b_" + k: v.clone() for k, v in bw.items() if T > 1 or k not in ("dgi", "dgh", "U")}})
+    for k in outs[0]:
+        assert torch.isfinite(outs[0][k]).all(), k
+        for o in outs[1:]:
+            assert torch.equal(outs[0][k], o[k]), k
+    # a permuted batch gives the permuted results, bit for bit (one workgroup per image, nothing shared)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+    f2, b2 = _run(P, X[perm], PE, wl[perm], ga, S, T, L, spc, True)
+    assert torch.equal(outs[0]["f_logits"][perm.cuda()], f2["logits"]) and torch.equal(outs[0]["f_attn"][perm.cuda()], f2["attn"])
+    assert torch.equal(outs[0]["b_dX"][perm.cuda()], b2["dX"]) and torch.equal(outs[0]["b_ds0"][perm.cuda()], b2["ds0"])
