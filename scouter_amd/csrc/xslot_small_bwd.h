@@ -18,7 +18,7 @@
 
 #define XS16_LDT 20            // row stride (floats) of the 16 x 16 bounce tiles: 16-byte rows
 static size_t xs_small_bwd_lds_bytes() {
-    return (size_t)(2 * 64 * XS_LD + 3 * XS16_UX_FLOATS + 2 * 16 * XS_LD + 4 * 2 * 16 * XS16_LDT + 64) * sizeof(float) +
+    return (size_t)(3 * 64 * XS_LD + 3 * XS16_UX_FLOATS + 2 * 16 * XS_LD + 4 * 2 * 16 * XS16_LDT + 64) * sizeof(float) +
            (size_t)(64 * 4 + 64) * sizeof(double);
 }
 
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
     float* dufull = sfull + 16 * XS_LD;             // [16][68] dU_t, row = slot
     float* tb = dufull + 16 * XS_LD;                // [4 waves][2][16][20] bounce tiles (dD | A), row = token
     float* gx = tb + 4 * 2 * 16 * XS16_LDT;         // [4][16] partial g_i
+    float* WL = gx + 64;                            // [64][68] to_k weight matrix of the MLP backward (rotates with uxA, uxB)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, g = lane >> 4;
     const int b = blockIdx.x, N = a.N, S = a.S, T = a.T;
@@ -43,23 +44,27 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
     const int jA = 16 * w + m;                      // token on this lane in the token-per-lane / A-operand layouts
     const int jB = 16 * w + 4 * g;                  // first of this lane's four tokens in the accumulator layout
 
+    XS16_STAMP_INIT();
+    XS16_STAMP();                           // 0: start
     // ---- staging: X and K of the image (LDS), this wave's GRU fragments (registers)
     {
-        f32x4 xv[4], kv[4];
+        // (rows beyond N: the load goes to the last valid row and the value is dropped -- no predicated loads, see
+        //  xslot_small_fwd.h)
+        f32x4 xv[4], kv[4], wv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = tid + k * 256, r = c >> 4, q = c & 15;
-            xv[k] = f32x4{0.f, 0.f, 0.f, 0.f}; kv[k] = xv[k];
-            if (r < N) {
-                xv[k] = *(const f32x4*)(a.X + ((long)b * N + r) * XS_D + q * 4);
-                kv[k] = *(const f32x4*)(a.Ksave + ((long)b * N + r) * XS_D + q * 4);
-            }
+            const int c = tid + k * 256, r = min(c >> 4, N - 1), q = c & 15;
+            xv[k] = *(const f32x4*)(a.X + ((long)b * N + r) * XS_D + q * 4);
+            kv[k] = *(const f32x4*)(a.Ksave + ((long)b * N + r) * XS_D + q * 4);
+            wv[k] = *(const f32x4*)(a.tok_w[a.L - 1] + c * 4);      // the to_k backward's first weight matrix
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = tid + k * 256, r = c >> 4, q = c & 15;
-            *(f32x4*)(Xs + r * XS_LD + q * 4) = xv[k];
-            *(f32x4*)(Ks + r * XS_LD + q * 4) = kv[k];
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(Xs + r * XS_LD + q * 4) = r < N ? xv[k] : z;
+            *(f32x4*)(Ks + r * XS_LD + q * 4) = r < N ? kv[k] : z;
+            *(f32x4*)(WL + r * XS_LD + q * 4) = wv[k];
         }
     }
     f32x4 Wg[3][2][4];                  // Wg[gate][ih | hh][t] = W[64 gate + 16 w + m][16 t + 4 g ..]       (rows = gate)
@@ -90,6 +95,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
     }
     const float g_area = a.g_area_sum ? a.g_area_sum[0] : 0.f;
     __syncthreads();
+    XS16_STAMP();                           // 1: staged
     {   // column sums of K in fp64 (the normaliser: see xs_rowdot_f64)
         const int c = tid & 63, q = tid >> 6;
         double s = 0.0;
@@ -100,20 +106,28 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
     if (tid < 64) ksum_s[tid] = (part[tid * 4] + part[tid * 4 + 1]) + (part[tid * 4 + 2] + part[tid * 4 + 3]);
     xs_lds_barrier();
 
+    XS16_STAMP();                           // 2: column sums
     f32x4 dKacc[4], dXacc[4], Pds[4];       // token-per-lane sums over the iterations; dL/ds_t handed down the iterations
 #pragma unroll
     for (int t = 0; t < 4; ++t) { dKacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dXacc[t] = dKacc[t]; Pds[t] = dKacc[t]; }
     float* tbd = tb + w * (2 * 16 * XS16_LDT);
     float* tba = tbd + 16 * XS16_LDT;
 
+    // s_t of the next iteration is requested one iteration ahead (an L2 round trip per iteration otherwise)
+    auto state_ptr = [&](int it) {
+        return (it == 0 ? a.slots0 : a.states + ((long)(it - 1) * a.B + b) * S * XS_D) + min(m, S - 1) * XS_D + 4 * g;
+    };
+    f32x4 Pn[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Pn[t] = *(const f32x4*)(state_ptr(T - 1) + 16 * t);
     for (int it = T - 1; it >= 0; --it) {
         const bool last = it == T - 1;
-        const float* sbase = it == 0 ? a.slots0 : a.states + ((long)(it - 1) * a.B + b) * S * XS_D;
         f32x4 Ps[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            Ps[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (iok) Ps[t] = *(const f32x4*)(sbase + m * XS_D + 16 * t + 4 * g);
+        for (int t = 0; t < 4; ++t) Ps[t] = iok ? Pn[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (it > 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Pn[t] = *(const f32x4*)(state_ptr(it - 1) + 16 * t);
         }
         *(f32x4*)(sfull + m * XS_LD + 16 * w + 4 * g) = xs16_pick(Ps, w);
         // ---- r_i, tau: the forward's fp64 normaliser, redundantly in every wave
@@ -132,6 +146,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
         const float tau = (float)xs16_rowsum_f64(r64);
         const float rr = iok ? (float)r64 : 1.f;
         const float ir = xs_recip(rr);
+        XS16_STAMP();                       // it.0: s_t loaded, r_i, tau
         // ---- recomputation: D^T = (K / 8) s^T, A = sigmoid(D / r_i * tau), partial U^T = (X / 64)^T A^T
         f32x4 D, A;
         {
@@ -181,6 +196,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
                     Ghn = mfma16(Wg[2][1][t][r], Ps[t][r], Ghn);
                 }
         }
+        XS16_STAMP();                       // it.1: S1, A, S2, W_hh half
         xs_lds_barrier();                   // #1: U partials, s_t rows
         f32x4 PdU[4], dhp[4];
 #pragma unroll
@@ -201,6 +217,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
                     Gz = mfma16(Wg[1][0][t][r], PU[t][r], Gz);
                     Gin = mfma16(Wg[2][0][t][r], PU[t][r], Gin);
                 }
+            XS16_STAMP();                   // it.2: barrier, U sum, W_ih half
             // ---- GRU backward of this wave's 16 hidden units (oracle/xslot_manual.py: backward, "GRU backward")
             const f32x4 dsn = xs16_pick(Pds, w), hold = xs16_pick(Ps, w), uown = xs16_pick(PU, w);
             f32x4 da_r, da_z, da_n, da_nr, dh_el;
@@ -252,6 +269,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
                 }
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) *(f32x4*)(uxB + (w * 16 + m) * XS_LD + 16 * ct + 4 * g) = dUp[ct];
+            XS16_STAMP();                   // it.3: gate gradients, stores, dU / dh partials
             xs_lds_barrier();               // #2: dU partials
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -265,6 +283,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) PdU[t] = f32x4{du, du, du, du};
         }
+        XS16_STAMP();                       // it.4: barrier, dU sum
         *(f32x4*)(dufull + m * XS_LD + 16 * w + 4 * g) = xs16_pick(PdU, w);
         // ---- dA^T = (X / 64) dU^T (+ area term), G = dA * A (1 - A), g_i = sum_j G_ij D_ij
         f32x4 Gm;
@@ -290,6 +309,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
         }
         gsum = xs16_gsum(gsum);
         if (g == 0) gx[w * 16 + m] = gsum;
+        XS16_STAMP();                       // it.5: dA, G, g_i partial
         xs_lds_barrier();                   // #3: g_i partials (and the dU rows)
         const float gi_ = (gx[m] + gx[16 + m]) + (gx[32 + m] + gx[48 + m]);
         const float c0 = xs16_rowsum(iok ? gi_ / rr : 0.f);
@@ -311,6 +331,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) *(f32x4*)(uxC + (w * 16 + m) * XS_LD + 16 * ct + 4 * g) = dhp[ct];
+        XS16_STAMP();                       // it.6: barrier, dD, ds partial
         // ---- contractions over the slot index: dK += (s_t / 8)^T dD, dX^a += (dU / 64)^T A, slots on the MFMA k axis
         {
 #pragma unroll
@@ -336,6 +357,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
                     dXacc[ct] = mfma16(da[ct][e], ba[e], dXacc[ct]);
                 }
         }
+        XS16_STAMP();                       // it.7: slot contractions
         xs_lds_barrier();                   // #4: ds partials
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -344,39 +366,29 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
                      (*(const f32x4*)(p + 32 * XS_LD) + *(const f32x4*)(p + 48 * XS_LD));
         }
     }
+    XS16_STAMP();                           // loop done
     if (iok) *(f32x4*)(a.ds0 + ((long)b * S + m) * XS_D + 16 * w + 4 * g) = xs16_pick(Pds, w);
 
-    // ---- to_k MLP backward, token-per-lane: dZ_{L-1} = dK ; dH_{l-1} = dZ_l W_l ; dZ_{l-1} = dH_{l-1} * (H_l > 0)
+    // ---- to_k MLP backward, token-per-lane: dZ_{L-1} = dK ; dH_{l-1} = dZ_l W_l ; dZ_{l-1} = dH_{l-1} * (H_l > 0).
+    // The A operand W_l^T[c][o] is four ROWS x one column per lane: W_l is staged row-major in LDS (WL, then the idle hand-off
+    // buffers, in rotation) and read with ds_read_b32; the next layer's matrix is requested before this layer multiplies.
     f32x4 dz[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) dz[t] = dKacc[t];
-    float Wt[4][4][4];                  // Wt[ct][t][r] = W_l[16 t + 4 g + r][16 ct + m]
-    {
-        const float* wl = a.tok_w[a.L - 1];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Wt[ct][t][r] = wl[(16 * t + 4 * g + r) * XS_D + 16 * ct + m];
-    }
-    for (int l = a.L - 1; l >= 0; --l) {
-        float Wn[4][4][4];
-        f32x4 hv[4];
+    float* wbuf[3] = {WL, uxA, uxB};
+    for (int l = a.L - 1, k = 0; l >= 0; --l, k = k == 2 ? 0 : k + 1) {
+        const float* Wl = k == 0 ? wbuf[0] : k == 1 ? wbuf[1] : wbuf[2];
+        float* Wnext = k == 0 ? wbuf[1] : k == 1 ? wbuf[2] : wbuf[0];
+        f32x4 wv[4], hv[4];
         if (l > 0) {
-            const float* wl = a.tok_w[l - 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[q] = *(const f32x4*)(a.tok_w[l - 1] + (tid + q * 256) * 4);
+            const int jc = min(jA, N - 1);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Wn[ct][t][r] = wl[(16 * t + 4 * g + r) * XS_D + 16 * ct + m];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                hv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (jA < N) hv[ct] = *(const f32x4*)(a.Hsave + (((long)l * a.B + b) * N + jA) * XS_D + 16 * ct + 4 * g);
-            }
+                hv[ct] = *(const f32x4*)(a.Hsave + (((long)l * a.B + b) * N + jc) * XS_D + 16 * ct + 4 * g);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (jA < N) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) *(f32x4*)(a.dZ + (((long)l * a.B + b) * N + jA) * XS_D + 16 * t + 4 * g) = dz[t];
@@ -385,25 +397,33 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+            float wt[4][4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wt[ct][r] = Wl[(16 * t + 4 * g + r) * XS_LD + 16 * ct + m];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(Wt[ct][t][r], dz[t][r], acc[ct]);
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(wt[ct][r], dz[t][r], acc[ct]);
+        }
         if (l > 0) {
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz[ct][r] = hv[ct][r] > 0.f ? acc[ct][r] : 0.f;
+                for (int r = 0; r < 4; ++r) dz[ct][r] = (jA < N && hv[ct][r] > 0.f) ? acc[ct][r] : 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Wt[ct][t][r] = Wn[ct][t][r];
+            for (int q = 0; q < 4; ++q) {
+                const int c = tid + q * 256;
+                *(f32x4*)(Wnext + (c >> 4) * XS_LD + (c & 15) * 4) = wv[q];
             }
+            xs_lds_barrier();
         } else if (jA < N) {
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
                 *(f32x4*)(a.dX + ((long)b * N + jA) * XS_D + 16 * ct + 4 * g) = acc[ct] + dXacc[ct];
         }
     }
+    XS16_STAMP();                           // end
 }

@@ -8,6 +8,16 @@
 #endif
 #define XS16_UX_FLOATS (4 * 16 * XS_LD)     // one LDS hand-off buffer: [4 waves][16 slots][68]
 
+// dev builds (tools_dev/xs_small_timing.hip): cycle stamps of wave 0 of every workgroup, [B][64]
+#ifdef XS16_TIMING
+__device__ long long* g_xs16_stamps = nullptr;
+#define XS16_STAMP() do { if (threadIdx.x == 0 && g_xs16_stamps) g_xs16_stamps[blockIdx.x * 64 + nstamp] = (long long)__builtin_amdgcn_s_memtime(); ++nstamp; } while (0)
+#define XS16_STAMP_INIT() int nstamp = 0
+#else
+#define XS16_STAMP() do { } while (0)
+#define XS16_STAMP_INIT() do { } while (0)
+#endif
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     // v_mfma_f32_16x16x4_f32: A[m = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15]; D col = l & 15, row = 4 (l >> 4) + r
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

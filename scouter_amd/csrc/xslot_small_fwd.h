@@ -56,17 +56,22 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
     const float scale = 0.125f, inv_d = 1.f / XS_D;
     const bool iok = m < S;
 
+    XS16_STAMP_INIT();
+    XS16_STAMP();                       // 0: start
     // ---- phase 0: every global operand is requested up front.  Order matters (loads return in order): what the MLP
     // needs first, the GRU weights last.
     f32x4 Q[NTW][4];                    // token-per-lane: lane (j = tile * 16 + m, g), Q[u][t][r] = H[j][16 t + 4 g + r]
     f32x4 Wm[4][4];                     // to_k layer: Wm[ot][t] = W[16 ot + m][16 t + 4 g ..]
+    // (rows beyond N / S: the load goes to the last valid row and the value is dropped -- a predicated load becomes a
+    //  branch with its own s_waitcnt, i.e. one exposed round trip per load: 18 k cycles of start-up, measured)
+    f32x4 Qp[NTW][4];
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
-        const int j = 16 * (w + 4 * u) + m;
+        const int j = min(16 * (w + 4 * u) + m, N - 1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            Q[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (j < N) Q[u][t] = *(const f32x4*)(Xg + j * XS_D + 16 * t + 4 * g) + *(const f32x4*)(a.PE + j * XS_D + 16 * t + 4 * g);
+            Q[u][t] = *(const f32x4*)(Xg + j * XS_D + 16 * t + 4 * g);
+            Qp[u][t] = *(const f32x4*)(a.PE + j * XS_D + 16 * t + 4 * g);
         }
     }
 #pragma unroll
@@ -75,10 +80,7 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
         for (int t = 0; t < 4; ++t) Wm[ot][t] = *(const f32x4*)(a.tok_w[0] + (16 * ot + m) * XS_D + 16 * t + 4 * g);
     f32x4 Ps[4];                        // slot state, slot-per-lane-16
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        Ps[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (iok) Ps[t] = *(const f32x4*)(a.slots0 + m * XS_D + 16 * t + 4 * g);
-    }
+    for (int t = 0; t < 4; ++t) Ps[t] = *(const f32x4*)(a.slots0 + min(m, S - 1) * XS_D + 16 * t + 4 * g);
     float Xa[NTW][4][4];                // AV operand: Xa[u][ct][r] = X[16 tile + 4 g + r][16 ct + m] / d
 #pragma unroll
     for (int u = 0; u < NTW; ++u)
@@ -86,8 +88,8 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = 16 * (w + 4 * u) + 4 * g + r;
-                Xa[u][ct][r] = j < N ? Xg[j * XS_D + 16 * ct + m] * inv_d : 0.f;
+                const int j = min(16 * (w + 4 * u) + 4 * g + r, N - 1);
+                Xa[u][ct][r] = Xg[j * XS_D + 16 * ct + m];
             }
     f32x4 Wg[3][2][4];                  // GRU: Wg[gate][ih | hh][t] = W[64 gate + 16 w + m][16 t + 4 g ..]
     f32x4 bg[4];                        // br | bz | b_in | b_hn of the hidden units 16 w + 4 g ..
@@ -105,15 +107,20 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
         bg[2] = *(const f32x4*)(a.b_ih + 128 + hb);
         bg[3] = *(const f32x4*)(a.b_hh + 128 + hb);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    XS16_STAMP();                       // 0a: loads issued
     // input of layer 0 (operand of the to_k weight gradients)
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
         const int j = 16 * (w + 4 * u) + m;
-        if (j < N)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) *(f32x4*)(a.Hsave + ((long)b * N + j) * XS_D + 16 * t + 4 * g) = Q[u][t];
+        for (int t = 0; t < 4; ++t) {
+            Q[u][t] = j < N ? Q[u][t] + Qp[u][t] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < N) *(f32x4*)(a.Hsave + ((long)b * N + j) * XS_D + 16 * t + 4 * g) = Q[u][t];
+        }
     }
 
+    XS16_STAMP();                       // 1: loads issued, Hsave stored
     // ---- phase 1: to_k MLP (slot_attention.py:37-42,49), token-per-lane from layer to layer
     f32x4 Kr[NTW][4];                   // K / 8: A operand of QK^T
     for (int l = 0; l < a.L; ++l) {
@@ -128,6 +135,9 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
         f32x4 bo[4];
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) bo[ot] = *(const f32x4*)(a.tok_b[l] + 16 * ot + 4 * g);
+        // (pinned: left alone the compiler sinks the next layer's loads behind this layer's MFMAs and waits for them at
+        //  the top of the next layer -- an exposed L2 round trip per layer)
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[NTW][4];
 #pragma unroll
         for (int u = 0; u < NTW; ++u)
@@ -165,8 +175,20 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) Wm[ot][t] = Wn[ot][t];
         }
+        XS16_STAMP();                   // layer l done
     }
 
+    XS16_STAMP();                       // 2: MLP done
+    // padded tokens / slots: zero operands (their loads went to the last valid row)
+#pragma unroll
+    for (int u = 0; u < NTW; ++u)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xa[u][ct][r] = 16 * (w + 4 * u) + 4 * g + r < N ? Xa[u][ct][r] * inv_d : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (!iok) Ps[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---- phase 2: column sums of K / 8 in fp64 (the normaliser r_i = s_i . sum_j K_j / 8, see xs_rowdot_f64)
 #pragma unroll
     for (int u = 0; u < NTW; ++u)
@@ -192,6 +214,7 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
             ks[t][r + 1] = v.y;
         }
 
+    XS16_STAMP();                       // 3: column sums done
     // ---- phase 3: iterations
     for (int it = 0; it < a.T; ++it) {
         const bool last = it == a.T - 1;
@@ -210,6 +233,7 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
         const float tau = (float)xs16_rowsum_f64(r64);
         const float rr = (float)r64;
         const float cc = iok ? -XS_LOG2E * (tau * xs_recip(rr)) : 0.f;
+        XS16_STAMP();                   // it.0: r_i, tau
         // S1: D^T = (K / 8) s^T, two partial chains per token tile (a dependent 16x16x4 chain issues every 40 cycles, not 32)
         f32x4 D[NTW][2];
 #pragma unroll
@@ -231,6 +255,7 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) A[u][r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(d[r] * cc));
         }
+        XS16_STAMP();                   // it.1: S1 + V1
         // S2: partial U^T = (X / 64)^T A^T over this wave's tokens   (slot_attention.py:59)
         f32x4 Up[4];
 #pragma unroll
@@ -256,6 +281,7 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
                     Ghn = mfma16(Wg[2][1][t][r], Ps[t][r], Ghn);
                 }
         }
+        XS16_STAMP();                   // it.2: S2 + W_hh half
         xs_lds_barrier();
         f32x4 PU[4];
 #pragma unroll
@@ -264,6 +290,7 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
             PU[t] = (*(const f32x4*)p + *(const f32x4*)(p + 16 * XS_LD)) +
                     (*(const f32x4*)(p + 32 * XS_LD) + *(const f32x4*)(p + 48 * XS_LD));
         }
+        XS16_STAMP();                   // it.3: barrier + U sum
         if (!last) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -277,9 +304,11 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
             if (iok) *(f32x4*)(a.states + (it_row + m) * XS_D + 16 * w + 4 * g) = hn;
             float* hb = hx[it & 1];
             *(f32x4*)(hb + m * XS_LD + 16 * w + 4 * g) = hn;
+            XS16_STAMP();               // it.4: W_ih half + gates
             xs_lds_barrier();
 #pragma unroll
             for (int t = 0; t < 4; ++t) Ps[t] = *(const f32x4*)(hb + m * XS_LD + 16 * t + 4 * g);
+            XS16_STAMP();               // it.5: state hand-off
         } else {
             // attention map, area, logits of the last iteration (slot_attention.py:68-96)
             float asum = 0.f;
@@ -307,6 +336,7 @@ __global__ __launch_bounds__(256) void xslot_small_fwd_kernel(XsFwdArgs a) {
                 a.logits[(long)b * a.C + c] = a.loss_status * v;
             }
             if (tid == 0) a.area_part[b] = (area_s[0] + area_s[1]) + (area_s[2] + area_s[3]);
+            XS16_STAMP();               // end
         }
     }
 }
