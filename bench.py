@@ -188,7 +188,16 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
                           "slot-index contractions + to_k MLP backward, fused)", "avg_launch_us": round(tb_ * 1e6, 1),
                 "flop_model": "3 x forward (recomputation + two GEMMs per forward GEMM)",
                 "achieved": round(3 * fl / tb_ / 1e12, 2), "frac": round(3 * fl / tb_ / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
-    return {"backward": backward, "kernel": "xslot_fwd_kernel (to_k MLP + 3 x [QK^T, sigmoid, AV, GRU] fused, v_mfma_f32_32x32x2_f32)",
+    fwd_kernel = "xslot_fwd_kernel (to_k MLP + 3 x [QK^T, sigmoid, AV, GRU] fused, v_mfma_f32_32x32x2_f32)"
+    if slots <= 16 and os.environ.get("SCOUTER_XSLOT_SMALL", "1") != "0":
+        # heads with <= 16 slots per image (the metric's own: 10 classes x 1 slot) run the small-S instantiation: a latency
+        # chain per image (one workgroup, four waves), not a throughput kernel -- the launch time is the figure, the
+        # roofline fraction is reported for completeness
+        fwd_kernel = ("xslot_small_fwd_kernel (same fused forward on v_mfma_f32_16x16x4_f32 tiles: slots on the 16 MFMA columns, "
+                      "token tiles / GRU hidden units split over four waves, GRU weights resident in registers)")
+        backward["kernel"] = ("xslot_small_bwd_kernel (same fused backward, 16x16x4 tiles, both GRU weight orientations in "
+                              "registers, four LDS hand-offs per iteration)") if tokens <= 64 else backward["kernel"]
+    return {"backward": backward, "kernel": fwd_kernel,
             "batch": batch, "slots": slots, "tokens": tokens, "to_k_layers": layers, "avg_launch_us": round(t * 1e6, 1),
             "achieved": round(fl / t / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "bound": "mfma",
@@ -582,6 +591,8 @@ def main():
             line["xslot_roofline"] = xslot_roofline(device)
             # the reference's default geometry (--img_size 260 -> 9 x 9 = 81 tokens, reference train.py:39)
             line["xslot_roofline_n81"] = xslot_roofline(device, tokens=81)
+            # the head of the configuration the metric is quoted on: 70 images x 10 slots
+            line["xslot_metric_head"] = xslot_roofline(device, batch=70, slots=10, spc=1)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

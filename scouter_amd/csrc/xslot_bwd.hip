@@ -8,7 +8,7 @@
 // lanes; A_t, dD_t, dU_t go to an L2-resident scratch and a final phase contracts them tile by tile, then runs the
 // to_k MLP backward.  Weight gradients of the GRU / to_k layers are plain GEMMs over all (image, slot) rows and
 // are left to the generic wgrad kernel (deterministic split-K) by the host.
-#include "xslot_common.h"
+#include "xslot_small_common.h"
 
 #include <stdlib.h>
 
@@ -19,6 +19,7 @@ struct XsBwdArgs {
     float* dX; float* dgi; float* dgh; float* Usave; float* ds0; float* dZ; float* ws;
     int B, N, S, C, spc, T, L;
     float loss_status;
+    int halves;             // leftover slot tiles as 16-slot half tiles (xslot_bwd_kernel; SCOUTER_XSLOT_BWD_HALVES=0: off)
 #ifdef XS_TIMING
     long long* stamps;      // dev build (tools_dev/xs_bwd_phase_timing.hip): [B][64] cycle stamps of wave 0
 #endif
@@ -550,7 +551,21 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.x, N = a.N, S = a.S, T = a.T;
-    const int ntiles = (S + 31) >> 5, Sp = ntiles * 32, TPW = (ntiles + 3) >> 2;
+    const int ntiles = (S + 31) >> 5, Sp = ntiles * 32;
+    // HALF TILES (round 6).  One or two leftover tiles (ntiles % 4 = 1, 2: 300 slots = 8 + 2 tiles) used to cost the waves
+    // that own them a whole tile's time while the other waves idled at the iteration's barrier (10 tiles: 3 + 3 + 2 + 2,
+    // the launch paced by 3).  They are walked as 16-slot half tiles instead, one per wave, on v_mfma_f32_16x16x4_f32
+    // (slot-per-lane-16 layout of xslot_small_common.h, every operand from the same LDS images): half the time of a tile,
+    // no exchange between waves -- 2.5 tiles per wave.  Their slot contractions feed the SAME 32 x 32 accumulators (eight
+    // k-steps instead of sixteen), so parks and the final reduction do not change.
+    const int rem4 = ntiles & 3;
+    const bool halves = !WG && NJT <= 2 && a.halves && (rem4 == 1 || rem4 == 2);
+    const int nfull = halves ? (ntiles & ~3) : ntiles;              // tiles walked 32 slots wide
+    const int TPW = (nfull + 3) >> 2;
+    const int nhalf = halves ? (S - 32 * nfull + 15) >> 4 : 0;      // live half tiles (<= 4): wave w walks half w
+    const int nent = nfull + nhalf;                                 // entries of the tau / c0 partial tables
+    const bool my_half = wave < nhalf;
+    const int hslot0 = 32 * nfull + 16 * wave, m16 = lane & 15, g4 = lane >> 4;
     const float scale = 0.125f, inv_d = 1.f / XS_D;
     int nstamp = 0;
     (void)nstamp;
@@ -589,6 +604,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     // tile partials of tau into red64[buf]
     // ... and colsum(s_t) over the wave's tiles into spart[buf][wave] (the c0 term of dK needs it)
     float rcur[4] = {0.f, 0.f, 0.f, 0.f};
+    float rcur_h = 0.f;                         // r_i of the half tile's slot hslot0 + m16
     auto phase_a = [&](int it, int buf) {
         const float* sbase = state_t(it);
         f32x16 hs[2], h[4][2];
@@ -599,7 +615,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int ti = wave + 4 * tt;
-            if (ti < ntiles) {
+            if (ti < nfull) {
                 const double r64 = xs_rowdot_f64(h[tt], ksum, hh) * (double)scale;   // same fp64 normaliser as the forward
                 rcur[tt] = (float)r64;
                 const double tr = xs_tilesum_f64(r64);
@@ -619,6 +635,34 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             v = xs_halfsum(v);
             if (hh == 0) spart[(buf * 4 + wave) * 64 + 32 * t + l31] = v;
         }
+        if (my_half) {                              // this wave's half tile: r_i, tau partial, colsum(s_t)
+            const int i = hslot0 + m16;
+            const float* sp = sbase + (long)min(i, S - 1) * XS_D + 4 * g4;
+            f32x4 ps[4];
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ps[t] = *(const f32x4*)(sp + 16 * t);
+                if (i >= S) ps[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const double2 k01 = *(const double2*)(ksum + 16 * t + 4 * g4);
+                const double2 k23 = *(const double2*)(ksum + 16 * t + 4 * g4 + 2);
+                a0 += (double)ps[t][0] * k01.x;
+                a1 += (double)ps[t][1] * k01.y;
+                a0 += (double)ps[t][2] * k23.x;
+                a1 += (double)ps[t][3] * k23.y;
+            }
+            const double r64 = xs16_gsum_f64(a0 + a1) * (double)scale;
+            rcur_h = (float)r64;
+            const double tr = xs16_rowsum_f64(r64);
+            if (lane == 0) red64[buf * 16 + nfull + wave] = tr;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = xs16_rowsum(ps[t][r]);
+                    if (m16 == 0) spart[(buf * 4 + wave) * 64 + 16 * t + 4 * g4 + r] += v;
+                }
+        }
     };
     phase_a(T - 1, 0);
     __syncthreads();
@@ -636,12 +680,12 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
         const bool last = it == T - 1;
         const float* sbase = state_t(it);
         double tau64 = 0.0;
-        for (int k = 0; k < ntiles; ++k) tau64 += red64[pb * 16 + k];
+        for (int k = 0; k < nent; ++k) tau64 += red64[pb * 16 + k];
         const float tau = (float)tau64;
         float cs_prev = 0.f;                    // d^-1/2 c0_{it+1}: completes the ds' handed over by that iteration
         if (!last) {
             float c0 = 0.f;
-            for (int k = 0; k < ntiles; ++k) c0 += redc[pb * 16 + k];
+            for (int k = 0; k < nent; ++k) c0 += redc[pb * 16 + k];
             corr_c += c0 * ssum_c;              // (threads 0..63: channel tid) c0_{it+1} colsum(s_{it+1})
             cs_prev = c0 * scale;
         }
@@ -651,7 +695,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
         XSB_STAMP();
         for (int tt = 0; tt < TPW; ++tt) {
             const int ti = wave + 4 * tt;
-            if (ti >= ntiles) continue;
+            if (ti >= nfull) continue;
             const int i = ti * 32 + l31;
             const bool iok = i < S;
             f32x16 h[2], A[NJT], D[NJT], U[2], dU[2], dhp[2];
@@ -910,6 +954,263 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             have_acc = true;
             if (tt == 0) XSB_STAMP();
         }
+
+        if constexpr (!WG && NJT <= 2) {
+        if (my_half) {
+            XSB_STAMP();                    // half tile: start
+            // ================= this wave's 16-slot half tile (slot-per-lane-16; see the note at `halves`)
+            constexpr int NTK = 2 * NJT;                    // 16-token tiles
+            const int i = hslot0 + m16;
+            const bool iok = i < S;
+            f32x4 Ps[4], PU[4], PdU[4], dhp[4], D[NTK], A[NTK];
+            {
+                const float* sp = sbase + (long)min(i, S - 1) * XS_D + 4 * g4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    Ps[t] = *(const f32x4*)(sp + 16 * t);
+                    if (!iok) Ps[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            const float r = rcur_h, ir = xs_recip(r);
+            // (operand reads are left to the compiler's scheduler here: requesting every block one block ahead through explicit
+            //  double buffers, pinned or not, measured 2.5 % slower on the whole launch -- tools_dev/xs_bwd_phase_timing.hip)
+#pragma unroll
+            for (int tk = 0; tk < NTK; ++tk) {              // D^T = K s^T / 8, A = sigmoid(D / r * tau)
+                f32x4 kr[4], d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) kr[t] = *(const f32x4*)(Ks + (16 * tk + m16) * XS_LD + 16 * t + 4 * g4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        d0 = mfma16(kr[t][e], Ps[t][e], d0);
+                        d1 = mfma16(kr[t + 2][e], Ps[t + 2][e], d1);
+                    }
+                D[tk] = (d0 + d1) * scale;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = xs_sigmoid(xs_div(D[tk][e], r, ir) * tau);
+                    A[tk][e] = (iok && 16 * tk + 4 * g4 + e < N) ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) { PU[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; PdU[ct] = PU[ct]; dhp[ct] = PU[ct]; }
+#pragma unroll
+            for (int tk = 0; tk < NTK; ++tk) {              // U^T = X^T A^T / d
+                float xa[4][4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xa[ct][e] = Xs[(16 * tk + 4 * g4 + e) * XS_LD + 16 * ct + m16];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) PU[ct] = mfma16(xa[ct][e], A[tk][e], PU[ct]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) PU[ct] *= inv_d;
+            XSB_STAMP();                    // half tile: D, A, U
+            if (last) {
+                const float du = iok ? a.loss_status * a.dlogits[(long)b * a.C + i / a.spc] : 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) PdU[ct] = f32x4{du, du, du, du};
+            } else {
+                // GRU backward, 16 hidden units at a time (xs_gru_bwd_tile, 16 wide): gates recomputed from (U, s_t)
+                const long row = ((long)it * a.B + b) * S + i;
+                const float cs = iok ? cs_prev : 0.f;
+                if (iok) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) *(f32x4*)(a.Usave + row * XS_D + 16 * t + 4 * g4) = PU[t];
+                }
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) {
+                    const f32x4 dsq = *(const f32x4*)(dsn + (long)i * 64 + 16 * ht + 4 * g4);
+                    f32x4 Gr = {0.f, 0.f, 0.f, 0.f}, Gz = Gr, Gin = Gr, Ghn = Gr;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float* wi = Wih + (16 * ht + m16) * XS_LD + 16 * t + 4 * g4;
+                        const float* wh = Whh + (16 * ht + m16) * XS_LD + 16 * t + 4 * g4;
+                        const f32x4 ir_ = *(const f32x4*)wi, iz_ = *(const f32x4*)(wi + 64 * XS_LD), in_ = *(const f32x4*)(wi + 128 * XS_LD);
+                        const f32x4 hr_ = *(const f32x4*)wh, hz_ = *(const f32x4*)(wh + 64 * XS_LD), hn_ = *(const f32x4*)(wh + 128 * XS_LD);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            Gr = mfma16(ir_[e], PU[t][e], Gr);
+                            Gz = mfma16(iz_[e], PU[t][e], Gz);
+                            Gin = mfma16(in_[e], PU[t][e], Gin);
+                            Gr = mfma16(hr_[e], Ps[t][e], Gr);
+                            Gz = mfma16(hz_[e], Ps[t][e], Gz);
+                            Ghn = mfma16(hn_[e], Ps[t][e], Ghn);
+                        }
+                    }
+                    const f32x4 b0 = *(const f32x4*)(bias + 16 * ht + 4 * g4), b1 = *(const f32x4*)(bias + 64 + 16 * ht + 4 * g4);
+                    const f32x4 b2 = *(const f32x4*)(bias + 128 + 16 * ht + 4 * g4), b3 = *(const f32x4*)(bias + 192 + 16 * ht + 4 * g4);
+                    const f32x4 kf = *(const f32x4*)(ksumf + 16 * ht + 4 * g4);
+                    f32x4 da_r, da_z, da_n, da_nr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float rg = xs_sigmoid(Gr[e] + b0[e]);
+                        const float zg = xs_sigmoid(Gz[e] + b1[e]);
+                        const float hnb = Ghn[e] + b3[e];
+                        const float ng = xs_tanh(Gin[e] + b2[e] + rg * hnb);
+                        const float ds = dsq[e] + cs * kf[e];
+                        da_n[e] = ds * (1.f - zg) * (1.f - ng * ng);
+                        da_z[e] = ds * (Ps[ht][e] - ng) * zg * (1.f - zg);
+                        da_r[e] = da_n[e] * hnb * rg * (1.f - rg);
+                        da_nr[e] = da_n[e] * rg;
+                        dhp[ht][e] += ds * zg;
+                    }
+                    if (iok) {
+                        float* gi = a.dgi + row * 192 + 16 * ht + 4 * g4;
+                        float* gh = a.dgh + row * 192 + 16 * ht + 4 * g4;
+                        *(f32x4*)gi = da_r; *(f32x4*)(gi + 64) = da_z; *(f32x4*)(gi + 128) = da_n;
+                        *(f32x4*)gh = da_r; *(f32x4*)(gh + 64) = da_z; *(f32x4*)(gh + 128) = da_nr;
+                    }
+                    // dU^T += W_ih^T dgi^T ; dh_prev^T += W_hh^T dgh^T   (k = these 16 hidden units of the three gates)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float* wi = Wih + (16 * ht + 4 * g4 + e) * XS_LD + m16;
+                        const float* wh = Whh + (16 * ht + 4 * g4 + e) * XS_LD + m16;
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) {
+                            PdU[ct] = mfma16(wi[16 * ct], da_r[e], PdU[ct]);
+                            dhp[ct] = mfma16(wh[16 * ct], da_r[e], dhp[ct]);
+                            PdU[ct] = mfma16(wi[64 * XS_LD + 16 * ct], da_z[e], PdU[ct]);
+                            dhp[ct] = mfma16(wh[64 * XS_LD + 16 * ct], da_z[e], dhp[ct]);
+                            PdU[ct] = mfma16(wi[128 * XS_LD + 16 * ct], da_n[e], PdU[ct]);
+                            dhp[ct] = mfma16(wh[128 * XS_LD + 16 * ct], da_nr[e], dhp[ct]);
+                        }
+                    }
+                }
+            }
+            if (!iok) {     // padded slots carry nothing
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) { PdU[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dhp[ct] = PdU[ct]; }
+            }
+            XSB_STAMP();                    // half tile: GRU
+            // dA^T = X dU^T / d (+ area term), G = dA * A (1 - A), g_i = sum_j G_ij D_ij ; G replaces D
+            float gsum = 0.f;
+#pragma unroll
+            for (int tk = 0; tk < NTK; ++tk) {
+                f32x4 xq[4], d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xq[t] = *(const f32x4*)(Xs + (16 * tk + m16) * XS_LD + 16 * t + 4 * g4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        d0 = mfma16(xq[t][e], PdU[t][e], d0);
+                        d1 = mfma16(xq[t + 2][e], PdU[t + 2][e], d1);
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float av = A[tk][e];
+                    float v = (d0[e] + d1[e]) * inv_d + (last ? g_area : 0.f);
+                    v = (iok && 16 * tk + 4 * g4 + e < N) ? v * av * (1.f - av) : 0.f;
+                    gsum += v * D[tk][e];
+                    D[tk][e] = v;
+                }
+            }
+            gsum = xs16_gsum(gsum);
+            const float tc = xs16_rowsum(iok ? gsum / r : 0.f);
+            if (lane == 0) redc[(pb ^ 1) * 16 + nfull + wave] = tc;
+            // dD' = G tau / r - g tau / r^2  (the + c0 is added by the readers), ds' = d^-1/2 dD' K + dh_prev
+            const float k1 = tau / r, k2 = gsum * tau / (r * r);
+#pragma unroll
+            for (int tk = 0; tk < NTK; ++tk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    D[tk][e] = (iok && 16 * tk + 4 * g4 + e < N) ? D[tk][e] * k1 - k2 : 0.f;
+            {
+                f32x4 ds[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) ds[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tk = 0; tk < NTK; ++tk) {
+                    float kt[4][4];
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) kt[ct][e] = Ks[(16 * tk + 4 * g4 + e) * XS_LD + 16 * ct + m16];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) ds[ct] = mfma16(kt[ct][e], D[tk][e], ds[ct]);
+                }
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ds[ct][e] = iok ? ds[ct][e] * scale + dhp[ct][e] : 0.f;
+                    *(f32x4*)(dsn + (long)i * 64 + 16 * ct + 4 * g4) = ds[ct];
+                }
+            }
+            XSB_STAMP();                    // half tile: dA, G, dD, ds
+            // contractions over these 16 slots into the 32 x 32 accumulators: dK'[j][c] += dD'[i][j] s[i][c],
+            // dX^a[j][c] += A[i][j] dU[i][c].  A 32-row x 16-slot block (lane = slot column m16, rows 4 g4 + e and
+            // 16 + 4 g4 + e) bounces through the wave's private buffer and comes back as the eight k-steps of the 32 x 32 MFMAs:
+            // lane (l31, hh) holds [row l31][slot 8 hh + e].
+            auto bounce16 = [&](const f32x4& lo, const f32x4& hi, f32x16& out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    tbuf[(4 * g4 + e) * XS_LDB + m16] = lo[e];
+                    tbuf[(16 + 4 * g4 + e) * XS_LDB + m16] = hi[e];
+                }
+                const f32x4 x0 = *(const f32x4*)(tbuf + l31 * XS_LDB + 8 * hh), x1 = *(const f32x4*)(tbuf + l31 * XS_LDB + 8 * hh + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { out[e] = x0[e]; out[4 + e] = x1[e]; }
+            };
+            auto acc_io = [&](f32x16 (&acc)[NJT][2], int base, bool store) {
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                            if (store) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = acc[jt][ct][4 * q + e];
+                                accpark[((base + jt * 2 + ct) * 4 + q) * 64] = v;
+                            } else {
+                                if (have_acc) v = accpark[((base + jt * 2 + ct) * 4 + q) * 64];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[jt][ct][4 * q + e] = v[e];
+                            }
+                        }
+            };
+            {
+                f32x16 acc[NJT][2], qT[2], pT;
+                xs_zero(qT[0]); xs_zero(qT[1]); xs_zero(pT);
+                acc_io(acc, 0, false);
+                bounce16(Ps[0], Ps[1], qT[0]);
+                bounce16(Ps[2], Ps[3], qT[1]);
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    bounce16(D[2 * jt], D[2 * jt + 1], pT);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[jt][ct] = mfma32(pT[e], qT[ct][e], acc[jt][ct]);
+                    XS_REGION_END();
+                }
+                acc_io(acc, 0, true);
+                acc_io(acc, 2 * NJT, false);
+                bounce16(PdU[0], PdU[1], qT[0]);
+                bounce16(PdU[2], PdU[3], qT[1]);
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    bounce16(A[2 * jt], A[2 * jt + 1], pT);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[jt][ct] = mfma32(pT[e], qT[ct][e], acc[jt][ct]);
+                    XS_REGION_END();
+                }
+                acc_io(acc, 2 * NJT, true);
+            }
+            XSB_STAMP();                    // half tile: slot contractions
+            have_acc = true;
+        }
+        }
         if (it > 0) phase_a(it - 1, pb ^ 1);
         xs_lds_barrier();        // LDS hand-off only: pending global stores keep flying
         pb ^= 1;
@@ -917,13 +1218,13 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
     }
     // c0 of iteration 0 completes ds_0 (the gradient of the initial slots); same lanes re-read their ds' tiles
     float c00 = 0.f;
-    for (int k = 0; k < ntiles; ++k) c00 += redc[pb * 16 + k];
+    for (int k = 0; k < nent; ++k) c00 += redc[pb * 16 + k];
     if (tid < 64) corr[tid] = (corr_c + c00 * ssum_c) * scale;
     {
         f32x16 ds[4][2];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)          // (tiles beyond the wave's last one re-read tile 0: no branch, the
-            xs_load_tile<2>(dsn + (long)(wave + 4 * tt < ntiles ? wave + 4 * tt : 0) * 32 * 64, 64, ds[tt], l31, hh,
+            xs_load_tile<2>(dsn + (long)(wave + 4 * tt < nfull ? wave + 4 * tt : 0) * 32 * 64, 64, ds[tt], l31, hh,
                             true);              //  loads of all tiles are in flight together)
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
@@ -936,8 +1237,17 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ds[tt][ct][4 * q + e] += c00 * scale * kq[e];
                 }
-            if (ti < ntiles && ti * 32 + l31 < S)
+            if (ti < nfull && ti * 32 + l31 < S)
                 xs_store_tile<2>(a.ds0 + ((long)b * S + ti * 32) * XS_D, XS_D, ds[tt], l31, hh);
+        }
+        if (my_half) {
+            const int i = hslot0 + m16;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                f32x4 v = *(const f32x4*)(dsn + (long)i * 64 + 16 * ct + 4 * g4);
+                v += (c00 * scale) * *(const f32x4*)(ksumf + 16 * ct + 4 * g4);
+                if (i < S) *(f32x4*)(a.ds0 + ((long)b * S + i) * XS_D + 16 * ct + 4 * g4) = v;
+            }
         }
     }
     XSB_STAMP();
@@ -953,7 +1263,7 @@ __global__ __launch_bounds__(256) void xslot_bwd_kernel(XsBwdArgs a) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 4; ++w) {                   // (a wave without tiles never wrote its park: wave 0's is
-                const bool has = w < ntiles;                //  read instead and dropped -- no branch between the loads)
+                const bool has = w < nfull || w < nhalf;    //  read instead and dropped -- no branch between the loads)
                 const f32x4 x = parks[(long)(has ? w : 0) * (4 * NJT * 4 * 64) + (tile * 4 + q) * 64 + lane];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += has ? x[e] : 0.f;
@@ -1022,7 +1332,8 @@ extern "C" int scouter_xslot_bwd_f32(const float* X, const float* PE, const floa
     }
     SC_UNSUPPORTED(L <= 8, "xslot_bwd: at most 8 to_k layers (got %d)", L);
     XsBwdArgs a{X, PE, {}, slots0, w_ih, w_hh, b_ih, b_hh, Ksave, Hsave, states, dlogits, g_area_sum,
-                dX, dgi, dgh, Usave, ds0, dZ, (float*)ws, B, N, S, S / spc, spc, T, L, loss_status};
+                dX, dgi, dgh, Usave, ds0, dZ, (float*)ws, B, N, S, S / spc, spc, T, L, loss_status, 1};
+    { const char* e = getenv("SCOUTER_XSLOT_BWD_HALVES"); if (e && e[0] == '0') a.halves = 0; }
     for (int l = 0; l < L; ++l) {
         SC_REQUIRE(tok_w[l], "xslot_bwd: null to_k layer %d", l);
         a.tok_w[l] = tok_w[l];

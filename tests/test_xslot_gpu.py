@@ -135,7 +135,11 @@ def test_xslot_large_batch_properties():
 @pytest.mark.parametrize("B,S,N,T,L,spc", [(2, 512, 64, 8, 2, 1),      # S, T at the kernel limits, 16 slot tiles
                                             (2, 512, 96, 3, 8, 2),      # N, L at the limits (scratch variant)
                                             (3, 33, 20, 1, 1, 3),       # a single iteration (no GRU), ragged tiles
-                                            (1, 96, 32, 2, 1, 1)])      # one image, N = one token tile exactly
+                                            (1, 96, 32, 2, 1, 1),       # one image, N = one token tile exactly
+                                            # leftover slot tiles walked as 16-slot half tiles by the backward (round 6):
+                                            (2, 289, 64, 2, 1, 1),      # 8 tiles + 3 halves, the last with ONE live slot
+                                            (2, 160, 25, 3, 2, 1),      # 4 tiles + 2 halves, one token tile
+                                            (2, 40, 33, 3, 1, 2)])      # no whole tile at all: 3 halves
 def test_xslot_kernels_at_their_limits_match_the_oracle(B, S, N, T, L, spc):
     """The fused forward / backward kernels straight through the C ABI at the supported maxima (S <= 512 slots, N <= 96
     tokens, T <= 8 iterations, L <= 8 to_k layers) and at degenerate sizes, against the fp64 oracle and its autograd.
@@ -192,6 +196,34 @@ def test_xslot_kernels_at_their_limits_match_the_oracle(B, S, N, T, L, spc):
     # first to_k layer: dW_0 = dZ_0^T (X + PE), db_0 = colsum(dZ_0)
     dz0 = bwd["dZ"][0].double().cpu().reshape(-1, d)
     close(dz0.t() @ (X + PE).double().reshape(-1, d), Q64["slot.to_k.0.weight"].grad, Q32["slot.to_k.0.weight"].grad, "dW_to_k0")
+
+
+@pytest.mark.parametrize("B,S,N,T", [(2, 300, 49, 3), (2, 289, 64, 2), (2, 160, 25, 3), (2, 40, 33, 3), (2, 21, 9, 3)])
+def test_xslot_backward_half_tiles_agree_with_whole_tiles(B, S, N, T, monkeypatch):
+    """ntiles % 4 = 1, 2: the leftover 32-slot tiles are walked as 16-slot half tiles, one per wave, on 16x16x4 MFMAs
+    (xslot_bwd.hip, `halves`); SCOUTER_XSLOT_BWD_HALVES=0 walks them as whole tiles.  Same maths, different summation order:
+    the two launches agree to rounding on every output."""
+    from scouter_amd import kernels as Kk
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + S)
+    r = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    d, L, spc = 64, 2, 1
+    X, PE = r(B, N, d).relu_(), r(N, d) * 0.3
+    tw, tb = [r(d, d) * 0.1 for _ in range(L)], [r(d) * 0.1 for _ in range(L)]
+    s0 = r(S, d).abs() * 0.5
+    gru = (r(3 * d, d) * 0.1, r(3 * d, d) * 0.1, r(3 * d) * 0.1, r(3 * d) * 0.1)
+    fwd = Kk.xslot_fwd(X, PE, tw, tb, s0, *gru, spc, T, 1)
+    dl, ga = r(B, S // spc), torch.full((1,), 0.01, device=dev)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SCOUTER_XSLOT_BWD_HALVES", flag)
+        o = Kk.xslot_bwd(X, PE, tw, s0, *gru, fwd, dl, ga, spc, T, 1)
+        torch.cuda.synchronize()
+        outs[flag] = {k: v.clone() for k, v in o.items()}
+    for k in outs["1"]:
+        a, b_ = outs["1"][k].double(), outs["0"][k].double()
+        assert torch.isfinite(a).all(), k
+        assert float((a - b_).abs().max()) <= 2e-4 * float(b_.abs().max()) + 1e-7, k
 
 
 @pytest.mark.parametrize("B,S,N,T", [(3, 300, 49, 3), (2, 64, 49, 2), (3, 160, 25, 3), (2, 96, 81, 3)])

@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     a.ds0 = dev_rand((size_t)B * S * d, 0, false); a.dZ = dev_rand((size_t)L * B * N * d, 0, false);
     size_t wsb = scouter_xslot_bwd_workspace_bytes(B, N, d, S, T);
     hipMalloc(&a.ws, wsb); hipMemset(a.ws, 0, wsb);
-    a.B = B; a.N = N; a.S = S; a.C = S / spc; a.spc = spc; a.T = T; a.L = L; a.loss_status = 1.f;
+    a.B = B; a.N = N; a.S = S; a.C = S / spc; a.spc = spc; a.T = T; a.L = L; a.loss_status = 1.f; a.halves = getenv("HALVES") ? atoi(getenv("HALVES")) : 1;
     hipMalloc(&a.stamps, (size_t)B * 64 * 8); hipMemset(a.stamps, 0, (size_t)B * 64 * 8);
     const int NJT = (N + 31) / 32;
     const size_t lds = xs_bwd_lds_bytes(NJT);
