@@ -177,7 +177,7 @@ class SlotModel(nn.Module):
     def set_side_stream(self, enabled):
         """Weight gradients on the side stream (default) or serially on the compute stream (per-kernel timing)."""
         for mod in self.modules():
-            if isinstance(mod, Conv2d):
+            if isinstance(mod, Conv2d) or hasattr(mod, "_param_grads"):        # (+ the xSlot head's parameter gradients)
                 mod.use_side_stream = bool(enabled)
 
     def dfs_freeze(self, model, freeze_layer_num):

@@ -3,6 +3,8 @@
 (:52-53), there is no softmax (:55-57), `eps` is unused, logits come from the last iteration's updates (:96)."""
 import math
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -42,6 +44,8 @@ class SlotAttention(nn.Module):
         self.slots_per_class = slots_per_class
         self.num_slots = num_classes * slots_per_class
         self.iters = iters
+        # parameter gradients next to the critical chain (bwd); SCOUTER_HEAD_SIDE=0: on the compute stream (A/B)
+        self.use_side_stream = K.SIDE_STREAM_DEFAULT and os.environ.get("SCOUTER_HEAD_SIDE", "1") != "0"
         self.eps = eps
         self.scale = dim ** -0.5
         self.loss_status = loss_status
@@ -87,6 +91,20 @@ class SlotAttention(nn.Module):
         r = K.xslot_bwd(X, PE, [m.weight for m in lay], self.initial_slots[0], g.weight_ih_l0, g.weight_hh_l0,
                         g.bias_ih_l0, g.bias_hh_l0, saved, dlogits, g_area_sum, self.slots_per_class, T,
                         self.loss_status)
+        # Everything below is parameter gradients -- two dozen 3-10 us launches (GEMMs over the rows the kernel emitted, column
+        # sums) that nothing on the way back to the backbone waits for: they go to the weight-gradient side stream like the
+        # convolutions' (nn_hip.Conv2d.bwd), and the step's critical chain continues with relu_bwd / conv1x1's input gradient
+        # right behind xslot_bwd (round 6: they sat in front of it on the compute stream with the GPU all but idle).
+        # SlotModel._fused_backward joins the side stream before anything reads the gradient arena.
+        with K.side_stream(X.device, r["ds0"], r["dgi"], r["dgh"], r["U"], r["dZ"], saved["H"], saved["states"],
+                           enabled=self.use_side_stream):
+            self._param_grads(r, saved, X)
+        return r["dX"]
+
+    def _param_grads(self, r, saved, X):
+        lay = self._to_k_layers()
+        g = self.gru
+        T, B, S, d = self.iters, X.shape[0], self.num_slots, self.dim
         if "initial_slots" in self._g:
             K.colsum(r["ds0"].view(B, S * d), self._g["initial_slots"].view(-1))
         if T > 1:
@@ -124,7 +142,6 @@ class SlotAttention(nn.Module):
                 K.matmul_tn(dz, hin, m._g["weight"])
             if "bias" in m._g:
                 K.colsum(dz, m._g["bias"])
-        return r["dX"]
 
     def vis_maps(self, attn=None):
         """The uint8 per-class maps of `--vis true` (slot_attention.py:68-83) for image `vis_id`."""
