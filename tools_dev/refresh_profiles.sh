@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --stats -d "$O/on" -- $B > "$O/on.log" 2>&1
 python tools_dev/rocpd_summary.py "$(db $O/on)" adamw_kernel:3 > "$O/sum_on.txt"
 rocprofv3 --kernel-trace --stats -d "$O/xs" -- python tools_dev/xslot_bench.py 256 300 3 49 3 3 > "$O/xs.log" 2>&1
 python tools_dev/rocpd_summary.py "$(db $O/xs)" > "$O/sum_xs.txt"
+rocprofv3 --kernel-trace --stats -d "$O/xsh" -- python tools_dev/xslot_bench.py 70 10 1 49 3 3 > "$O/xsh.log" 2>&1
+python tools_dev/rocpd_summary.py "$(db $O/xsh)" > "$O/sum_xs_head.txt"
 rocprofv3 --kernel-trace --stats -d "$O/xs81" -- python tools_dev/xslot_bench.py 256 300 3 81 3 3 > "$O/xs81.log" 2>&1
 python tools_dev/rocpd_summary.py "$(db $O/xs81)" > "$O/sum_xs81.txt"
 SCOUTER_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/fetch" -- $B3 > "$O/fetch.log" 2>&1
