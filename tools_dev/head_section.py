@@ -1,6 +1,7 @@
 """Timeline of the kernels around the xSlot head in one steady-state training step (rocprofv3 rocpd database of bench.py):
 start offset, duration and the idle gap in front of each dispatch, from 12 dispatches before xslot_fwd to 30 after.
-usage: python tools_dev/head_section.py <rocpd.db> [before=12] [after=30]"""
+usage: python tools_dev/head_section.py <rocpd.db> [before=12] [after=30] [anchor kernel substring = xslot*fwd]
+(anchor "adamw": the end of the step -- what the weight-gradient side stream still runs after the compute stream is done)"""
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 12
@@ -14,7 +15,8 @@ dcols = [r[1] for r in cur.execute("pragma table_info(%s)" % disp)]
 qcol = "queue_id" if "queue_id" in dcols else ("stream_id" if "stream_id" in dcols else None)
 rows = list(cur.execute("select s.%s, d.start, d.end%s from %s d join %s s on d.kernel_id=s.id order by d.start" % (
     namecol, (", d." + qcol) if qcol else "", disp, sym)))
-idx = [i for i, r in enumerate(rows) if "xslot" in r[0] and "fwd" in r[0]]
+anchor = sys.argv[4] if len(sys.argv) > 4 else None
+idx = [i for i, r in enumerate(rows) if (anchor in r[0] if anchor else ("xslot" in r[0] and "fwd" in r[0]))]
 i0 = idx[-2] if len(idx) > 1 else idx[-1]          # the second-to-last step
 t0 = rows[i0][1]
 prev_end = rows[i0 - nb - 1][2]
