@@ -910,6 +910,8 @@ def conv2d_wgrad_planes(xp, dyp, dw_hwio, pad, groups=1):
 
 
 _side = {}
+_side_rr = [0]
+SIDE_STREAMS = max(1, int(os.environ.get("SCOUTER_SIDE_STREAMS", "1")))      # weight-gradient side streams (round-robin)
 # default of nn_hip.Conv2d.use_side_stream (a per-layer / per-model setting: SlotModel.set_side_stream)
 SIDE_STREAM_DEFAULT = os.environ.get("SCOUTER_SIDE_STREAM", "1") != "0"
 
@@ -929,7 +931,14 @@ class side_stream:
         self.ctx = None
         if not self.enabled:
             return None
-        key = (self.device.type, self.device.index, self.which)
+        which = self.which
+        if which == "wgrad" and SIDE_STREAMS > 1:
+            # weight gradients alternate between SIDE_STREAMS streams: the stem's long weight gradients (0.2-0.5 ms each,
+            # at the very end of the backward) no longer queue behind one another while the compute stream runs the
+            # HBM-bound BatchNorm passes they could overlap with -- join_side_stream waits for all of them
+            n = _side_rr[0] = (_side_rr[0] + 1) % SIDE_STREAMS
+            which = "wgrad" if n == 0 else "wgrad%d" % n
+        key = (self.device.type, self.device.index, which)
         st = _side.get(key)
         if st is None:
             st = _side[key] = torch.cuda.Stream(device=self.device)
@@ -946,9 +955,11 @@ class side_stream:
 
 
 def join_side_stream(device, which="wgrad"):
-    st = _side.get((device.type, device.index, which))
-    if st is not None:
-        torch.cuda.current_stream(device).wait_stream(st)
+    names = [which] + (["wgrad%d" % n for n in range(1, SIDE_STREAMS)] if which == "wgrad" else [])
+    for name in names:
+        st = _side.get((device.type, device.index, name))
+        if st is not None:
+            torch.cuda.current_stream(device).wait_stream(st)
 
 
 # (tile, split-K) plans of the fp32 / bf16-input weight-gradient kernels: -1 = the library's static plan; the others
