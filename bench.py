@@ -196,7 +196,7 @@ def xslot_roofline(device, batch=256, slots=300, spc=3, tokens=49, iters=3, laye
         fwd_kernel = ("xslot_small_fwd_kernel (same fused forward on v_mfma_f32_16x16x4_f32 tiles: slots on the 16 MFMA columns, "
                       "token tiles / GRU hidden units split over four waves, GRU weights resident in registers)")
         backward["kernel"] = ("xslot_small_bwd_kernel (same fused backward, 16x16x4 tiles, both GRU weight orientations in "
-                              "registers, four LDS hand-offs per iteration)") if tokens <= 64 else backward["kernel"]
+                              "registers, four LDS hand-offs per iteration)")
     return {"backward": backward, "kernel": fwd_kernel,
             "batch": batch, "slots": slots, "tokens": tokens, "to_k_layers": layers, "avg_launch_us": round(t * 1e6, 1),
             "achieved": round(fl / t / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

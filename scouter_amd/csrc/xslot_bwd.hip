@@ -1343,10 +1343,20 @@ extern "C" int scouter_xslot_bwd_f32(const float* X, const float* PE, const floa
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * (double)B * (2.0 * L * N * d * d + (double)T * 4.0 * S * N * d + (T - 1) * 12.0 * S * d * d);
     ScProfScope prof("xslot_bwd", st, flops, 4.0 * B * (3.0 * N * d + (double)S * d));
-    if (S <= 16 && N <= 64 && xs_small_bwd_enabled()) {        // the metric's own head: xslot_small_bwd.h
-        const int slds = (int)xs_small_bwd_lds_bytes();
-        hipFuncSetAttribute((const void*)xslot_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, slds);
-        hipLaunchKernelGGL(xslot_small_bwd_kernel, dim3(B), dim3(256), slds, st, a);
+    if (S <= 16 && xs_small_bwd_enabled()) {        // the metric's own head: xslot_small_bwd.h
+        const int NTW = N <= 64 ? 1 : 2;
+        const int slds = (int)xs_small_bwd_lds_bytes(NTW);
+        if (ws_bytes < xs_small_bwd_park_bytes(B, NTW)) {
+            sc_set_error("xslot_bwd: workspace too small");
+            return SC_ERR_WORKSPACE;
+        }
+        if (NTW == 1) {
+            hipFuncSetAttribute((const void*)xslot_small_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, slds);
+            hipLaunchKernelGGL(xslot_small_bwd_kernel<1>, dim3(B), dim3(256), slds, st, a);
+        } else {
+            hipFuncSetAttribute((const void*)xslot_small_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, slds);
+            hipLaunchKernelGGL(xslot_small_bwd_kernel<2>, dim3(B), dim3(256), slds, st, a);
+        }
         return sc_check_launch("xslot_small_bwd");
     }
 #define XSB_LAUNCH(KERN)                                                                                   \

@@ -1,5 +1,7 @@
-// Small-S instantiation of the fused xSlot backward: S <= 16 slots per image, N <= 64 tokens (the metric's own head:
-// 10 classes x 1 slot on the 7 x 7 grid; sloter/utils/slot_attention.py:44-96).  Included by xslot_bwd.hip; same arguments,
+// Small-S instantiation of the fused xSlot backward: S <= 16 slots per image, N <= 64 tokens (NTW = 1: the metric's own head,
+// 10 classes x 1 slot on the 7 x 7 grid) or N <= 96 (NTW = 2: the reference's default 9 x 9 grid, train.py:39: waves 0 and 1
+// walk two token tiles; the dK / dX^a sums then wait in a wave-private global park between the iterations instead of in
+// registers); sloter/utils/slot_attention.py:44-96.  Included by xslot_bwd.hip; same arguments,
 // same outputs as xslot_bwd_kernel; the maths is oracle/xslot_manual.py.  Register layouts and the division of labour
 // between the four waves are those of xslot_small_fwd.h:
 //   * slot-per-lane-16: lane (i = lane & 15, g = lane >> 4), register r of tile t <-> M^T[c = 16 t + 4 g + r][i];
@@ -17,18 +19,24 @@
 #include "xslot_small_common.h"
 
 #define XS16_LDT 20            // row stride (floats) of the 16 x 16 bounce tiles: 16-byte rows
-static size_t xs_small_bwd_lds_bytes() {
-    return (size_t)(3 * 64 * XS_LD + 3 * XS16_UX_FLOATS + 2 * 16 * XS_LD + 4 * 2 * 16 * XS16_LDT + 64) * sizeof(float) +
+static size_t xs_small_bwd_lds_bytes(int NTW) {
+    const int NPR = NTW == 1 ? 64 : 96;
+    return (size_t)((2 * NPR + 64) * XS_LD + 3 * XS16_UX_FLOATS + 2 * 16 * XS_LD + 4 * 2 * 16 * XS16_LDT + 64) * sizeof(float) +
            (size_t)(64 * 4 + 64) * sizeof(double);
 }
+static size_t xs_small_bwd_park_bytes(int B, int NTW) {       // (inside scouter_xslot_bwd_workspace_bytes' in-loop figure)
+    return NTW == 1 ? 0 : (size_t)B * 4 * NTW * 2 * 4 * 64 * sizeof(f32x4);
+}
 
+template <int NTW>
 __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
+    constexpr int NPR = NTW == 1 ? 64 : 96;         // token rows held in LDS (16-token tiles: 4 or 6)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     double* part = (double*)lds;                    // [64][4]
     double* ksum_s = part + 256;                    // [64]
-    float* Xs = (float*)(ksum_s + 64);              // [64][68] X (rows >= N zero)
-    float* Ks = Xs + 64 * XS_LD;                    // [64][68] K (rows >= N zero)
-    float* uxA = Ks + 64 * XS_LD;                   // [4][16][68] partial U of the four waves
+    float* Xs = (float*)(ksum_s + 64);              // [NPR][68] X (rows >= N zero)
+    float* Ks = Xs + NPR * XS_LD;                   // [NPR][68] K (rows >= N zero)
+    float* uxA = Ks + NPR * XS_LD;                  // [4][16][68] partial U of the four waves
     float* uxB = uxA + XS16_UX_FLOATS;              // partial dU
     float* uxC = uxB + XS16_UX_FLOATS;              // partial ds_t
     float* sfull = uxC + XS16_UX_FLOATS;            // [16][68] s_t, row = slot
@@ -41,8 +49,16 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
     const int b = blockIdx.x, N = a.N, S = a.S, T = a.T;
     const float scale = 0.125f, inv_d = 1.f / XS_D;
     const bool iok = m < S;
-    const int jA = 16 * w + m;                      // token on this lane in the token-per-lane / A-operand layouts
-    const int jB = 16 * w + 4 * g;                  // first of this lane's four tokens in the accumulator layout
+    // token tile u of this wave = tile w + 4 u (wave-uniform: waves 2, 3 have no second tile at NTW = 2)
+    int jA[NTW], jB[NTW];                           // token on this lane in the token-per-lane / A-operand layouts; first of this
+    bool uon[NTW];                                  // lane's four tokens in the accumulator layout
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        uon[u] = 16 * (w + 4 * u) < NPR;
+        jA[u] = uon[u] ? 16 * (w + 4 * u) + m : 0;
+        jB[u] = uon[u] ? 16 * (w + 4 * u) + 4 * g : 0;
+    }
+    f32x4* park = (f32x4*)a.ws + ((long)b * 4 + w) * (NTW * 2 * 4 * 64) + lane;      // [u][dK | dX][ct][lane] (NTW = 2)
 
     XS16_STAMP_INIT();
     XS16_STAMP();                           // 0: start
@@ -50,21 +66,27 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
     {
         // (rows beyond N: the load goes to the last valid row and the value is dropped -- no predicated loads, see
         //  xslot_small_fwd.h)
-        f32x4 xv[4], kv[4], wv[4];
+        constexpr int XQ = NPR / 16;
+        f32x4 xv[XQ], kv[XQ], wv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < XQ; ++k) {
             const int c = tid + k * 256, r = min(c >> 4, N - 1), q = c & 15;
             xv[k] = *(const f32x4*)(a.X + ((long)b * N + r) * XS_D + q * 4);
             kv[k] = *(const f32x4*)(a.Ksave + ((long)b * N + r) * XS_D + q * 4);
-            wv[k] = *(const f32x4*)(a.tok_w[a.L - 1] + c * 4);      // the to_k backward's first weight matrix
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4; ++k) wv[k] = *(const f32x4*)(a.tok_w[a.L - 1] + (tid + k * 256) * 4);      // the to_k backward's first weight matrix
+#pragma unroll
+        for (int k = 0; k < XQ; ++k) {
             const int c = tid + k * 256, r = c >> 4, q = c & 15;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             *(f32x4*)(Xs + r * XS_LD + q * 4) = r < N ? xv[k] : z;
             *(f32x4*)(Ks + r * XS_LD + q * 4) = r < N ? kv[k] : z;
-            *(f32x4*)(WL + r * XS_LD + q * 4) = wv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = tid + k * 256;
+            *(f32x4*)(WL + (c >> 4) * XS_LD + (c & 15) * 4) = wv[k];
         }
     }
     f32x4 Wg[3][2][4];                  // Wg[gate][ih | hh][t] = W[64 gate + 16 w + m][16 t + 4 g ..]       (rows = gate)
@@ -99,7 +121,7 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
     {   // column sums of K in fp64 (the normaliser: see xs_rowdot_f64)
         const int c = tid & 63, q = tid >> 6;
         double s = 0.0;
-        for (int j = q; j < 64; j += 4) s += (double)Ks[j * XS_LD + c];
+        for (int j = q; j < NPR; j += 4) s += (double)Ks[j * XS_LD + c];
         part[c * 4 + q] = s;
     }
     xs_lds_barrier();
@@ -107,7 +129,8 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
     xs_lds_barrier();
 
     XS16_STAMP();                           // 2: column sums
-    f32x4 dKacc[4], dXacc[4], Pds[4];       // token-per-lane sums over the iterations; dL/ds_t handed down the iterations
+    f32x4 dKacc[4], dXacc[4], Pds[4];       // token-per-lane sums over the iterations (NTW = 1; parked in global memory
+                                            // otherwise); dL/ds_t handed down the iterations
 #pragma unroll
     for (int t = 0; t < 4; ++t) { dKacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dXacc[t] = dKacc[t]; Pds[t] = dKacc[t]; }
     float* tbd = tb + w * (2 * 16 * XS16_LDT);
@@ -148,12 +171,17 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
         const float ir = xs_recip(rr);
         XS16_STAMP();                       // it.0: s_t loaded, r_i, tau
         // ---- recomputation: D^T = (K / 8) s^T, A = sigmoid(D / r_i * tau), partial U^T = (X / 64)^T A^T
-        f32x4 D, A;
-        {
+        f32x4 D[NTW], A[NTW], Up[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) Up[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) {
+            D[u] = f32x4{0.f, 0.f, 0.f, 0.f}; A[u] = D[u];
+            if (!uon[u]) continue;
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
             f32x4 kr[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) kr[t] = *(const f32x4*)(Ks + jA * XS_LD + 16 * t + 4 * g) * scale;
+            for (int t = 0; t < 4; ++t) kr[t] = *(const f32x4*)(Ks + jA[u] * XS_LD + 16 * t + 4 * g) * scale;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -161,26 +189,21 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
                     d0 = mfma16(kr[t][r], Ps[t][r], d0);
                     d1 = mfma16(kr[t + 2][r], Ps[t + 2][r], d1);
                 }
-            D = d0 + d1;
+            D[u] = d0 + d1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = xs_sigmoid(xs_div(D[r], rr, ir) * tau);
-                A[r] = (iok && jB + r < N) ? v : 0.f;
+                const float v = xs_sigmoid(xs_div(D[u][r], rr, ir) * tau);
+                A[u][r] = (iok && jB[u] + r < N) ? v : 0.f;
             }
-        }
-        f32x4 Up[4];
-        {
             float xa[4][4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xa[ct][r] = Xs[(jB + r) * XS_LD + 16 * ct + m] * inv_d;
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) Up[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 4; ++r) xa[ct][r] = Xs[(jB[u] + r) * XS_LD + 16 * ct + m] * inv_d;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) Up[ct] = mfma16(xa[ct][r], A[r], Up[ct]);
+                for (int ct = 0; ct < 4; ++ct) Up[ct] = mfma16(xa[ct][r], A[u][r], Up[ct]);
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) *(f32x4*)(uxA + (w * 16 + m) * XS_LD + 16 * ct + 4 * g) = Up[ct];
@@ -286,13 +309,16 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
         XS16_STAMP();                       // it.4: barrier, dU sum
         *(f32x4*)(dufull + m * XS_LD + 16 * w + 4 * g) = xs16_pick(PdU, w);
         // ---- dA^T = (X / 64) dU^T (+ area term), G = dA * A (1 - A), g_i = sum_j G_ij D_ij
-        f32x4 Gm;
+        f32x4 Gm[NTW];
         float gsum = 0.f;
-        {
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) {
+            Gm[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!uon[u]) continue;
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
             f32x4 xq[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xq[t] = *(const f32x4*)(Xs + jA * XS_LD + 16 * t + 4 * g) * inv_d;
+            for (int t = 0; t < 4; ++t) xq[t] = *(const f32x4*)(Xs + jA[u] * XS_LD + 16 * t + 4 * g) * inv_d;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -303,8 +329,8 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = (d0[r] + d1[r]) + (last ? g_area : 0.f);
-                Gm[r] = (iok && jB + r < N) ? v * A[r] * (1.f - A[r]) : 0.f;
-                gsum += Gm[r] * D[r];
+                Gm[u][r] = (iok && jB[u] + r < N) ? v * A[u][r] * (1.f - A[u][r]) : 0.f;
+                gsum += Gm[u][r] * D[u][r];
             }
         }
         gsum = xs16_gsum(gsum);
@@ -314,33 +340,29 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
         const float gi_ = (gx[m] + gx[16 + m]) + (gx[32 + m] + gx[48 + m]);
         const float c0 = xs16_rowsum(iok ? gi_ / rr : 0.f);
         // ---- dD = G tau / r_i - g_i tau / r_i^2 + c0 ; partial ds_t^T = (K / 8)^T dD^T (+ this wave's dh partial)
-        f32x4 dD;
-        {
+        f32x4 dD[NTW];
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) {
+            dD[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!uon[u]) continue;
             const float k1 = tau / rr, k2 = gi_ * tau / (rr * rr);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dD[r] = (iok && jB + r < N) ? Gm[r] * k1 - k2 + c0 : 0.f;
+            for (int r = 0; r < 4; ++r) dD[u][r] = (iok && jB[u] + r < N) ? Gm[u][r] * k1 - k2 + c0 : 0.f;
             float kt[4][4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) kt[ct][r] = Ks[(jB + r) * XS_LD + 16 * ct + m] * scale;
+                for (int r = 0; r < 4; ++r) kt[ct][r] = Ks[(jB[u] + r) * XS_LD + 16 * ct + m] * scale;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) dhp[ct] = mfma16(kt[ct][r], dD[r], dhp[ct]);
+                for (int ct = 0; ct < 4; ++ct) dhp[ct] = mfma16(kt[ct][r], dD[u][r], dhp[ct]);
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) *(f32x4*)(uxC + (w * 16 + m) * XS_LD + 16 * ct + 4 * g) = dhp[ct];
         XS16_STAMP();                       // it.6: barrier, dD, ds partial
         // ---- contractions over the slot index: dK += (s_t / 8)^T dD, dX^a += (dU / 64)^T A, slots on the MFMA k axis
         {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                tbd[(4 * g + r) * XS16_LDT + m] = dD[r];
-                tba[(4 * g + r) * XS16_LDT + m] = A[r];
-            }
-            const f32x4 bd = *(const f32x4*)(tbd + m * XS16_LDT + 4 * g);        // dD[slot 4 g + e][token m]
-            const f32x4 ba = *(const f32x4*)(tba + m * XS16_LDT + 4 * g);
             float sa[4][4], da[4][4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
@@ -350,12 +372,37 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
                     da[ct][e] = dufull[(4 * g + e) * XS_LD + 16 * ct + m] * inv_d;
                 }
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int u = 0; u < NTW; ++u) {
+                if (!uon[u]) continue;
+                if constexpr (NTW > 1) {        // this tile's sums so far come back from the park (zero in the first iteration)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    dKacc[ct] = mfma16(sa[ct][e], bd[e], dKacc[ct]);
-                    dXacc[ct] = mfma16(da[ct][e], ba[e], dXacc[ct]);
+                    for (int ct = 0; ct < 4; ++ct) {
+                        dKacc[ct] = last ? f32x4{0.f, 0.f, 0.f, 0.f} : park[((u * 2 + 0) * 4 + ct) * 64];
+                        dXacc[ct] = last ? f32x4{0.f, 0.f, 0.f, 0.f} : park[((u * 2 + 1) * 4 + ct) * 64];
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    tbd[(4 * g + r) * XS16_LDT + m] = dD[u][r];
+                    tba[(4 * g + r) * XS16_LDT + m] = A[u][r];
+                }
+                const f32x4 bd = *(const f32x4*)(tbd + m * XS16_LDT + 4 * g);        // dD[slot 4 g + e][token m]
+                const f32x4 ba = *(const f32x4*)(tba + m * XS16_LDT + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        dKacc[ct] = mfma16(sa[ct][e], bd[e], dKacc[ct]);
+                        dXacc[ct] = mfma16(da[ct][e], ba[e], dXacc[ct]);
+                    }
+                if constexpr (NTW > 1) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        park[((u * 2 + 0) * 4 + ct) * 64] = dKacc[ct];
+                        park[((u * 2 + 1) * 4 + ct) * 64] = dXacc[ct];
+                    }
+                }
+            }
         }
         XS16_STAMP();                       // it.7: slot contractions
         xs_lds_barrier();                   // #4: ds partials
@@ -372,30 +419,47 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
     // ---- to_k MLP backward, token-per-lane: dZ_{L-1} = dK ; dH_{l-1} = dZ_l W_l ; dZ_{l-1} = dH_{l-1} * (H_l > 0).
     // The A operand W_l^T[c][o] is four ROWS x one column per lane: W_l is staged row-major in LDS (WL, then the idle hand-off
     // buffers, in rotation) and read with ds_read_b32; the next layer's matrix is requested before this layer multiplies.
-    f32x4 dz[4];
+    f32x4 dz[NTW][4], dxa[NTW][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) dz[t] = dKacc[t];
+    for (int u = 0; u < NTW; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if constexpr (NTW > 1) {
+                dz[u][t] = uon[u] ? park[((u * 2 + 0) * 4 + t) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+                dxa[u][t] = uon[u] ? park[((u * 2 + 1) * 4 + t) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                dz[u][t] = dKacc[t];
+                dxa[u][t] = dXacc[t];
+            }
+        }
     float* wbuf[3] = {WL, uxA, uxB};
     for (int l = a.L - 1, k = 0; l >= 0; --l, k = k == 2 ? 0 : k + 1) {
         const float* Wl = k == 0 ? wbuf[0] : k == 1 ? wbuf[1] : wbuf[2];
         float* Wnext = k == 0 ? wbuf[1] : k == 1 ? wbuf[2] : wbuf[0];
-        f32x4 wv[4], hv[4];
+        f32x4 wv[4], hv[NTW][4];
         if (l > 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) wv[q] = *(const f32x4*)(a.tok_w[l - 1] + (tid + q * 256) * 4);
-            const int jc = min(jA, N - 1);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-                hv[ct] = *(const f32x4*)(a.Hsave + (((long)l * a.B + b) * N + jc) * XS_D + 16 * ct + 4 * g);
+            for (int u = 0; u < NTW; ++u) {
+                const int jc = min(jA[u], N - 1);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    hv[u][ct] = *(const f32x4*)(a.Hsave + (((long)l * a.B + b) * N + jc) * XS_D + 16 * ct + 4 * g);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (jA < N) {
+        f32x4 acc[NTW][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) *(f32x4*)(a.dZ + (((long)l * a.B + b) * N + jA) * XS_D + 16 * t + 4 * g) = dz[t];
+        for (int u = 0; u < NTW; ++u) {
+            if (uon[u] && jA[u] < N) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    *(f32x4*)(a.dZ + (((long)l * a.B + b) * N + jA[u]) * XS_D + 16 * t + 4 * g) = dz[u][t];
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[u][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        f32x4 acc[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float wt[4][4];
@@ -404,25 +468,36 @@ __global__ __launch_bounds__(256) void xslot_small_bwd_kernel(XsBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) wt[ct][r] = Wl[(16 * t + 4 * g + r) * XS_LD + 16 * ct + m];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int u = 0; u < NTW; ++u) {
+                if (!uon[u]) continue;
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(wt[ct][r], dz[t][r], acc[ct]);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[u][ct] = mfma16(wt[ct][r], dz[u][t][r], acc[u][ct]);
+            }
         }
         if (l > 0) {
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int u = 0; u < NTW; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz[ct][r] = (jA < N && hv[ct][r] > 0.f) ? acc[ct][r] : 0.f;
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dz[u][ct][r] = (uon[u] && jA[u] < N && hv[u][ct][r] > 0.f) ? acc[u][ct][r] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = tid + q * 256;
                 *(f32x4*)(Wnext + (c >> 4) * XS_LD + (c & 15) * 4) = wv[q];
             }
             xs_lds_barrier();
-        } else if (jA < N) {
+        } else {
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-                *(f32x4*)(a.dX + ((long)b * N + jA) * XS_D + 16 * ct + 4 * g) = acc[ct] + dXacc[ct];
+            for (int u = 0; u < NTW; ++u)
+                if (uon[u] && jA[u] < N) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        *(f32x4*)(a.dX + ((long)b * N + jA[u]) * XS_D + 16 * ct + 4 * g) = acc[u][ct] + dxa[u][ct];
+                }
         }
     }
     XS16_STAMP();                           // end

@@ -20,7 +20,7 @@ SHAPES = [(70, 10, 49, 3, 3, 1),     # BASELINE configs[1]: bs70, 10 classes, 7x
           (3, 6, 9, 2, 2, 2),        # slots_per_class = 2, one sparse token tile
           (2, 5, 1, 3, 1, 1),        # a single token (D / r_i == 1)
           (4, 12, 49, 1, 1, 3),      # one iteration: no GRU, no saved states
-          (3, 10, 81, 3, 1, 1),      # 9 x 9 grid: two token tiles per wave
+          (3, 10, 81, 3, 1, 1),      # 9 x 9 grid: two token tiles on waves 0 / 1 (backward: dK / dX^a sums parked in global memory)
           (2, 7, 96, 4, 2, 1),       # N at the kernels' limit (two token tiles per wave), T = 4
           (3, 1, 17, 3, 2, 1)]       # one slot
 
