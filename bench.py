@@ -227,7 +227,7 @@ CLASSES = {
         "labels": ("pconv_fwd<bf16x3>", "pconv_dgrad<bf16x3>", "pwgrad<bf16x3>", "xconv_fwd<bf16x3>", "xconv_dgrad<bf16x3>",
                    "xconv_dgrad+bn_bwd<bf16x3>", "xwgrad<bf16x3>", "xconv3_fwd<bf16x3>", "xconv3_dgrad<bf16x3>",
                    "xconv3_dgrad+bn_bwd<bf16x3>", "xpw_dgrad+bn_bwd<bf16x3>", "xpw_fwd<bf16x3>", "xhalo_fwd<bf16x3>",
-                   "xhalo_dgrad<bf16x3>", "xhalo_dgrad+bn_bwd<bf16x3>"),
+                   "xhalo_dgrad<bf16x3>", "xhalo_dgrad+bn_bwd<bf16x3>", "xwgrad_taps<bf16x3>"),
         "rocprof": ("void pconv_kernel<", "void phalo_kernel<", "void pwgrad_kernel<", "void ppersist_kernel<",
                     "void pwgrad_taps_kernel<", "void xgemm_kernel<", "void xwgrad_kernel<", "void xpw_fused_kernel<", "void xpw_fwd_kernel<",
                     "void xhalo_kernel<"),

@@ -13,6 +13,7 @@
 #include "conv_common.h"
 #include "conv_wgrad_bf16.h"
 #include "conv_wgrad_taps.h"
+#include "conv_wgrad_taps_x3.h"
 #include "conv_pw_persist.h"
 #include "conv_pw_persist_x3.h"
 
@@ -1054,10 +1055,16 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
         const int bn = g.Ng % 64 == 0 ? 64 : 32;
         const int co_tiles = g.Ng / bn;
         const long tiles = (long)co_tiles * groups;
-        long want = 1024 / tiles;
+        // default (SCOUTER_XWT=0: off): the register-split bf16x3 kernel (64-pixel chunks, rows up to 112 pixels wide).  One workgroup per CU
+        // (147 KB of LDS) and a five-unit prologue per workgroup: ONE round of long pixel ranges, not four of short ones
+        const char* xe = getenv("SCOUTER_XWT");
+        const bool xwt = !(xe && xe[0] == '0') && g.W <= 112 && g.H >= 2 && BK == 32;
+        const char* xw = getenv("SCOUTER_XWT_WGS");
+        long want = (xwt ? (xw ? atoi(xw) : 256) : 1024) / tiles;
         if (want < 1) want = 1;
         long chunks = (g.M + BK - 1) / BK, cps = (chunks + want - 1) / want;
         if (cps < 8) cps = 8;
+        if (xwt) cps += cps & 1;
         const long pps = cps * BK;
         const int splits = (int)((g.M + pps - 1) / pps);
         const long slab_t = (long)9 * g.Cg * Cout;
@@ -1067,7 +1074,23 @@ extern "C" int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* 
             float* out = splits > 1 ? (float*)ws : dw;
             unsigned* arr = splits > 1 && arrival && tiles <= arrival_slots ? (unsigned*)arrival : nullptr;
             const size_t lds = (size_t)(9 * 32 * 32 + 32 * bn) * sizeof(float);
-            {
+            if (xwt && pps % XWT_CH == 0) {
+                // the same tile on the bf16 matrix cores, operands split in registers (conv_wgrad_taps_x3.h)
+                const size_t xlds = xwgrad_taps_lds_bytes(bn);
+                ScProfScope prof("xwgrad_taps<bf16x3>", st, 2.0 * g.M * Cout * g.Cg * 9,
+                                 4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
+                if (bn == 64) {
+                    auto kern = xwgrad_taps_kernel<64>;
+                    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), xlds, st, x, dy, out, g,
+                                       co_tiles, pps, slab_t, dw, arr);
+                } else {
+                    auto kern = xwgrad_taps_kernel<32>;
+                    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), xlds, st, x, dy, out, g,
+                                       co_tiles, pps, slab_t, dw, arr);
+                }
+            } else {
                 ScProfScope prof("wgrad_taps", st, 2.0 * g.M * Cout * g.Cg * 9,
                                  4.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
                 if (bn == 64) {

@@ -968,6 +968,8 @@ def join_side_stream(device, which="wgrad"):
 # process (the cache), not across processes; SCOUTER_WGRAD_TUNE=0 or SCOUTER_AUTOTUNE=0 pin the static plan.
 # Measured on the benchmark step: +0.7 % images/sec (3 x 120 steps, interleaved, one box).
 _WGRAD_PLANS = (-1,)
+# SCOUTER_XWT=0: the 32-channel-group 3x3 weight gradients stay on the exact-fp32 MFMA kernels (read by the library too)
+XWT = os.environ.get("SCOUTER_XWT", "1") != "0"
 if os.environ.get("SCOUTER_WGRAD_TUNE", "1") == "1":
     _WGRAD_PLANS += tuple(t | b for t in (0, 16, 32, 48) for b in (0, 1, 2, 3))
 
@@ -1010,7 +1012,13 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
             _native.check(L.scouter_conv2d_wgrad_f32(*args, st), "conv2d_wgrad")
         return True
 
-    launch(_pick_tile(("wgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, _WGRAD_PLANS))
+    plan = _pick_tile(("wgrad", bf16, B, H, W, Cin, Cout, kh, kw, stride, pad, groups), launch, _WGRAD_PLANS)
+    if XWT and not bf16 and kh == 3 and kw == 3 and stride == 1 and pad == 1 and cg == 32 and W <= 112 and H >= 2:
+        # the 32-channel-group 3x3 layers (deep stem, layer1's radix convolutions): the library's own plan, which is the tap-fused
+        # register-split bf16x3 kernel (csrc/conv_wgrad_taps_x3.h) -- a static rule of the shape that overrides the table's
+        # (tile, split-K) entry for the exact-fp32 kernels, like SCOUTER_X3 does for the layers it moves
+        plan = -1
+    launch(plan)
     return dw_hwio
 
 
