@@ -14,6 +14,7 @@
 #include "conv_wgrad_bf16.h"
 #include "conv_wgrad_taps.h"
 #include "conv_wgrad_taps_x3.h"
+#include "conv_wgrad_taps_bf16.h"
 #include "conv_pw_persist.h"
 #include "conv_pw_persist_x3.h"
 
@@ -1195,6 +1196,53 @@ extern "C" int scouter_conv2d_wgrad_bf16_io(const void* x, const void* dy, float
     const int mode = !same ? 0 : (kh == 1 && kw == 1 && pad == 0) ? 2 : (64 / g.Wo + 1 < g.Ho ? 1 : 0);
     SC_UNSUPPORTED(mode != 0 && g.Cg % 32 == 0 && g.Ng % 32 == 0 && g.M < (1L << 31),
                    "conv2d_wgrad_bf16: shape not covered by the bf16 kernel");
+    // 3x3 / stride 1 / pad 1 with 32 input channels per group, both operands stored as bf16: tap-fused kernel (conv_wgrad_taps_bf16.h;
+    // the library's own plan, SCOUTER_BWT=0: off) -- every X row fetched once per workgroup instead of once per tap
+    if (plan_hint < 0 && xb && db && kh == 3 && kw == 3 && stride == 1 && pad == 1 && g.Cg == 32 && g.W <= 112 && g.H >= 2 &&
+        BWT_CH / g.Wo + 1 < g.Ho && (g.M + 512) * (long)(g.C > g.N ? g.C : g.N) * 2 < (1L << 31)) {
+        const char* be = getenv("SCOUTER_BWT");
+        const int bn = g.Ng % 64 == 0 ? 64 : 32;
+        const int co_tiles = g.Ng / bn;
+        const long tiles = (long)co_tiles * groups;
+        const char* bw = getenv("SCOUTER_BWT_WGS");
+        long want = (bw ? atoi(bw) : 512) / tiles;                 // two workgroups per CU
+        if (want < 1) want = 1;
+        long chunks = (g.M + BWT_CH - 1) / BWT_CH, cps = (chunks + want - 1) / want;
+        if (cps < 4) cps = 4;
+        const long pps = cps * BWT_CH;
+        const int splits = (int)((g.M + pps - 1) / pps);
+        const long slab_t = (long)9 * g.Cg * Cout;
+        const size_t need_t = splits > 1 ? (size_t)splits * slab_t * sizeof(float) : 0;
+        if (!(be && be[0] == '0') && need_t <= ws_bytes && (!need_t || ws)) {
+            hipStream_t st = (hipStream_t)stream;
+            float* out = splits > 1 ? (float*)ws : dw;
+            unsigned* arr = splits > 1 && arrival && tiles <= arrival_slots ? (unsigned*)arrival : nullptr;
+            const size_t blds = bwgrad_taps_lds_bytes(bn);
+            {
+            ScProfScope prof("bwgrad_taps<bf16>", st, 2.0 * g.M * Cout * g.Cg * 9, 2.0 * ((double)B * H * W * Cin + (double)g.M * Cout));
+            if (bn == 64) {
+                auto kern = bwgrad_taps_kernel<64>;
+                hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
+                hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), blds, st, (const unsigned short*)x,
+                                   (const unsigned short*)dy, out, g, co_tiles, pps, slab_t, dw, arr);
+            } else {
+                auto kern = bwgrad_taps_kernel<32>;
+                hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
+                hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), blds, st, (const unsigned short*)x,
+                                   (const unsigned short*)dy, out, g, co_tiles, pps, slab_t, dw, arr);
+            }
+            }
+            int rc = sc_check_launch("conv2d_wgrad_taps_bf16");
+            if (rc) return rc;
+            if (splits > 1 && !arr) {
+                ScProfScope prof2("slab_reduce", st, 0, 4.0 * (double)slab_t * (splits + 1));
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3(sc_cdiv(slab_t / 4, 8)), dim3(256), 0, st, (const float*)ws,
+                                   dw, slab_t, splits, slab_t);
+                rc = sc_check_launch("conv2d_wgrad_taps_bf16_reduce");
+            }
+            return rc;
+        }
+    }
     const bool ragged = g.Cg % 64 != 0 || g.Ng % 64 != 0;
     WgradPlan p = wgrad_plan(g, plan_hint, true, 64);                        // the bf16 kernel has no 32-wide tiles
     const long slab = (long)kh * kw * g.Cg * Cout;

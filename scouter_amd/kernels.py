@@ -970,6 +970,8 @@ def join_side_stream(device, which="wgrad"):
 _WGRAD_PLANS = (-1,)
 # SCOUTER_XWT=0: the 32-channel-group 3x3 weight gradients stay on the exact-fp32 MFMA kernels (read by the library too)
 XWT = os.environ.get("SCOUTER_XWT", "1") != "0"
+# SCOUTER_BWT=0: the bf16-stored twins of those layers stay on the per-tap bf16 kernel (read by the library too)
+BWT = os.environ.get("SCOUTER_BWT", "1") != "0"
 if os.environ.get("SCOUTER_WGRAD_TUNE", "1") == "1":
     _WGRAD_PLANS += tuple(t | b for t in (0, 16, 32, 48) for b in (0, 1, 2, 3))
 
@@ -1017,6 +1019,11 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
         # the 32-channel-group 3x3 layers (deep stem, layer1's radix convolutions): the library's own plan, which is the tap-fused
         # register-split bf16x3 kernel (csrc/conv_wgrad_taps_x3.h) -- a static rule of the shape that overrides the table's
         # (tile, split-K) entry for the exact-fp32 kernels, like SCOUTER_X3 does for the layers it moves
+        plan = -1
+    if (BWT and bf16 and x.dtype == BF16 and dy.dtype == BF16 and kh == 3 and kw == 3 and stride == 1 and pad == 1 and cg == 32
+            and W <= 112 and H >= 2):
+        # the same layers with both operands STORED as bf16 (BASELINE configs[4]): the library's own plan is the tap-fused
+        # one-plane kernel (csrc/conv_wgrad_taps_bf16.h) instead of one workgroup per tap
         plan = -1
     launch(plan)
     return dw_hwio
