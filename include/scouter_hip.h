@@ -148,7 +148,10 @@ int scouter_conv2d_dgrad_bn_partial_rows_bf16(int B, int H, int W, int Cin, int 
 int scouter_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int kh,
                               int kw, int stride, int pad, int groups, int plan_hint, void* ws, size_t ws_bytes,
                               void* arrival, int arrival_slots, void* stream);
-/* io: SCOUTER_IO_X_BF16 -- x is stored as bf16, SCOUTER_IO_R_BF16 -- dy is */
+/* io: SCOUTER_IO_X_BF16 -- x is stored as bf16, SCOUTER_IO_R_BF16 -- dy is.  plan_hint < 0 (the library's own plan) with BOTH
+ * operands stored as bf16 on a 3x3 / stride 1 / pad 1 layer with 32 input channels per group and rows of at most 112 pixels: the
+ * tap-fused kernel (every x row fetched once per workgroup, not once per tap; csrc/conv_wgrad_taps_bf16.h; SCOUTER_BWT=0: off).
+ * Same workspace bound (scouter_conv2d_wgrad_workspace_bytes with the same plan_hint) and deterministic slab sum. */
 int scouter_conv2d_wgrad_bf16_io(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,
                                  int kh, int kw, int stride, int pad, int groups, int plan_hint, void* ws,
                                  size_t ws_bytes, void* arrival, int arrival_slots, int io, void* stream);
