@@ -1020,10 +1020,16 @@ def conv2d_wgrad(x, dy, dw_hwio, stride=1, pad=0, groups=1, precision="fp32"):
         # register-split bf16x3 kernel (csrc/conv_wgrad_taps_x3.h) -- a static rule of the shape that overrides the table's
         # (tile, split-K) entry for the exact-fp32 kernels, like SCOUTER_X3 does for the layers it moves
         plan = -1
-    if (BWT and bf16 and x.dtype == BF16 and dy.dtype == BF16 and kh == 3 and kw == 3 and stride == 1 and pad == 1 and cg == 32
-            and W <= 112 and H >= 2):
-        # the same layers with both operands STORED as bf16 (BASELINE configs[4]): the library's own plan is the tap-fused
-        # one-plane kernel (csrc/conv_wgrad_taps_bf16.h) instead of one workgroup per tap
+    if (BWT and bf16 and kh == 3 and kw == 3 and stride == 1 and pad == 1 and cg == 32 and W <= 112 and H >= 2 and
+            B * H * W * max(Cin, Cout) * 2 < (1 << 31) - (1 << 20)):
+        # the same layers in bf16 mode (BASELINE configs[4]): the library's own plan for bf16-STORED operands is the tap-fused
+        # one-plane kernel (csrc/conv_wgrad_taps_bf16.h) instead of one workgroup per tap.  The rule is a function of the SHAPE
+        # only: an operand stored as fp32 (SCOUTER_BF16_STORAGE=0 / SCOUTER_BF16_GRADS=0) is rounded to bf16 (RNE: the value
+        # the per-tap kernel's loader rounds it to) by one extra pass first, so storage stays bit-neutral
+        if x.dtype != BF16:
+            x = planes_split(x, 1)[0]
+        if dy.dtype != BF16:
+            dy = planes_split(dy, 1)[0]
         plan = -1
     launch(plan)
     return dw_hwio

@@ -60,14 +60,16 @@ def test_weight_gradient_is_as_close_to_fp64_as_the_per_tap_kernel(cfg, monkeypa
     assert torch.equal(dt, again)                                   # deterministic split-K
 
 
-def test_mixed_storage_keeps_the_per_tap_kernel(monkeypatch):
-    """Only the both-bf16 case is routed to the tap-fused kernel: an fp32-stored operand is rounded by the per-tap kernel's loader."""
+def test_storage_is_bit_neutral(monkeypatch):
+    """The rule is a function of the shape only: an fp32-stored operand is rounded to bf16 (RNE) by one extra pass and meets the
+    same kernel -- bit for bit the gradient of the bf16-stored operands (the contract of tests/test_storage_gpu.py)."""
     gen = torch.Generator(device="cuda"); gen.manual_seed(11)
     x = torch.randn(8, 16, 16, 32, device="cuda", generator=gen)
-    dy = (torch.randn(8, 16, 16, 64, device="cuda", generator=gen) * 0.1).to(torch.bfloat16)
-    a = _wgrad(monkeypatch, True, x, dy, 1)
-    b = _wgrad(monkeypatch, False, x, dy, 1)
-    assert torch.equal(a, b)
+    dy = torch.randn(8, 16, 16, 64, device="cuda", generator=gen) * 0.1
+    xb, dyb = x.to(torch.bfloat16), dy.to(torch.bfloat16)
+    ref = _wgrad(monkeypatch, True, xb, dyb, 1)
+    for a, b in ((x, dyb), (xb, dy), (x, dy), (xb.float(), dyb.float())):
+        assert torch.equal(_wgrad(monkeypatch, True, a, b, 1), ref)
 
 
 def test_library_profile_names_the_kernel(monkeypatch):
