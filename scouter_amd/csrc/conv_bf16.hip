@@ -16,6 +16,7 @@
 // (buffer descriptors), block epilogue and BatchNorm-statistics fusion as conv_igemm.hip (conv_common.h).
 #include "conv_common.h"
 #include "conv_pw_persist_bf16.h"
+#include "conv_halo_dgrad_bf16.h"
 
 #include <type_traits>
 
@@ -275,6 +276,10 @@ static void launch_bf16(const void* src, const void* w, const float* bias, const
     if (g.Cg % 64 == 0) go(igemm_bf16_kernel<BM, BN, WM, WN, 64, DGRAD>, 64);
     else go(igemm_bf16_kernel<BM, BN, WM, WN, 32, DGRAD>, 32);
 }
+static bool bhalo_dgrad_on(const ConvGeom& g, int io) {        // SCOUTER_BHALO=0: the tile kernel
+    const char* e = getenv("SCOUTER_BHALO");
+    return !(e && e[0] == '0') && bhalo_dgrad_ok(g, io);
+}
 template <bool DGRAD>
 static int dispatch_bf16(const void* src, const void* w, const float* bias, const float* addend, float* dst,
                          double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st,
@@ -285,7 +290,23 @@ static int dispatch_bf16(const void* src, const void* w, const float* bias, cons
         case 0: launch_bf16<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
         case 1: launch_bf16<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
         case 2: launch_bf16<64, 64, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
-        default: launch_bf16<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
+        default:
+            if (DGRAD && bhalo_dgrad_on(g, io) && !fz.part2 && !bias && !bn_part && !relu) {
+                // resident dy rows for all nine taps (conv_halo_dgrad_bf16.h): same tiles, partial rows and epilogue as <128, 32>
+                const int mtiles = sc_cdiv(g.M, 128), halves = g.Cg / 32;
+                const size_t blds = bhalo_lds_bytes(halves);
+                const char* we = getenv("SCOUTER_BHALO_WGS");
+                long wgs = we ? atoi(we) : (halves == 1 ? 768 : 512);          // three / two workgroups per CU
+                if (wgs > (long)mtiles * g.groups) wgs = (long)mtiles * g.groups;
+                wgs -= wgs % g.groups;                                         // one group per workgroup (weights resident)
+                if (wgs < g.groups) wgs = g.groups;
+                hipFuncSetAttribute((const void*)bhalo_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
+                hipLaunchKernelGGL(bhalo_dgrad_kernel, dim3((unsigned)wgs), dim3(256), blds, st, (const unsigned short*)src,
+                                   (const float*)w, addend, dst, g, mtiles, fz, (io & SC_IO_Y_BF16) ? 1 : 0);
+                break;
+            }
+            launch_bf16<128, 32, 32, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io);
+            break;
     }
     return sc_check_launch(DGRAD ? "conv2d_dgrad_bf16" : "conv2d_fwd_bf16");
 }
@@ -504,7 +525,8 @@ extern "C" int scouter_conv2d_dgrad_bnbwd_bf16_io(const void* dy, const float* w
     const int tile = tile_hint == 4 ? 4 : bf16_tile(g, tile_hint);
     // algorithmic bytes: dy, dx and -- the fused launch -- the shortcut gradient, the BatchNorm input(s) and the ReLU bits
     const double out_elems = (double)g.M * Cin;
-    ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw,
+    const bool bhalo = tile == 3 && !part2 && bhalo_dgrad_on(g, io_xy);
+    ScProfScope prof(bhalo ? "bhalo_dgrad<bf16>" : names[tile], (hipStream_t)stream, 2.0 * g.M * Cin * Cog * kh * kw,
                      ((io & 8) ? 2.0 : 4.0) * B * Ho * Wo * Cout + ((io & 16) ? 2.0 : 4.0) * out_elems +
                          (addend ? ((io & 4) ? 2.0 : 4.0) * out_elems : 0.0) +
                          (part1 ? ((io & 1) ? 2.0 : 4.0) * out_elems + (part2 ? ((io & 2) ? 2.0 : 4.0) * out_elems : 0.0) +

@@ -416,6 +416,12 @@ def conv2d_dgrad(dy, w_hwio, x_shape, addend=None, stride=1, pad=0, groups=1, pr
     # (BatchNorm inputs stored as bf16: only the bf16-input kernel's epilogue reads them; otherwise that BatchNorm's own
     #  backward -- typed -- does the reduction)
     fuse = _fuse_wanted(post, kh) and (bf16 or post.x_io() == 0)
+    if (BHALO and bf16 and dy.dtype == F32 and kh == 3 and kw == 3 and pad == 1 and Cin // groups == 32 and
+            Cout // groups in (32, 64) and W <= 112 and H >= 2 and B * H * W * Cout * 2 < (1 << 31) - (1 << 20)):
+        # 3x3 layers with 32 input channels per group: the library's resident-rows input gradient (csrc/conv_halo_dgrad_bf16.h)
+        # reads a bf16-STORED dy.  The rule is a function of the shape only -- an fp32-stored dy (SCOUTER_BF16_GRADS=0) is rounded
+        # to bf16 (RNE: the value the tile kernel's loader rounds it to) by one extra pass first: storage stays bit-neutral
+        dy = planes_split(dy, 1)[0]
     if out_dtype == BF16 and not (fuse and bf16):
         out_dtype = F32           # (bf16 storage is for the MASKED block-output gradient the fused epilogue writes)
     dx = torch.empty(x_shape, dtype=out_dtype, device=dy.device)
@@ -970,6 +976,8 @@ def join_side_stream(device, which="wgrad"):
 _WGRAD_PLANS = (-1,)
 # SCOUTER_XWT=0: the 32-channel-group 3x3 weight gradients stay on the exact-fp32 MFMA kernels (read by the library too)
 XWT = os.environ.get("SCOUTER_XWT", "1") != "0"
+# SCOUTER_BHALO=0: the input gradients of those layers in bf16 mode stay on the 128 x 32 tile kernel (read by the library too)
+BHALO = os.environ.get("SCOUTER_BHALO", "1") != "0"
 # SCOUTER_BWT=0: the bf16-stored twins of those layers stay on the per-tap bf16 kernel (read by the library too)
 BWT = os.environ.get("SCOUTER_BWT", "1") != "0"
 if os.environ.get("SCOUTER_WGRAD_TUNE", "1") == "1":
