@@ -237,8 +237,8 @@ CLASSES = {
                                       "TFLOP/s of algorithmic work"},
     "bf16_mfma_conv": {
         "labels": ("igemm_fwd_bf16<", "igemm_dgrad_bf16<", "igemm_dgrad_bf16+bn_bwd<", "wgrad_bf16", "pconv_fwd<bf16>",
-                   "pconv_dgrad<bf16>", "pwgrad<bf16>", "bwgrad_taps<bf16>", "bhalo_dgrad<bf16>"),
-        "rocprof": ("void igemm_bf16_kernel<", "void wgrad_bf16_kernel<", "void bwgrad_taps_kernel<", "bhalo_dgrad_kernel", "void pconv_kernel<", "void phalo_kernel<",
+                   "pconv_dgrad<bf16>", "pwgrad<bf16>", "bwgrad_taps<bf16>", "bhalo_dgrad<bf16>", "bhalo_fwd<bf16>"),
+        "rocprof": ("void igemm_bf16_kernel<", "void wgrad_bf16_kernel<", "void bwgrad_taps_kernel<", "bhalo_dgrad_kernel", "void bhalo_fwd_kernel<", "void pconv_kernel<", "void phalo_kernel<",
                     "void pwgrad_kernel<", "void pwgrad_taps_kernel<", "void ppersist_kernel<", "void pwb_fused_kernel<",
                     "void pwb_fwd_kernel<"),
         "peak": 2500.0, "sustained": 1886.0, "what": "bf16-input convolutions (--precision bf16), v_mfma_f32_32x32x16_bf16, fp32 accumulate"},

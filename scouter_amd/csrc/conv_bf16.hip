@@ -280,12 +280,37 @@ static bool bhalo_dgrad_on(const ConvGeom& g, int io) {        // SCOUTER_BHALO=
     const char* e = getenv("SCOUTER_BHALO");
     return !(e && e[0] == '0') && bhalo_dgrad_ok(g, io);
 }
+static bool bhalo_fwd_on(const ConvGeom& g, int io, int tile) {  // tiles 1 (128 x 64) / 3 (128 x 32): the same 128-pixel partial rows
+    const char* e = getenv("SCOUTER_BHALO");
+    return !(e && e[0] == '0') && bhalo_fwd_ok(g, io) && tile == (g.Ng == 64 ? 1 : 3);
+}
+template <int NB>
+static void launch_bhalo_fwd(const void* src, const void* w, const float* bias, const float* addend, float* dst, double* bn_part,
+                             const ConvGeom& g, int relu, hipStream_t st, int io) {
+    const int mtiles = sc_cdiv(g.M, 128);
+    const size_t blds = bhalo_fwd_lds_bytes(NB);
+    const char* we = getenv("SCOUTER_BHALO_WGS");
+    long wgs = we ? atoi(we) : (NB == 1 ? 768 : 512);            // three / two workgroups per CU
+    if (wgs > (long)mtiles * g.groups) wgs = (long)mtiles * g.groups;
+    wgs -= wgs % g.groups;                                       // one group per workgroup (weights resident)
+    if (wgs < g.groups) wgs = g.groups;
+    auto kern = bhalo_fwd_kernel<NB>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), blds, st, (const unsigned short*)src, (const unsigned short*)w, bias,
+                       addend, dst, bn_part, g, relu, mtiles, (io & SC_IO_Y_BF16) ? 1 : 0);
+}
 template <bool DGRAD>
 static int dispatch_bf16(const void* src, const void* w, const float* bias, const float* addend, float* dst,
                          double* bn_part, const ConvGeom& g, int relu, int tile, hipStream_t st,
                          const BnBwdFuse& fz = BnBwdFuse{}, int io = 0) {
     SC_UNSUPPORTED(g.M < (1L << 31) && (long)g.H * g.W * g.C < (1L << 28),
                    "conv2d_bf16: more than 2^31 output pixels or an image above 2^28 elements is not supported");
+    if (!DGRAD && bhalo_fwd_on(g, io, tile)) {
+        // resident x rows for all nine taps (conv_halo_dgrad_bf16.h): bit-identical to tiles 1 / 3, same partial rows
+        if (g.Ng == 64) launch_bhalo_fwd<2>(src, w, bias, addend, dst, bn_part, g, relu, st, io);
+        else launch_bhalo_fwd<1>(src, w, bias, addend, dst, bn_part, g, relu, st, io);
+        return sc_check_launch("conv2d_fwd_bf16(resident rows)");
+    }
     switch (tile) {
         case 0: launch_bf16<128, 128, 64, 64, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
         case 1: launch_bf16<128, 64, 64, 32, DGRAD>(src, w, bias, addend, dst, bn_part, g, relu, st, fz, io); break;
@@ -466,7 +491,7 @@ extern "C" int scouter_conv2d_fwd_bf16_io(const void* x, const void* wt_bf16, co
                    "conv2d_fwd_bf16: tile 4 (persistent) covers 1x1 / stride 1 / groups 1 layers with 64 / 128 / 256 / 512 input "
                    "channels stored as bf16, 128-multiples of output channels, no bias / addend / ReLU");
     const int tile = tile_hint == 4 ? 4 : bf16_tile(g, tile_hint);
-    ScProfScope prof(names[tile], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
+    ScProfScope prof(bhalo_fwd_on(g, io, tile) ? "bhalo_fwd<bf16>" : names[tile], (hipStream_t)stream, 2.0 * g.M * Cout * g.Cg * kh * kw,
                      ((io & SC_IO_X_BF16) ? 2.0 : 4.0) * B * H * W * Cin + ((io & SC_IO_Y_BF16) ? 2.0 : 4.0) * g.M * Cout);
     if (tile == 4) {
         launch_pwb_fwd(x, wt_bf16, y, bn_partial, g, (hipStream_t)stream, io);

@@ -226,3 +226,106 @@ __global__ __launch_bounds__(256, 3) void bhalo_dgrad_kernel(const unsigned shor
         }
     }
 }
+
+// ---- FORWARD of the same layers (x stored as bf16; 32 input channels per group, 32 / 64 output channels per group): the same
+// resident rows -- 130 + 2 W x rows per 128-pixel tile, fetched once for all nine taps --, the group's bf16 W^T rows ([tap][co][32
+// ci], the forward's pre-transposed weights) copied once per persistent workgroup, K order tap outer / k-step inner: the MFMA
+// sequence of igemm_bf16_kernel per accumulator, so the result -- and the fused BatchNorm statistics, one partial row per 128-pixel
+// tile -- is BIT-IDENTICAL to the tile kernels' (tiles 1 / 3 of scouter_conv2d_fwd_bf16_io, through which it is reached).
+static bool bhalo_fwd_ok(const ConvGeom& g, int io) {
+    return g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.Cg == 32 && (g.Ng == 32 || g.Ng == 64) && (io & SC_IO_X_BF16) &&
+           g.W <= 112 && g.H >= 2 && g.Ho == g.H && g.Wo == g.W && (g.M + 512) * (long)g.C * 2 < (1L << 31);
+}
+static size_t bhalo_fwd_lds_bytes(int nb) {
+    const size_t stage = (size_t)4 * (32 * nb) * (32 + 4) * 4;
+    return (stage > BH_IMG_BYTES ? stage : (size_t)BH_IMG_BYTES) + 256 + (size_t)9 * 32 * nb * 64;
+}
+
+template <int NB>       // 32-column blocks per group: 1 | 2
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void bhalo_fwd_kernel(const unsigned short* __restrict__ src,
+                                                                         const unsigned short* __restrict__ wt,
+                                                                         const float* __restrict__ bias,
+                                                                         const float* __restrict__ addend, float* __restrict__ dst,
+                                                                         double* __restrict__ bn_part, ConvGeom g, int relu,
+                                                                         int mtiles, int dst_bf16) {
+    constexpr int BN = 32 * NB;
+    constexpr int STAGE = 4 * (32 * NB) * (32 + 4) * 4;           // igemm_epilogue_typed's staging, on top of the (dead) image
+    constexpr int IMGR = STAGE > BH_IMG_BYTES ? STAGE : BH_IMG_BYTES;
+    extern __shared__ __attribute__((aligned(1024))) char bh_lds[];
+    char* img = bh_lds;
+    char* zero = bh_lds + IMGR;
+    char* wl = bh_lds + IMGR + 256;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = mtiles * g.groups;
+    const int grp = blockIdx.x % g.groups;                       // (the grid is a multiple of the groups: one group per workgroup)
+    const int W = g.W, H = g.H, hw = H * W;
+    const BnBwdFuse nofz{};
+
+    if (tid < 16) *(float*)(zero + tid * 4) = 0.f;
+    // ---- the group's weights, once per workgroup: rows (tap, co) of 32 ci = 64 bytes, 16-byte pieces permuted by bits 2-3 of co
+    for (int idx = tid; idx < 9 * BN * 4; idx += 256) {
+        const int row = idx >> 2, p = idx & 3, tap = row / BN, co = row - tap * BN;
+        const bh_bf16x8 v = *(const bh_bf16x8*)(wt + ((long)tap * g.N + grp * BN + co) * 32 + 8 * p);
+        *(bh_bf16x8*)(wl + row * 64 + ((p ^ ((co >> 2) & 3)) * 16)) = v;
+    }
+    const int rows = 130 + 2 * W, ninst = (rows + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)grp * 32), 0, 0x7fffffff, 0x00020000);
+
+    // wave layout of the tile kernels (so that the fp64 statistics are summed in the same order): NB = 1: four waves along the
+    // pixels, 32 x 32 each (tile 3); NB = 2: two along the pixels x two along the columns, 64 x 32 each (tile 1)
+    constexpr int MT = NB;
+    const int wm = wave / NB, wn = wave % NB;
+    for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
+        const int mt_id = bid / g.groups;
+        const long m0 = (long)mt_id * 128;
+        unsigned vmask[MT];
+        int jbase[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int prow = wm * (32 * MT) + 32 * i + l31;
+            const long m = m0 + prow;
+            vmask[i] = 0;
+            if (m < g.M) {
+                const int rem = (int)(m % hw), y = rem / W, x = rem - y * W;
+                const unsigned cb = (x >= 1 ? 1u : 0u) | 2u | (x + 1 < W ? 4u : 0u);       // q = 0: x - 1, q = 2: x + 1
+                vmask[i] = (y >= 1 ? cb : 0u) | (cb << 3) | (y + 1 < H ? (cb << 6) : 0u); // r = 0: y - 1, r = 2: y + 1
+            }
+            jbase[i] = prow + (W + 1);
+        }
+        __syncthreads();                                          // every wave is done with the image / the previous tile's staging
+        for (int i = wave; i < ninst; i += 4) {
+            const int j = 16 * i + (lane >> 2), s = lane & 3, c = s ^ ((j >> 2) & 3);
+            long p = m0 - (W + 1) + j;
+            p = p < 0 ? 0 : (p >= g.M ? g.M - 1 : p);
+            bh_dma16(rs, img + i * 1024, (unsigned)((p * g.C + 8 * c) * 2));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 acc[MT][1];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.f;
+        const int swb = (l31 >> 2) & 3;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const char* brow = wl + (t * BN + wn * 32 + l31) * 64;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bh_bf16x8 b = *(const bh_bf16x8*)(brow + (((2 * ks + h) ^ swb) * 16));
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int j = jbase[i] + (t / 3 - 1) * W + (t % 3 - 1);
+                    const bool ok = (vmask[i] >> t) & 1u;
+                    const char* arow = ok ? img + j * 64 : zero;
+                    const int sw = ok ? (j >> 2) & 3 : 0;
+                    const bh_bf16x8 a = *(const bh_bf16x8*)(arow + (((2 * ks + h) ^ sw) * 16));
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][0], 0, 0, 0);
+                }
+            }
+        }
+        igemm_epilogue_typed<128, BN, 32 * MT, 32, false>(acc, (float*)bh_lds, g, bias, addend, dst, bn_part, relu, m0, 0, grp, mt_id,
+                                                     &nofz, dst_bf16 != 0);
+    }
+}

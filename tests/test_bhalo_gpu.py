@@ -100,6 +100,42 @@ def test_fused_batchnorm_backward_epilogue_matches_the_tile_kernel(x_bf16, monke
     np.testing.assert_allclose(ph.cpu().numpy(), pt.cpu().numpy(), rtol=1e-5, atol=1e-4 * sc)
 
 
+FWD_SHAPES = [(2, 24, 24, 64, 128, 2), (3, 20, 19, 32, 32, 1), (1, 12, 112, 32, 64, 1), (9, 14, 9, 96, 96, 3), (40, 9, 3, 32, 64, 1),
+              (2, 112, 112, 32, 64, 1)]
+
+
+@pytest.mark.parametrize("cfg", FWD_SHAPES)
+def test_forward_is_bit_identical_to_the_tile_kernel(cfg, monkeypatch):
+    """bhalo_fwd_kernel keeps the tile kernel's MFMA sequence per accumulator (tap outer, k-step inner): output, fused BatchNorm
+    statistics rows and the bf16-stored output agree bit for bit; an fp32-stored x (the tile kernel) gives the same bits too."""
+    from scouter_amd import kernels as K
+    B, H, W, Cin, Cout, groups = cfg
+    gen = torch.Generator(device="cuda"); gen.manual_seed(sum(cfg) + 1)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=gen).to(BF16)
+    w = torch.randn(3, 3, Cin // groups, Cout, device="cuda", generator=gen) * 0.1
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setenv("SCOUTER_BHALO", "1" if flag else "0")
+        monkeypatch.setattr(K, "BHALO", flag)
+        if not flag:                     # the same 128-pixel tile, so that the statistics rows line up
+            K._tile_cache[("fwd", True, B, H, W, Cin, Cout, 3, 3, 1, 1, groups)] = 1 if Cout // groups == 64 else 3
+        y, (p, rows) = K.conv2d_fwd(x, w, None, None, 1, 1, groups, False, bn_stats=True, precision="bf16")
+        yb = K.conv2d_fwd(x, w, None, None, 1, 1, groups, False, precision="bf16", out_dtype=BF16)
+        yr = K.conv2d_fwd(x, w, None, None, 1, 1, groups, True, precision="bf16")
+        torch.cuda.synchronize()
+        res[flag] = (y, p[:rows].clone(), yb, yr)
+    K._tile_cache.clear()
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[True][2], res[True][0].to(BF16)) and torch.equal(res[True][3], res[True][0].clamp_min(0))
+    monkeypatch.setenv("SCOUTER_BHALO", "1"); monkeypatch.setattr(K, "BHALO", True)
+    y32, (p32, rows) = K.conv2d_fwd(x.float(), w, None, None, 1, 1, groups, False, bn_stats=True, precision="bf16")
+    assert torch.equal(y32, res[True][0]) and torch.equal(p32[:rows], res[True][1])
+    ref = torch.nn.functional.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.to(BF16).double().cpu().permute(3, 2, 0, 1),
+                                     padding=1, groups=groups).permute(0, 2, 3, 1)
+    assert float((res[True][0].cpu().double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
 def test_library_profile_names_the_kernel(monkeypatch):
     import ctypes
     from scouter_amd import _native
@@ -108,9 +144,12 @@ def test_library_profile_names_the_kernel(monkeypatch):
     gen = torch.Generator(device="cuda"); gen.manual_seed(5)
     dy = torch.randn(8, 16, 16, 64, device="cuda", generator=gen).to(BF16)
     w = torch.randn(3, 3, 32, 64, device="cuda", generator=gen)
-    for flag, name in ((True, "bhalo_dgrad<bf16>"), (False, "igemm_dgrad_bf16<128x32>")):
+    from scouter_amd import kernels as K
+    for flag, name, fname in ((True, "bhalo_dgrad<bf16>", "bhalo_fwd<bf16>"), (False, "igemm_dgrad_bf16<128x32>", "igemm_fwd_bf16<")):
         L.scouter_prof_collect(buf, len(buf)); L.scouter_prof_enable(1)
         _dgrad(monkeypatch, flag, dy, w, (8, 16, 16, 32), 1)
+        K.conv2d_fwd(dy[..., :32].contiguous(), w, None, None, 1, 1, 1, precision="bf16")
+        torch.cuda.synchronize()
         L.scouter_prof_enable(0); L.scouter_prof_collect(buf, len(buf))
         names = [row.split("\t")[0] for row in buf.value.decode().splitlines()]
-        assert name in names, (flag, names)
+        assert name in names and any(n.startswith(fname) for n in names), (flag, names)
