@@ -172,6 +172,14 @@ int scouter_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int B, 
 int scouter_im2col_nchw_f32(const float* x, float* col, int B, int Cin, int H, int W, int k, int stride, int pad,
                             int Kpad, void* stream);
 int scouter_pad_rows_f32(const float* w, float* wpad, long nvalid, long ntotal, void* stream);
+/* deep stem's first convolution (timm/models/resnet.py deep stem conv1[0], the 3 -> 32 channel 3x3 / stride 2 / pad 1 layer of
+ * resnest26d / resnest50d), direct: x NCHW [B][3][H][W], w HWIO [3][3][3][32], y NHWC [B][Ho][Wo][32]; no patch rows are
+ * written.  bn_partial (optional): [scouter_stem_direct_partial_rows(B, H)][32][2] fp64 (sum, sum of squares) of y, the layout
+ * scouter_bn_fwd_f32 takes from scouter_conv2d_fwd_f32.  Cout != 32 or an image too wide for the LDS row stage: SC_ERR_UNSUPPORTED
+ * (the caller keeps the im2col route). */
+int scouter_stem_direct_partial_rows(int B, int H);
+int scouter_stem_direct_fwd_f32(const float* x, const float* w, float* y, double* bn_partial, int B, int H, int W, int Cout,
+                                void* stream);
 
 /* ---- BatchNorm2d (+ReLU, +residual add): timm/models/resnet.py:383 (norm_layer), BasicBlock :172-199,
  * ResNestBottleneck resnest.py:111-143.  Training mode: batch statistics (fp64 accumulation), running stats

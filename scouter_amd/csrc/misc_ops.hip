@@ -456,6 +456,157 @@ extern "C" int scouter_im2col_nchw_f32(const float* x, float* col, int B, int Ci
     hipLaunchKernelGGL(im2col_nchw_kernel, dim3(ew_blocks(n) * 2), dim3(256), 0, (hipStream_t)stream, x, col, B, Cin, H, W, Ho, Wo, k, stride, pad, Kpad);
     return sc_check_launch("im2col");
 }
+// ---------------------------------------------------------------------------------------------------------------
+// Deep stem's first convolution, direct: 3x3 / stride 2 / pad 1, Cin = 3, NCHW image in, NHWC rows of 32 channels out
+// (timm/models/resnet.py deep stem, conv1[0]; resnest.py stems).  27 x 32 FLOP pairs per output pixel against 3 x 4 bytes in and 128 bytes
+// out: an HBM stream.  The im2col + GEMM route writes 128 bytes per pixel of patch rows, reads them again and pays a
+// one-K-tile GEMM launch (88 + 182 us at 70 x 224^2); here a workgroup stages the 2 * ROWS + 1 image rows of its ROWS
+// output rows in LDS (coalesced), eight lanes share an output pixel -- lane & 7 owns four output channels, its 27 x 4
+// weights live in registers -- so a wave's store instruction writes 1 KB of consecutive NHWC bytes.  The BatchNorm
+// statistics of the tile (fp64 from the first addition, as igemm_epilogue) go to bn_part[workgroup][32][2].
+// Each filter row's nine terms are one fmaf chain (patch-column order kk = (ky * 3 + kx) * 3 + ci); the three chains are added in row order.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int ROWS, bool VEC4>
+__global__ __launch_bounds__(256) void stem_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, double* __restrict__ bn_part, int H,
+                                                          int W, int Ho, int Wo, int rblocks) {
+    extern __shared__ __attribute__((aligned(16))) float st_lds[];      // [2 * ROWS + 1][3][WP], column j = ix + PADL
+    constexpr int IR = 2 * ROWS + 1;
+    constexpr int PADL = VEC4 ? 4 : 1;                // (VEC4: image columns sit 16-byte aligned in the stage)
+    const int WP = VEC4 ? W + 4 : 2 * Wo + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / rblocks, oy0 = (blockIdx.x - b * rblocks) * ROWS;
+    const int cg = tid & 7;
+    const float* xb = x + (long)b * 3 * H * W;
+    const int iy0 = 2 * oy0 - 1;
+    // stage: one (image row, channel) line per wave and turn, lanes along the line (coalesced, no divisions)
+    if constexpr (VEC4) {
+        // W % 4 == 0, W <= 512: every line is at most two 16-byte loads per lane; all of a wave's loads are in flight
+        // before the first is written to LDS (the stage is what a workgroup waits for)
+        constexpr int TURNS = (IR * 3 + 3) / 4;
+        f32x4 v[TURNS][2];
+        const int nq = W >> 2;
+#pragma unroll
+        for (int t = 0; t < TURNS; ++t) {
+            const int rc = wave + 4 * t, r = rc / 3, ci = rc - r * 3, iy = iy0 + r;
+            const bool row_ok = rc < IR * 3 && iy >= 0 && iy < H;
+            const f32x4* src = (const f32x4*)(xb + ((long)ci * H + (row_ok ? iy : 0)) * W);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = lane + 64 * h;
+                v[t][h] = (row_ok && q < nq) ? src[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TURNS; ++t) {
+            const int rc = wave + 4 * t;
+            if (rc < IR * 3) {
+                float* dst = st_lds + rc * WP;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = lane + 64 * h;
+                    if (q < nq) *(f32x4*)(dst + 4 + 4 * q) = v[t][h];
+                }
+                if (lane == 0) dst[3] = 0.f;          // ix = -1 (W is even: no patch reaches ix = W)
+            }
+        }
+    } else {
+        for (int rc = wave; rc < IR * 3; rc += 4) {
+            const int r = rc / 3, ci = rc - r * 3, iy = iy0 + r;
+            const bool row_ok = iy >= 0 && iy < H;
+            const float* src = xb + ((long)ci * H + (row_ok ? iy : 0)) * W - 1;
+            float* dst = st_lds + rc * WP;
+            for (int j = lane; j < WP; j += 64) dst[j] = (row_ok && j >= 1 && j <= W) ? src[j] : 0.f;
+        }
+    }
+    f32x2 wr[27][2];                                  // this lane's four output channels of every patch column
+#pragma unroll
+    for (int kk = 0; kk < 27; ++kk) {
+        const f32x4 q = *(const f32x4*)(w + kk * 32 + cg * 4);
+        wr[kk][0] = f32x2{q[0], q[1]};
+        wr[kk][1] = f32x2{q[2], q[3]};
+    }
+    __syncthreads();
+    double as[4] = {0.0, 0.0, 0.0, 0.0}, aq[4] = {0.0, 0.0, 0.0, 0.0};
+    const int npix = ROWS * Wo;
+    int ro = 0, ox = tid >> 3;                        // pixel p = ro * Wo + ox, stepped by 32 without divisions
+    while (ox >= Wo) { ox -= Wo; ++ro; }
+    for (int p = tid >> 3; p < npix; p += 32) {
+        if (oy0 + ro >= Ho) break;                    // (rows are walked in order: every later pixel of this thread is outside too)
+        const float* base = st_lds + (2 * ro) * 3 * WP + 2 * ox + (PADL - 1);
+        f32x2 acc[3][2];                              // one chain per filter row (nine terms each), summed in row order
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            acc[ky][0] = f32x2{0.f, 0.f}; acc[ky][1] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = base[(ky * 3 + ci) * WP + kx];
+                    const f32x2 vv = {v, v};
+                    const int kk = (ky * 3 + kx) * 3 + ci;
+                    acc[ky][0] = __builtin_elementwise_fma(vv, wr[kk][0], acc[ky][0]);
+                    acc[ky][1] = __builtin_elementwise_fma(vv, wr[kk][1], acc[ky][1]);
+                }
+        }
+        const f32x2 lo = (acc[0][0] + acc[1][0]) + acc[2][0], hi = (acc[0][1] + acc[1][1]) + acc[2][1];
+        const f32x4 out = {lo[0], lo[1], hi[0], hi[1]};
+        *(f32x4*)(y + (((long)b * Ho + oy0 + ro) * Wo + ox) * 32 + cg * 4) = out;
+        if (bn_part) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double v = (double)out[e];
+                as[e] += v;
+                aq[e] = fma(v, v, aq[e]);
+            }
+        }
+        ox += 32;
+        while (ox >= Wo) { ox -= Wo; ++ro; }
+    }
+    if (!bn_part) return;
+    // lanes with the same lane & 7 hold the same four channels: fixed-order butterfly over the other lane bits, then the waves
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { as[e] += __shfl_xor(as[e], o, 64); aq[e] += __shfl_xor(aq[e], o, 64); }
+    __shared__ double red[4][32][2];
+    if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[wave][cg * 4 + e][0] = as[e]; red[wave][cg * 4 + e][1] = aq[e]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int c = tid >> 1, h = tid & 1;
+        bn_part[((long)blockIdx.x * 32 + c) * 2 + h] = ((red[0][c][h] + red[1][c][h]) + red[2][c][h]) + red[3][c][h];
+    }
+}
+static constexpr int STEM_ROWS = 2;
+extern "C" int scouter_stem_direct_partial_rows(int B, int H) {
+    const int Ho = (H + 2 - 3) / 2 + 1;
+    return B * ((Ho + STEM_ROWS - 1) / STEM_ROWS);
+}
+extern "C" int scouter_stem_direct_fwd_f32(const float* x, const float* w, float* y, double* bn_partial, int B, int H, int W,
+                                           int Cout, void* stream) {
+    SC_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0, "stem_direct_fwd: bad arguments");
+    SC_UNSUPPORTED(Cout == 32, "stem_direct_fwd: the direct kernel is built for 3 -> 32 channels (got Cout = %d)", Cout);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int rblocks = (Ho + STEM_ROWS - 1) / STEM_ROWS;
+    const long grid = (long)B * rblocks;
+    const bool vec4 = W % 4 == 0 && W <= 512 && ((uintptr_t)x & 15) == 0;
+    const size_t lds = (size_t)(2 * STEM_ROWS + 1) * 3 * (vec4 ? W + 4 : 2 * Wo + 1) * sizeof(float);
+    SC_UNSUPPORTED(lds <= 60 * 1024 && grid < (1L << 31) && (long)B * Ho * Wo * 32 < (1L << 40),
+                   "stem_direct_fwd: image too wide for the row stage (W = %d)", W);
+    hipStream_t st = (hipStream_t)stream;
+    ScProfScope prof("stem_fwd<direct>", st, 2.0 * B * Ho * Wo * 27 * 32, 4.0 * ((double)B * 3 * H * W + (double)B * Ho * Wo * 32));
+    if (vec4)
+        hipLaunchKernelGGL((stem_direct_kernel<STEM_ROWS, true>), dim3((unsigned)grid), dim3(256), lds, st, x, w, y, bn_partial, H,
+                           W, Ho, Wo, rblocks);
+    else
+        hipLaunchKernelGGL((stem_direct_kernel<STEM_ROWS, false>), dim3((unsigned)grid), dim3(256), lds, st, x, w, y, bn_partial, H,
+                           W, Ho, Wo, rblocks);
+    return sc_check_launch("stem_direct_fwd");
+}
 extern "C" int scouter_pad_rows_f32(const float* w, float* wpad, long nvalid, long ntotal, void* stream) {
     hipLaunchKernelGGL(pad_rows_kernel, dim3(sc_cdiv(ntotal, 256)), dim3(256), 0, (hipStream_t)stream, w, wpad, nvalid, ntotal);
     return sc_check_launch("pad_rows");

@@ -1068,6 +1068,38 @@ def im2col_nchw(x, k, stride, pad, kpad):
     return col
 
 
+# SCOUTER_STEM_DIRECT=1: the deep stem's 3 -> 32 convolution (fp32 mode) as ONE direct pass over the NCHW image instead of im2col +
+# GEMM (csrc/misc_ops.hip stem_direct_kernel: 88 -> 55 us at 70 x 224^2, no 112 MB of patch rows kept for the backward).  A
+# forward-changing option -- three nine-term fmaf chains instead of the MFMA's K order: half the GEMM route's error against
+# fp64, other bits -- and like every such option it is one more draw of rounding noise for the single-draw gradient bounds of
+# tests/test_model_gpu.py (resnest26d_96: one squeeze-path tensor at 1.06e-3 of its scale against the 1e-3 bound); the step
+# does not notice the 34 us (4 927 vs 4 929 img/s, 3 x 60 steps interleaved).  Off by default.
+STEM_DIRECT = os.environ.get("SCOUTER_STEM_DIRECT", "0") == "1"
+
+
+def stem_direct_eligible(Cin, Cout, k, stride, pad, W):
+    """The direct kernel of the deep stem's first convolution (csrc/misc_ops.hip stem_direct_kernel): 3 -> 32 channels,
+    3x3 / stride 2 / pad 1, rows narrow enough for its LDS stage.  A static rule of the layer shape."""
+    return Cin == 3 and Cout == 32 and k == 3 and stride == 2 and pad == 1 and W <= 1000
+
+
+def stem_direct_fwd(x, w_hwio, bn_stats=False):
+    """y[B][Ho][Wo][32] = conv3x3 / 2 of the NCHW image x with w (HWIO); bn_stats: also the (partials, rows) pair conv2d_fwd
+    returns for the BatchNorm behind it."""
+    _chk(x, "image"); _chk(w_hwio, "weight")
+    B, Cin, H, W = x.shape
+    Cout = w_hwio.shape[-1]
+    Ho, Wo = conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1)
+    L = _native.lib()
+    y = torch.empty((B, Ho, Wo, Cout), dtype=F32, device=x.device)
+    part, rows = None, 0
+    if bn_stats:
+        rows = L.scouter_stem_direct_partial_rows(B, H)
+        part = torch.empty((rows, Cout, 2), dtype=torch.float64, device=x.device)
+    _native.check(L.scouter_stem_direct_fwd_f32(_p(x), _p(w_hwio), _p(y), _p(part), B, H, W, Cout, _stream()), "stem_direct_fwd")
+    return (y, (part, rows)) if bn_stats else y
+
+
 def pad_rows(w_flat, nvalid, ntotal):
     out = torch.empty(ntotal, dtype=F32, device=w_flat.device)
     _native.check(_native.lib().scouter_pad_rows_f32(_p(w_flat), _p(out), nvalid, ntotal, _stream()), "pad_rows")

@@ -290,7 +290,8 @@ class Conv2d(nn.Module):
 
 class StemConv2d(Conv2d):
     """First convolution of the network (Cin = 1 or 3, NCHW image in): im2col into [M][Kpad] rows (zero padded to a
-    multiple of 32) + the generic MFMA GEMM, for the forward and the weight gradient.  No input gradient."""
+    multiple of 32) + the generic MFMA GEMM, for the forward and the weight gradient.  No input gradient.
+    SCOUTER_STEM_DIRECT=1 (opt-in, kernels.STEM_DIRECT): the deep stem's 3 -> 32 layer runs its forward as one direct pass."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding):
         nn.Module.__init__(self)
@@ -306,12 +307,22 @@ class StemConv2d(Conv2d):
         self.use_side_stream = K.SIDE_STREAM_DEFAULT
         self.planes = 0
         self.x3 = 0
+        self._saved_image = False
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
     def fwd(self, x_nchw, save, relu=False, addend=None, bn_stats=False):
         if x_nchw.dim() != 4 or x_nchw.shape[1] != self.in_channels:
             raise RuntimeError("expected an NCHW image batch with %d channel(s), got shape %s"
                                % (self.in_channels, tuple(x_nchw.shape)))
+        if (K.STEM_DIRECT and self.precision == "fp32" and not relu and addend is None and x_nchw.dtype == torch.float32 and
+                K.stem_direct_eligible(self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
+                                       x_nchw.shape[3])):
+            # deep stem (3 -> 32, 3x3 / 2), SCOUTER_STEM_DIRECT=1: one direct pass over the image, no patch rows; the weight
+            # gradient builds its patch rows itself, on its side stream (bwd)
+            y = K.stem_direct_fwd(x_nchw, K.hwio(self.weight), bn_stats)
+            self._saved_image = True
+            return y, (x_nchw if save else None)
+        self._saved_image = False
         col = K.im2col_nchw(x_nchw, self.kernel_size, self.stride, self.padding, self.kpad)
         wflat = K.hwio(self.weight).reshape(-1)
         wpad = K.pad_rows(wflat, wflat.numel(), self.kpad * self.out_channels).view(1, 1, self.kpad, self.out_channels)
@@ -323,6 +334,8 @@ class StemConv2d(Conv2d):
             raise NotImplementedError("gradient w.r.t. the input image is not part of the training hot path")
         if self._dw is not None:
             with K.side_stream(dy.device, ctx, dy, enabled=self.use_side_stream):
+                if self._saved_image:             # (the direct forward saved the image, not patch rows)
+                    ctx = K.im2col_nchw(ctx, self.kernel_size, self.stride, self.padding, self.kpad)
                 dwpad = torch.empty((1, 1, self.kpad, self.out_channels), dtype=torch.float32, device=dy.device)
                 K.conv2d_wgrad(ctx, dy, dwpad, precision=self.precision)
                 n = self.kdim * self.out_channels
