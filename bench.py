@@ -422,6 +422,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # development (tools_dev/priority_ab.sh): the whole step on a high-priority compute stream instead of the default stream
+    if os.environ.get("SCOUTER_MAIN_PRIORITY"):
+        main_stream = torch.cuda.Stream(device=device, priority=int(os.environ["SCOUTER_MAIN_PRIORITY"]))
+        main_stream.wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(main_stream)
+
     # setup, outside the W warm-up steps: the first pass through every layer shape picks its block tile (each candidate is
     # timed once, scouter_amd/kernels.py:_pick_tile) -- like building the model, it happens once per process
     step()

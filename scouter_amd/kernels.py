@@ -929,6 +929,13 @@ SIDE_STREAMS = max(1, int(os.environ.get("SCOUTER_SIDE_STREAMS", "1")))      # w
 SIDE_STREAM_DEFAULT = os.environ.get("SCOUTER_SIDE_STREAM", "1") != "0"
 
 
+def _side_priority(which):
+    """HIP queue priority of a side stream (torch: -1 high, 0 normal): SCOUTER_SIDE_PRIORITY for the weight-gradient streams,
+    SCOUTER_BRANCH_PRIORITY for the shortcut-branch stream.  Development switches (tools_dev/priority_ab.sh)."""
+    name = "SCOUTER_BRANCH_PRIORITY" if which == "branch" else "SCOUTER_SIDE_PRIORITY"
+    return int(os.environ.get(name, "0"))
+
+
 class side_stream:
     """Context manager: run the enclosed launches on the per-device WEIGHT-GRADIENT side stream, ordered after
     everything queued so far on the current stream.  In the backward pass only dgrad feeds the next layer; wgrad
@@ -954,7 +961,7 @@ class side_stream:
         key = (self.device.type, self.device.index, which)
         st = _side.get(key)
         if st is None:
-            st = _side[key] = torch.cuda.Stream(device=self.device)
+            st = _side[key] = torch.cuda.Stream(device=self.device, priority=_side_priority(which))
         st.wait_stream(torch.cuda.current_stream(self.device))
         for t in self.tensors:                 # the caching allocator must not recycle them while the side stream runs
             if t is not None:
