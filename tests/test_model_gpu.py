@@ -264,7 +264,7 @@ def _seed_model(seed):
 # the forward-option sets the distribution tests cover: the defaults (round 6: every option on), round 5's defaults, each option
 # alone on top of those, and the exact-fp32 / plane-free path
 NOISE_SWITCHES = [{}, {"x3": 15, "halo": 2}, {"x3": 31, "halo": 2}, {"x3": 47, "halo": 2}, {"x3": 15, "halo": 3},
-                  {"x3": 0, "halo": 2}]
+                  {"x3": 0, "halo": 2}, {"stem_direct": True}]     # (last: the defaults + the opt-in direct first convolution)
 
 
 @pytest.mark.parametrize("switches", NOISE_SWITCHES)
@@ -289,6 +289,8 @@ def test_gradient_noise_over_five_seeds(switches, monkeypatch):
     g = np.load(os.path.join(GOLD, "model_%s_seeds.npz" % SEED_CASE))
     if "halo" in switches:
         monkeypatch.setattr(K, "HALO_TILE", switches["halo"])
+    if "stem_direct" in switches:
+        monkeypatch.setattr(K, "STEM_DIRECT", switches["stem_direct"])
     keys = [str(k) for k in g["grad_keys"]]
     head = [str(k) for k in g["head_keys"]]
     offs = np.concatenate([[0], np.cumsum(g["head_sizes"])])
@@ -343,6 +345,8 @@ def test_rounding_noise_over_five_seeds(switches, monkeypatch):
     g = np.load(os.path.join(GOLD, "model_%s_seeds.npz" % SEED_CASE))
     if "halo" in switches:
         monkeypatch.setattr(K, "HALO_TILE", switches["halo"])
+    if "stem_direct" in switches:
+        monkeypatch.setattr(K, "STEM_DIRECT", switches["stem_direct"])
     ratios = []
     for i, seed in enumerate(g["seeds"]):
         m, images, labels = _seed_model(seed)
